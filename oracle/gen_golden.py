@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref, built by oracle/Makefile from
+/root/reference). Runs only in the dev container; the fixtures it writes are data (inputs + expected
+outputs) and are committed. Re-run: `python oracle/gen_golden.py`.
+
+Every fixture records results of both reference builds:
+  *_avx     libggml_ref.so         (-march=x86-64-v3: the AVX2 branches, what a real x86 run executes)
+  *_scalar  libggml_ref_scalar.so  (SIMD disabled: the reference's portable #else branches)
+The spread between the two is the legitimate float-association / rounding-flavour spread of the reference.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import binding as ob  # noqa: E402
+import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def weights_digest(w):
+    h = hashlib.sha256()
+    for name in ("tok_emb", "lm_head", "out_norm_w", "out_norm_b"):
+        h.update(np.ascontiguousarray(w[name]).tobytes())
+    for lw in w["layers"]:
+        for name in sorted(lw):
+            h.update(np.ascontiguousarray(lw[name]).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    ob.build_oracle()
+    O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---- 1. quantize / dequantize / vec_dot (the functions tests/test-quantize-fns.cpp pins) -------------
+    d = {}
+    n = 4096
+    x_cos = (0.1 + 2.0 * np.cos(np.arange(n, dtype=np.float32) + 0.0)).astype(np.float32)   # test-quantize-fns.cpp:24-30
+    x_cos1 = (0.1 + 2.0 * np.cos(np.arange(n, dtype=np.float32) + 1.0)).astype(np.float32)
+    rng = np.random.default_rng(20240917)
+    x_gau = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    d["x_cos"], d["x_cos1"], d["x_gau"] = x_cos, x_cos1, x_gau
+    for t in ob.WEIGHT_TYPES:
+        nm = ob.TYPE_NAME[t]
+        for xn, xv in (("cos", x_cos), ("gau", x_gau)):
+            q = R.quantize(t, xv)                       # quantize_row_q_reference (also for k-quants)
+            d[f"{nm}_{xn}_q"] = q
+            d[f"{nm}_{xn}_deq"] = R.dequantize(t, q, n)
+            act_avx = R.quantize_dot(t, x_cos1)
+            act_sc = RS.quantize_dot(t, x_cos1)
+            d[f"{nm}_act_avx"], d[f"{nm}_act_scalar"] = act_avx, act_sc
+            d[f"{nm}_{xn}_dot_avx"] = np.float32(R.vec_dot(t, n, q, act_avx))
+            d[f"{nm}_{xn}_dot_scalar"] = np.float32(RS.vec_dot(t, n, q, act_sc))
+    # Falcon-7B row lengths (legacy types only: 4544 % 256 != 0) and 18176
+    for K in (4544, 18176):
+        xk = rng.standard_normal(K).astype(np.float32)
+        wk = (rng.standard_normal((3, K)) * 0.02).astype(np.float32)
+        d[f"x_{K}"], d[f"w_{K}"] = xk, wk
+        for t in ob.WEIGHT_TYPES:
+            if K % ob.BLCK[t]:
+                continue
+            nm = ob.TYPE_NAME[t]
+            q = np.stack([R.quantize(t, wk[r]) for r in range(3)])
+            d[f"{nm}_{K}_q"] = q
+            a_sc = RS.quantize_dot(t, xk)
+            d[f"{nm}_{K}_dot_avx"] = np.array([R.vec_dot(t, K, q[r], R.quantize_dot(t, xk)) for r in range(3)], np.float32)
+            d[f"{nm}_{K}_dot_scalar"] = np.array([RS.vec_dot(t, K, q[r], a_sc) for r in range(3)], np.float32)
+    np.savez_compressed(os.path.join(OUT, "quant_fns.npz"), **d)
+
+    # ---- 2. mul_mat through ggml_graph_compute ---------------------------------------------------------
+    d = {}
+    for t in ob.WEIGHT_TYPES:
+        nm = ob.TYPE_NAME[t]
+        K, M, N = 512, 48, 5
+        r2 = np.random.default_rng(100 + t)
+        w = R.quantize(t, (r2.standard_normal((M, K)) * 0.02).astype(np.float32))
+        x = r2.standard_normal((N, K)).astype(np.float32)
+        d[f"{nm}_w"], d[f"{nm}_x"] = w, x
+        d[f"{nm}_y_avx"] = R.mul_mat(t, w, K, M, x, 3)
+        d[f"{nm}_y_scalar"] = RS.mul_mat(t, w, K, M, x, 2)
+    np.savez_compressed(os.path.join(OUT, "mul_mat.npz"), **d)
+
+    # ---- 3. block ops ----------------------------------------------------------------------------------
+    d = {}
+    r3 = np.random.default_rng(7)
+    xn = (r3.standard_normal((5, 4544)) * 3 + 0.5).astype(np.float32)
+    d["norm_x"], d["norm_y"] = xn, RS.norm(xn)
+    assert np.array_equal(R.norm(xn), d["norm_y"])
+    gx = np.concatenate([r3.standard_normal(4096).astype(np.float32) * 3,
+                         np.array([0, -0.0, 1e-8, 11.0, -11.0, 60000, -60000], np.float32)])
+    d["gelu_x"], d["gelu_y"] = gx, RS.gelu(gx)
+    assert np.array_equal(R.gelu(gx), d["gelu_y"])
+    # the full fp16 GELU table through the op (all 65536 halves as inputs), and exp through soft_max is
+    # covered by softmax below; the gelu table is stored packed as fp16 bits.
+    allh = np.arange(1 << 16, dtype=np.uint16).view(np.float16).astype(np.float32)
+    finite = np.isfinite(allh)
+    gy = RS.gelu(allh[finite])
+    d["gelu_all_in_bits"] = np.arange(1 << 16, dtype=np.uint16)[finite]
+    d["gelu_all_out_bits"] = gy.astype(np.float16).view(np.uint16)   # exact: outputs are fp16-representable
+    assert np.array_equal(gy.astype(np.float16).astype(np.float32), gy)
+    for n_ctx in (2048, 8192):
+        xr = r3.standard_normal((3, 5, 64)).astype(np.float32)
+        d[f"rope_x_{n_ctx}"] = xr
+        d[f"rope_y_{n_ctx}"] = RS.rope(xr, 64, 5, 3, 1021, n_ctx)
+        assert np.array_equal(R.rope(xr, 64, 5, 3, 1021, n_ctx), d[f"rope_y_{n_ctx}"])
+    kq = (r3.standard_normal((4, 3, 40)) * 6).astype(np.float32)
+    d["sm_kq"], d["sm_n_past"] = kq, np.int32(37)
+    d["sm_p"] = RS.scale_mask_softmax(kq, 37, 0.125)
+    assert np.array_equal(R.scale_mask_softmax(kq, 37, 0.125), d["sm_p"])
+    np.savez_compressed(os.path.join(OUT, "block_ops.npz"), **d)
+
+    # ---- 4. whole tiny Falcon models (weights regenerated from the seed; digest pins them) --------------
+    d = {}
+    cases = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+             ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)]
+    for name, hp, t in cases:
+        w = synth.make_model(O, hp, t, seed=1234)
+        d[f"{name}_digest"] = np.frombuffer(bytes.fromhex(weights_digest(w)), np.uint8)
+        toks = synth.tokens(12, hp["n_vocab"], seed=42)
+        d[f"{name}_tokens"] = toks
+        for tag, lib in (("avx", R), ("scalar", RS)):
+            m = lib.model(w, 64)
+            lg, hid = m.eval(toks[:8], 0, 2, want_hidden=True)
+            d[f"{name}_prefill_logits_{tag}"] = lg
+            d[f"{name}_prefill_hidden_{tag}"] = hid
+            dec = [m.eval(toks[i:i + 1], i, 2) for i in range(8, 12)]
+            d[f"{name}_decode_logits_{tag}"] = np.concatenate(dec)
+    np.savez_compressed(os.path.join(OUT, "tiny_models.npz"), **d)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

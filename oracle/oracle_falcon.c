@@ -1,0 +1,213 @@
+/*
+ * oracle_falcon.c -- TEST INFRASTRUCTURE (see oracle.h). CPU restatement of the non-mat-mul ops of a
+ * Falcon decoder block and of falcon_eval_internal's op sequence (libfalcon.cpp:2115-2466).
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ fp16 lookup tables (ggml.c:4276-4290) */
+static uint16_t g_gelu_tab[1 << 16];
+static uint16_t g_exp_tab[1 << 16];
+static int      g_tab_ready = 0;
+
+static float gelu_exact(float x) {                 /* ggml.c:3465-3467 */
+    const float a = 0.044715f, s2pi = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(s2pi * x * (1.0f + a * x * x)));
+}
+
+void orc_tables_init(void) {
+    if (g_tab_ready) return;
+    for (uint32_t i = 0; i < (1u << 16); ++i) {
+        const float f = orc_fp16_to_fp32((uint16_t) i);
+        g_gelu_tab[i] = orc_fp32_to_fp16(gelu_exact(f));
+        g_exp_tab[i]  = orc_fp32_to_fp16(expf(f));
+    }
+    g_tab_ready = 1;
+}
+
+const uint16_t * orc_gelu_table(void) { orc_tables_init(); return g_gelu_tab; }
+const uint16_t * orc_exp_table(void)  { orc_tables_init(); return g_exp_tab; }
+
+float orc_gelu(float x)    { orc_tables_init(); return orc_fp16_to_fp32(g_gelu_tab[orc_fp32_to_fp16(x)]); }   /* ggml.c:3477-3484 */
+float orc_exp_f16(float x) { orc_tables_init(); return orc_fp16_to_fp32(g_exp_tab[orc_fp32_to_fp16(x)]); }    /* ggml.c:12436-12442 */
+
+/* ------------------------------------------------------------------ norm (ggml.c:10540-10594) */
+void orc_norm(const float * x, int64_t n, int64_t rows, float * y) {
+    for (int64_t r = 0; r < rows; ++r, x += n, y += n) {
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; ++i) sum += (double) x[i];
+        const float mean = (float)(sum / (double) n);
+        double sum2 = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const float v = x[i] - mean;
+            y[i] = v;
+            sum2 += (double)(v * v);
+        }
+        const float variance = (float)(sum2 / (double) n);
+        const float scale = 1.0f / sqrtf(variance + 1e-5f);
+        for (int64_t i = 0; i < n; ++i) y[i] *= scale;
+    }
+}
+
+/* norm -> * weight -> + bias  (libfalcon.cpp:2166-2188) */
+void orc_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y) {
+    orc_norm(x, n, rows, y);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t i = 0; i < n; ++i) y[r * n + i] = y[r * n + i] * w[i] + b[i];
+}
+
+/* ------------------------------------------------------------------ RoPE, NeoX pairing, dynamic NTK */
+/* ggml.c:12875-12898 with DYNAMIC_MODE = 1 and NTK_ALPHA = 2 (libfalcon.cpp:2231-2234). n_ctx/2048 is an
+ * INTEGER division in the reference. */
+float orc_rope_theta_scale(int n_dims, int n_ctx) {
+    float alpha = 1.0f;
+    if (n_ctx >= 2048) alpha = powf((float)(((n_ctx / 2048) - 1) * 2.0f + 1), (float)(n_dims / (n_dims - 2.0)));
+    return powf(alpha * 10000.0f, -2.0f / (float) n_dims);
+}
+
+/* x: [head_dim][n_head][N] contiguous, rotated in place; position of token t is n_past + t.
+ * theta is advanced by repeated f32 multiplication exactly as ggml.c:12962-12966. */
+void orc_rope_neox(float * x, int head_dim, int n_head, int N, int n_past, int n_ctx) {
+    const float ts = orc_rope_theta_scale(head_dim, n_ctx);
+    const int half = head_dim / 2;
+    for (int t = 0; t < N; ++t) {
+        for (int h = 0; h < n_head; ++h) {
+            float * v = x + ((size_t) t * n_head + h) * head_dim;
+            float theta = (float)(n_past + t);
+            for (int k = 0; k < half; ++k) {
+                const float c = cosf(theta), s = sinf(theta);
+                theta *= ts;
+                const float x0 = v[k], x1 = v[k + half];
+                v[k]        = x0 * c - x1 * s;
+                v[k + half] = x0 * s + x1 * c;
+            }
+        }
+    }
+}
+
+/* cos/sin table the product precomputes on the host: entry [p][k] = {cosf(theta_pk), sinf(theta_pk)} */
+void orc_rope_table(float * cs, int head_dim, int n_pos, int n_ctx) {
+    const float ts = orc_rope_theta_scale(head_dim, n_ctx);
+    const int half = head_dim / 2;
+    for (int p = 0; p < n_pos; ++p) {
+        float theta = (float) p;
+        for (int k = 0; k < half; ++k) {
+            cs[((size_t) p * half + k) * 2 + 0] = cosf(theta);
+            cs[((size_t) p * half + k) * 2 + 1] = sinf(theta);
+            theta *= ts;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ soft_max rows (ggml.c:12389-12456) */
+void orc_softmax_rows(float * x, int64_t nc, int64_t nr) {
+    orc_tables_init();
+    for (int64_t r = 0; r < nr; ++r, x += nc) {
+        float mx = -INFINITY;
+        for (int64_t i = 0; i < nc; ++i) if (x[i] > mx) mx = x[i];
+        double sum = 0.0;
+        for (int64_t i = 0; i < nc; ++i) {
+            if (x[i] == -INFINITY) { x[i] = 0.0f; continue; }
+            const float v = orc_fp16_to_fp32(g_exp_tab[orc_fp32_to_fp16(x[i] - mx)]);
+            sum += (double) v;
+            x[i] = v;
+        }
+        const float inv = (float)(1.0 / sum);           /* ggml_vec_scale_f32(nc, dp, sum) takes a float */
+        for (int64_t i = 0; i < nc; ++i) x[i] *= inv;
+    }
+}
+
+/* ------------------------------------------------------------------ whole model */
+/* ggml_vec_dot_f32, portable branch (ggml.c:2296-2300): f32 products accumulated in double, left to right.
+ * (The SIMD branches, ggml.c:2270-2294, keep 32 f32 partial sums instead; only the association differs.) */
+static float dot_f32(const float * a, const float * b, int64_t n, int64_t stride_a) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += (double)(a[i * stride_a] * b[i]);
+    return (float) s;
+}
+
+void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_past, int n_threads,
+                     int flavour, float * logits_out, float * hidden_out) {
+    orc_tables_init();
+    const orc_hparams * hp = &m->hp;
+    const int64_t E = hp->n_embd, H = hp->n_head, HKV = hp->n_head_kv, D = E / H, L = hp->n_layer, FF = hp->n_ff;
+    const int64_t QKV = (H + 2 * HKV) * D;
+    const int64_t n_kv = n_past + N;
+    const int group = (int)(H / HKV);                      /* i02 = i12 / (ne12/ne02), ggml.c:11074 */
+    const size_t erow = orc_row_bytes(hp->wtype, E);
+
+    float * inp   = (float *) malloc(sizeof(float) * N * E);
+    float * ln    = (float *) malloc(sizeof(float) * N * E);
+    float * ln2   = (float *) malloc(sizeof(float) * N * E);
+    float * qkv   = (float *) malloc(sizeof(float) * N * QKV);
+    float * qrot  = (float *) malloc(sizeof(float) * N * H * D);
+    float * krot  = (float *) malloc(sizeof(float) * N * HKV * D);
+    float * att   = (float *) malloc(sizeof(float) * N * E);
+    float * wo    = (float *) malloc(sizeof(float) * N * E);
+    float * up    = (float *) malloc(sizeof(float) * N * FF);
+    float * down  = (float *) malloc(sizeof(float) * N * E);
+    float * p     = (float *) malloc(sizeof(float) * n_kv);
+
+    /* embedding lookup = dequantize_row of the token's row (ggml_compute_forward_get_rows_q, ggml.c:11975) */
+    for (int t = 0; t < N; ++t)
+        orc_dequantize_row(hp->wtype, (const uint8_t *) m->tok_emb + (size_t) tokens[t] * erow, inp + (size_t) t * E, E);
+
+    for (int il = 0; il < L; ++il) {
+        const orc_layer * ly = &m->layers[il];
+        if (hidden_out) memcpy(hidden_out + (size_t) il * N * E, inp, sizeof(float) * N * E);
+
+        orc_layer_norm(inp, E, N, ly->ln_w, ly->ln_b, ln);
+        const float * attn_in = ln;
+        if (hp->two_norms) { orc_layer_norm(inp, E, N, ly->ln2_w, ly->ln2_b, ln2); attn_in = ln2; }
+
+        orc_mul_mat_q(hp->wtype, ly->qkv, E, QKV, attn_in, N, qkv, n_threads, flavour);
+
+        /* split fused QKV row: [n_head Q heads | n_head_kv K heads | n_head_kv V heads] (libfalcon.cpp:2205-2227) */
+        float * kc = m->k_cache + (size_t) il * hp->n_ctx * HKV * D;
+        float * vc = m->v_cache + (size_t) il * hp->n_ctx * HKV * D;
+        for (int t = 0; t < N; ++t) {
+            memcpy(qrot + (size_t) t * H * D,   qkv + (size_t) t * QKV,               sizeof(float) * H * D);
+            memcpy(krot + (size_t) t * HKV * D, qkv + (size_t) t * QKV + H * D,       sizeof(float) * HKV * D);
+            memcpy(vc + (size_t)(n_past + t) * HKV * D, qkv + (size_t) t * QKV + (H + HKV) * D, sizeof(float) * HKV * D);
+        }
+        orc_rope_neox(qrot, (int) D, (int) H,   N, n_past, hp->rope_n_ctx);
+        orc_rope_neox(krot, (int) D, (int) HKV, N, n_past, hp->rope_n_ctx);
+        memcpy(kc + (size_t) n_past * HKV * D, krot, sizeof(float) * N * HKV * D);      /* libfalcon.cpp:2238-2244 */
+
+        const float kq_scale = 1.0f / sqrtf((float) D);
+        for (int t = 0; t < N; ++t) {
+            for (int h = 0; h < H; ++h) {
+                const int hk = h / group;
+                const float * q = qrot + ((size_t) t * H + h) * D;
+                for (int64_t s = 0; s < n_kv; ++s) {
+                    float v = dot_f32(kc + ((size_t) s * HKV + hk) * D, q, D, 1) * kq_scale;  /* K.Q then scale */
+                    if (s > n_past + t) v = -INFINITY;                                    /* ggml.c:12341-12347 */
+                    p[s] = v;
+                }
+                orc_softmax_rows(p, n_kv, 1);
+                float * o = att + (size_t) t * E + (size_t) h * D;                        /* merged [n_embd, N] */
+                for (int64_t d = 0; d < D; ++d) {
+                    o[d] = dot_f32(vc + (size_t) hk * D + d, p, n_kv, HKV * D);    /* V^T row . P row */
+                }
+            }
+        }
+        orc_mul_mat_q(hp->wtype, ly->wo, E, E, att, N, wo, n_threads, flavour);
+
+        orc_mul_mat_q(hp->wtype, ly->up, E, FF, ln, N, up, n_threads, flavour);
+        for (int64_t i = 0; i < (int64_t) N * FF; ++i) up[i] = orc_gelu(up[i]);
+        orc_mul_mat_q(hp->wtype, ly->down, FF, E, up, N, down, n_threads, flavour);
+
+        /* cur = (mlp + attn) + inpL  (libfalcon.cpp:2399-2400) */
+        for (int64_t i = 0; i < (int64_t) N * E; ++i) inp[i] = (down[i] + wo[i]) + inp[i];
+    }
+    if (hidden_out) memcpy(hidden_out + (size_t) L * N * E, inp, sizeof(float) * N * E);
+
+    orc_layer_norm(inp, E, N, m->out_norm_w, m->out_norm_b, ln);
+    orc_mul_mat_q(hp->wtype, m->lm_head, E, hp->n_vocab, ln, N, logits_out, n_threads, flavour);
+
+    free(inp); free(ln); free(ln2); free(qkv); free(qrot); free(krot); free(att); free(wo); free(up); free(down); free(p);
+}

@@ -1,0 +1,501 @@
+/*
+ * oracle_quants.c -- TEST INFRASTRUCTURE (see oracle.h). Scalar CPU restatement of the reference's
+ * block formats, (de)quantizers, integer dot products and quantized mat-mul.
+ *
+ * Written against the bit-level format description in SURVEY.md 8(a'); blocks are addressed by byte
+ * offset (no structs) so the layout knowledge is explicit:
+ *
+ *   Q4_0 18 B: d:f16 @0, qs[16] @2            Q4_1 20 B: d @0, m @2, qs[16] @4
+ *   Q5_0 22 B: d @0, qh:u32 @2, qs[16] @6     Q5_1 24 B: d @0, m @2, qh:u32 @4, qs[16] @8
+ *   Q8_0 34 B: d:f16 @0, qs[32]:i8 @2         Q8_1 40 B: d:f32 @0, s:f32 @4, qs[32] @8
+ *   Q2_K 84 B: scales[16] @0, qs[64] @16, d @80, dmin @82
+ *   Q3_K 110 B: hmask[32] @0, qs[64] @32, scales[12] @96, d @108
+ *   Q4_K 144 B: d @0, dmin @2, scales[12] @4, qs[128] @16
+ *   Q5_K 176 B: d @0, dmin @2, scales[12] @4, qh[32] @16, qs[128] @48
+ *   Q6_K 210 B: ql[128] @0, qh[64] @128, scales[16]:i8 @192, d @208
+ *   Q8_K 292 B: d:f32 @0, qs[256]:i8 @4, bsums[16]:i16 @260
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------ fp16 <-> fp32 (IEEE, RNE) */
+/* The reference uses F16C (_cvtss_sh / _cvtsh_ss, ggml.c:345-351) or the bit-twiddling fallback
+ * (ggml.c:360-410); both are IEEE round-to-nearest-even with subnormals. */
+float orc_fp16_to_fp32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp  = (h >> 10) & 0x1Fu;
+    uint32_t man        = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {                       /* subnormal half -> normal float */
+            int e = -1;
+            do { man <<= 1; ++e; } while ((man & 0x400u) == 0);
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3FFu) << 13;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | man << 13;
+    } else {
+        bits = sign | (exp + 112u) << 23 | man << 13;
+    }
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+uint16_t orc_fp32_to_fp16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) {                         /* inf / nan */
+        return (uint16_t)(sign | 0x7C00u | (ax > 0x7F800000u ? (0x200u | ((ax >> 13) & 0x3FFu)) : 0u));
+    }
+    if (ax >= 0x477FF000u) {                         /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (ax < 0x33000001u) {                          /* <= 2^-25 rounds to zero (tie at 2^-25 -> even = 0) */
+        return sign;
+    }
+    const int e = (int)(ax >> 23) - 127;
+    uint32_t man = (ax & 0x7FFFFFu) | 0x800000u;     /* 24-bit significand */
+    int shift;                                       /* bits to drop */
+    uint32_t hexp;
+    if (e < -14) { shift = 13 + (-14 - e); hexp = 0; }
+    else         { shift = 13;             hexp = (uint32_t)(e + 15); }
+    const uint32_t kept = man >> shift;
+    const uint32_t rem  = man & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    uint32_t r = kept;
+    if (rem > half || (rem == half && (kept & 1u))) r += 1;
+    uint32_t out;
+    if (hexp == 0) out = r;                          /* subnormal; carry into exponent field is the right encoding */
+    else           out = ((hexp << 10) + (r - 0x400u)); /* r includes the implicit bit; carry bumps exponent */
+    return (uint16_t)(sign | out);
+}
+
+static inline float    rd_f16(const uint8_t * p) { uint16_t h; memcpy(&h, p, 2); return orc_fp16_to_fp32(h); }
+static inline void     wr_f16(uint8_t * p, float f) { const uint16_t h = orc_fp32_to_fp16(f); memcpy(p, &h, 2); }
+static inline float    rd_f32(const uint8_t * p) { float f; memcpy(&f, p, 4); return f; }
+static inline void     wr_f32(uint8_t * p, float f) { memcpy(p, &f, 4); }
+static inline uint32_t rd_u32(const uint8_t * p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline int16_t  rd_i16(const uint8_t * p) { int16_t v; memcpy(&v, p, 2); return v; }
+
+/* ------------------------------------------------------------------ type table (ggml.c:3342-3418) */
+int orc_blck_size(int type) {
+    switch (type) {
+        case ORC_F32: case ORC_F16: return 1;
+        case ORC_Q4_0: case ORC_Q4_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_Q8_0: case ORC_Q8_1: return 32;
+        case ORC_Q2_K: case ORC_Q3_K: case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: return 256;
+    }
+    return 0;
+}
+size_t orc_type_size(int type) {
+    switch (type) {
+        case ORC_F32: return 4;   case ORC_F16: return 2;
+        case ORC_Q4_0: return 18; case ORC_Q4_1: return 20; case ORC_Q5_0: return 22; case ORC_Q5_1: return 24;
+        case ORC_Q8_0: return 34; case ORC_Q8_1: return 40;
+        case ORC_Q2_K: return 84; case ORC_Q3_K: return 110; case ORC_Q4_K: return 144; case ORC_Q5_K: return 176;
+        case ORC_Q6_K: return 210; case ORC_Q8_K: return 292;
+    }
+    return 0;
+}
+int orc_vec_dot_type(int wtype) {
+    switch (wtype) {
+        case ORC_Q4_0: case ORC_Q5_0: case ORC_Q8_0: return ORC_Q8_0;
+        case ORC_Q4_1: case ORC_Q5_1: case ORC_Q8_1: return ORC_Q8_1;
+        case ORC_Q2_K: case ORC_Q3_K: case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: return ORC_Q8_K;
+    }
+    return -1;
+}
+size_t orc_row_bytes(int type, int64_t k) { return (size_t)(k / orc_blck_size(type)) * orc_type_size(type); }
+
+/* ------------------------------------------------------------------ legacy weight quantizers */
+/* Symmetric formats: scale from the signed element of largest magnitude (ggml.c:927-962 Q4_0,
+ * 1009-1048 Q5_0). levels = 8 (4 bit) or 16 (5 bit); the float->int step is trunc(v*id + levels + .5)
+ * through an int8 cast, clamped at 2*levels-1. */
+static void quant_sym(const float * x, uint8_t * blk, int levels, uint8_t * qs, uint32_t * qh_out) {
+    float amax = 0.0f, vmax = 0.0f;
+    for (int j = 0; j < 32; ++j) {
+        const float v = x[j];
+        if (amax < fabsf(v)) { amax = fabsf(v); vmax = v; }
+    }
+    const float d  = vmax / (float)(-levels);
+    const float id = d ? 1.0f / d : 0.0f;
+    wr_f16(blk, d);
+    uint32_t qh = 0;
+    const int top = 2 * levels - 1;
+    for (int j = 0; j < 16; ++j) {
+        int a = (int8_t)(x[j]      * id + ((float) levels + 0.5f));
+        int b = (int8_t)(x[j + 16] * id + ((float) levels + 0.5f));
+        if (a > top) a = top;
+        if (b > top) b = top;
+        const uint8_t ua = (uint8_t) a, ub = (uint8_t) b;
+        qs[j] = (uint8_t)((ua & 0x0F) | ((ub & 0x0F) << 4));
+        qh |= (uint32_t)((ua >> 4) & 1u) << j;
+        qh |= (uint32_t)((ub >> 4) & 1u) << (j + 16);
+    }
+    if (qh_out) *qh_out = qh;
+}
+
+/* Affine formats (ggml.c:968-1003 Q4_1, 1054-1096 Q5_1): d = (max-min)/(2^bits-1), q = trunc((v-min)*id + .5) */
+static void quant_affine(const float * x, uint8_t * blk, int bits, uint8_t * qs, uint32_t * qh_out) {
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (int j = 0; j < 32; ++j) {
+        if (x[j] < mn) mn = x[j];
+        if (x[j] > mx) mx = x[j];
+    }
+    const float d  = (mx - mn) / (float)((1 << bits) - 1);
+    const float id = d ? 1.0f / d : 0.0f;
+    wr_f16(blk, d);
+    wr_f16(blk + 2, mn);
+    uint32_t qh = 0;
+    for (int j = 0; j < 16; ++j) {
+        const float a = (x[j]      - mn) * id;
+        const float b = (x[j + 16] - mn) * id;
+        uint8_t ua, ub;
+        if (bits == 4) {           /* int8 cast then clamp to 15 */
+            int ia = (int8_t)(a + 0.5f), ib = (int8_t)(b + 0.5f);
+            ua = (uint8_t)(ia > 15 ? 15 : ia);
+            ub = (uint8_t)(ib > 15 ? 15 : ib);
+        } else {                   /* straight uint8 cast, no clamp (ggml.c:1080-1081) */
+            ua = (uint8_t)(a + 0.5f);
+            ub = (uint8_t)(b + 0.5f);
+        }
+        qs[j] = (uint8_t)((ua & 0x0F) | ((ub & 0x0F) << 4));
+        qh |= (uint32_t)((ua >> 4) & 1u) << j;
+        qh |= (uint32_t)((ub >> 4) & 1u) << (j + 16);
+    }
+    if (qh_out) *qh_out = qh;
+}
+
+void orc_quantize_row(int type, const float * x, void * out, int64_t k) {
+    uint8_t * o = (uint8_t *) out;
+    const int64_t nb = k / 32;
+    for (int64_t i = 0; i < nb; ++i, x += 32) {
+        uint32_t qh;
+        switch (type) {
+            case ORC_Q4_0: quant_sym(x, o, 8, o + 2, NULL);            o += 18; break;
+            case ORC_Q4_1: quant_affine(x, o, 4, o + 4, NULL);         o += 20; break;
+            case ORC_Q5_0: quant_sym(x, o, 16, o + 6, &qh);  memcpy(o + 2, &qh, 4); o += 22; break;
+            case ORC_Q5_1: quant_affine(x, o, 5, o + 8, &qh); memcpy(o + 4, &qh, 4); o += 24; break;
+            case ORC_Q8_0: orc_quantize_act(ORC_Q8_0, x, o, 32, ORC_ROUND_REFERENCE); o += 34; break;
+            default: abort();
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ activation quantizers */
+/* round-half-even for |v| < 2^22 via the 1.5*2^23 magic constant (k_quants.c:50-55 nearest_int) */
+static inline int nearest_even(float v) {
+    const float t = v + 12582912.0f;
+    int32_t i; memcpy(&i, &t, 4);
+    return (i & 0x007FFFFF) - 0x00400000;
+}
+
+static void quant_q8_block(const float * x, float * d_out, int8_t * qs, int * isum, int flavour) {
+    float amax = 0.0f;
+    for (int j = 0; j < 32; ++j) { const float a = fabsf(x[j]); if (a > amax) amax = a; }
+    const float d = amax / 127.0f;
+    float id;
+    if (flavour == ORC_ROUND_AVX) id = (amax != 0.0f) ? 127.0f / amax : 0.0f;    /* ggml.c:1205 */
+    else                          id = d ? 1.0f / d : 0.0f;                      /* ggml.c:1118 */
+    int s = 0;
+    for (int j = 0; j < 32; ++j) {
+        const float v = x[j] * id;
+        const int q = (flavour == ORC_ROUND_AVX) ? nearest_even(v) : (int) roundf(v);
+        qs[j] = (int8_t) q;
+        s += qs[j];
+    }
+    *d_out = d;
+    *isum = s;
+}
+
+/* Q8_K (k_quants.c:899-934): scale from the signed max-magnitude element, iscale = -128/max,
+ * q = min(127, nearest_even(iscale*x)), d = 1/iscale, 16 partial sums of 16. */
+static void quant_q8_K_block(const float * x, uint8_t * blk) {
+    float vmax = 0.0f, amax = 0.0f;
+    for (int j = 0; j < 256; ++j) {
+        const float a = fabsf(x[j]);
+        if (a > amax) { amax = a; vmax = x[j]; }
+    }
+    int8_t * qs = (int8_t *)(blk + 4);
+    if (amax == 0.0f) {
+        /* reference leaves bsums untouched here (k_quants.c:913-918); we zero them: d == 0 nulls every use */
+        memset(blk, 0, 292);
+        return;
+    }
+    const float iscale = -128.0f / vmax;
+    for (int j = 0; j < 256; ++j) {
+        int v = nearest_even(iscale * x[j]);
+        qs[j] = (int8_t)(v > 127 ? 127 : v);
+    }
+    for (int g = 0; g < 16; ++g) {
+        int s = 0;
+        for (int j = 0; j < 16; ++j) s += qs[g * 16 + j];
+        const int16_t s16 = (int16_t) s;
+        memcpy(blk + 260 + 2 * g, &s16, 2);
+    }
+    wr_f32(blk, 1.0f / iscale);
+}
+
+void orc_quantize_act(int act_type, const float * x, void * out, int64_t k, int flavour) {
+    uint8_t * o = (uint8_t *) out;
+    if (act_type == ORC_Q8_K) {
+        for (int64_t i = 0; i < k / 256; ++i) quant_q8_K_block(x + i * 256, o + i * 292);
+        return;
+    }
+    for (int64_t i = 0; i < k / 32; ++i, x += 32) {
+        float d; int s;
+        if (act_type == ORC_Q8_0) {
+            quant_q8_block(x, &d, (int8_t *)(o + 2), &s, flavour);
+            wr_f16(o, d);
+            o += 34;
+        } else if (act_type == ORC_Q8_1) {
+            quant_q8_block(x, &d, (int8_t *)(o + 8), &s, flavour);
+            wr_f32(o, d);
+            wr_f32(o + 4, (float) s * d);        /* ggml.c:1323 y.s = sum*d (AVX: d*sum, same product) */
+            o += 40;
+        } else abort();
+    }
+}
+
+/* ------------------------------------------------------------------ integer decode of one block */
+/* Produces the integer code q[e] and the (scale, offset) so that w[e] = scale[e]*q[e] - offset[e];
+ * callers either apply the floats (dequantize) or keep q for the integer dot. */
+
+static inline int q5_bit(uint32_t qh, int e) { return (int)((qh >> e) & 1u); }   /* bit e of qh = 5th bit of element e */
+
+/* 6-bit (scale, min) pair j of a Q4_K/Q5_K block, k_quants.c:264-272 */
+static void k4_scale_min(const uint8_t * s, int j, int * sc, int * mn) {
+    if (j < 4) { *sc = s[j] & 63;  *mn = s[j + 4] & 63; }
+    else       { *sc = (s[j + 4] & 0x0F) | ((s[j - 4] >> 6) << 4);
+                 *mn = (s[j + 4] >> 4)   | ((s[j]     >> 6) << 4); }
+}
+
+/* sixteen 6-bit Q3_K scales out of 12 bytes (k_quants.c:491-496), value still biased by +32 */
+static void q3_scales(const uint8_t * s12, int sc[16]) {
+    for (int j = 0; j < 16; ++j) {
+        const int lo = (j < 8) ? (s12[j] & 0x0F) : (s12[j - 8] >> 4);
+        const int hi = (s12[8 + (j & 3)] >> (2 * (j >> 2))) & 3;
+        sc[j] = lo | (hi << 4);
+    }
+}
+
+void orc_dequantize_row(int type, const void * in, float * y, int64_t k) {
+    const uint8_t * b = (const uint8_t *) in;
+    if (orc_blck_size(type) == 32) {
+        for (int64_t i = 0; i < k / 32; ++i, y += 32, b += orc_type_size(type)) {
+            switch (type) {
+                case ORC_Q4_0: { const float d = rd_f16(b);                          /* ggml.c:1509-1527 */
+                    for (int j = 0; j < 16; ++j) { y[j] = (float)((b[2 + j] & 15) - 8) * d; y[j + 16] = (float)((b[2 + j] >> 4) - 8) * d; } } break;
+                case ORC_Q4_1: { const float d = rd_f16(b), m = rd_f16(b + 2);       /* ggml.c:1529-1548 */
+                    for (int j = 0; j < 16; ++j) { y[j] = (float)(b[4 + j] & 15) * d + m; y[j + 16] = (float)(b[4 + j] >> 4) * d + m; } } break;
+                case ORC_Q5_0: { const float d = rd_f16(b); const uint32_t qh = rd_u32(b + 2);   /* ggml.c:1550-1574 */
+                    for (int j = 0; j < 16; ++j) {
+                        y[j]      = (float)(((b[6 + j] & 15) | (q5_bit(qh, j)      << 4)) - 16) * d;
+                        y[j + 16] = (float)(((b[6 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) - 16) * d; } } break;
+                case ORC_Q5_1: { const float d = rd_f16(b), m = rd_f16(b + 2); const uint32_t qh = rd_u32(b + 4);  /* ggml.c:1576-1601 */
+                    for (int j = 0; j < 16; ++j) {
+                        y[j]      = (float)((b[8 + j] & 15) | (q5_bit(qh, j)      << 4)) * d + m;
+                        y[j + 16] = (float)((b[8 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) * d + m; } } break;
+                case ORC_Q8_0: { const float d = rd_f16(b);                          /* ggml.c:1603-1619 */
+                    for (int j = 0; j < 32; ++j) y[j] = (float)((const int8_t *) b)[2 + j] * d; } break;
+                default: abort();
+            }
+        }
+        return;
+    }
+    for (int64_t i = 0; i < k / 256; ++i, y += 256, b += orc_type_size(type)) {
+        switch (type) {
+            case ORC_Q2_K: {                                                         /* k_quants.c:344-375 */
+                const float d = rd_f16(b + 80), dmin = rd_f16(b + 82);
+                for (int e = 0; e < 256; ++e) {
+                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
+                    const int sc = b[sb];
+                    const int q  = (b[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+                    const float dl = d * (float)(sc & 0x0F), ml = dmin * (float)(sc >> 4);
+                    y[e] = dl * (float) q - ml;
+                } } break;
+            case ORC_Q3_K: {                                                         /* k_quants.c:472-521 */
+                const float d = rd_f16(b + 108);
+                int sc[16]; q3_scales(b + 96, sc);
+                for (int e = 0; e < 256; ++e) {
+                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
+                    const int lo = (b[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+                    const int hb = (b[e % 32] >> (e / 32)) & 1;
+                    const float dl = d * (float)(sc[sb] - 32);
+                    y[e] = dl * (float)(lo - (hb ? 0 : 4));
+                } } break;
+            case ORC_Q4_K: {                                                         /* k_quants.c:607-631 */
+                const float d = rd_f16(b), dmin = rd_f16(b + 2);
+                for (int e = 0; e < 256; ++e) {
+                    const int c = e / 64, hi = (e % 64) / 32;
+                    int sc, mn; k4_scale_min(b + 4, 2 * c + hi, &sc, &mn);
+                    const int byte = b[16 + 32 * c + e % 32];
+                    const int q = hi ? (byte >> 4) : (byte & 15);
+                    const float dl = d * (float) sc, ml = dmin * (float) mn;
+                    y[e] = dl * (float) q - ml;
+                } } break;
+            case ORC_Q5_K: {                                                         /* k_quants.c:734-760 */
+                const float d = rd_f16(b), dmin = rd_f16(b + 2);
+                for (int e = 0; e < 256; ++e) {
+                    const int c = e / 64, hi = (e % 64) / 32;
+                    int sc, mn; k4_scale_min(b + 4, 2 * c + hi, &sc, &mn);
+                    const int byte = b[48 + 32 * c + e % 32];
+                    const int q = (hi ? (byte >> 4) : (byte & 15)) + (((b[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
+                    const float dl = d * (float) sc, ml = dmin * (float) mn;
+                    y[e] = dl * (float) q - ml;
+                } } break;
+            case ORC_Q6_K: {                                                         /* k_quants.c:845-876 */
+                const float d = rd_f16(b + 208);
+                const int8_t * sc = (const int8_t *)(b + 192);
+                for (int e = 0; e < 256; ++e) {
+                    const int h = e / 128, t = (e % 128) / 32, l = e % 32;
+                    const int byte = b[64 * h + 32 * (t & 1) + l];
+                    const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
+                    const int hi = (b[128 + 32 * h + l] >> (2 * t)) & 3;
+                    const int q  = (int)(int8_t)(lo | (hi << 4)) - 32;
+                    y[e] = d * (float) sc[8 * h + 2 * t + l / 16] * (float) q;      /* (d*sc)*q, left to right */
+                } } break;
+            case ORC_Q8_K: {                                                         /* k_quants.c:936-945 */
+                const float d = rd_f32(b);
+                for (int e = 0; e < 256; ++e) y[e] = d * (float)((const int8_t *) b)[4 + e];
+                } break;
+            default: abort();
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ integer dot products */
+float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
+    const uint8_t * w = (const uint8_t *) wv;
+    const uint8_t * a = (const uint8_t *) av;
+    float sumf = 0.0f;
+    if (orc_blck_size(wtype) == 32) {
+        const int at = orc_vec_dot_type(wtype);
+        for (int64_t i = 0; i < n / 32; ++i, w += orc_type_size(wtype), a += orc_type_size(at)) {
+            const int8_t * q8 = (const int8_t *)(a + (at == ORC_Q8_0 ? 2 : 8));
+            int sumi = 0;
+            switch (wtype) {
+                case ORC_Q4_0:                                                       /* ggml.c:2591-2609 */
+                    for (int j = 0; j < 16; ++j) sumi += ((w[2 + j] & 15) - 8) * q8[j] + ((w[2 + j] >> 4) - 8) * q8[j + 16];
+                    sumf += (float) sumi * rd_f16(w) * rd_f16(a);
+                    break;
+                case ORC_Q4_1:                                                       /* ggml.c:2716-2735 */
+                    for (int j = 0; j < 16; ++j) sumi += (w[4 + j] & 15) * q8[j] + (w[4 + j] >> 4) * q8[j + 16];
+                    sumf += (rd_f16(w) * rd_f32(a)) * (float) sumi + rd_f16(w + 2) * rd_f32(a + 4);
+                    break;
+                case ORC_Q5_0: { const uint32_t qh = rd_u32(w + 2);                  /* ggml.c:2951-2972 */
+                    for (int j = 0; j < 16; ++j)
+                        sumi += (((w[6 + j] & 15) | (q5_bit(qh, j) << 4)) - 16) * q8[j]
+                              + (((w[6 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) - 16) * q8[j + 16];
+                    sumf += (rd_f16(w) * rd_f16(a)) * (float) sumi; } break;
+                case ORC_Q5_1: { const uint32_t qh = rd_u32(w + 4);                  /* ggml.c:3207-3228 */
+                    for (int j = 0; j < 16; ++j)
+                        sumi += ((w[8 + j] & 15) | (q5_bit(qh, j) << 4)) * q8[j]
+                              + ((w[8 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) * q8[j + 16];
+                    sumf += (rd_f16(w) * rd_f32(a)) * (float) sumi + rd_f16(w + 2) * rd_f32(a + 4); } break;
+                case ORC_Q8_0:                                                       /* ggml.c:3317-3329 */
+                    for (int j = 0; j < 32; ++j) sumi += ((const int8_t *) w)[2 + j] * q8[j];
+                    sumf += (float) sumi * (rd_f16(w) * rd_f16(a));
+                    break;
+                default: abort();
+            }
+        }
+        return sumf;
+    }
+    /* k-quants against Q8_K. Integer parts are exact; the float epilogue is d*isum (- dmin*msum) per super-block.
+     * The reference's scalar code keeps 8 float lanes (k_quants.c:1699-1743) and its AVX2 code 8 SIMD lanes; only
+     * the association of the float sums differs. */
+    for (int64_t i = 0; i < n / 256; ++i, w += orc_type_size(wtype), a += 292) {
+        const float  dy = rd_f32(a);
+        const int8_t * q8 = (const int8_t *)(a + 4);
+        int isum = 0, msum = 0;
+        switch (wtype) {
+            case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
+                for (int sb = 0; sb < 16; ++sb) msum += rd_i16(a + 260 + 2 * sb) * (w[sb] >> 4);
+                for (int e = 0; e < 256; ++e) {
+                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
+                    const int q  = (w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+                    isum += (w[sb] & 15) * q * q8[e];
+                }
+                sumf += (dy * rd_f16(w + 80)) * (float) isum - (dy * rd_f16(w + 82)) * (float) msum; } break;
+            case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
+                int sc[16]; q3_scales(w + 96, sc);
+                for (int e = 0; e < 256; ++e) {
+                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
+                    const int lo = (w[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+                    const int hb = (w[e % 32] >> (e / 32)) & 1;
+                    isum += (sc[sb] - 32) * (lo - (hb ? 0 : 4)) * q8[e];
+                }
+                sumf += (rd_f16(w + 108) * dy) * (float) isum; } break;
+            case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
+                const int qs_off = (wtype == ORC_Q4_K) ? 16 : 48;
+                for (int g = 0; g < 16; ++g) { int sc, mn; k4_scale_min(w + 4, g / 2, &sc, &mn); msum += rd_i16(a + 260 + 2 * g) * mn; }
+                for (int e = 0; e < 256; ++e) {
+                    const int c = e / 64, hi = (e % 64) / 32;
+                    int sc, mn; k4_scale_min(w + 4, 2 * c + hi, &sc, &mn);
+                    const int byte = w[qs_off + 32 * c + e % 32];
+                    int q = hi ? (byte >> 4) : (byte & 15);
+                    if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
+                    isum += sc * q * q8[e];
+                }
+                sumf += (rd_f16(w) * dy) * (float) isum - (rd_f16(w + 2) * dy) * (float) msum; } break;
+            case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
+                const int8_t * sc = (const int8_t *)(w + 192);
+                for (int e = 0; e < 256; ++e) {
+                    const int h = e / 128, t = (e % 128) / 32, l = e % 32;
+                    const int byte = w[64 * h + 32 * (t & 1) + l];
+                    const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
+                    const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
+                    isum += sc[8 * h + 2 * t + l / 16] * ((int)(int8_t)(lo | (hi << 4)) - 32) * q8[e];
+                }
+                sumf += (rd_f16(w + 208) * dy) * (float) isum; } break;
+            default: abort();
+        }
+    }
+    return sumf;
+}
+
+/* ------------------------------------------------------------------ quantized mat-mul (ggml.c:11318-11529) */
+typedef struct {
+    int wtype; const uint8_t * w; int64_t K, M, N; const uint8_t * act; size_t act_row; float * dst;
+    int ith, nth;
+} mm_job;
+
+static void * mm_worker(void * arg) {
+    const mm_job * j = (const mm_job *) arg;
+    const size_t wrow = orc_row_bytes(j->wtype, j->K);
+    const int64_t dr = (j->M + j->nth - 1) / j->nth;               /* rows of W split evenly over threads */
+    const int64_t r0 = dr * j->ith, r1 = (r0 + dr < j->M) ? r0 + dr : j->M;
+    for (int64_t n = 0; n < j->N; ++n) {
+        const uint8_t * col = j->act + (size_t) n * j->act_row;
+        for (int64_t r = r0; r < r1; ++r) {
+            j->dst[n * j->M + r] = orc_vec_dot(j->wtype, j->K, j->w + (size_t) r * wrow, col);
+        }
+    }
+    return NULL;
+}
+
+void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float * x, int64_t N,
+                   float * dst, int n_threads, int flavour) {
+    const int at = orc_vec_dot_type(wtype);
+    const size_t act_row = orc_row_bytes(at, K);
+    uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
+    /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */
+    for (int64_t n = 0; n < N; ++n) orc_quantize_act(at, x + n * K, act + (size_t) n * act_row, K, flavour);
+    if (n_threads < 1) n_threads = 1;
+    mm_job   * jobs = (mm_job *) malloc(sizeof(mm_job) * (size_t) n_threads);
+    pthread_t * th  = (pthread_t *) malloc(sizeof(pthread_t) * (size_t) n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t] = (mm_job){ wtype, (const uint8_t *) w, K, M, N, act, act_row, dst, t, n_threads };
+        if (t > 0) pthread_create(&th[t], NULL, mm_worker, &jobs[t]);
+    }
+    mm_worker(&jobs[0]);
+    for (int t = 1; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs); free(act);
+}

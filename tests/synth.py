@@ -1,0 +1,81 @@
+"""Synthetic tensors / models shared by the tests, smoke() and bench.py.
+
+Weights: f32 N(0, 0.02^2) quantized with the oracle's legacy quantizers, or -- for k-quants, whose
+quantizers are a "next" row -- random VALID super-blocks (every bit pattern is a legal block) with the
+super-block scales chosen so that the dequantized weights are roughly zero-mean with std ~0.02-0.05.
+"""
+import numpy as np
+
+from oracle import binding as ob
+
+Q = ob
+
+_K_SCALES = {  # (d, dmin/d)
+    ob.Q2_K: (4e-3, 1.5), ob.Q3_K: (5e-4, 0.0), ob.Q4_K: (1e-4, 7.5), ob.Q5_K: (5e-5, 15.5), ob.Q6_K: (2e-5, 0.0),
+}
+# byte offsets of (d, dmin) inside a super-block
+_K_DOFF = {ob.Q2_K: (80, 82), ob.Q3_K: (108, None), ob.Q4_K: (0, 2), ob.Q5_K: (0, 2), ob.Q6_K: (208, None)}
+
+
+def random_kquant_rows(t, rows, k, rng):
+    """rows x (k/256) random valid blocks of k-quant type t -> uint8 [rows, row_bytes]."""
+    nb = k // 256
+    ts = ob.TSIZE[t]
+    blk = rng.integers(0, 256, size=(rows, nb, ts), dtype=np.uint8)
+    d0, ratio = _K_SCALES[t]
+    d = (d0 * rng.uniform(0.5, 1.5, size=(rows, nb))).astype(np.float16)
+    doff, moff = _K_DOFF[t]
+    blk[:, :, doff:doff + 2] = d.view(np.uint8).reshape(rows, nb, 2)
+    if moff is not None:
+        dm = (d.astype(np.float32) * ratio * rng.uniform(0.8, 1.2, size=(rows, nb))).astype(np.float16)
+        blk[:, :, moff:moff + 2] = dm.view(np.uint8).reshape(rows, nb, 2)
+    return blk.reshape(rows, nb * ts)
+
+
+def quantized_matrix(oracle, t, rows, k, rng, std=0.02):
+    """[rows, row_bytes] uint8 of type t (ggml row-major layout: row r = output row r, k/blck blocks)."""
+    if t in ob.KQUANTS:
+        return random_kquant_rows(t, rows, k, rng)
+    w = (rng.standard_normal((rows, k)) * std).astype(np.float32)
+    return oracle.quantize(t, w).reshape(rows, ob.row_bytes(t, k))
+
+
+HP_7B = dict(n_vocab=65024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=32, n_ff=18176, two_norms=False)
+HP_40B = dict(n_vocab=65024, n_embd=8192, n_head=128, n_head_kv=8, n_layer=60, n_ff=32768, two_norms=True)
+# tiny models for parity tests (head_dim is always 64 in Falcon)
+HP_TINY_MQA = dict(n_vocab=512, n_embd=256, n_head=4, n_head_kv=1, n_layer=2, n_ff=1024, two_norms=False)
+HP_TINY_GQA = dict(n_vocab=512, n_embd=512, n_head=8, n_head_kv=2, n_layer=2, n_ff=2048, two_norms=True)
+
+
+def make_model(oracle, hp, wtype, seed=1234, emb_type=None):
+    """dict of numpy arrays describing a Falcon model with random-init weights (ggml block bytes)."""
+    E, H, HKV, L, FF, V = hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_layer"], hp["n_ff"], hp["n_vocab"]
+    D = E // H
+    idx = [0]
+
+    def rng():
+        idx[0] += 1
+        return np.random.default_rng(seed + idx[0])
+
+    def mat(rows, k):
+        return quantized_matrix(oracle, wtype, rows, k, rng())
+
+    def ln():
+        r = rng()
+        return ((1.0 + 0.02 * r.standard_normal(E)).astype(np.float32), (0.02 * r.standard_normal(E)).astype(np.float32))
+
+    m = dict(hparams=dict(hp), wtype=wtype, layers=[])
+    m["tok_emb"] = mat(V, E)
+    for _ in range(L):
+        lw = dict(qkv=mat((H + 2 * HKV) * D, E), wo=mat(E, E), up=mat(FF, E), down=mat(E, FF))
+        lw["ln_w"], lw["ln_b"] = ln()
+        if hp.get("two_norms"):
+            lw["ln2_w"], lw["ln2_b"] = ln()
+        m["layers"].append(lw)
+    m["out_norm_w"], m["out_norm_b"] = ln()
+    m["lm_head"] = mat(V, E)
+    return m
+
+
+def tokens(n, n_vocab, seed=42):
+    return np.random.default_rng(seed).integers(0, n_vocab, size=n, dtype=np.int32)
