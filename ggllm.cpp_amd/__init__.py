@@ -1,0 +1,250 @@
+"""ggllm.cpp_amd -- thin ctypes view of libggml_hip.so (the MI355X-native backend for ggllm.cpp's hot path).
+
+The product is the C-ABI shared library built from csrc/ (HIP kernels for gfx950 + the C entry points declared in
+include/*.h). This module only loads it and wraps pointers for tests / bench.py; there is no Python compute path and
+no CPU fallback: importing works anywhere, but every call needs the library AND a HIP device, otherwise it raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libggml_hip.so")
+
+# enum ggml_type values (ggml.h:247-268)
+F32, F16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
+Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K = 10, 11, 12, 13, 14, 15
+BLCK = {Q4_0: 32, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32, Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
+TSIZE = {Q4_0: 18, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_0: 34, Q8_1: 40, Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
+VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}
+
+EXPORTS_OPS = """ggml_hip_init ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
+ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
+ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
+ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_acts_alloc ggml_hip_acts_free
+ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
+ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
+EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
+falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_decode_greedy
+falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph""".split()
+
+
+def build(verbose=False):
+    """hipcc every HIP source for gfx950 into ggllm.cpp_amd/libggml_hip.so (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-j", str(min(16, os.cpu_count() or 4))]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class HParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_vocab", "n_embd", "n_head", "n_head_kv", "n_layer", "n_ff", "two_norms", "layer_begin", "layer_end")]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the signatures. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first; there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+    sig = {
+        "ggml_hip_init": (C.c_int, [C.c_int]), "ggml_hip_device_count": (C.c_int, []), "ggml_hip_stream": (vp, []),
+        "ggml_hip_malloc": (vp, [sz]), "ggml_hip_free": (None, [vp]),
+        "ggml_hip_memcpy_h2d": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2h": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2d": (None, [vp, vp, sz]),
+        "ggml_hip_memset": (None, [vp, C.c_int, sz]), "ggml_hip_synchronize": (None, []),
+        "ggml_hip_event_create": (vp, []), "ggml_hip_event_record": (None, [vp]), "ggml_hip_event_elapsed_ms": (C.c_float, [vp, vp]),
+        "ggml_hip_profile_begin": (None, []), "ggml_hip_profile_end": (None, [vp, vp, vp]),
+        "ggml_hip_event_destroy": (None, [vp]), "ggml_hip_gelu_table_dev": (vp, []), "ggml_hip_exp_table_dev": (vp, []),
+        "ggml_hip_weight_upload": (vp, [C.c_int, vp, i64, i64]), "ggml_hip_weight_free": (None, [vp]), "ggml_hip_weight_nbytes": (sz, [vp]),
+        "ggml_hip_dequantize_rows": (None, [vp, vp, i64, vp]),
+        "ggml_hip_acts_alloc": (vp, [C.c_int, i64, i64]), "ggml_hip_acts_free": (None, [vp]),
+        "ggml_hip_quantize_acts": (None, [vp, vp, i64, i64]), "ggml_hip_acts_export": (None, [vp, i64, vp]),
+        "ggml_hip_mul_mat_q": (None, [vp, vp, i64, i64, vp, i64]),
+        "ggml_hip_mul_mat_q_acts": (None, [vp, vp, i64, vp, i64, C.c_int, vp, vp]),
+        "ggml_hip_layer_norm": (None, [vp, i64, i64, vp, vp, vp]), "ggml_hip_gelu": (None, [vp, vp, i64]),
+        "ggml_hip_add3": (None, [vp, vp, vp, vp, i64]), "ggml_hip_rope_table_create": (vp, [C.c_int, C.c_int, C.c_int]),
+        "ggml_hip_rope_kv_store": (None, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+        "ggml_hip_attention": (None, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+        "falcon_hip_model_create": (vp, [C.POINTER(HParams)]), "falcon_hip_model_free": (None, [vp]),
+        "falcon_hip_model_set_tensor": (C.c_int, [vp, C.c_char_p, C.c_int, vp, i64, i64]),
+        "falcon_hip_model_weight_bytes": (sz, [vp]),
+        "falcon_hip_context_create": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_free": (None, [vp]),
+        "falcon_hip_eval": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+        "falcon_hip_eval_stage": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "falcon_hip_decode_greedy": (C.c_int, [vp, i32, C.c_int, C.c_int, vp]),
+        "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
+        "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)          # AttributeError here = an include/*.h symbol is not exported
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def init(device=0):
+    """Initialise the HIP backend on `device`. Aborts (exit 1) when no GPU is visible -- by design."""
+    return load().ggml_hip_init(device)
+
+
+# ------------------------------------------------------------------------------------------- small host helpers
+class DevBuf:
+    """device allocation + numpy transfer (tests / bench plumbing)"""
+
+    def __init__(self, nbytes=None, host=None):
+        L = load()
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            nbytes = host.nbytes
+        self.nbytes = int(nbytes)
+        self.ptr = L.ggml_hip_malloc(max(self.nbytes, 16))
+        if host is not None and self.nbytes:
+            L.ggml_hip_memcpy_h2d(self.ptr, host.ctypes.data, self.nbytes)
+
+    def to_host(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        load().ggml_hip_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes)
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().ggml_hip_free(self.ptr)
+            self.ptr = None
+
+
+class Weight:
+    def __init__(self, wtype, blocks, K, M):
+        blocks = np.ascontiguousarray(blocks, np.uint8)
+        assert blocks.size == M * (K // BLCK[wtype]) * TSIZE[wtype]
+        self.type, self.K, self.M = wtype, K, M
+        self.h = load().ggml_hip_weight_upload(wtype, blocks.ctypes.data, K, M)
+
+    def dequantize(self, rows=None):
+        L = load()
+        n = self.M if rows is None else len(rows)
+        out = DevBuf(n * self.K * 4)
+        rb = DevBuf(host=np.asarray(rows, np.int32)) if rows is not None else None
+        L.ggml_hip_dequantize_rows(self.h, rb.ptr if rb else None, n, out.ptr)
+        y = out.to_host(np.float32, (n, self.K))
+        out.free()
+        if rb:
+            rb.free()
+        return y
+
+    def mul_mat(self, x):
+        """x: [N, K] f32 -> [N, M] f32 through ggml_hip_mul_mat_q"""
+        L = load()
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.K)
+        N = x.shape[0]
+        xb, yb = DevBuf(host=x), DevBuf(N * self.M * 4)
+        L.ggml_hip_mul_mat_q(self.h, xb.ptr, self.K, N, yb.ptr, self.M)
+        y = yb.to_host(np.float32, (N, self.M))
+        xb.free()
+        yb.free()
+        return y
+
+    def free(self):
+        if self.h:
+            load().ggml_hip_weight_free(self.h)
+            self.h = None
+
+
+def quantize_acts(act_type, x):
+    """x: [N, K] f32 -> ggml block bytes [N, K/blck*tsize] produced on the device"""
+    L = load()
+    x = np.ascontiguousarray(x, np.float32)
+    N, K = x.shape
+    a = L.ggml_hip_acts_alloc(act_type, K, N)
+    xb = DevBuf(host=x)
+    L.ggml_hip_quantize_acts(a, xb.ptr, K, N)
+    nbytes = N * (K // BLCK[act_type]) * TSIZE[act_type]
+    ob = DevBuf(nbytes)
+    L.ggml_hip_acts_export(a, N, ob.ptr)
+    out = ob.to_host(np.uint8, (N, nbytes // N))
+    for b in (xb, ob):
+        b.free()
+    L.ggml_hip_acts_free(a)
+    return out
+
+
+TENSOR_NAMES_7B = dict(ln_w="input_layernorm.weight", ln_b="input_layernorm.bias")
+TENSOR_NAMES_40B = dict(ln_w="ln_mlp.weight", ln_b="ln_mlp.bias", ln2_w="ln_attn.weight", ln2_b="ln_attn.bias")
+
+
+class FalconModel:
+    """weights dict (tests/synth.py::make_model layout) -> device-resident model + context"""
+
+    def __init__(self, weights, n_ctx, n_batch, rope_n_ctx=0, layer_begin=0, layer_end=0):
+        L = load()
+        hp = weights["hparams"]
+        self.hp = hp
+        wt = weights["wtype"]
+        E, H, HKV, FF, V = hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_ff"], hp["n_vocab"]
+        self.c_hp = HParams(V, E, H, HKV, hp["n_layer"], FF, 1 if hp.get("two_norms") else 0, layer_begin, layer_end or hp["n_layer"])
+        self.m = L.falcon_hip_model_create(C.byref(self.c_hp))
+
+        def put(name, t, arr, ne0, ne1):
+            arr = np.ascontiguousarray(arr)
+            L.falcon_hip_model_set_tensor(self.m, name.encode(), t, arr.ctypes.data, ne0, ne1)
+
+        put("transformer.word_embeddings.weight", wt, weights["tok_emb"], E, V)
+        put("lm_head.weight", wt, weights["lm_head"], E, V)
+        put("transformer.ln_f.weight", F32, weights["out_norm_w"], E, 1)
+        put("transformer.ln_f.bias", F32, weights["out_norm_b"], E, 1)
+        names = TENSOR_NAMES_40B if hp.get("two_norms") else TENSOR_NAMES_7B
+        for i, lw in enumerate(weights["layers"]):
+            if lw is None:
+                continue
+            p = f"transformer.h.{i}."
+            put(p + "self_attention.query_key_value.weight", wt, lw["qkv"], E, (H + 2 * HKV) * 64)
+            put(p + "self_attention.dense.weight", wt, lw["wo"], E, E)
+            put(p + "mlp.dense_h_to_4h.weight", wt, lw["up"], E, FF)
+            put(p + "mlp.dense_4h_to_h.weight", wt, lw["down"], FF, E)
+            for k, leaf in names.items():
+                put(p + leaf, F32, lw[k], E, 1)
+        self.ctx = L.falcon_hip_context_create(self.m, n_ctx, n_batch, rope_n_ctx)
+        self.n_local = (layer_end or hp["n_layer"]) - layer_begin
+
+    def eval(self, tokens, n_past, logits_all=True, want_hidden=False):
+        L = load()
+        tok = np.ascontiguousarray(tokens, np.int32)
+        N = tok.size
+        if want_hidden:
+            L.falcon_hip_context_keep_hidden(self.ctx, 1)
+        L.falcon_hip_eval(self.ctx, tok.ctypes.data, N, n_past, 1 if logits_all else 0)
+        rows = N if logits_all else 1
+        lg = np.ctypeslib.as_array(L.falcon_hip_get_logits(self.ctx), (rows, self.hp["n_vocab"])).copy()
+        if want_hidden:
+            hid = np.empty((self.n_local + 1, N, self.hp["n_embd"]), np.float32)
+            L.falcon_hip_get_hidden(self.ctx, hid.ctypes.data)
+            L.falcon_hip_context_keep_hidden(self.ctx, 0)
+            return lg, hid
+        return lg
+
+    def decode_greedy(self, first_token, n_past, n_steps, use_graph=False):
+        L = load()
+        L.falcon_hip_context_use_graph(self.ctx, 1 if use_graph else 0)
+        out = np.zeros(n_steps, np.int32)
+        L.falcon_hip_decode_greedy(self.ctx, int(first_token), n_past, n_steps, out.ctypes.data)
+        return out
+
+    def weight_bytes(self):
+        return load().falcon_hip_model_weight_bytes(self.m)
+
+    def free(self):
+        L = load()
+        L.falcon_hip_context_free(self.ctx)
+        L.falcon_hip_model_free(self.m)

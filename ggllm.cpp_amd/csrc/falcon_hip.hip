@@ -1,0 +1,372 @@
+// falcon_hip.hip -- device-resident Falcon decoder stack (include/falcon-hip.h).
+//
+// Op sequence = falcon_eval_internal (libfalcon.cpp:2115-2466), one launch list per block:
+//   LN(x) [+ LN2(x) on 40B]  -> Q8 activations        (ggml_norm/mul/add 2166-2188; mul_mat INIT ggml.c:11462)
+//   QKV = Wqkv . a                                     (2192)
+//   RoPE(Q,K) neox + KV append                         (2229-2280)
+//   att = softmax(mask(K.Q/8)) V, heads merged         (2285-2366)
+//   wo  = Wo . q8(att)                                 (2370)
+//   up  = gelu(Wup . a)                                (2389-2392)
+//   x   = (Wdown . q8(up) + wo) + x                    (2394-2400)
+// then ln_f + lm_head (2421-2440). Everything runs on the library stream; a decode step (N = 1) reads its token id
+// and n_past from device memory, so one captured hipGraph is replayed for every generated token.
+#include "fq_device.h"
+#include "kernels.h"
+#include "hip_context.h"
+#include "../../include/falcon-hip.h"
+
+#include <string>
+#include <string.h>
+#include <vector>
+
+struct layer_weights {
+    fq_weight qkv{}, wo{}, up{}, down{};
+    float * ln_w = nullptr, * ln_b = nullptr, * ln2_w = nullptr, * ln2_b = nullptr;
+};
+
+struct falcon_hip_model {
+    falcon_hip_hparams hp{};
+    fq_weight tok_emb{}, lm_head{};
+    float * out_norm_w = nullptr, * out_norm_b = nullptr;
+    std::vector<layer_weights> layers;        // local layers only
+    std::vector<void *> allocs;
+    size_t weight_bytes = 0;                   // quantized bytes streamed per decoded token (local layers [+ lm_head])
+    bool first_stage() const { return hp.layer_begin == 0; }
+    bool last_stage()  const { return hp.layer_end == hp.n_layer; }
+};
+
+struct falcon_hip_context {
+    falcon_hip_model * m = nullptr;
+    int n_ctx = 0, n_batch = 0, rope_n_ctx = 0;
+    float * x = nullptr, * ln = nullptr, * ln2 = nullptr, * qkv = nullptr, * att = nullptr, * wo_out = nullptr, * up = nullptr;
+    float * logits_dev = nullptr;
+    fq_act act_e{}, act_e2{}, act_att{}, act_ff{};
+    float * k_cache = nullptr, * v_cache = nullptr;
+    float * rope_cs = nullptr;
+    int * n_past_dev = nullptr;
+    int32_t * tokens_dev = nullptr, * out_tokens_dev = nullptr;
+    float * hidden_dev = nullptr;
+    bool keep_hidden = false;
+    int  hidden_tokens = 0;
+    std::vector<float> logits_host;
+    std::vector<void *> allocs;
+    bool use_graph = false;
+    hipGraphExec_t decode_graph = nullptr;
+    int  graph_base = -1;                      // n_past the captured graph was built for
+};
+
+static void * dev_alloc(std::vector<void *> & keep, size_t bytes) {
+    void * p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    keep.push_back(p);
+    return p;
+}
+
+extern "C" falcon_hip_model * falcon_hip_model_create(const falcon_hip_hparams * hp) {
+    fq_ctx();
+    falcon_hip_model * m = new falcon_hip_model();
+    m->hp = *hp;
+    if (m->hp.layer_end <= 0 || m->hp.layer_end > hp->n_layer) m->hp.layer_end = hp->n_layer;
+    if (m->hp.layer_begin < 0) m->hp.layer_begin = 0;
+    if (hp->n_embd % hp->n_head || hp->n_embd / hp->n_head != 64 || hp->n_head % hp->n_head_kv) {
+        fprintf(stderr, "falcon-hip: unsupported head geometry (n_embd %d, n_head %d, n_head_kv %d)\n", hp->n_embd, hp->n_head, hp->n_head_kv);
+        exit(1);
+    }
+    m->layers.resize((size_t)(m->hp.layer_end - m->hp.layer_begin));
+    return m;
+}
+
+extern "C" void falcon_hip_model_free(falcon_hip_model * m) {
+    if (!m) return;
+    for (void * p : m->allocs) HIP_CHECK(hipFree(p));
+    delete m;
+}
+
+static fq_weight upload_weight(falcon_hip_model * m, int type, const void * data, int64_t K, int64_t M) {
+    hip_context & c = fq_ctx();
+    void * slab = nullptr;
+    fq_weight w = fq_weight_alloc(type, K, M, &slab);
+    m->allocs.push_back(slab);
+    const fq_type_desc d = fq_desc(type);
+    const size_t row_bytes = (size_t) w.nblk * d.tsize;
+    int64_t rows_per_chunk = (int64_t)((256u << 20) / row_bytes);
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (rows_per_chunk > M) rows_per_chunk = M;
+    uint8_t * stage = nullptr;
+    HIP_CHECK(hipMalloc((void **) &stage, (size_t) rows_per_chunk * row_bytes));
+    for (int64_t r0 = 0; r0 < M; r0 += rows_per_chunk) {
+        const int64_t nr = (M - r0 < rows_per_chunk) ? M - r0 : rows_per_chunk;
+        HIP_CHECK(hipMemcpyAsync(stage, (const uint8_t *) data + (size_t) r0 * row_bytes, (size_t) nr * row_bytes, hipMemcpyHostToDevice, c.stream));
+        fq_weight sub = w;
+        sub.M = nr;
+        for (int p = 0; p < d.nplanes; ++p) sub.plane[p] = w.plane[p] + (size_t) r0 * w.nblk * d.plane[p].bytes;
+        fq_launch_retile(stage, sub, c.stream);
+        HIP_CHECK(hipStreamSynchronize(c.stream));
+    }
+    HIP_CHECK(hipFree(stage));
+    return w;
+}
+
+static float * upload_f32(falcon_hip_model * m, const void * data, int64_t n) {
+    float * p = (float *) dev_alloc(m->allocs, (size_t) n * 4);
+    HIP_CHECK(hipMemcpy(p, data, (size_t) n * 4, hipMemcpyHostToDevice));
+    return p;
+}
+
+extern "C" int falcon_hip_model_set_tensor(falcon_hip_model * m, const char * name_c, int type, const void * data, int64_t ne0, int64_t ne1) {
+    const std::string name(name_c);
+    const falcon_hip_hparams & hp = m->hp;
+    auto want2d = [&](int64_t k, int64_t rows) {
+        if (ne0 != k || ne1 != rows) { fprintf(stderr, "falcon-hip: %s has shape [%lld,%lld], expected [%lld,%lld]\n", name_c, (long long) ne0, (long long) ne1, (long long) k, (long long) rows); exit(1); }
+    };
+    auto want_f32 = [&]() { if (type != FQ_F32 || ne0 != hp.n_embd) { fprintf(stderr, "falcon-hip: %s must be f32[%d]\n", name_c, hp.n_embd); exit(1); } };
+    const int64_t E = hp.n_embd, D = 64, QKV = (int64_t)(hp.n_head + 2 * hp.n_head_kv) * D;
+    if (name == "transformer.word_embeddings.weight") {
+        if (!m->first_stage()) return -1;
+        want2d(E, hp.n_vocab); m->tok_emb = upload_weight(m, type, data, E, hp.n_vocab); return 0;
+    }
+    if (name == "lm_head.weight") {
+        if (!m->last_stage()) return -1;
+        want2d(E, hp.n_vocab); m->lm_head = upload_weight(m, type, data, E, hp.n_vocab); m->weight_bytes += m->lm_head.bytes; return 0;
+    }
+    if (name == "transformer.ln_f.weight") { if (!m->last_stage()) return -1; want_f32(); m->out_norm_w = upload_f32(m, data, E); return 0; }
+    if (name == "transformer.ln_f.bias")   { if (!m->last_stage()) return -1; want_f32(); m->out_norm_b = upload_f32(m, data, E); return 0; }
+    const std::string pre = "transformer.h.";
+    if (name.compare(0, pre.size(), pre) != 0) return -1;
+    const size_t dot = name.find('.', pre.size());
+    if (dot == std::string::npos) return -1;
+    const int il = atoi(name.substr(pre.size(), dot - pre.size()).c_str());
+    if (il < hp.layer_begin || il >= hp.layer_end) return -1;
+    layer_weights & L = m->layers[(size_t)(il - hp.layer_begin)];
+    const std::string leaf = name.substr(dot + 1);
+    if (leaf == "self_attention.query_key_value.weight") { want2d(E, QKV);     L.qkv  = upload_weight(m, type, data, E, QKV);      m->weight_bytes += L.qkv.bytes;  return 0; }
+    if (leaf == "self_attention.dense.weight")           { want2d(E, E);       L.wo   = upload_weight(m, type, data, E, E);        m->weight_bytes += L.wo.bytes;   return 0; }
+    if (leaf == "mlp.dense_h_to_4h.weight")              { want2d(E, hp.n_ff); L.up   = upload_weight(m, type, data, E, hp.n_ff);  m->weight_bytes += L.up.bytes;   return 0; }
+    if (leaf == "mlp.dense_4h_to_h.weight")              { want2d(hp.n_ff, E); L.down = upload_weight(m, type, data, hp.n_ff, E);  m->weight_bytes += L.down.bytes; return 0; }
+    // norms: 7B has input_layernorm (shared); 40B/180B have ln_mlp (-> MLP input) and ln_attn (-> QKV input), libfalcon.cpp:1845-1855
+    if (leaf == "input_layernorm.weight" || leaf == "ln_mlp.weight") { want_f32(); L.ln_w  = upload_f32(m, data, E); return 0; }
+    if (leaf == "input_layernorm.bias"   || leaf == "ln_mlp.bias")   { want_f32(); L.ln_b  = upload_f32(m, data, E); return 0; }
+    if (leaf == "ln_attn.weight") { want_f32(); L.ln2_w = upload_f32(m, data, E); return 0; }
+    if (leaf == "ln_attn.bias")   { want_f32(); L.ln2_b = upload_f32(m, data, E); return 0; }
+    return -1;
+}
+
+extern "C" size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m) { return m->weight_bytes; }
+
+static fq_act ctx_act(falcon_hip_context * c, int act_type, int64_t K, int64_t cols) {
+    void * slab = nullptr;
+    fq_act a = fq_act_alloc(act_type, K, cols, &slab);
+    c->allocs.push_back(slab);
+    return a;
+}
+
+extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx) {
+    const falcon_hip_hparams & hp = m->hp;
+    for (size_t i = 0; i < m->layers.size(); ++i) {
+        const layer_weights & L = m->layers[i];
+        if (!L.qkv.plane[0] || !L.wo.plane[0] || !L.up.plane[0] || !L.down.plane[0] || !L.ln_w || !L.ln_b || (hp.two_norms && (!L.ln2_w || !L.ln2_b))) {
+            fprintf(stderr, "falcon-hip: layer %d is missing tensors\n", hp.layer_begin + (int) i); exit(1);
+        }
+    }
+    if (m->first_stage() && !m->tok_emb.plane[0]) { fprintf(stderr, "falcon-hip: missing word_embeddings\n"); exit(1); }
+    if (m->last_stage() && (!m->lm_head.plane[0] || !m->out_norm_w || !m->out_norm_b)) { fprintf(stderr, "falcon-hip: missing ln_f / lm_head\n"); exit(1); }
+
+    falcon_hip_context * c = new falcon_hip_context();
+    c->m = m; c->n_ctx = n_ctx; c->n_batch = n_batch; c->rope_n_ctx = rope_n_ctx > 0 ? rope_n_ctx : n_ctx;
+    const int64_t E = hp.n_embd, D = 64, QKV = (int64_t)(hp.n_head + 2 * hp.n_head_kv) * D, FF = hp.n_ff, B = n_batch;
+    const int64_t nl = (int64_t) m->layers.size();
+    c->x      = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    c->ln     = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    c->ln2    = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    c->qkv    = (float *) dev_alloc(c->allocs, (size_t) B * QKV * 4);
+    c->att    = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    c->wo_out = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    c->up     = (float *) dev_alloc(c->allocs, (size_t) B * FF * 4);
+    if (m->last_stage()) c->logits_dev = (float *) dev_alloc(c->allocs, (size_t) B * hp.n_vocab * 4);
+    const int wt = nl ? m->layers[0].qkv.type : m->lm_head.type;
+    const int at = fq_desc(wt).act_type;
+    c->act_e   = ctx_act(c, at, E, B);
+    c->act_e2  = ctx_act(c, at, E, B);
+    c->act_att = ctx_act(c, at, E, B);
+    c->act_ff  = ctx_act(c, nl ? fq_desc(m->layers[0].down.type).act_type : at, FF, B);
+    const size_t kvb = (size_t) nl * n_ctx * hp.n_head_kv * D * 4;
+    c->k_cache = (float *) dev_alloc(c->allocs, kvb);
+    c->v_cache = (float *) dev_alloc(c->allocs, kvb);
+    HIP_CHECK(hipMemset(c->k_cache, 0, kvb ? kvb : 16));
+    HIP_CHECK(hipMemset(c->v_cache, 0, kvb ? kvb : 16));
+    {
+        std::vector<float> cs = fq_rope_table_host((int) D, n_ctx, c->rope_n_ctx);
+        c->rope_cs = (float *) dev_alloc(c->allocs, cs.size() * 4);
+        HIP_CHECK(hipMemcpy(c->rope_cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->n_past_dev     = (int *) dev_alloc(c->allocs, 256);
+    c->tokens_dev     = (int32_t *) dev_alloc(c->allocs, (size_t) B * 4 + 256);
+    c->out_tokens_dev = (int32_t *) dev_alloc(c->allocs, (size_t) n_ctx * 4 + 256);
+    return c;
+}
+
+extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
+    if (!c) return;
+    if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
+    for (void * p : c->allocs) HIP_CHECK(hipFree(p));
+    delete c;
+}
+
+extern "C" void falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep) {
+    c->keep_hidden = keep != 0;
+    if (keep && !c->hidden_dev)
+        c->hidden_dev = (float *) dev_alloc(c->allocs, (size_t)(c->m->layers.size() + 1) * c->n_batch * c->m->hp.n_embd * 4);
+}
+extern "C" void falcon_hip_get_hidden(falcon_hip_context * c, float * dst) {
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+    HIP_CHECK(hipMemcpy(dst, c->hidden_dev, (size_t)(c->m->layers.size() + 1) * c->hidden_tokens * c->m->hp.n_embd * 4, hipMemcpyDeviceToHost));
+}
+extern "C" void falcon_hip_context_use_graph(falcon_hip_context * c, int enable) { c->use_graph = enable != 0; }
+
+// ------------------------------------------------------------------------------------------------ one eval
+// Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
+// n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
+static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
+    falcon_hip_model * m = c->m;
+    const falcon_hip_hparams & hp = m->hp;
+    hip_context & hc = fq_ctx();
+    const int64_t E = hp.n_embd, D = 64, H = hp.n_head, HKV = hp.n_head_kv, QKV = (H + 2 * HKV) * D, FF = hp.n_ff;
+    const fq_gemv_epi store{ FQ_EPI_STORE, hc.gelu_table, nullptr, nullptr, 0 };
+
+    if (m->first_stage()) fq_launch_dequant_rows(m->tok_emb, c->tokens_dev, N, c->x, st);    // ggml_get_rows, libfalcon.cpp:2120
+
+    auto acts = [&](const fq_act & a, int64_t n) { fq_act v = a; v.ncols = n; return v; };
+    for (size_t li = 0; li < m->layers.size(); ++li) {
+        const layer_weights & L = m->layers[li];
+        if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
+        fq_launch_layer_norm(c->x, E, N, L.ln_w, L.ln_b, c->ln, st);
+        fq_launch_quantize_act(c->ln, E, acts(c->act_e, N), st);
+        const fq_act * attn_in = &c->act_e;
+        if (hp.two_norms) {
+            fq_launch_layer_norm(c->x, E, N, L.ln2_w, L.ln2_b, c->ln2, st);
+            fq_launch_quantize_act(c->ln2, E, acts(c->act_e2, N), st);
+            attn_in = &c->act_e2;
+        }
+        fq_mul_mat_q_acts(L.qkv, acts(*attn_in, N), N, c->qkv, QKV, store, st);
+        float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
+        float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
+        fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st);
+        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table, c->att, st);
+        fq_launch_quantize_act(c->att, E, acts(c->act_att, N), st);
+        fq_mul_mat_q_acts(L.wo, acts(c->act_att, N), N, c->wo_out, E, store, st);
+        const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
+        fq_mul_mat_q_acts(L.up, acts(c->act_e, N), N, c->up, FF, gelu, st);
+        fq_launch_quantize_act(c->up, FF, acts(c->act_ff, N), st);
+        const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place
+        fq_mul_mat_q_acts(L.down, acts(c->act_ff, N), N, c->x, E, resid, st);
+    }
+    if (c->keep_hidden) {
+        HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
+        c->hidden_tokens = N;
+    }
+    if (m->last_stage()) {
+        fq_launch_layer_norm(c->x, E, N, m->out_norm_w, m->out_norm_b, c->ln, st);
+        fq_launch_quantize_act(c->ln, E, acts(c->act_e, N), st);
+        fq_mul_mat_q_acts(m->lm_head, acts(c->act_e, N), N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
+    }
+}
+
+extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tokens, const float * hidden_in_dev, int N,
+                                     int n_past, int logits_all, float * hidden_out_dev) {
+    hip_context & hc = fq_ctx();
+    falcon_hip_model * m = c->m;
+    if (N < 1 || N > c->n_batch || n_past < 0 || n_past + N > c->n_ctx) {
+        fprintf(stderr, "falcon-hip: eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, c->n_batch, c->n_ctx);
+        exit(1);
+    }
+    hipStream_t st = hc.stream;
+    HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
+    if (m->first_stage()) HIP_CHECK(hipMemcpyAsync(c->tokens_dev, tokens, (size_t) N * 4, hipMemcpyHostToDevice, st));
+    else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));        // n_past / tokens may live on the caller's stack
+    launch_stage(c, N, n_past + N, st);
+    if (m->last_stage()) {
+        const int64_t V = m->hp.n_vocab;
+        if (logits_all) {
+            c->logits_host.resize((size_t) N * V);
+            HIP_CHECK(hipMemcpyAsync(c->logits_host.data(), c->logits_dev, (size_t) N * V * 4, hipMemcpyDeviceToHost, st));
+        } else {                                                                         // libfalcon.cpp:2545-2547
+            c->logits_host.resize((size_t) V);
+            HIP_CHECK(hipMemcpyAsync(c->logits_host.data(), c->logits_dev + (size_t)(N - 1) * V, (size_t) V * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+    } else if (hidden_out_dev) {
+        HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, int n_tokens, int n_past, int logits_all) {
+    if (!c->m->first_stage() || !c->m->last_stage()) { fprintf(stderr, "falcon-hip: falcon_hip_eval needs the whole model in one process\n"); exit(1); }
+    return falcon_hip_eval_stage(c, tokens, nullptr, n_tokens, n_past, logits_all, nullptr);
+}
+
+extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) { return c->logits_host.data(); }
+
+// ------------------------------------------------------------------------------------------------ greedy decode
+// argmax with first-maximum tie-break (std::max_element in llama_sample_token_greedy, libfalcon.cpp:3440-3450);
+// also advances the device-side loop state: next token id, n_past + 1, output slot.
+__global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restrict__ logits, int n, int32_t * __restrict__ token,
+                                                         int * __restrict__ n_past, int32_t * __restrict__ out, int n_past0) {
+    __shared__ float bv[16];
+    __shared__ int   bi[16];
+    float best = -INFINITY; int idx = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = logits[i]; if (v > best || (v == best && i < idx)) { best = v; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { bv[wid] = best; bi[wid] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        const int np = *n_past;
+        out[np - n_past0] = idx;
+        token[0] = idx;
+        *n_past = np + 1;
+    }
+}
+
+extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens) {
+    hip_context & hc = fq_ctx();
+    falcon_hip_model * m = c->m;
+    if (!m->first_stage() || !m->last_stage()) { fprintf(stderr, "falcon-hip: greedy decode needs the whole model in one process\n"); exit(1); }
+    if (n_past + n_steps > c->n_ctx) { fprintf(stderr, "falcon-hip: decode past n_ctx\n"); exit(1); }
+    hipStream_t st = hc.stream;
+    HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->tokens_dev, &first_token, 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const bool was_keep = c->keep_hidden;
+    c->keep_hidden = false;
+    auto one_step = [&](hipStream_t s, int max_kv) {
+        launch_stage(c, 1, max_kv, s);
+        hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+    };
+    if (c->use_graph) {
+        // the graph bakes n_past0 into k_argmax_advance's arguments: re-capture when the base position changes
+        if (!c->decode_graph || c->graph_base != n_past) {
+            if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
+            hipGraph_t g;
+            HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            one_step(st, c->n_ctx);
+            HIP_CHECK(hipStreamEndCapture(st, &g));
+            HIP_CHECK(hipGraphInstantiate(&c->decode_graph, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            c->graph_base = n_past;
+        }
+        for (int s = 0; s < n_steps; ++s) HIP_CHECK(hipGraphLaunch(c->decode_graph, st));
+    } else {
+        for (int s = 0; s < n_steps; ++s) one_step(st, n_past + n_steps);
+    }
+    HIP_CHECK(hipMemcpyAsync(out_tokens, c->out_tokens_dev, (size_t) n_steps * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->keep_hidden = was_keep;
+    return 0;
+}

@@ -1,0 +1,292 @@
+// ggml_hip_ops.hip -- the operator-level C ABI (include/ggml-hip-ops.h) on top of the kernels.
+#include "fq_device.h"
+#include "kernels.h"
+#include "hip_context.h"
+#include "../../include/ggml-hip-ops.h"
+
+#include <math.h>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+struct ggml_hip_weight { fq_weight w; void * slab; };
+struct ggml_hip_acts   { fq_act a; int64_t max_cols; void * slab; };
+
+static hip_context g_ctx;
+static std::once_flag g_once;
+
+hip_context & fq_ctx() {
+    if (!g_ctx.ready) { fprintf(stderr, "ggml-hip: not initialised (call ggml_hip_init / ggml_init_cublas first)\n"); exit(1); }
+    return g_ctx;
+}
+
+// GELU / EXP fp16 tables, computed on the host with the host libm exactly as ggml_init does (ggml.c:4276-4290)
+static void build_tables(hip_context & c) {
+    std::vector<uint16_t> gelu(1 << 16), ex(1 << 16);
+    for (uint32_t i = 0; i < (1u << 16); ++i) {
+        const uint16_t hb = (uint16_t) i;
+        const float f = (float) __builtin_bit_cast(_Float16, hb);
+        const float g = 0.5f * f * (1.0f + tanhf(0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f)));
+        gelu[i] = __builtin_bit_cast(uint16_t, (_Float16) g);
+        ex[i]   = __builtin_bit_cast(uint16_t, (_Float16) expf(f));
+    }
+    HIP_CHECK(hipMalloc((void **) &c.gelu_table, 1 << 17));
+    HIP_CHECK(hipMalloc((void **) &c.exp_table, 1 << 17));
+    HIP_CHECK(hipMemcpy(c.gelu_table, gelu.data(), 1 << 17, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c.exp_table, ex.data(), 1 << 17, hipMemcpyHostToDevice));
+}
+
+extern "C" int ggml_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ggml_hip_init(int device) {
+    std::call_once(g_once, [&]() {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0) {
+            fprintf(stderr, "ggml-hip: no HIP device visible (%s) -- this backend has no CPU fallback\n", hipGetErrorString(e));
+            exit(1);
+        }
+        if (device < 0 || device >= n) device = 0;
+        HIP_CHECK(hipSetDevice(device));
+        g_ctx.device = device;
+        g_ctx.n_devices = n;
+        HIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        g_ctx.n_cu = prop.multiProcessorCount;
+        snprintf(g_ctx.name, sizeof(g_ctx.name), "%s", prop.name);
+        build_tables(g_ctx);
+        HIP_CHECK(hipMalloc((void **) &g_ctx.scalar_i32, 256));
+        g_ctx.ready = true;
+    });
+    return g_ctx.n_devices;
+}
+
+extern "C" void * ggml_hip_stream(void) { return (void *) fq_ctx().stream; }
+
+extern "C" void * ggml_hip_malloc(size_t bytes) {
+    fq_ctx();
+    void * p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+extern "C" void ggml_hip_free(void * dev) { if (dev) HIP_CHECK(hipFree(dev)); }
+extern "C" void ggml_hip_memcpy_h2d(void * d, const void * s, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, fq_ctx().stream));
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+}
+extern "C" void ggml_hip_memcpy_d2h(void * d, const void * s, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, fq_ctx().stream));
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+}
+extern "C" void ggml_hip_memcpy_d2d(void * d, const void * s, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, fq_ctx().stream));
+}
+extern "C" void ggml_hip_memset(void * d, int v, size_t n) { HIP_CHECK(hipMemsetAsync(d, v, n, fq_ctx().stream)); }
+extern "C" void ggml_hip_synchronize(void) { HIP_CHECK(hipStreamSynchronize(fq_ctx().stream)); }
+
+extern "C" void * ggml_hip_event_create(void) { hipEvent_t e; fq_ctx(); HIP_CHECK(hipEventCreate(&e)); return (void *) e; }
+extern "C" void   ggml_hip_event_record(void * ev) { HIP_CHECK(hipEventRecord((hipEvent_t) ev, fq_ctx().stream)); }
+extern "C" float  ggml_hip_event_elapsed_ms(void * a, void * b) {
+    HIP_CHECK(hipEventSynchronize((hipEvent_t) b));
+    float ms = 0.0f; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t) a, (hipEvent_t) b)); return ms;
+}
+extern "C" void   ggml_hip_event_destroy(void * ev) { HIP_CHECK(hipEventDestroy((hipEvent_t) ev)); }
+extern "C" const uint16_t * ggml_hip_gelu_table_dev(void) { return fq_ctx().gelu_table; }
+extern "C" const uint16_t * ggml_hip_exp_table_dev(void)  { return fq_ctx().exp_table; }
+
+// ------------------------------------------------------------------------------------------------ weights
+fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out) {
+    const fq_type_desc d = fq_desc(type);
+    if (d.blck == 0 || K % d.blck != 0) { fprintf(stderr, "ggml-hip: weight type %d with K=%lld unsupported\n", type, (long long) K); exit(1); }
+    fq_weight w{};
+    w.type = type; w.K = K; w.M = M; w.nblk = K / d.blck;
+    w.bytes = (size_t) M * w.nblk * d.tsize;
+    size_t off[FQ_MAX_PLANES], total = 0;
+    for (int p = 0; p < d.nplanes; ++p) { off[p] = total; total += ((size_t) M * w.nblk * d.plane[p].bytes + 255) & ~(size_t) 255; }
+    uint8_t * slab = nullptr;
+    HIP_CHECK(hipMalloc((void **) &slab, total + 256));        // +256: clamped tail loads never leave the allocation
+    for (int p = 0; p < d.nplanes; ++p) w.plane[p] = slab + off[p];
+    *slab_out = slab;
+    return w;
+}
+
+extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_blocks, int64_t K, int64_t M) {
+    hip_context & c = fq_ctx();
+    ggml_hip_weight * hw = new ggml_hip_weight();
+    hw->w = fq_weight_alloc(type, K, M, &hw->slab);
+    // stage the ggml bytes in HBM in bounded chunks of rows, re-tile on the device
+    const fq_type_desc d = fq_desc(type);
+    const size_t row_bytes = (size_t) hw->w.nblk * d.tsize;
+    int64_t rows_per_chunk = (int64_t) ((256u << 20) / (row_bytes ? row_bytes : 1));
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (rows_per_chunk > M) rows_per_chunk = M;
+    uint8_t * stage = nullptr;
+    HIP_CHECK(hipMalloc((void **) &stage, (size_t) rows_per_chunk * row_bytes));
+    for (int64_t r0 = 0; r0 < M; r0 += rows_per_chunk) {
+        const int64_t nr = (M - r0 < rows_per_chunk) ? M - r0 : rows_per_chunk;
+        HIP_CHECK(hipMemcpyAsync(stage, (const uint8_t *) host_blocks + (size_t) r0 * row_bytes, (size_t) nr * row_bytes, hipMemcpyHostToDevice, c.stream));
+        fq_weight sub = hw->w;
+        sub.M = nr;
+        for (int p = 0; p < d.nplanes; ++p) sub.plane[p] = hw->w.plane[p] + (size_t) r0 * hw->w.nblk * d.plane[p].bytes;
+        fq_launch_retile(stage, sub, c.stream);
+        HIP_CHECK(hipStreamSynchronize(c.stream));
+    }
+    HIP_CHECK(hipFree(stage));
+    return hw;
+}
+extern "C" void ggml_hip_weight_free(ggml_hip_weight * w) { if (!w) return; HIP_CHECK(hipFree(w->slab)); delete w; }
+extern "C" size_t ggml_hip_weight_nbytes(const ggml_hip_weight * w) { return w->w.bytes; }
+
+extern "C" void ggml_hip_dequantize_rows(const ggml_hip_weight * w, const int32_t * rows_dev, int64_t nrows, float * dst_dev) {
+    fq_launch_dequant_rows(w->w, rows_dev, nrows, dst_dev, fq_ctx().stream);
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+fq_act fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_out) {
+    if (act_type != FQ_Q8_0 && act_type != FQ_Q8_1 && act_type != FQ_Q8_K) { fprintf(stderr, "ggml-hip: bad activation type %d\n", act_type); exit(1); }
+    if (K % (act_type == FQ_Q8_K ? 256 : 32)) { fprintf(stderr, "ggml-hip: K=%lld not a multiple of the activation block\n", (long long) K); exit(1); }
+    fq_act a{};
+    a.type = act_type; a.K = K; a.ncols = max_cols;
+    uint8_t * slab = nullptr;
+    HIP_CHECK(hipMalloc((void **) &slab, fq_act_col_bytes(act_type, K) * (size_t) max_cols + 256));
+    a.base = slab;
+    *slab_out = slab;
+    return a;
+}
+extern "C" ggml_hip_acts * ggml_hip_acts_alloc(int act_type, int64_t K, int64_t max_cols) {
+    fq_ctx();
+    ggml_hip_acts * h = new ggml_hip_acts();
+    h->a = fq_act_alloc(act_type, K, max_cols, &h->slab);
+    h->max_cols = max_cols;
+    return h;
+}
+extern "C" void ggml_hip_acts_free(ggml_hip_acts * a) { if (!a) return; HIP_CHECK(hipFree(a->slab)); delete a; }
+extern "C" void ggml_hip_quantize_acts(ggml_hip_acts * a, const float * x_dev, int64_t ldx, int64_t ncols) {
+    if (ncols > a->max_cols) { fprintf(stderr, "ggml-hip: quantize_acts: %lld columns > capacity %lld\n", (long long) ncols, (long long) a->max_cols); exit(1); }
+    fq_act v = a->a; v.ncols = ncols;
+    fq_launch_quantize_act(x_dev, ldx, v, fq_ctx().stream);
+}
+extern "C" void ggml_hip_acts_export(const ggml_hip_acts * a, int64_t ncols, void * out_dev) {
+    fq_act v = a->a; v.ncols = ncols;
+    fq_launch_act_export(v, (uint8_t *) out_dev, fq_ctx().stream);
+}
+
+// ------------------------------------------------------------------------------------------------ mat-mul
+// column c of an activation set (SoA arrays are [ncols][...] so a column range is a pointer offset)
+static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
+    fq_act v = a;
+    v.base = a.base + (size_t) c0 * fq_act_col_bytes(a.type, a.K);
+    v.ncols = n;
+    return v;
+}
+
+// ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
+static double g_prof_bytes = 0.0;
+
+extern "C" void ggml_hip_profile_begin(void) {
+    for (auto & p : g_prof_ev) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+    g_prof_ev.clear(); g_prof_bytes = 0.0; g_prof_on = true;
+}
+extern "C" void ggml_hip_profile_end(int64_t * n_launches, double * total_us, double * total_bytes) {
+    g_prof_on = false;
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+    double us = 0.0;
+    for (auto & p : g_prof_ev) { float ms = 0.0f; HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second)); us += 1e3 * (double) ms; }
+    *n_launches = (int64_t) g_prof_ev.size(); *total_us = us; *total_bytes = g_prof_bytes;
+    for (auto & p : g_prof_ev) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+    g_prof_ev.clear();
+}
+
+void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {
+    hip_context & c = fq_ctx();
+    if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }
+    const int max_blocks = c.n_cu * 4;
+    int64_t n0 = 0;
+    while (n0 < N) {
+        const int64_t left = N - n0;
+        const int nc = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        fq_gemv_epi ep = ep0;
+        if (ep.add1) ep.add1 += n0 * ep.ld_add;
+        if (ep.add2) ep.add2 += n0 * ep.ld_add;
+        if (g_prof_on) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, st));
+            fq_launch_gemv(w, act_cols(a, n0, nc), nc, dst + n0 * ldd, ldd, ep, max_blocks, st);
+            HIP_CHECK(hipEventRecord(e1, st));
+            g_prof_ev.emplace_back(e0, e1);
+            g_prof_bytes += (double) w.bytes;         // algorithmic bytes of the launch = the weight matrix, read once
+        } else {
+            fq_launch_gemv(w, act_cols(a, n0, nc), nc, dst + n0 * ldd, ldd, ep, max_blocks, st);
+        }
+        n0 += nc;
+    }
+}
+
+extern "C" void ggml_hip_mul_mat_q_acts(const ggml_hip_weight * w, const ggml_hip_acts * a, int64_t N, float * dst_dev,
+                                        int64_t ldd, int epilogue, const float * add1_dev, const float * add2_dev) {
+    fq_gemv_epi ep{ epilogue, fq_ctx().gelu_table, add1_dev, add2_dev, ldd };
+    fq_mul_mat_q_acts(w->w, a->a, N, dst_dev, ldd, ep, fq_ctx().stream);
+}
+
+extern "C" void ggml_hip_mul_mat_q(const ggml_hip_weight * w, const float * x_dev, int64_t ldx, int64_t N, float * dst_dev, int64_t ldd) {
+    hip_context & c = fq_ctx();
+    void * slab = nullptr;
+    fq_act a = fq_act_alloc(fq_desc(w->w.type).act_type, w->w.K, N, &slab);
+    fq_launch_quantize_act(x_dev, ldx, a, c.stream);
+    fq_gemv_epi ep{ FQ_EPI_STORE, c.gelu_table, nullptr, nullptr, ldd };
+    fq_mul_mat_q_acts(w->w, a, N, dst_dev, ldd, ep, c.stream);
+    HIP_CHECK(hipStreamSynchronize(c.stream));
+    HIP_CHECK(hipFree(slab));
+}
+
+// ------------------------------------------------------------------------------------------------ block ops
+extern "C" void ggml_hip_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y) {
+    fq_launch_layer_norm(x, n, rows, w, b, y, fq_ctx().stream);
+}
+extern "C" void ggml_hip_gelu(const float * x, float * y, int64_t n) { fq_launch_gelu(x, y, n, fq_ctx().gelu_table, fq_ctx().stream); }
+extern "C" void ggml_hip_add3(const float * a, const float * b, const float * c, float * y, int64_t n) { fq_launch_add3(a, b, c, y, n, fq_ctx().stream); }
+
+// host-side table: theta advanced by repeated f32 multiplication, cosf/sinf of the host libm (ggml.c:12962-12966)
+std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx) {
+    float alpha = 1.0f;                                                      // ggml.c:12880-12887, DYNAMIC_MODE=1, NTK_ALPHA=2
+    if (rope_n_ctx >= 2048) alpha = powf((float)(((rope_n_ctx / 2048) - 1) * 2.0f + 1), (float)(head_dim / (head_dim - 2.0)));
+    const float theta_scale = powf(alpha * 10000.0f, -2.0f / (float) head_dim);    // ggml.c:12898
+    const int half = head_dim / 2;
+    std::vector<float> cs((size_t) n_pos * half * 2);
+    for (int p = 0; p < n_pos; ++p) {
+        float theta = (float) p;
+        for (int k = 0; k < half; ++k) {
+            cs[((size_t) p * half + k) * 2 + 0] = cosf(theta);
+            cs[((size_t) p * half + k) * 2 + 1] = sinf(theta);
+            theta *= theta_scale;
+        }
+    }
+    return cs;
+}
+extern "C" float * ggml_hip_rope_table_create(int head_dim, int n_pos, int rope_n_ctx) {
+    std::vector<float> cs = fq_rope_table_host(head_dim, n_pos, rope_n_ctx);
+    float * dev = (float *) ggml_hip_malloc(cs.size() * 4);
+    ggml_hip_memcpy_h2d(dev, cs.data(), cs.size() * 4);
+    return dev;
+}
+// the kernels read n_past from device memory (so a captured graph can be replayed for every token)
+static const int * upload_n_past(int n_past) {
+    hip_context & c = fq_ctx();
+    HIP_CHECK(hipMemcpyAsync(c.scalar_i32, &n_past, sizeof(int), hipMemcpyHostToDevice, c.stream));
+    HIP_CHECK(hipStreamSynchronize(c.stream));       // n_past lives on the caller's stack
+    return c.scalar_i32;
+}
+extern "C" void ggml_hip_rope_kv_store(float * qkv, int N, int H, int HKV, int D, int n_past, const float * rope_table, float * kc, float * vc) {
+    fq_launch_rope_kv(qkv, N, H, HKV, D, upload_n_past(n_past), rope_table, kc, vc, fq_ctx().stream);
+}
+extern "C" void ggml_hip_attention(const float * qkv, int N, int H, int HKV, int D, int n_past, const float * kc, const float * vc, float * att) {
+    fq_launch_attention(qkv, N, H, HKV, D, upload_n_past(n_past), n_past + N, kc, vc, fq_ctx().exp_table, att, fq_ctx().stream);
+}

@@ -1,0 +1,27 @@
+// hip_context.h -- per-process device state of libggml_hip.so (one process drives one GPU; multi-GPU = one
+// process per GPU, see pipeline.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "fq_types.h"
+#include "kernels.h"
+
+struct hip_context {
+    bool        ready = false;
+    int         device = 0;
+    int         n_devices = 0;
+    int         n_cu = 256;
+    char        name[128] = {0};
+    hipStream_t stream = nullptr;
+    uint16_t *  gelu_table = nullptr;     // device, 65536 x fp16
+    uint16_t *  exp_table = nullptr;      // device, 65536 x fp16
+    int *       scalar_i32 = nullptr;     // device scratch scalar for the op-level API
+};
+
+hip_context & fq_ctx();
+fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out);
+fq_act    fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_out);
+void      fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd,
+                            const fq_gemv_epi & ep, hipStream_t st);
+std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);

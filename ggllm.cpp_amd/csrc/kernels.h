@@ -1,0 +1,37 @@
+// kernels.h -- host-callable launchers of the HIP kernels (internal to libggml_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fq_types.h"
+
+enum { FQ_EPI_STORE = 0, FQ_EPI_GELU = 1, FQ_EPI_ADD2 = 2 };
+
+struct fq_gemv_epi {
+    int              mode;
+    const uint16_t * gelu_table;   // 65536 fp16 entries (FQ_EPI_GELU)
+    const float    * add1;         // FQ_EPI_ADD2: dst = (v + add1) + add2
+    const float    * add2;
+    int64_t          ld_add;       // column stride of add1/add2
+};
+
+// kernels_quant.hip
+void   fq_launch_retile(const uint8_t * src_dev, const fq_weight & w, hipStream_t st);
+void   fq_launch_dequant_rows(const fq_weight & w, const int32_t * rows_dev, int64_t nrows, float * dst, hipStream_t st);
+void   fq_launch_quantize_act(const float * x, int64_t ldx, const fq_act & a, hipStream_t st);
+void   fq_launch_act_export(const fq_act & a, uint8_t * out, hipStream_t st);
+
+// kernels_gemv.hip
+#define FQ_GEMV_MAX_COLS 4
+size_t fq_gemv_lds_bytes(int act_type, int64_t K, int ncols);
+void   fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float * dst, int64_t ldd,
+                      const fq_gemv_epi & ep, int max_blocks, hipStream_t st);
+
+// kernels_block.hip
+void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
+void   fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st);
+void   fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st);
+// qkv: [N][(H+2HKV)*D] fused rows; rotates Q (in place) and K, appends K/V at positions n_past.. of the layer's cache
+void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs,
+                         float * k_cache, float * v_cache, hipStream_t st);
+// att[N][H*D] = softmax(mask(K.Q * scale)) V, one workgroup per (head, token)
+void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
+                           const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);

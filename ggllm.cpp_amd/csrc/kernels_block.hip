@@ -1,0 +1,161 @@
+// kernels_block.hip -- the non-mat-mul ops of a Falcon decoder block, device resident (gfx950).
+//
+// In the reference these always run on the CPU, even in its CUDA build (libfalcon.cpp:2309, 2356 set
+// cuda_op_directive = 0; ggml-cuda.cu:2433 supports rope mode 0 only). Arithmetic follows the CPU ops so that
+// logits match the CPU reference:
+//   layer norm  ggml.c:10540-10594  (f64 sums, eps 1e-5) then * weight + bias (libfalcon.cpp:2166-2188)
+//   gelu        ggml.c:3477-3484    fp16 table lookup (table built on the host exactly like ggml.c:4276-4290)
+//   rope        ggml.c:12957-12978  NeoX pairing (i, i+32); cos/sin come from a host-built table whose theta is
+//                                   advanced by repeated f32 multiplication like the reference loop
+//   attention   K.Q (ggml.c:11049-11088, GQA broadcast i02 = i12/(H/HKV)), scale, causal mask (ggml.c:12300-12351),
+//               soft_max with the fp16 exp table and an f64 sum (ggml.c:12389-12456), V.P
+// Built with -ffp-contract=off.
+#include "fq_device.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ layer norm
+// one 256-thread workgroup per row; the row lives in LDS between the passes
+__global__ void __launch_bounds__(256) k_layer_norm(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
+                                                    const float * __restrict__ b, float * __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float  * row = (float *) smem;
+    double * red = (double *)(smem + ((n * 4 + 15) & ~(int64_t) 15));
+    const float * xr = x + (int64_t) blockIdx.x * n;
+    float * yr = y + (int64_t) blockIdx.x * n;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; row[i] = v; s += (double) v; }
+    s = block_sum(s, red);
+    const float mean = (float)(s / (double) n);
+    double s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = row[i] - mean; row[i] = v; s2 += (double)(v * v); }
+    s2 = block_sum(s2, red);
+    const float variance = (float)(s2 / (double) n);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = row[i] * scale;
+        yr[i] = w ? v * w[i] + b[i] : v;
+    }
+}
+
+void fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st) {
+    const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
+    hipLaunchKernelGGL(k_layer_norm, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y);
+}
+
+// ------------------------------------------------------------------------------------------------ gelu / add
+__global__ void k_gelu(const float * __restrict__ x, float * __restrict__ y, int64_t n, const uint16_t * __restrict__ tab) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+        y[i] = h2f_bits(tab[f2h_bits(x[i])]);
+}
+void fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st) {
+    const int blocks = (int) ((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_gelu, dim3(blocks), dim3(256), 0, st, x, y, n, gelu_table);
+}
+__global__ void k_add3(const float * __restrict__ a, const float * __restrict__ b, const float * __restrict__ c, float * __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+        y[i] = (a[i] + b[i]) + c[i];
+}
+void fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st) {
+    const int blocks = (int) ((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_add3, dim3(blocks), dim3(256), 0, st, a, b, c, y, n);
+}
+
+// ------------------------------------------------------------------------------------------------ rope + KV append
+// thread = one rotation pair (or one V element pair). Heads 0..H-1 are Q (rotated in place), H..H+HKV-1 are K
+// (rotated into the cache), H+HKV.. are V (copied into the cache). Caches: [n_ctx][HKV][D] f32 for this layer.
+__global__ void k_rope_kv(float * __restrict__ qkv, int N, int H, int HKV, int D, const int * __restrict__ n_past_ptr, const float * __restrict__ cs,
+                          float * __restrict__ kc, float * __restrict__ vc) {
+    const int half = D >> 1;
+    const int heads = H + 2 * HKV;
+    const int n_past = *n_past_ptr;          // device scalar: one captured hipGraph serves every decode step
+    const int64_t total = (int64_t) N * heads * half;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int k = (int)(i % half);
+        const int h = (int)((i / half) % heads);
+        const int t = (int)(i / ((int64_t) half * heads));
+        float * v = qkv + ((int64_t) t * heads + h) * D;
+        const int pos = n_past + t;
+        if (h < H + HKV) {
+            const float c = cs[((int64_t) pos * half + k) * 2], s = cs[((int64_t) pos * half + k) * 2 + 1];
+            const float x0 = v[k], x1 = v[k + half];
+            const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;     // ggml.c:12974-12975
+            if (h < H) { v[k] = r0; v[k + half] = r1; }
+            else { float * o = kc + ((int64_t) pos * HKV + (h - H)) * D; o[k] = r0; o[k + half] = r1; }
+        } else {
+            float * o = vc + ((int64_t) pos * HKV + (h - H - HKV)) * D;
+            o[k] = v[k]; o[k + half] = v[k + half];
+        }
+    }
+}
+void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs, float * k_cache, float * v_cache, hipStream_t st) {
+    const int64_t total = (int64_t) N * (H + 2 * HKV) * (D / 2);
+    const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rope_kv, dim3(blocks), dim3(256), 0, st, qkv, N, H, HKV, D, n_past_dev, rope_cs, k_cache, v_cache);
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One 256-thread workgroup per (head, token). D = 64 (every Falcon). n_kv = n_past + t + 1 keys are visible.
+//   phase 1: 16 lanes per key row (one float4 each), f32 products accumulated in f64 -> score * 1/sqrt(D) -> LDS
+//   phase 2: max, exp via the fp16 table, f64 sum, scale by (float)(1/sum)
+//   phase 3: out[d] = sum_j V[j][d] * p[j], thread = (d, j mod 4), f64 accumulation
+// f64 accumulation of f32 products reproduces the reference's portable ggml_vec_dot_f32 (ggml.c:2296-2300) up to
+// the association of an f64 sum, i.e. bit-exact after the final rounding except with probability ~1e-9.
+__global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                   const float * __restrict__ kc, const float * __restrict__ vc,
+                                                   const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
+    constexpr int D = 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int h = blockIdx.x, t = blockIdx.y;
+    const int n_kv = *n_past_ptr + t + 1;
+    float  * p    = (float *) smem;                                      // n_kv scores
+    double * red  = (double *)(smem + (((size_t) n_kv * 4 + 15) & ~(size_t) 15));   // 4 x 64 doubles
+    float  * redf = (float *)(red + 4 * 64);
+    const int heads = H + 2 * HKV;
+    const int hk = h / (H / HKV);
+    const float * q = qkv + ((int64_t) t * heads + h) * D;
+    const int tid = threadIdx.x, sub = tid & 15, rowi = tid >> 4;
+    const float4 q4 = *(const float4 *)(q + 4 * sub);
+
+    float lmax = -INFINITY;
+    for (int j0 = 0; j0 < n_kv; j0 += 16) {
+        const int j = j0 + rowi;
+        const int jc = j < n_kv ? j : n_kv - 1;
+        const float4 k4 = *(const float4 *)(kc + ((int64_t) jc * HKV + hk) * D + 4 * sub);
+        double s = (double)(k4.x * q4.x); s += (double)(k4.y * q4.y); s += (double)(k4.z * q4.z); s += (double)(k4.w * q4.w);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float sc = (float) s * 0.125f;                             // 1/sqrt(64), libfalcon.cpp:2313-2317
+        if (sub == 0 && j < n_kv) p[j] = sc;
+        if (j < n_kv) lmax = fmaxf(lmax, sc);
+    }
+    const float mx = block_max(lmax, redf);
+    __syncthreads();
+    double lsum = 0.0;
+    for (int j = tid; j < n_kv; j += blockDim.x) {
+        const float e = h2f_bits(exp_tab[f2h_bits(p[j] - mx)]);          // ggml.c:12436-12442
+        p[j] = e;
+        lsum += (double) e;
+    }
+    const double sum = block_sum(lsum, red);
+    const float inv = (float)(1.0 / sum);
+    __syncthreads();
+    for (int j = tid; j < n_kv; j += blockDim.x) p[j] *= inv;
+    __syncthreads();
+
+    const int d = tid & 63, part = tid >> 6;
+    double acc = 0.0;
+    for (int j = part; j < n_kv; j += 4) acc += (double)(vc[((int64_t) j * HKV + hk) * D + d] * p[j]);
+    red[part * 64 + d] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const double o = ((red[d] + red[64 + d]) + red[128 + d]) + red[192 + d];
+        att[(int64_t) t * H * D + (int64_t) h * D + d] = (float) o;
+    }
+}
+
+void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
+                         const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+    if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
+    const size_t lds = (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15) + 4 * 64 * 8 + 64;    // sized for the largest n_past + N the launch may see
+    if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
+    hipLaunchKernelGGL(k_attention, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
+}

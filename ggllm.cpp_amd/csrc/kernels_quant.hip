@@ -1,0 +1,257 @@
+// kernels_quant.hip -- weight re-tiling, dequantize_row, activation quantizers (gfx950).
+//
+//  * k_retile        ggml array-of-blocks -> planes (upload time; replaces the raw cudaMemcpy of
+//                    ggml_cuda_transform_tensor, reference ggml-cuda.cu:3030-3073)
+//  * k_dequant_rows  dequantize_row_q* (ggml.c:1509-1619, k_quants.c:344-876): bit-exact, used by get_rows
+//                    (embedding lookup, ggml.c:11975) and by the parity tests
+//  * k_quantize_q8   quantize_row_q8_0/q8_1 "_reference" semantics (ggml.c:1106-1129, 1292-1325)
+//  * k_quantize_q8K  quantize_row_q8_K_reference (k_quants.c:899-934)
+//  * k_act_export    SoA activations -> ggml block_q8_0 / block_q8_1 / block_q8_K bytes (tests, shim)
+//
+// Built with -ffp-contract=off: every a*b+c below is two roundings, as in the reference C.
+#include "fq_device.h"
+#include "fq_units.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ re-tile
+__global__ void k_retile(const uint8_t * __restrict__ src, fq_weight w, int type) {
+    const fq_type_desc d = fq_desc(type);
+    const int64_t total = w.M * w.nblk;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const uint8_t * s = src + (size_t) i * d.tsize;
+        for (int p = 0; p < d.nplanes; ++p) {
+            uint8_t * o = w.plane[p] + (size_t) i * d.plane[p].bytes;
+            for (int b = 0; b < d.plane[p].bytes; ++b) o[b] = s[d.plane[p].src_off + b];
+        }
+    }
+}
+
+void fq_launch_retile(const uint8_t * src_dev, const fq_weight & w, hipStream_t st) {
+    const int64_t total = w.M * w.nblk;
+    const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_retile, dim3(blocks), dim3(256), 0, st, src_dev, w, w.type);
+}
+
+// ------------------------------------------------------------------------------------------------ dequantize
+// element e of a row, arithmetic order exactly as the reference's dequantize_row_* (cited per case)
+template <int TYPE>
+__device__ __forceinline__ float dequant_elem(const fq_wrow & r, int64_t e) {
+    if constexpr (TYPE == FQ_Q4_0) {                                 // ggml.c:1509-1527
+        const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
+        const int q = hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15);
+        return (float)(q - 8) * fq_h2f(ld_u16(r.p1 + 2 * b));
+    } else if constexpr (TYPE == FQ_Q4_1) {                          // ggml.c:1529-1548
+        const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
+        const int q = hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15);
+        const uint32_t dm = ld_u32(r.p1 + 4 * b);
+        return (float) q * fq_h2f((uint16_t) dm) + fq_h2f((uint16_t)(dm >> 16));
+    } else if constexpr (TYPE == FQ_Q5_0) {                          // ggml.c:1550-1574
+        const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
+        const int q = (hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15)) | (int)(((ld_u32(r.p1 + 4 * b) >> (e & 31)) & 1u) << 4);
+        return (float)(q - 16) * fq_h2f(ld_u16(r.p2 + 2 * b));
+    } else if constexpr (TYPE == FQ_Q5_1) {                          // ggml.c:1576-1601
+        const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
+        const int q = (hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15)) | (int)(((ld_u32(r.p1 + 4 * b) >> (e & 31)) & 1u) << 4);
+        const uint32_t dm = ld_u32(r.p2 + 4 * b);
+        return (float) q * fq_h2f((uint16_t) dm) + fq_h2f((uint16_t)(dm >> 16));
+    } else if constexpr (TYPE == FQ_Q8_0) {                          // ggml.c:1603-1619
+        return (float)(int)(int8_t) r.p0[e] * fq_h2f(ld_u16(r.p1 + 2 * (e >> 5)));
+    } else if constexpr (TYPE == FQ_Q2_K) {                          // k_quants.c:344-375
+        const int64_t sb = e >> 8; const int i = e & 255;
+        const int is = (i >> 7) * 8 + ((i & 127) >> 5) * 2 + ((i & 31) >> 4);
+        const int sc = r.p1[16 * sb + is];
+        const int q  = (r.p0[64 * sb + (i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
+        const uint32_t dm = ld_u32(r.p2 + 4 * sb);
+        const float dl = fq_h2f((uint16_t) dm) * (float)(sc & 15), ml = fq_h2f((uint16_t)(dm >> 16)) * (float)(sc >> 4);
+        return dl * (float) q - ml;
+    } else if constexpr (TYPE == FQ_Q3_K) {                          // k_quants.c:472-521
+        const int64_t sb = e >> 8; const int i = e & 255;
+        const int is = (i >> 7) * 8 + ((i & 127) >> 5) * 2 + ((i & 31) >> 4);
+        const int lo = (r.p0[64 * sb + (i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
+        const int hb = (r.p1[32 * sb + (i & 31)] >> (i >> 5)) & 1;
+        const int sc = q3_scale(ld_u32(r.p2 + 12 * sb), ld_u32(r.p2 + 12 * sb + 4), ld_u32(r.p2 + 12 * sb + 8), is);
+        const float dl = fq_h2f(ld_u16(r.p3 + 2 * sb)) * (float)(sc - 32);
+        return dl * (float)(lo - (hb ? 0 : 4));
+    } else if constexpr (TYPE == FQ_Q4_K || TYPE == FQ_Q5_K) {      // k_quants.c:607-631, 734-760
+        const int64_t sb = e >> 8; const int i = e & 255;
+        const int c = i >> 6, hi = (i >> 5) & 1;
+        const uint8_t * scp = (TYPE == FQ_Q4_K) ? r.p1 + 12 * sb : r.p2 + 12 * sb;
+        int sc, mn; k4_scale_min(ld_u32(scp), ld_u32(scp + 4), ld_u32(scp + 8), 2 * c + hi, sc, mn);
+        const int byte = r.p0[128 * sb + 32 * c + (i & 31)];
+        int q = hi ? (byte >> 4) : (byte & 15);
+        if constexpr (TYPE == FQ_Q5_K) q += ((r.p1[32 * sb + (i & 31)] >> (i >> 5)) & 1) ? 16 : 0;
+        const uint32_t dm = ld_u32((TYPE == FQ_Q4_K ? r.p2 : r.p3) + 4 * sb);
+        const float dl = fq_h2f((uint16_t) dm) * (float) sc, ml = fq_h2f((uint16_t)(dm >> 16)) * (float) mn;
+        return dl * (float) q - ml;
+    } else {                                                         // Q6_K, k_quants.c:845-876
+        const int64_t sb = e >> 8; const int i = e & 255;
+        const int h = i >> 7, t = (i & 127) >> 5, l = i & 31;
+        const int byte = r.p0[128 * sb + 64 * h + 32 * (t & 1) + l];
+        const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
+        const int hi = (r.p1[64 * sb + 32 * h + l] >> (2 * t)) & 3;
+        const int q = (int)(int8_t)(lo | (hi << 4)) - 32;
+        const int sc = (int)(int8_t) r.p2[16 * sb + 8 * h + 2 * t + (l >> 4)];
+        return fq_h2f(ld_u16(r.p3 + 2 * sb)) * (float) sc * (float) q;
+    }
+}
+
+// rows[i] selects the weight row written to dst row i (rows == nullptr: identity)
+template <int TYPE>
+__global__ void k_dequant_rows(fq_weight w, const int32_t * __restrict__ rows, int64_t nrows, float * __restrict__ dst) {
+    const int64_t total = nrows * w.K;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t ri = i / w.K, e = i - ri * w.K;
+        const int64_t src = rows ? (int64_t) rows[ri] : ri;
+        dst[i] = dequant_elem<TYPE>(fq_row<TYPE>(w, src), e);
+    }
+}
+
+void fq_launch_dequant_rows(const fq_weight & w, const int32_t * rows_dev, int64_t nrows, float * dst, hipStream_t st) {
+    const int64_t total = nrows * w.K;
+    const int blocks = (int) ((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+#define FQ_CASE(T) case T: hipLaunchKernelGGL(k_dequant_rows<T>, dim3(blocks), dim3(256), 0, st, w, rows_dev, nrows, dst); break;
+    switch (w.type) {
+        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
+        FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
+        default: fprintf(stderr, "ggml-hip: dequantize: unsupported type %d\n", w.type); exit(1);
+    }
+#undef FQ_CASE
+}
+
+// column accessors of the activation image (fq_types.h)
+__device__ __forceinline__ int8_t * act_qs (const fq_act & a, int64_t col) { return (int8_t *)(a.base + (size_t) col * fq_act_col_bytes(a.type, a.K)); }
+__device__ __forceinline__ float  * act_d  (const fq_act & a, int64_t col) { return (float *)(a.base + (size_t) col * fq_act_col_bytes(a.type, a.K) + fq_act_d_off(a.type, a.K)); }
+__device__ __forceinline__ uint8_t * act_aux(const fq_act & a, int64_t col) { return a.base + (size_t) col * fq_act_col_bytes(a.type, a.K) + fq_act_aux_off(a.type, a.K); }
+
+// ------------------------------------------------------------------------------------------------ Q8_0 / Q8_1
+// One thread = 4 consecutive elements, 8 threads = one 32-block. x is [ncols][K] with row stride ldx (floats).
+template <int ACT>
+__global__ void k_quantize_q8(const float * __restrict__ x, int64_t ldx, fq_act a) {
+    const int64_t K = a.K;
+    const int64_t quads_per_col = K >> 2;
+    const int64_t total = quads_per_col * a.ncols;
+    // whole waves stay in the loop together (total is a multiple of 8 and the shuffles are within groups of 8)
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 63) & ~(int64_t) 63); i += (int64_t) gridDim.x * blockDim.x) {
+        const bool live = i < total;
+        const int64_t ii = live ? i : total - 1;
+        const int64_t col = ii / quads_per_col, q4 = ii - col * quads_per_col;
+        const float4 v = *(const float4 *)(x + col * ldx + 4 * q4);
+        float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+        const float d  = amax / 127.0f;                       // ggml.c:1116 / 1302
+        const float id = d ? 1.0f / d : 0.0f;
+        const int q0 = (int) roundf(v.x * id), q1 = (int) roundf(v.y * id), q2 = (int) roundf(v.z * id), q3 = (int) roundf(v.w * id);
+        int s = q0 + q1 + q2 + q3;
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (live) {
+            const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+            *(uint32_t *)(act_qs(a, col) + 4 * q4) = packed;
+            if ((q4 & 7) == 0) {
+                const int64_t b = q4 >> 3;
+                if constexpr (ACT == FQ_Q8_0) {
+                    act_d(a, col)[b] = h2f_bits(f2h_bits(d));             // the block stores d as fp16 (ggml.c:1120)
+                    ((int32_t *) act_aux(a, col))[b] = s;
+                } else {
+                    act_d(a, col)[b] = d;                                 // ggml.c:1306
+                    ((float *) act_aux(a, col))[b] = (float) s * d;       // ggml.c:1323  y.s = sum*d
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Q8_K
+// One wave = one 256-element super-block; lane l holds elements 4l..4l+3.
+__global__ void k_quantize_q8K(const float * __restrict__ x, int64_t ldx, fq_act a) {
+    const int64_t K = a.K;
+    const int64_t sb_per_col = K >> 8;
+    const int64_t total_sb = sb_per_col * a.ncols;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+    for (int64_t sbi = wave0; sbi < total_sb; sbi += nwaves) {
+        const int64_t col = sbi / sb_per_col, sb = sbi - col * sb_per_col;
+        const float4 v = *(const float4 *)(x + col * ldx + 256 * sb + 4 * lane);
+        // element of largest magnitude, FIRST one on ties (strict '>' scan, k_quants.c:906-911)
+        float ax = fabsf(v.x), mx = v.x; int idx = 4 * lane;
+        if (fabsf(v.y) > ax) { ax = fabsf(v.y); mx = v.y; idx = 4 * lane + 1; }
+        if (fabsf(v.z) > ax) { ax = fabsf(v.z); mx = v.z; idx = 4 * lane + 2; }
+        if (fabsf(v.w) > ax) { ax = fabsf(v.w); mx = v.w; idx = 4 * lane + 3; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float oax = __shfl_xor(ax, o), omx = __shfl_xor(mx, o); const int oidx = __shfl_xor(idx, o);
+            if (oax > ax || (oax == ax && oidx < idx)) { ax = oax; mx = omx; idx = oidx; }
+        }
+        int8_t * qo = act_qs(a, col) + 256 * sb + 4 * lane;
+        int16_t * bs = (int16_t *) act_aux(a, col) + 16 * sb;
+        if (ax == 0.0f) {
+            *(uint32_t *) qo = 0u;
+            if ((lane & 3) == 0) bs[lane >> 2] = 0;
+            if (lane == 0) act_d(a, col)[sb] = 0.0f;
+            continue;
+        }
+        const float iscale = -128.0f / mx;
+        int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y);     // nearest_int = round-half-even (k_quants.c:50-55)
+        int q2 = (int) __builtin_rintf(iscale * v.z), q3 = (int) __builtin_rintf(iscale * v.w);
+        q0 = q0 > 127 ? 127 : q0; q1 = q1 > 127 ? 127 : q1; q2 = q2 > 127 ? 127 : q2; q3 = q3 > 127 ? 127 : q3;
+        *(uint32_t *) qo = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        int s = q0 + q1 + q2 + q3;
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
+        if (lane == 0) act_d(a, col)[sb] = 1.0f / iscale;
+    }
+}
+
+void fq_launch_quantize_act(const float * x, int64_t ldx, const fq_act & a, hipStream_t st) {
+    if (a.type == FQ_Q8_K) {
+        const int64_t total_sb = (a.K >> 8) * a.ncols;
+        const int blocks = (int) ((total_sb + 3) / 4 > 4096 ? 4096 : (total_sb + 3) / 4);
+        hipLaunchKernelGGL(k_quantize_q8K, dim3(blocks), dim3(256), 0, st, x, ldx, a);
+        return;
+    }
+    const int64_t total = (a.K >> 2) * a.ncols;
+    const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (a.type == FQ_Q8_0) hipLaunchKernelGGL(k_quantize_q8<FQ_Q8_0>, dim3(blocks), dim3(256), 0, st, x, ldx, a);
+    else                   hipLaunchKernelGGL(k_quantize_q8<FQ_Q8_1>, dim3(blocks), dim3(256), 0, st, x, ldx, a);
+}
+
+// ------------------------------------------------------------------------------------------------ export (tests / shim)
+__global__ void k_act_export(fq_act a, uint8_t * __restrict__ out) {
+    const int64_t K = a.K;
+    if (a.type == FQ_Q8_K) {
+        const int64_t per_col = K >> 8, total = per_col * a.ncols;
+        for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+            const int64_t col = i / per_col, sb = i - col * per_col;
+            uint8_t * o = out + i * 292;
+            const float d = act_d(a, col)[sb];
+            for (int b = 0; b < 4; ++b) o[b] = ((const uint8_t *) &d)[b];
+            const int8_t * q = act_qs(a, col) + 256 * sb;
+            for (int j = 0; j < 256; ++j) o[4 + j] = (uint8_t) q[j];
+            const uint8_t * bs = act_aux(a, col) + 32 * sb;
+            for (int j = 0; j < 32; ++j) o[260 + j] = bs[j];
+        }
+        return;
+    }
+    const int64_t per_col = K >> 5, total = per_col * a.ncols;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t col = i / per_col, b = i - col * per_col;
+        const int8_t * q = act_qs(a, col) + 32 * b;
+        if (a.type == FQ_Q8_0) {
+            uint8_t * o = out + i * 34;
+            const uint16_t h = f2h_bits(act_d(a, col)[b]);
+            o[0] = (uint8_t) h; o[1] = (uint8_t)(h >> 8);
+            for (int j = 0; j < 32; ++j) o[2 + j] = (uint8_t) q[j];
+        } else {
+            uint8_t * o = out + i * 40;
+            const float d = act_d(a, col)[b], sv = ((const float *) act_aux(a, col))[b];
+            for (int k = 0; k < 4; ++k) { o[k] = ((const uint8_t *) &d)[k]; o[4 + k] = ((const uint8_t *) &sv)[k]; }
+            for (int j = 0; j < 32; ++j) o[8 + j] = (uint8_t) q[j];
+        }
+    }
+}
+
+void fq_launch_act_export(const fq_act & a, uint8_t * out, hipStream_t st) {
+    const int64_t total = (a.type == FQ_Q8_K ? (a.K >> 8) : (a.K >> 5)) * a.ncols;
+    const int blocks = (int) ((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_act_export, dim3(blocks), dim3(256), 0, st, a, out);
+}

@@ -1,0 +1,72 @@
+/*
+ * falcon-hip.h -- C ABI of libggml_hip.so, model level: a device-resident Falcon decoder stack.
+ *
+ * Mirrors the part of libfalcon.h that sits on the hot path (cmp-nct/ggllm.cpp):
+ *   falcon_hip_model_*    <- falcon_model / falcon_model_load_internal   (libfalcon.cpp:1552-1959)
+ *   falcon_hip_context_*  <- falcon_context_prepare / kv_cache_init      (libfalcon.cpp:3755, 1335-1385)
+ *   falcon_hip_eval       <- falcon_eval -> falcon_eval_internal         (libfalcon.cpp:4566, 2011-2588)
+ *   falcon_hip_get_logits <- falcon_get_logits                           (libfalcon.cpp:4678)
+ * Unlike the reference (which rebuilds a ggml graph per call, runs attention/LN/GELU on the CPU and round-trips
+ * every mat-mul over PCIe), all weights, the KV cache and every activation stay in HBM; only token ids go in and
+ * logits come out. A context may own a contiguous range of layers (a pipeline STAGE): the first
+ * stage embeds tokens, inner stages take/give the residual stream as device pointers, the last stage applies
+ * ln_f + lm_head.
+ */
+#ifndef FALCON_HIP_H
+#define FALCON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct falcon_hip_model   falcon_hip_model;
+typedef struct falcon_hip_context falcon_hip_context;
+
+typedef struct falcon_hip_hparams {      /* falcon_hparams, libfalcon.cpp:146-160 */
+    int32_t n_vocab, n_embd, n_head, n_head_kv, n_layer, n_ff;
+    int32_t two_norms;                   /* 1: ln_attn + ln_mlp per block (40B / 180B), 0: shared input_layernorm (7B) */
+    int32_t layer_begin, layer_end;      /* this process holds blocks [layer_begin, layer_end)                         */
+} falcon_hip_hparams;
+
+falcon_hip_model * falcon_hip_model_create(const falcon_hip_hparams * hp);
+void               falcon_hip_model_free(falcon_hip_model * m);
+/* Upload one tensor by its model-file name (libfalcon.cpp:1764-1861), e.g.
+ *   transformer.word_embeddings.weight, transformer.h.<i>.self_attention.query_key_value.weight,
+ *   transformer.h.<i>.self_attention.dense.weight, transformer.h.<i>.mlp.dense_h_to_4h.weight,
+ *   transformer.h.<i>.mlp.dense_4h_to_h.weight, transformer.h.<i>.input_layernorm.{weight,bias} (7B),
+ *   transformer.h.<i>.ln_mlp.* / ln_attn.* (40B), transformer.ln_f.{weight,bias}, lm_head.weight
+ * type: enum ggml_type value (0 = f32 for the norms). data: host bytes in ggml layout. Returns 0, or -1 if the
+ * name is unknown / outside this stage's layer range (tensor ignored).                                         */
+int  falcon_hip_model_set_tensor(falcon_hip_model * m, const char * name, int type, const void * data, int64_t ne0, int64_t ne1);
+size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m);   /* quantized bytes read per decoded token */
+
+/* n_ctx: KV capacity; n_batch: largest N of one eval; rope_n_ctx: the n_ctx handed to ggml_rope
+ * (n_max_real_ctx or n_ctx, libfalcon.cpp:2229-2230)                                                           */
+falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx);
+void                 falcon_hip_context_free(falcon_hip_context * c);
+
+/* Evaluate n_tokens at position n_past (falcon_eval). Whole model in this process: tokens are host ids.
+ * logits_all = 0 keeps the last row only. Returns 0.                                                           */
+int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, int n_tokens, int n_past, int logits_all);
+/* Pipeline-stage form: hidden_in_dev / hidden_out_dev are device [n_tokens][n_embd] f32 (NULL where the stage
+ * embeds tokens / produces logits).                                                                             */
+int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tokens, const float * hidden_in_dev, int n_tokens,
+                          int n_past, int logits_all, float * hidden_out_dev);
+/* Greedy decode loop entirely stream-ordered: evaluates `first_token` at n_past, then n_steps-1 more argmax-sampled
+ * tokens (falcon_main --temp 0, falcon_main.cpp:958-960); out_tokens receives n_steps ids. No host sync per step. */
+int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens);
+
+const float * falcon_hip_get_logits(falcon_hip_context * c);        /* host, n_vocab (or n_tokens*n_vocab) floats */
+/* test hook: residual stream entering each local layer (+ leaving the last), device->host, after an eval with
+ * falcon_hip_context_keep_hidden(c, 1): (n_local_layers + 1) * n_tokens * n_embd floats                          */
+void  falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep);
+void  falcon_hip_get_hidden(falcon_hip_context * c, float * dst_host);
+void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* capture decode steps into a hipGraph */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+/*
+ * ggml-hip-ops.h -- C ABI of libggml_hip.so, operator level. Plain pointers and sizes only.
+ *
+ * Each entry point names the reference operator it replaces (file:line in cmp-nct/ggllm.cpp). Pointers called
+ * *_dev are device (HBM) addresses obtained from ggml_hip_malloc; everything runs on the library's stream
+ * (ggml_hip_stream) unless stated. Errors are fatal (message + exit(1)), the reference backend's convention
+ * (CUDA_CHECK, ggml-cuda.cu:22-51). There is NO CPU fallback: without a HIP device every call aborts.
+ */
+#ifndef GGML_HIP_OPS_H
+#define GGML_HIP_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ggml_hip_weight ggml_hip_weight;   /* a quantized weight matrix resident in HBM (re-tiled)  */
+typedef struct ggml_hip_acts   ggml_hip_acts;     /* quantized activations (Q8_0 / Q8_1 / Q8_K) in HBM      */
+
+/* ---- device / memory plumbing (reference: ggml_init_cublas ggml-cuda.cu:1982-2041, pool 1738-1853) ---- */
+int     ggml_hip_init(int device);                /* idempotent; returns number of visible HIP devices        */
+int     ggml_hip_device_count(void);
+void *  ggml_hip_stream(void);                    /* hipStream_t used for every launch of this library        */
+void *  ggml_hip_malloc(size_t bytes);
+void    ggml_hip_free(void * dev);
+void    ggml_hip_memcpy_h2d(void * dst_dev, const void * src_host, size_t bytes);   /* stream-ordered, then waits */
+void    ggml_hip_memcpy_d2h(void * dst_host, const void * src_dev, size_t bytes);   /* stream-ordered, then waits */
+void    ggml_hip_memcpy_d2d(void * dst_dev, const void * src_dev, size_t bytes);    /* stream-ordered, async      */
+void    ggml_hip_memset(void * dst_dev, int value, size_t bytes);
+void    ggml_hip_synchronize(void);
+/* timing on the library's stream (hipEvent); elapsed in milliseconds */
+void *  ggml_hip_event_create(void);
+void    ggml_hip_event_record(void * ev);
+float   ggml_hip_event_elapsed_ms(void * ev_start, void * ev_stop);   /* synchronises on ev_stop */
+void    ggml_hip_event_destroy(void * ev);
+/* per-launch timing of the quantized mat-vec kernels (hipEvents on the launch stream) for the roofline report:
+ * between begin and end every GEMV launch is bracketed; end returns #launches, summed microseconds and summed
+ * algorithmic bytes (the weight matrix of each launch, read once)                                            */
+void    ggml_hip_profile_begin(void);
+void    ggml_hip_profile_end(int64_t * n_launches, double * total_us, double * total_bytes);
+const uint16_t * ggml_hip_gelu_table_dev(void);   /* 65536 fp16 entries, built like ggml.c:4276-4290 */
+const uint16_t * ggml_hip_exp_table_dev(void);
+
+/* ---- weights: ggml_cuda_transform_tensor (ggml-cuda.cu:3030-3073) ---------------------------------------- */
+/* host_blocks: M rows of K/blck ggml blocks exactly as in a model file (type = enum ggml_type value).         */
+ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_blocks, int64_t K, int64_t M);
+void    ggml_hip_weight_free(ggml_hip_weight * w);                 /* ggml_cuda_free_data, ggml-cuda.cu:3075-3092 */
+size_t  ggml_hip_weight_nbytes(const ggml_hip_weight * w);         /* == ggml_nbytes of the tensor               */
+
+/* dequantize_row_q* (ggml.c:1509-1619, k_quants.c:344-876) / ggml_compute_forward_get_rows_q (ggml.c:11975):
+ * dst_dev[i][0..K) = dequantized weight row rows_dev[i] (rows_dev == NULL: rows 0..nrows-1)                  */
+void    ggml_hip_dequantize_rows(const ggml_hip_weight * w, const int32_t * rows_dev, int64_t nrows, float * dst_dev);
+
+/* ---- activations: INIT phase of mul_mat_q (ggml.c:11462-11476) ------------------------------------------- */
+/* act_type: 8 = Q8_0 (ggml.c:1106-1129), 9 = Q8_1 (ggml.c:1292-1325), 15 = Q8_K (k_quants.c:899-934)          */
+ggml_hip_acts * ggml_hip_acts_alloc(int act_type, int64_t K, int64_t max_cols);
+void    ggml_hip_acts_free(ggml_hip_acts * a);
+void    ggml_hip_quantize_acts(ggml_hip_acts * a, const float * x_dev, int64_t ldx, int64_t ncols);
+/* writes ncols * K/blck ggml blocks (block_q8_0 / block_q8_1 / block_q8_K bytes) for bit-exact comparison     */
+void    ggml_hip_acts_export(const ggml_hip_acts * a, int64_t ncols, void * out_dev);
+
+/* ---- quantized mat-mul: ggml_compute_forward_mul_mat_q_f32 (ggml.c:11318-11529) --------------------------- */
+/* dst_dev[n*ldd + m] = sum_k W[m][k] * x[n][k] for n < N, m < M with the reference CPU arithmetic
+ * (activations quantized to the weight type's vec_dot_type, exact integer block dots, f32 epilogue).          */
+void    ggml_hip_mul_mat_q(const ggml_hip_weight * w, const float * x_dev, int64_t ldx, int64_t N,
+                           float * dst_dev, int64_t ldd);
+/* same, activations already quantized; epilogue: 0 = store, 1 = GELU (ggml.c:3477-3484),
+ * 2 = dst = (v + add1) + add2 (libfalcon.cpp:2399-2400; add1/add2 have column stride ldd)                      */
+void    ggml_hip_mul_mat_q_acts(const ggml_hip_weight * w, const ggml_hip_acts * a, int64_t N, float * dst_dev,
+                                int64_t ldd, int epilogue, const float * add1_dev, const float * add2_dev);
+
+/* ---- the other ops of a Falcon block ------------------------------------------------------------------------ */
+/* ggml_norm (ggml.c:10540-10594) followed by * w + b (libfalcon.cpp:2166-2188); w_dev == NULL: plain norm       */
+void    ggml_hip_layer_norm(const float * x_dev, int64_t n, int64_t rows, const float * w_dev, const float * b_dev, float * y_dev);
+void    ggml_hip_gelu(const float * x_dev, float * y_dev, int64_t n);                 /* ggml.c:3477-3484 */
+void    ggml_hip_add3(const float * a, const float * b, const float * c, float * y, int64_t n);   /* (a+b)+c */
+/* cos/sin table for ggml_rope mode 2 with Falcon's dynamic-NTK flags (ggml.c:12875-12898, libfalcon.cpp:2229-2234):
+ * returns a device table [n_pos][head_dim/2][2]                                                                */
+float * ggml_hip_rope_table_create(int head_dim, int n_pos, int rope_n_ctx);
+/* rotate Q in place, rotate K into k_cache, copy V into v_cache at positions n_past..n_past+N-1
+ * (ggml.c:12957-12978, libfalcon.cpp:2238-2280). qkv_dev rows are [H q-heads | HKV k-heads | HKV v-heads] x D. */
+void    ggml_hip_rope_kv_store(float * qkv_dev, int N, int H, int HKV, int D, int n_past, const float * rope_table_dev,
+                               float * k_cache_dev, float * v_cache_dev);
+/* K.Q, scale 1/sqrt(D), causal mask, soft_max, V.P, merge heads (libfalcon.cpp:2285-2366):
+ * att_dev[N][H*D]; caches are [n_ctx][HKV][D] f32 for ONE layer                                                */
+void    ggml_hip_attention(const float * qkv_dev, int N, int H, int HKV, int D, int n_past,
+                           const float * k_cache_dev, const float * v_cache_dev, float * att_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+// Host-side check of ggllm.cpp_amd/csrc/fq_units.h (the exact header the GEMV kernels compile): re-tile one ggml
+// row into planes, re-tile ggml activation blocks into the SoA layout, and sum the per-unit dots.
+#include "fq_units.h"
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+
+template <int TYPE>
+static float row_dot(const fq_weight & w, const fq_actcol & a, int64_t K) {
+    const fq_wrow r = fq_row<TYPE>(w, 0);
+    const int units = (int)(K / fq_unit<TYPE>::ELEMS);
+    float acc = 0.0f;
+    for (int u = 0; u < units; ++u) acc += fq_unit<TYPE>::dot(fq_unit<TYPE>::load(r, u), a, u);
+    return acc;
+}
+
+extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks) {
+    const fq_type_desc d = fq_desc(type);
+    const int64_t nblk = K / d.blck;
+    fq_weight w{}; w.type = type; w.K = K; w.M = 1; w.nblk = nblk;
+    std::vector<std::vector<uint8_t>> planes(FQ_MAX_PLANES);
+    for (int p = 0; p < d.nplanes; ++p) {
+        planes[p].resize((size_t) nblk * d.plane[p].bytes + 16);
+        for (int64_t b = 0; b < nblk; ++b)
+            memcpy(planes[p].data() + fq_plane_offset(d, p, nblk, 0, b), row + (size_t) b * d.tsize + d.plane[p].src_off, d.plane[p].bytes);
+        w.plane[p] = planes[p].data();
+    }
+    // activations: ggml blocks -> SoA
+    std::vector<int8_t> qs((size_t) K + 64);
+    int8_t * qsa = (int8_t *)(((uintptr_t) qs.data() + 15) & ~(uintptr_t) 15);
+    std::vector<float> dd((size_t) K / 32 + 1);
+    std::vector<uint8_t> aux((size_t) K / 16 * 4 + 16);
+    if (d.act_type == FQ_Q8_0) {
+        for (int64_t b = 0; b < K / 32; ++b) {
+            const uint8_t * s = act_blocks + b * 34; uint16_t h; memcpy(&h, s, 2);
+            dd[b] = fq_h2f(h); memcpy(qsa + b * 32, s + 2, 32);
+            int t = 0; for (int j = 0; j < 32; ++j) t += (int8_t) s[2 + j];
+            ((int32_t *) aux.data())[b] = t;
+        }
+    } else if (d.act_type == FQ_Q8_1) {
+        for (int64_t b = 0; b < K / 32; ++b) {
+            const uint8_t * s = act_blocks + b * 40;
+            memcpy(&dd[b], s, 4); memcpy((float *) aux.data() + b, s + 4, 4); memcpy(qsa + b * 32, s + 8, 32);
+        }
+    } else {
+        for (int64_t b = 0; b < K / 256; ++b) {
+            const uint8_t * s = act_blocks + b * 292;
+            memcpy(&dd[b], s, 4); memcpy(qsa + b * 256, s + 4, 256); memcpy((int16_t *) aux.data() + b * 16, s + 260, 32);
+        }
+    }
+    fq_actcol a{ qsa, dd.data(), aux.data() };
+    switch (type) {
+        case FQ_Q4_0: return row_dot<FQ_Q4_0>(w, a, K); case FQ_Q4_1: return row_dot<FQ_Q4_1>(w, a, K);
+        case FQ_Q5_0: return row_dot<FQ_Q5_0>(w, a, K); case FQ_Q5_1: return row_dot<FQ_Q5_1>(w, a, K);
+        case FQ_Q8_0: return row_dot<FQ_Q8_0>(w, a, K); case FQ_Q2_K: return row_dot<FQ_Q2_K>(w, a, K);
+        case FQ_Q3_K: return row_dot<FQ_Q3_K>(w, a, K); case FQ_Q4_K: return row_dot<FQ_Q4_K>(w, a, K);
+        case FQ_Q5_K: return row_dot<FQ_Q5_K>(w, a, K); case FQ_Q6_K: return row_dot<FQ_Q6_K>(w, a, K);
+    }
+    abort();
+}

@@ -1,0 +1,145 @@
+"""GPU parity: layer norm, GELU, RoPE + KV append, attention -- against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    g.init(0)
+
+
+def relrms(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
+
+
+def test_tables_match_reference(oracle, golden):
+    """the fp16 GELU / EXP tables the kernels index are the reference's (ggml.c:4276-4290), bit for bit"""
+    L = g.load()
+    gelu = np.empty(1 << 16, np.uint16)
+    ex = np.empty(1 << 16, np.uint16)
+    L.ggml_hip_memcpy_d2h(gelu.ctypes.data, L.ggml_hip_gelu_table_dev(), 1 << 17)
+    L.ggml_hip_memcpy_d2h(ex.ctypes.data, L.ggml_hip_exp_table_dev(), 1 << 17)
+    gb = golden["block_ops"]
+    assert np.array_equal(gelu[gb["gelu_all_in_bits"]], gb["gelu_all_out_bits"])
+    fin = np.isfinite(np.arange(1 << 16, dtype=np.uint16).view(np.float16).astype(np.float32))
+    assert np.array_equal(gelu[fin], oracle.gelu_table()[fin])
+    assert np.array_equal(ex[fin], oracle.exp_table()[fin])
+
+
+@pytest.mark.parametrize("n,rows", [(4544, 5), (8192, 3), (256, 9)])
+def test_layer_norm(oracle, golden, n, rows):
+    L = g.load()
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((rows, n)) * 3 + 0.5).astype(np.float32)
+    if n == 4544:
+        x = golden["block_ops"]["norm_x"]
+    w = (1 + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    b = (0.02 * rng.standard_normal(n)).astype(np.float32)
+    xb, wb, bb, yb = g.DevBuf(host=x), g.DevBuf(host=w), g.DevBuf(host=b), g.DevBuf(x.nbytes)
+    L.ggml_hip_layer_norm(xb.ptr, n, rows, None, None, yb.ptr)
+    plain = yb.to_host(np.float32, x.shape)
+    L.ggml_hip_layer_norm(xb.ptr, n, rows, wb.ptr, bb.ptr, yb.ptr)
+    full = yb.to_host(np.float32, x.shape)
+    # f64 sums: only their association differs from the reference -> equal up to 1 ulp of the f32 mean/variance
+    assert relrms(plain, oracle.norm(x)) <= 1e-6
+    assert relrms(full, oracle.layer_norm(x, w, b)) <= 1e-6
+    if n == 4544:
+        assert relrms(plain, golden["block_ops"]["norm_y"]) <= 1e-6
+    print("layer_norm bit-identical elements:", float((plain == oracle.norm(x)).mean()))
+
+
+def test_gelu_bit_exact(oracle, golden):
+    L = g.load()
+    gb = golden["block_ops"]
+    x = gb["gelu_x"]
+    xb, yb = g.DevBuf(host=x), g.DevBuf(x.nbytes)
+    L.ggml_hip_gelu(xb.ptr, yb.ptr, x.size)
+    assert np.array_equal(yb.to_host(np.float32, x.shape), gb["gelu_y"])
+
+
+@pytest.mark.parametrize("n_ctx", [2048, 8192])
+def test_rope_kv_store(oracle, golden, n_ctx):
+    L = g.load()
+    gb = golden["block_ops"]
+    N, H, HKV, D, n_past = 3, 4, 1, 64, 1021
+    x = gb[f"rope_x_{n_ctx}"]                    # [3, 5, 64] = per token: 4 q heads + 1 k head
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal((N, HKV, D)).astype(np.float32)
+    qkv = np.concatenate([x, v], axis=1)         # [N, H + 2*HKV, D]
+    tab = L.ggml_hip_rope_table_create(D, n_past + N, n_ctx)
+    qb = g.DevBuf(host=qkv)
+    kc, vc = g.DevBuf((n_past + N) * HKV * D * 4), g.DevBuf((n_past + N) * HKV * D * 4)
+    L.ggml_hip_rope_kv_store(qb.ptr, N, H, HKV, D, n_past, tab, kc.ptr, vc.ptr)
+    out = qb.to_host(np.float32, qkv.shape)
+    ref = gb[f"rope_y_{n_ctx}"]
+    assert np.array_equal(out[:, :H], ref[:, :H])                       # Q rotated in place
+    kcache = kc.to_host(np.float32, (n_past + N, HKV, D))
+    vcache = vc.to_host(np.float32, (n_past + N, HKV, D))
+    assert np.array_equal(kcache[n_past:], ref[:, H:H + HKV])           # K rotated into the cache
+    assert np.array_equal(vcache[n_past:], v)
+    assert np.array_equal(out[:, H:], qkv[:, H:])                       # K/V slots of the fused row untouched
+    assert np.array_equal(ref, oracle.rope(x, 64, 5, 3, n_past, n_ctx))
+
+
+def _attention_ref(oracle, q, kc, vc, n_past, H, HKV):
+    """numpy restatement of K.Q -> scale -> mask -> soft_max -> V.P with f32 products / f64 accumulation"""
+    N = q.shape[0]
+    D = 64
+    out = np.zeros((N, H * D), np.float32)
+    for t in range(N):
+        n_kv = n_past + t + 1
+        for h in range(H):
+            hk = h // (H // HKV)
+            prod = (kc[:n_kv, hk, :] * q[t, h][None, :]).astype(np.float32)
+            s = (prod.astype(np.float64).sum(axis=1)).astype(np.float32) * np.float32(0.125)
+            p = oracle.softmax_rows(s[None, :])[0]
+            pv = (vc[:n_kv, hk, :] * p[:, None]).astype(np.float32)
+            out[t, h * D:(h + 1) * D] = pv.astype(np.float64).sum(axis=0).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 1, 0), (71, 1, 1, 300), (8, 2, 5, 37), (16, 8, 3, 1000)])
+def test_attention(oracle, H, HKV, N, n_past):
+    L = g.load()
+    D = 64
+    rng = np.random.default_rng(H * 100 + N)
+    n_kv = n_past + N
+    qkv = rng.standard_normal((N, H + 2 * HKV, D)).astype(np.float32)
+    kc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    vc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    qb, kb, vb, ob_ = g.DevBuf(host=qkv), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(N * H * D * 4)
+    L.ggml_hip_attention(qb.ptr, N, H, HKV, D, n_past, kb.ptr, vb.ptr, ob_.ptr)
+    got = ob_.to_host(np.float32, (N, H * D))
+    exp = _attention_ref(oracle, qkv[:, :H], kc, vc, n_past, H, HKV)
+    assert relrms(got, exp) <= 2e-6, relrms(got, exp)
+    print("attention bit-identical elements:", float((got == exp).mean()))
+
+
+def test_softmax_golden_through_attention(oracle, golden):
+    """golden soft_max rows (scale + causal mask + fp16-table exp) reproduced by the attention kernel with V = I"""
+    L = g.load()
+    gb = golden["block_ops"]
+    kq = gb["sm_kq"]                            # [n_head=4, N=3, n_kv=40] raw K.Q values
+    n_past = int(gb["sm_n_past"])
+    H, N, n_kv = kq.shape
+    D = 64
+    # choose q = e_0 * 1 and K[j] = kq value in component 0 so that K.Q reproduces kq for head h, token t: needs one
+    # kv head per (h, t) pair -> run each (h, t) as its own single-head launch
+    for h in range(H):
+        for t in range(N):
+            nk = n_past + t + 1
+            q = np.zeros((1, 3, D), np.float32)
+            q[0, 0, 0] = 1.0
+            kc = np.zeros((nk, 1, D), np.float32)
+            kc[:, 0, 0] = kq[h, t, :nk]
+            vc = np.zeros((nk, 1, D), np.float32)
+            vc[:min(nk, D), 0, :][np.arange(min(nk, D)), np.arange(min(nk, D))] = 1.0      # V = identity on the first 64 keys
+            qb, kb, vb, o = g.DevBuf(host=q), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(D * 4)
+            L.ggml_hip_attention(qb.ptr, 1, 1, 1, D, nk - 1, kb.ptr, vb.ptr, o.ptr)
+            got = o.to_host(np.float32, (D,))
+            assert np.array_equal(got[:min(nk, D)], gb["sm_p"][h, t, :min(nk, D)])

@@ -1,0 +1,112 @@
+"""GPU parity: the device-resident Falcon stack against the oracle and against logits captured from the reference."""
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+
+# north_star: logits within 1e-3 relative of the CPU reference. Metric: max |diff| / rms(reference logits).
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    g.init(0)
+
+
+def relrms(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
+
+
+CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+         ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)]
+
+
+@pytest.mark.parametrize("name,hp,t", CASES)
+def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t):
+    gt = golden["tiny_models"]
+    w = synth.make_model(oracle, hp, t, seed=1234)
+    toks = gt[f"{name}_tokens"]
+    m = g.FalconModel(w, n_ctx=64, n_batch=8)
+    lg, hid = m.eval(toks[:8], 0, logits_all=True, want_hidden=True)
+    dec = np.concatenate([m.eval(toks[i:i + 1], i, logits_all=True) for i in range(8, 12)])
+    m.free()
+    e_h, e_l, e_d = (relrms(hid, gt[f"{name}_prefill_hidden_scalar"]), relrms(lg, gt[f"{name}_prefill_logits_scalar"]),
+                     relrms(dec, gt[f"{name}_decode_logits_scalar"]))
+    print(name, "hidden %.2e prefill logits %.2e decode logits %.2e" % (e_h, e_l, e_d))
+    assert e_l <= LOGIT_TOL and e_d <= LOGIT_TOL and e_h <= LOGIT_TOL
+    assert np.array_equal(lg.argmax(1), gt[f"{name}_prefill_logits_scalar"].argmax(1))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_1, ob.Q5_0, ob.Q2_K, ob.Q3_K, ob.Q5_K, ob.Q6_K])
+def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
+    hp = synth.HP_TINY_GQA
+    w = synth.make_model(oracle, hp, t, seed=77)
+    toks = synth.tokens(10, hp["n_vocab"], seed=5)
+    m = g.FalconModel(w, n_ctx=32, n_batch=6)
+    mo = oracle.model(w, 32)
+    lg = m.eval(toks[:6], 0)
+    lo = mo.eval(toks[:6], 0, 4)
+    d = [m.eval(toks[i:i + 1], i) for i in range(6, 10)]
+    do = [mo.eval(toks[i:i + 1], i, 4) for i in range(6, 10)]
+    m.free()
+    assert relrms(lg, lo) <= LOGIT_TOL
+    assert relrms(np.concatenate(d), np.concatenate(do)) <= LOGIT_TOL
+
+
+def test_prefill_equals_incremental_and_graph(oracle):
+    """size-independent properties: batch-invariance (N tokens at once == one at a time, bit-identical) and
+    greedy decode through the captured hipGraph == plain launches == oracle greedy"""
+    hp = synth.HP_TINY_MQA
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=3)
+    toks = synth.tokens(9, hp["n_vocab"], seed=8)
+    m = g.FalconModel(w, n_ctx=64, n_batch=9)
+    full = m.eval(toks, 0)
+    inc = np.concatenate([m.eval(toks[i:i + 1], i) for i in range(9)])
+    assert np.array_equal(full, inc)
+    first = int(full[-1].argmax())
+    plain = m.decode_greedy(first, 9, 12, use_graph=False)
+    m.eval(toks, 0)                                   # rewind the KV cache to the same state
+    graph = m.decode_greedy(first, 9, 12, use_graph=True)
+    assert np.array_equal(plain, graph)
+    mo = oracle.model(w, 64)
+    mo.eval(toks, 0, 2)
+    cur, ref = first, []
+    for i in range(12):
+        cur = int(mo.eval(np.array([cur], np.int32), 9 + i, 2)[0].argmax())
+        ref.append(cur)
+    assert list(plain) == ref
+    m.free()
+
+
+def test_falcon7b_shaped_layer_vs_oracle(oracle):
+    """one block with the real 7B dimensions (n_embd 4544, 71 heads MQA, n_ff 18176), small vocab"""
+    hp = dict(n_vocab=1024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=1, n_ff=18176, two_norms=False)
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=9)
+    toks = synth.tokens(4, 1024, seed=2)
+    m = g.FalconModel(w, n_ctx=16, n_batch=3)
+    mo = oracle.model(w, 16)
+    lg, hid = m.eval(toks[:3], 0, want_hidden=True)
+    lo, ho = mo.eval(toks[:3], 0, 8, want_hidden=True)
+    d, do = m.eval(toks[3:4], 3), mo.eval(toks[3:4], 3, 8)
+    m.free()
+    print("7B-shaped block: hidden %.2e logits %.2e decode %.2e" % (relrms(hid, ho), relrms(lg, lo), relrms(d, do)))
+    assert relrms(hid, ho) <= LOGIT_TOL and relrms(lg, lo) <= LOGIT_TOL and relrms(d, do) <= LOGIT_TOL
+
+
+def test_falcon40b_shaped_layer_vs_oracle(oracle):
+    """one block with the 40B geometry (n_embd 8192, 128 heads, 8 kv heads, two norms), Q4_K weights"""
+    hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
+    w = synth.make_model(oracle, hp, ob.Q4_K, seed=10)
+    toks = synth.tokens(3, 512, seed=4)
+    m = g.FalconModel(w, n_ctx=16, n_batch=2)
+    mo = oracle.model(w, 16)
+    lg = m.eval(toks[:2], 0)
+    lo = mo.eval(toks[:2], 0, 8)
+    d, do = m.eval(toks[2:3], 2), mo.eval(toks[2:3], 2, 8)
+    m.free()
+    print("40B-shaped block: logits %.2e decode %.2e" % (relrms(lg, lo), relrms(d, do)))
+    assert relrms(lg, lo) <= LOGIT_TOL and relrms(d, do) <= LOGIT_TOL

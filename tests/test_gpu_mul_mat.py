@@ -1,0 +1,128 @@
+"""GPU parity: quantized mat-mul (ggml_compute_forward_mul_mat_q_f32) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance: results may differ from the reference only by the association of the f32 sum over blocks.
+# max |diff| <= TOL * rms(reference row); north_star asks for 1e-3 on logits, the kernels are held to 2e-5.
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    g.init(0)
+
+
+def relrms(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
+
+
+@pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
+@pytest.mark.parametrize("K,M", [(512, 37), (4544, 70), (8192, 129), (18176, 33)])
+@pytest.mark.parametrize("N", [1, 2, 3, 5])
+def test_mul_mat_vs_oracle(oracle, t, K, M, N):
+    if K % ob.BLCK[t]:
+        pytest.skip("k-quants need K % 256 == 0")
+    rng = np.random.default_rng(K * 31 + M + N + t)
+    w = synth.quantized_matrix(oracle, t, M, K, rng)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    dw = g.Weight(t, w, K, M)
+    got = dw.mul_mat(x)
+    exp = oracle.mul_mat(t, w, K, M, x, 4)
+    dw.free()
+    assert relrms(got, exp) <= TOL, relrms(got, exp)
+
+
+@pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
+def test_mul_mat_golden(golden, t):
+    gm = golden["mul_mat"]
+    nm = ob.TYPE_NAME[t]
+    dw = g.Weight(t, gm[f"{nm}_w"], 512, 48)
+    got = dw.mul_mat(gm[f"{nm}_x"])
+    dw.free()
+    assert relrms(got, gm[f"{nm}_y_scalar"]) <= TOL
+    assert relrms(got, gm[f"{nm}_y_avx"]) <= 1e-3          # other rounding flavour of the activation quantizer
+
+
+def _integer_case(t, K, M, rng):
+    """weights/activations whose scales are exactly 1 so that every partial sum is an integer < 2^24:
+    the result is then independent of summation order and must be BIT-EXACT."""
+    x = rng.integers(-127, 128, size=(2, K)).astype(np.float32)
+    x[:, ::32] = 127.0                                  # amax = 127 in every block -> d = 1 (Q8_0/Q8_1)
+    if t == ob.Q8_0:
+        blk = np.zeros((M, K // 32, 34), np.uint8)
+        blk[:, :, 0:2] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+        blk[:, :, 2:] = rng.integers(-20, 21, size=(M, K // 32, 32)).astype(np.int8).view(np.uint8)
+        return blk.reshape(M, -1), x
+    if t == ob.Q4_0:
+        blk = np.zeros((M, K // 32, 18), np.uint8)
+        blk[:, :, 0:2] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+        blk[:, :, 2:] = rng.integers(0, 256, size=(M, K // 32, 16), dtype=np.uint8)
+        return blk.reshape(M, -1), x
+    raise AssertionError
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q8_0])
+@pytest.mark.parametrize("K", [64, 4544, 18176])
+def test_integer_dot_bit_exact(oracle, t, K):
+    rng = np.random.default_rng(K + t)
+    M = 67
+    w, x = _integer_case(t, K, M, rng)
+    dw = g.Weight(t, w, K, M)
+    got = dw.mul_mat(x)
+    dw.free()
+    exp = oracle.mul_mat(t, w, K, M, x, 2)
+    assert np.array_equal(got, exp)
+    # and against plain integer arithmetic
+    deq = np.stack([oracle.dequantize(t, w[r], K) for r in range(M)]).astype(np.int64)
+    assert np.array_equal(got.astype(np.int64), x.astype(np.int64) @ deq.T)
+
+
+def test_epilogues(oracle):
+    L = g.load()
+    rng = np.random.default_rng(5)
+    K, M, N = 512, 100, 2
+    t = ob.Q4_0
+    w = synth.quantized_matrix(oracle, t, M, K, rng)
+    x = rng.standard_normal((N, K)).astype(np.float32) * 3
+    a1 = rng.standard_normal((N, M)).astype(np.float32)
+    a2 = rng.standard_normal((N, M)).astype(np.float32)
+    base = oracle.mul_mat(t, w, K, M, x, 2)
+    dw = g.Weight(t, w, K, M)
+    acts = L.ggml_hip_acts_alloc(ob.Q8_0, K, N)
+    xb, yb, b1, b2 = g.DevBuf(host=x), g.DevBuf(N * M * 4), g.DevBuf(host=a1), g.DevBuf(host=a2)
+    L.ggml_hip_quantize_acts(acts, xb.ptr, K, N)
+    L.ggml_hip_mul_mat_q_acts(dw.h, acts, N, yb.ptr, M, 0, None, None)
+    plain = yb.to_host(np.float32, (N, M))
+    assert relrms(plain, base) <= TOL
+    L.ggml_hip_mul_mat_q_acts(dw.h, acts, N, yb.ptr, M, 1, None, None)
+    assert np.array_equal(yb.to_host(np.float32, (N, M)), oracle.gelu(plain))
+    L.ggml_hip_mul_mat_q_acts(dw.h, acts, N, yb.ptr, M, 2, b1.ptr, b2.ptr)
+    assert np.array_equal(yb.to_host(np.float32, (N, M)), (plain + a1) + a2)
+    # in place: dst aliases add2 (the residual stream update of a decoder block)
+    L.ggml_hip_mul_mat_q_acts(dw.h, acts, N, b2.ptr, M, 2, b1.ptr, b2.ptr)
+    assert np.array_equal(b2.to_host(np.float32, (N, M)), (plain + a1) + a2)
+    L.ggml_hip_acts_free(acts)
+    dw.free()
+
+
+@pytest.mark.parametrize("t,K,M", [(ob.Q4_0, 4544, 4672), (ob.Q4_0, 18176, 4544), (ob.Q4_K, 8192, 9216), (ob.Q6_K, 32768, 1024), (ob.Q2_K, 8192, 4100)])
+def test_falcon_shapes_properties(oracle, t, K, M):
+    """BASELINE-size shapes: sampled rows against the oracle + batch-invariance (N=1 vs N=4 columns bit-identical)"""
+    rng = np.random.default_rng(K + M)
+    w = synth.quantized_matrix(oracle, t, M, K, rng) if t in ob.KQUANTS else \
+        oracle.quantize(t, (rng.standard_normal((M, K)) * 0.02).astype(np.float32)).reshape(M, -1)
+    x = rng.standard_normal((4, K)).astype(np.float32)
+    dw = g.Weight(t, w, K, M)
+    y4 = dw.mul_mat(x)
+    y1 = np.concatenate([dw.mul_mat(x[i:i + 1]) for i in range(4)])
+    dw.free()
+    assert np.array_equal(y4, y1)
+    rows = rng.choice(M, size=24, replace=False)
+    exp = oracle.mul_mat(t, np.ascontiguousarray(w[rows]), K, len(rows), x, 4)
+    assert relrms(y4[:, rows], exp) <= TOL
