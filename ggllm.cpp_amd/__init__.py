@@ -29,7 +29,8 @@ ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_decode_greedy
-falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph""".split()
+falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
+falcon_hip_context_set_fused""".split()
 
 
 def build(verbose=False):
@@ -85,7 +86,7 @@ def load():
         "falcon_hip_decode_greedy": (C.c_int, [vp, i32, C.c_int, C.c_int, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)          # AttributeError here = an include/*.h symbol is not exported
@@ -240,6 +241,9 @@ class FalconModel:
         out = np.zeros(n_steps, np.int32)
         L.falcon_hip_decode_greedy(self.ctx, int(first_token), n_past, n_steps, out.ctypes.data)
         return out
+
+    def set_fused(self, on):
+        load().falcon_hip_context_set_fused(self.ctx, 1 if on else 0)
 
     def weight_bytes(self):
         return load().falcon_hip_model_weight_bytes(self.m)

@@ -51,6 +51,7 @@ struct falcon_hip_context {
     std::vector<float> logits_host;
     std::vector<void *> allocs;
     bool use_graph = false;
+    bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
     hipGraphExec_t decode_graph = nullptr;
     int  graph_base = -1;                      // n_past the captured graph was built for
 };
@@ -222,6 +223,10 @@ extern "C" void falcon_hip_get_hidden(falcon_hip_context * c, float * dst) {
     HIP_CHECK(hipMemcpy(dst, c->hidden_dev, (size_t)(c->m->layers.size() + 1) * c->hidden_tokens * c->m->hp.n_embd * 4, hipMemcpyDeviceToHost));
 }
 extern "C" void falcon_hip_context_use_graph(falcon_hip_context * c, int enable) { c->use_graph = enable != 0; }
+extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int enable) {
+    if (c->fused_decode != (enable != 0) && c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
+    c->fused_decode = enable != 0;
+}
 
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
@@ -236,6 +241,37 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     if (m->first_stage()) fq_launch_dequant_rows(m->tok_emb, c->tokens_dev, N, c->x, st);    // ggml_get_rows, libfalcon.cpp:2120
 
     auto acts = [&](const fq_act & a, int64_t n) { fq_act v = a; v.ncols = n; return v; };
+    if (N == 1 && c->fused_decode) {
+        // ---- fused single-token path: 3 launches per block (kernels_decode.hip), bit-identical to the list below
+        for (size_t li = 0; li < m->layers.size(); ++li) {
+            const layer_weights & L = m->layers[li];
+            if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
+            const int ff_act = fq_desc(L.down.type).act_type;
+            const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
+            fq_gemv_ln_args ga{};
+            ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table;
+            ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
+            ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, (int)((QKV + 31) / 32) };
+            fq_launch_gemv_ln(ga, st);
+            if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
+            float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
+            float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
+            fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table, c->att, st);
+            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, c->x, c->x };
+            fq_launch_gemv_out(go, st);
+        }
+        if (c->keep_hidden) {
+            HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
+            c->hidden_tokens = 1;
+        }
+        if (m->last_stage()) {
+            fq_gemv_ln_args ga{};
+            ga.x = c->x; ga.E = E; ga.nseg = 1; ga.gelu_table = hc.gelu_table;
+            ga.seg[0] = { m->lm_head, m->out_norm_w, m->out_norm_b, FQ_LNEPI_STORE, c->logits_dev, nullptr, 0, 0 };
+            fq_launch_gemv_ln(ga, st);
+        }
+        return;
+    }
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const layer_weights & L = m->layers[li];
         if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));

@@ -1,0 +1,128 @@
+// fq_block_dev.h -- device building blocks shared by the stand-alone kernels (kernels_quant.hip, kernels_block.hip)
+// and by the fused decode kernels (kernels_decode.hip): identical arithmetic => bit-identical results on both paths.
+#pragma once
+#include "fq_device.h"
+#include "fq_units.h"
+
+// pointers into one activation image (fq_types.h), in global memory or LDS
+struct act_image_ptr { int8_t * qs; float * d; uint8_t * aux; };
+
+__device__ __forceinline__ act_image_ptr act_image_at(uint8_t * base, int act_type, int64_t K) {
+    return { (int8_t *) base, (float *)(base + fq_act_d_off(act_type, K)), base + fq_act_aux_off(act_type, K) };
+}
+
+// ---- Q8_0 / Q8_1 (ggml.c:1106-1129, 1292-1325): one thread = 4 consecutive elements (quad q4 of the row), the 8
+// threads of a 32-block are 8 consecutive lanes. All 8 lanes of a group must call together.
+template <int ACT>
+__device__ __forceinline__ void quant_q8_quad(const float4 v, int64_t q4, const act_image_ptr & o, bool live) {
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    const float d  = amax / 127.0f;                       // ggml.c:1116 / 1302
+    const float id = d ? 1.0f / d : 0.0f;
+    const int q0 = (int) roundf(v.x * id), q1 = (int) roundf(v.y * id), q2 = (int) roundf(v.z * id), q3 = (int) roundf(v.w * id);
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (live) {
+        *(uint32_t *)(o.qs + 4 * q4) = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        if ((q4 & 7) == 0) {
+            const int64_t b = q4 >> 3;
+            if constexpr (ACT == FQ_Q8_0) {
+                o.d[b] = h2f_bits(f2h_bits(d));                           // the block stores d as fp16 (ggml.c:1120)
+                ((int32_t *) o.aux)[b] = s;
+            } else {
+                o.d[b] = d;                                               // ggml.c:1306
+                ((float *) o.aux)[b] = (float) s * d;                     // ggml.c:1323  y.s = sum*d
+            }
+        }
+    }
+}
+
+// ---- Q8_K (k_quants.c:899-934): one WAVE = one 256-element super-block sb, lane l holds elements 4l..4l+3.
+__device__ __forceinline__ void quant_q8K_wave(const float4 v, int lane, int64_t sb, const act_image_ptr & o) {
+    // element of largest magnitude, FIRST one on ties (strict '>' scan, k_quants.c:906-911)
+    float ax = fabsf(v.x), mx = v.x; int idx = 4 * lane;
+    if (fabsf(v.y) > ax) { ax = fabsf(v.y); mx = v.y; idx = 4 * lane + 1; }
+    if (fabsf(v.z) > ax) { ax = fabsf(v.z); mx = v.z; idx = 4 * lane + 2; }
+    if (fabsf(v.w) > ax) { ax = fabsf(v.w); mx = v.w; idx = 4 * lane + 3; }
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+        const float oax = __shfl_xor(ax, o2), omx = __shfl_xor(mx, o2); const int oidx = __shfl_xor(idx, o2);
+        if (oax > ax || (oax == ax && oidx < idx)) { ax = oax; mx = omx; idx = oidx; }
+    }
+    int8_t  * qo = o.qs + 256 * sb + 4 * lane;
+    int16_t * bs = (int16_t *) o.aux + 16 * sb;
+    if (ax == 0.0f) {
+        *(uint32_t *) qo = 0u;
+        if ((lane & 3) == 0) bs[lane >> 2] = 0;
+        if (lane == 0) o.d[sb] = 0.0f;
+        return;
+    }
+    const float iscale = -128.0f / mx;
+    int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y);     // nearest_int: round-half-even (k_quants.c:50-55)
+    int q2 = (int) __builtin_rintf(iscale * v.z), q3 = (int) __builtin_rintf(iscale * v.w);
+    q0 = q0 > 127 ? 127 : q0; q1 = q1 > 127 ? 127 : q1; q2 = q2 > 127 ? 127 : q2; q3 = q3 > 127 ? 127 : q3;
+    *(uint32_t *) qo = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
+    if (lane == 0) o.d[sb] = 1.0f / iscale;
+}
+
+// quantize one f32 row of length K held in LDS (or global) into an image, by a whole 256-thread workgroup
+template <int ACT>
+__device__ __forceinline__ void quantize_row_block(const float * __restrict__ row, int64_t K, const act_image_ptr & o) {
+    const int tid = threadIdx.x;
+    if constexpr (ACT == FQ_Q8_K) {
+        const int lane = tid & 63;
+        for (int64_t sb = tid >> 6; sb < (K >> 8); sb += (blockDim.x >> 6))
+            quant_q8K_wave(*(const float4 *)(row + 256 * sb + 4 * lane), lane, sb, o);
+    } else {
+        const int64_t quads = K >> 2;
+        for (int64_t q4 = tid; q4 < ((quads + 63) & ~(int64_t) 63); q4 += blockDim.x) {
+            const bool live = q4 < quads;
+            quant_q8_quad<ACT>(*(const float4 *)(row + 4 * (live ? q4 : quads - 1)), live ? q4 : quads - 1, o, live);
+        }
+    }
+}
+
+// ---- layer norm of one row by a 256-thread workgroup (ggml.c:10540-10594 + libfalcon.cpp:2166-2188).
+// x: global, n % 4 == 0. Result (norm * w + b, or plain norm when w == nullptr) is left in `row` (LDS, n floats).
+// All global loads of a chunk are issued before the first use (a single row is latency- not bandwidth-bound).
+__device__ __forceinline__ void layer_norm_row_block(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
+                                                     const float * __restrict__ b, float * row, double * red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t nv = n >> 2;
+    double s = 0.0;
+    for (int64_t base = 0; base < nv; base += 8 * nt) {
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t) k * nt + tid; t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = base + (int64_t) k * nt + tid;
+            if (i < nv) { ((float4 *) row)[i] = t[k]; s += (double) t[k].x; s += (double) t[k].y; s += (double) t[k].z; s += (double) t[k].w; }
+        }
+    }
+    s = block_sum(s, red);
+    const float mean = (float)(s / (double) n);
+    double s2 = 0.0;
+    for (int64_t i = tid; i < nv; i += nt) {
+        float4 v = ((float4 *) row)[i];
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        ((float4 *) row)[i] = v;
+        s2 += (double)(v.x * v.x); s2 += (double)(v.y * v.y); s2 += (double)(v.z * v.z); s2 += (double)(v.w * v.w);
+    }
+    s2 = block_sum(s2, red);
+    const float variance = (float)(s2 / (double) n);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+    for (int64_t i = tid; i < nv; i += nt) {
+        float4 v = ((float4 *) row)[i];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (w) {
+            const float4 ww = ((const float4 *) w)[i], bb = ((const float4 *) b)[i];
+            v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
+        }
+        ((float4 *) row)[i] = v;
+    }
+    __syncthreads();
+}

@@ -35,3 +35,28 @@ void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * 
 // att[N][H*D] = softmax(mask(K.Q * scale)) V, one workgroup per (head, token)
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                            const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);
+
+// kernels_decode.hip -- fused N = 1 decode kernels
+enum { FQ_LNEPI_STORE = 0, FQ_LNEPI_GELU_QUANT = 1, FQ_LNEPI_GELU_STORE = 2 };
+struct fq_gemv_ln_seg {
+    fq_weight     w;               // K = n_embd rows of this segment
+    const float * ln_w, * ln_b;    // LayerNorm feeding the segment
+    int           epi;             // FQ_LNEPI_*
+    float *       dst;             // f32 output (STORE / GELU_STORE)
+    uint8_t *     dst_image;       // Q8_0 / Q8_1 activation image of length w.M (GELU_QUANT)
+    int           next_act_type;
+    int           block_begin;     // first workgroup of the segment (32 rows per workgroup)
+};
+struct fq_gemv_ln_args { const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; };
+struct fq_gemv_out_args {
+    fq_weight w_down, w_wo;
+    const uint8_t * act_ff_image;  // quantized gelu(up), image of length w_down.K
+    const float *   att;           // f32 attention output, quantized in the prologue
+    const float *   resid;         // residual stream (may alias dst)
+    float *         dst;
+};
+size_t fq_gemv_ln_lds(int type, int64_t E);
+void   fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st);
+void   fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st);
+void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
+                             float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);

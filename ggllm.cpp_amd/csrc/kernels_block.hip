@@ -10,7 +10,7 @@
 //   attention   K.Q (ggml.c:11049-11088, GQA broadcast i02 = i12/(H/HKV)), scale, causal mask (ggml.c:12300-12351),
 //               soft_max with the fp16 exp table and an f64 sum (ggml.c:12389-12456), V.P
 // Built with -ffp-contract=off.
-#include "fq_device.h"
+#include "fq_block_dev.h"
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------ layer norm
@@ -20,21 +20,9 @@ __global__ void __launch_bounds__(256) k_layer_norm(const float * __restrict__ x
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float  * row = (float *) smem;
     double * red = (double *)(smem + ((n * 4 + 15) & ~(int64_t) 15));
-    const float * xr = x + (int64_t) blockIdx.x * n;
+    layer_norm_row_block(x + (int64_t) blockIdx.x * n, n, w, b, row, red);
     float * yr = y + (int64_t) blockIdx.x * n;
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; row[i] = v; s += (double) v; }
-    s = block_sum(s, red);
-    const float mean = (float)(s / (double) n);
-    double s2 = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = row[i] - mean; row[i] = v; s2 += (double)(v * v); }
-    s2 = block_sum(s2, red);
-    const float variance = (float)(s2 / (double) n);
-    const float scale = 1.0f / sqrtf(variance + 1e-5f);
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = row[i] * scale;
-        yr[i] = w ? v * w[i] + b[i] : v;
-    }
+    for (int64_t i = threadIdx.x; i < (n >> 2); i += blockDim.x) ((float4 *) yr)[i] = ((const float4 *) row)[i];
 }
 
 void fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st) {

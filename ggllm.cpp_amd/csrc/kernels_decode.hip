@@ -1,0 +1,295 @@
+// kernels_decode.hip -- fused single-token (N = 1) decode kernels for a Falcon block (gfx950, wave64).
+//
+// A decode step streams ~117 MB of Q4_0 weights per block in ~18 us at HBM speed, so every extra launch (~1.5 us of
+// boundary + a few us of latency-bound prologue) costs as much as megabytes of weights. The stand-alone kernels
+// (layer norm, activation quantizer, rope, four GEMVs, attention, residual add) are therefore folded into three:
+//
+//   k_gemv_ln   rows [Wqkv | Wup]: every workgroup re-derives the LayerNorm of the 18 KB residual row and its Q8
+//               image in LDS (cheaper than a launch), streams 32 weight rows, and finishes with either a plain store
+//               (QKV) or GELU + Q8 quantization of its 32 outputs straight into the next mat-vec's activation image.
+//   k_attn_decode  per head: RoPE of q (and of the new k), KV append, K.Q, soft_max, V.P.
+//   k_gemv_out  x = (Wdown . q8(gelu(up)) + Wo . q8(att)) + x: two weight sources per output row, the attention
+//               output is quantized in the prologue, the residual is added in the epilogue.
+//
+// Arithmetic is the stand-alone kernels' arithmetic (same device functions, same per-lane unit order, same reductions):
+// logits are bit-identical to the unfused path, which the tests check.
+#include "fq_block_dev.h"
+#include "kernels.h"
+
+template <int TYPE> struct act_of { static constexpr int value =
+    (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1) ? FQ_Q8_1 : ((TYPE == FQ_Q4_0 || TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0) ? FQ_Q8_0 : FQ_Q8_K); };
+
+// R rows x all units of one weight matrix against one activation image in LDS; loads of a chunk issued back to back
+template <int TYPE, int R, int UNROLL>
+__device__ __forceinline__ void rows_dot(const fq_weight & w, int64_t row0, const fq_actcol & col, float (&acc)[R]) {
+    constexpr int ELEMS = fq_unit<TYPE>::ELEMS;
+    const int lane = threadIdx.x & 63;
+    const int units = (int)(w.K / ELEMS);
+    fq_wrow rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int64_t row = row0 + r; rows[r] = fq_row<TYPE>(w, row < w.M ? row : w.M - 1); }
+    for (int u0 = 0; u0 < units; u0 += 64 * UNROLL) {
+        fq_unit_regs regs[UNROLL][R];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int u = u0 + i * 64 + lane; const int uc = u < units ? u : units - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int u = u0 + i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); acc[r] += ok ? v : 0.0f; }
+        }
+    }
+}
+
+__device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_type, int64_t K) {
+    return { (const int8_t *) base, (const float *)(base + fq_act_d_off(act_type, K)), (const void *)(base + fq_act_aux_off(act_type, K)) };
+}
+
+// =============================================================================================== k_gemv_ln
+// one workgroup = 32 consecutive rows of one segment; wave w owns rows 8w..8w+7 (two passes of 4)
+template <int TYPE>
+__global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int ACT = act_of<TYPE>::value;
+    const int64_t E = a.E;
+    const int sidx = (a.nseg > 1 && (int) blockIdx.x >= a.seg[1].block_begin) ? 1 : 0;
+    const fq_gemv_ln_seg sg = sidx ? a.seg[1] : a.seg[0];       // whole-struct select: no runtime-indexed kernarg array
+    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    // LDS: f32 row [E] | image | out32 | reduction scratch
+    float   * rowf  = (float *) smem;
+    uint8_t * image = smem + (((size_t) E * 4 + 15) & ~(size_t) 15);
+    float   * out32 = (float *)(image + fq_act_col_bytes(ACT, E));
+    double  * red   = (double *)(out32 + 32);
+
+    layer_norm_row_block(a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
+    quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));       // identical to k_quantize_q8 / q8K
+    __syncthreads();
+    const fq_actcol col = actcol_at(image, ACT, E);
+
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        rows_dot<TYPE, 4, 2>(sg.w, row0 + 8 * wid + 4 * pass, col, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out32[8 * wid + 4 * pass + r] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                   // wave 0 finishes the 32 rows (lanes 32..63 mirror 0..31)
+        const int j = lane & 31;
+        const int64_t row = row0 + j;
+        float v = out32[j];
+        if (sg.epi == FQ_LNEPI_STORE) {
+            if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
+        } else {
+            v = h2f_bits(a.gelu_table[f2h_bits(v)]);                                  // ggml.c:3477-3484
+            if (sg.epi == FQ_LNEPI_GELU_STORE) {
+                if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
+            } else {                                                                  // GELU -> Q8_0 / Q8_1 block of 32
+                float amax = fabsf(v);
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+                const float d  = amax / 127.0f;
+                const float id = d ? 1.0f / d : 0.0f;
+                const int q = (int) roundf(v * id);
+                int s = q;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+                const act_image_ptr o = act_image_at(sg.dst_image, sg.next_act_type, sg.w.M);
+                if (lane < 32) o.qs[row] = (int8_t) q;
+                if (lane == 0) {
+                    const int64_t b = row0 >> 5;
+                    if (sg.next_act_type == FQ_Q8_0) { o.d[b] = h2f_bits(f2h_bits(d)); ((int32_t *) o.aux)[b] = s; }
+                    else                             { o.d[b] = d; ((float *) o.aux)[b] = (float) s * d; }
+                }
+            }
+        }
+    }
+}
+
+size_t fq_gemv_ln_lds(int type, int64_t E) {
+    const int act = fq_desc(type).act_type;
+    return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 32 * 4 + 64;
+}
+
+void fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st) {
+    int blocks = 0;
+    for (int s = 0; s < a.nseg; ++s) blocks = a.seg[s].block_begin + (int)((a.seg[s].w.M + 31) / 32);
+    const int type = a.seg[0].w.type;
+    const size_t lds = fq_gemv_ln_lds(type, a.E);
+#define FQ_CASE(T) case T: { \
+        if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
+        hipLaunchKernelGGL(k_gemv_ln<T>, dim3((unsigned) blocks), dim3(256), lds, st, a); } break;
+    switch (type) {
+        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
+        FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
+        default: fprintf(stderr, "ggml-hip: gemv_ln: unsupported weight type %d\n", type); exit(1);
+    }
+#undef FQ_CASE
+}
+
+// =============================================================================================== k_gemv_out
+// one workgroup = 8 consecutive output rows (wave w: rows 2w, 2w+1); x[row] = (down + wo) + x[row]
+template <int TYPE>
+__global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int ACT = act_of<TYPE>::value;
+    const int64_t E = a.w_wo.K, FF = a.w_down.K;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint8_t * img_ff  = smem;                                           // image of gelu(up), already quantized
+    uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
+
+    // stage the FF image (flat 16-byte copy, loads batched) and quantize the attention output into its image
+    {
+        const int64_t nvec = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
+        const fq_u4 * src = (const fq_u4 *) a.act_ff_image;
+        fq_u4 * dst = (fq_u4 *) img_ff;
+        for (int64_t base = 0; base < nvec; base += 8 * 256) {
+            fq_u4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + tid; t[k] = src[i < nvec ? i : nvec - 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + tid; if (i < nvec) dst[i] = t[k]; }
+        }
+    }
+    quantize_row_block<ACT>(a.att, E, act_image_at(img_att, ACT, E));
+    __syncthreads();
+
+    const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
+    float acc_d[2] = {0.0f, 0.0f}, acc_o[2] = {0.0f, 0.0f};
+    rows_dot<TYPE, 2, 4>(a.w_down, row0, actcol_at(img_ff, ACT, FF), acc_d);
+    rows_dot<TYPE, 2, 2>(a.w_wo,   row0, actcol_at(img_att, ACT, E), acc_o);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { acc_d[r] = wave_sum(acc_d[r]); acc_o[r] = wave_sum(acc_o[r]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t row = row0 + r;
+            if (row < a.w_wo.M) a.dst[row] = (acc_d[r] + acc_o[r]) + a.resid[row];                  // libfalcon.cpp:2399-2400
+        }
+    }
+}
+
+void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {
+    const int type = a.w_wo.type;
+    const int act = fq_desc(type).act_type;
+    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K);
+    const unsigned blocks = (unsigned)((a.w_wo.M + 7) / 8);
+#define FQ_CASE(T) case T: { \
+        if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
+        hipLaunchKernelGGL(k_gemv_out<T>, dim3(blocks), dim3(256), lds, st, a); } break;
+    switch (type) {
+        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
+        FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
+        default: fprintf(stderr, "ggml-hip: gemv_out: unsupported weight type %d\n", type); exit(1);
+    }
+#undef FQ_CASE
+}
+
+// =============================================================================================== k_attn_decode
+// one workgroup per query head, N = 1. Rotates q and the new k itself (ggml.c:12957-12978), appends k/v to the cache
+// (first head of each kv group), then K.Q / soft_max / V.P exactly as k_attention (kernels_block.hip) with the key at
+// position n_past taken from LDS instead of the cache. Loads are issued in batches of 4 (scores) / 8 (values).
+__global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                     const float * __restrict__ cs, float * __restrict__ kc, float * __restrict__ vc,
+                                                     const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
+    constexpr int D = 64, HALF = 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int np = *n_past_ptr, n_kv = np + 1;
+    const int group = H / HKV, hk = h / group;
+    float  * qr   = (float *) smem;                 // rotated q [64]
+    float  * kr   = qr + D;                         // rotated new k [64]
+    float  * vn   = kr + D;                         // new v [64]
+    float  * redf = vn + D;                         // 16 floats
+    double * red  = (double *)(redf + 16);          // 4 x 64 doubles
+    float  * p    = (float *)(red + 4 * D);         // n_kv scores
+    const float * qh = qkv + (int64_t) h * D;
+    const float * kh = qkv + (int64_t)(H + hk) * D;
+    const float * vh = qkv + (int64_t)(H + HKV + hk) * D;
+    if (tid < 2 * HALF) {
+        const int k = tid & (HALF - 1);
+        const float * src = tid < HALF ? qh : kh;
+        const float c = cs[((int64_t) np * HALF + k) * 2], s = cs[((int64_t) np * HALF + k) * 2 + 1];
+        const float x0 = src[k], x1 = src[k + HALF];
+        const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;                      // ggml.c:12974-12975
+        float * dst = tid < HALF ? qr : kr;
+        dst[k] = r0; dst[k + HALF] = r1;
+        if (tid >= HALF && h % group == 0) { float * o = kc + ((int64_t) np * HKV + hk) * D; o[k] = r0; o[k + HALF] = r1; }
+    } else if (tid < 2 * HALF + D) {
+        const int d = tid - 2 * HALF;
+        const float v = vh[d];
+        vn[d] = v;
+        if (h % group == 0) vc[((int64_t) np * HKV + hk) * D + d] = v;
+    }
+    __syncthreads();
+
+    const int sub = tid & 15, rowi = tid >> 4;
+    const float4 q4 = *(const float4 *)(qr + 4 * sub);
+    float lmax = -INFINITY;
+    for (int j0 = 0; j0 < n_kv; j0 += 64) {
+        float4 k4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + 16 * b + rowi;
+            const int jc = j < np ? j : (np > 0 ? np - 1 : 0);
+            k4[b] = (np > 0) ? *(const float4 *)(kc + ((int64_t) jc * HKV + hk) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + 16 * b + rowi;
+            if (j == np) k4[b] = *(const float4 *)(kr + 4 * sub);                     // the new key lives in LDS
+            double s = (double)(k4[b].x * q4.x); s += (double)(k4[b].y * q4.y); s += (double)(k4[b].z * q4.z); s += (double)(k4[b].w * q4.w);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            const float sc = (float) s * 0.125f;                                      // 1/sqrt(64), libfalcon.cpp:2313-2317
+            if (j < n_kv) { if (sub == 0) p[j] = sc; lmax = fmaxf(lmax, sc); }
+        }
+    }
+    const float mx = block_max(lmax, redf);
+    __syncthreads();
+    double lsum = 0.0;
+    for (int j = tid; j < n_kv; j += 256) {
+        const float e = h2f_bits(exp_tab[f2h_bits(p[j] - mx)]);                       // ggml.c:12436-12442
+        p[j] = e;
+        lsum += (double) e;
+    }
+    const double sum = block_sum(lsum, red);
+    const float inv = (float)(1.0 / sum);
+    __syncthreads();
+    for (int j = tid; j < n_kv; j += 256) p[j] *= inv;
+    __syncthreads();
+
+    const int d = tid & 63, part = tid >> 6;
+    double acc = 0.0;
+    for (int j0 = part; j0 < np; j0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const int j = j0 + 4 * b; v[b] = vc[((int64_t)(j < np ? j : np - 1) * HKV + hk) * D + d]; }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const int j = j0 + 4 * b; if (j < np) acc += (double)(v[b] * p[j]); }
+    }
+    if ((np & 3) == part) acc += (double)(vn[d] * p[np]);                             // the new value, last of its residue class
+    red[part * 64 + d] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const double o = ((red[d] + red[64 + d]) + red[128 + d]) + red[192 + d];
+        att[(int64_t) h * D + d] = (float) o;
+    }
+}
+
+void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
+                           float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+    const size_t lds = (64 * 3 + 16) * 4 + 4 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15) + 64;
+    if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
+    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
+    hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att);
+}

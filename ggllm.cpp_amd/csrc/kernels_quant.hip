@@ -9,8 +9,7 @@
 //  * k_act_export    SoA activations -> ggml block_q8_0 / block_q8_1 / block_q8_K bytes (tests, shim)
 //
 // Built with -ffp-contract=off: every a*b+c below is two roundings, as in the reference C.
-#include "fq_device.h"
-#include "fq_units.h"
+#include "fq_block_dev.h"
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------ re-tile
@@ -127,78 +126,29 @@ __device__ __forceinline__ uint8_t * act_aux(const fq_act & a, int64_t col) { re
 // One thread = 4 consecutive elements, 8 threads = one 32-block. x is [ncols][K] with row stride ldx (floats).
 template <int ACT>
 __global__ void k_quantize_q8(const float * __restrict__ x, int64_t ldx, fq_act a) {
-    const int64_t K = a.K;
-    const int64_t quads_per_col = K >> 2;
+    const int64_t quads_per_col = a.K >> 2;
     const int64_t total = quads_per_col * a.ncols;
     // whole waves stay in the loop together (total is a multiple of 8 and the shuffles are within groups of 8)
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 63) & ~(int64_t) 63); i += (int64_t) gridDim.x * blockDim.x) {
         const bool live = i < total;
         const int64_t ii = live ? i : total - 1;
         const int64_t col = ii / quads_per_col, q4 = ii - col * quads_per_col;
-        const float4 v = *(const float4 *)(x + col * ldx + 4 * q4);
-        float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
-        const float d  = amax / 127.0f;                       // ggml.c:1116 / 1302
-        const float id = d ? 1.0f / d : 0.0f;
-        const int q0 = (int) roundf(v.x * id), q1 = (int) roundf(v.y * id), q2 = (int) roundf(v.z * id), q3 = (int) roundf(v.w * id);
-        int s = q0 + q1 + q2 + q3;
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-        if (live) {
-            const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-            *(uint32_t *)(act_qs(a, col) + 4 * q4) = packed;
-            if ((q4 & 7) == 0) {
-                const int64_t b = q4 >> 3;
-                if constexpr (ACT == FQ_Q8_0) {
-                    act_d(a, col)[b] = h2f_bits(f2h_bits(d));             // the block stores d as fp16 (ggml.c:1120)
-                    ((int32_t *) act_aux(a, col))[b] = s;
-                } else {
-                    act_d(a, col)[b] = d;                                 // ggml.c:1306
-                    ((float *) act_aux(a, col))[b] = (float) s * d;       // ggml.c:1323  y.s = sum*d
-                }
-            }
-        }
+        const act_image_ptr o = { act_qs(a, col), act_d(a, col), act_aux(a, col) };
+        quant_q8_quad<ACT>(*(const float4 *)(x + col * ldx + 4 * q4), q4, o, live);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ Q8_K
-// One wave = one 256-element super-block; lane l holds elements 4l..4l+3.
 __global__ void k_quantize_q8K(const float * __restrict__ x, int64_t ldx, fq_act a) {
-    const int64_t K = a.K;
-    const int64_t sb_per_col = K >> 8;
+    const int64_t sb_per_col = a.K >> 8;
     const int64_t total_sb = sb_per_col * a.ncols;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
     for (int64_t sbi = wave0; sbi < total_sb; sbi += nwaves) {
         const int64_t col = sbi / sb_per_col, sb = sbi - col * sb_per_col;
-        const float4 v = *(const float4 *)(x + col * ldx + 256 * sb + 4 * lane);
-        // element of largest magnitude, FIRST one on ties (strict '>' scan, k_quants.c:906-911)
-        float ax = fabsf(v.x), mx = v.x; int idx = 4 * lane;
-        if (fabsf(v.y) > ax) { ax = fabsf(v.y); mx = v.y; idx = 4 * lane + 1; }
-        if (fabsf(v.z) > ax) { ax = fabsf(v.z); mx = v.z; idx = 4 * lane + 2; }
-        if (fabsf(v.w) > ax) { ax = fabsf(v.w); mx = v.w; idx = 4 * lane + 3; }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float oax = __shfl_xor(ax, o), omx = __shfl_xor(mx, o); const int oidx = __shfl_xor(idx, o);
-            if (oax > ax || (oax == ax && oidx < idx)) { ax = oax; mx = omx; idx = oidx; }
-        }
-        int8_t * qo = act_qs(a, col) + 256 * sb + 4 * lane;
-        int16_t * bs = (int16_t *) act_aux(a, col) + 16 * sb;
-        if (ax == 0.0f) {
-            *(uint32_t *) qo = 0u;
-            if ((lane & 3) == 0) bs[lane >> 2] = 0;
-            if (lane == 0) act_d(a, col)[sb] = 0.0f;
-            continue;
-        }
-        const float iscale = -128.0f / mx;
-        int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y);     // nearest_int = round-half-even (k_quants.c:50-55)
-        int q2 = (int) __builtin_rintf(iscale * v.z), q3 = (int) __builtin_rintf(iscale * v.w);
-        q0 = q0 > 127 ? 127 : q0; q1 = q1 > 127 ? 127 : q1; q2 = q2 > 127 ? 127 : q2; q3 = q3 > 127 ? 127 : q3;
-        *(uint32_t *) qo = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-        int s = q0 + q1 + q2 + q3;
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-        if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
-        if (lane == 0) act_d(a, col)[sb] = 1.0f / iscale;
+        const act_image_ptr o = { act_qs(a, col), act_d(a, col), act_aux(a, col) };
+        quant_q8K_wave(*(const float4 *)(x + col * ldx + 256 * sb + 4 * lane), lane, sb, o);
     }
 }
 

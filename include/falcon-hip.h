@@ -65,6 +65,8 @@ const float * falcon_hip_get_logits(falcon_hip_context * c);        /* host, n_v
 void  falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep);
 void  falcon_hip_get_hidden(falcon_hip_context * c, float * dst_host);
 void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* capture decode steps into a hipGraph */
+/* N == 1 evals: 1 (default) = fused decode kernels (3 launches per block), 0 = one launch per graph op (A/B, tests) */
+void  falcon_hip_context_set_fused(falcon_hip_context * c, int enable);
 
 #ifdef __cplusplus
 }

@@ -371,10 +371,26 @@ void orc_dequantize_row(int type, const void * in, float * y, int64_t k) {
 }
 
 /* ------------------------------------------------------------------ integer dot products */
+/* Test knob: association of the f32 sum over blocks. 0 = the reference's scalar left-to-right loop; 1 = 64 strided
+ * partial sums + butterfly (what a 64-lane wave does). Used only to MEASURE how far a legitimate re-association moves
+ * the logits of a whole model (tests/test_oracle_spread.py); the oracle proper always runs with 0. */
+static int g_sum_order = 0;
+void orc_set_sum_order(int mode) { g_sum_order = mode; }
+
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     const uint8_t * w = (const uint8_t *) wv;
     const uint8_t * a = (const uint8_t *) av;
     float sumf = 0.0f;
+    if (orc_blck_size(wtype) == 32 && g_sum_order == 1 && n > 32) {
+        const int at = orc_vec_dot_type(wtype);
+        float lane[64] = {0};
+        for (int64_t i = 0; i < n / 32; ++i) {
+            const float one = orc_vec_dot(wtype, 32, w + i * orc_type_size(wtype), a + i * orc_type_size(at));
+            lane[i & 63] += one;
+        }
+        for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; ++l) lane[l] = lane[l] + lane[l + o];
+        return lane[0];
+    }
     if (orc_blck_size(wtype) == 32) {
         const int at = orc_vec_dot_type(wtype);
         for (int64_t i = 0; i < n / 32; ++i, w += orc_type_size(wtype), a += orc_type_size(at)) {
