@@ -145,7 +145,7 @@ def main():
         L.ggml_hip_profile_end(C.byref(nl), C.byref(us), C.byref(by))
         if nl.value:
             ach = by.value / (us.value * 1e-6) / 1e9
-            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv", launches=nl.value,
+            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln + k_gemv_out (fused quantized mat-vec)", launches=nl.value,
                         avg_launch_us=us.value / nl.value, bytes_per_launch=by.value / nl.value)
     step_gbs = b_tok * tok_s / 1e9
     roof.update(step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok)

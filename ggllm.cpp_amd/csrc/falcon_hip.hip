@@ -252,13 +252,18 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table;
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, (int)((QKV + 31) / 32) };
+            const bool prof = fq_prof_active();
+            if (prof) fq_prof_open(st);
             fq_launch_gemv_ln(ga, st);
+            if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
             if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table, c->att, st);
             fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, c->x, c->x };
+            if (prof) fq_prof_open(st);
             fq_launch_gemv_out(go, st);
+            if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
         }
         if (c->keep_hidden) {
             HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
@@ -268,7 +273,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_gemv_ln_args ga{};
             ga.x = c->x; ga.E = E; ga.nseg = 1; ga.gelu_table = hc.gelu_table;
             ga.seg[0] = { m->lm_head, m->out_norm_w, m->out_norm_b, FQ_LNEPI_STORE, c->logits_dev, nullptr, 0, 0 };
+            const bool prof = fq_prof_active();
+            if (prof) fq_prof_open(st);
             fq_launch_gemv_ln(ga, st);
+            if (prof) fq_prof_close(st, (double) m->lm_head.bytes);
         }
         return;
     }

@@ -87,13 +87,28 @@ __device__ __forceinline__ void quantize_row_block(const float * __restrict__ ro
 
 // ---- layer norm of one row by a 256-thread workgroup (ggml.c:10540-10594 + libfalcon.cpp:2166-2188).
 // x: global, n % 4 == 0. Result (norm * w + b, or plain norm when w == nullptr) is left in `row` (LDS, n floats).
-// All global loads of a chunk are issued before the first use (a single row is latency- not bandwidth-bound).
-__device__ __forceinline__ void layer_norm_row_block(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
-                                                     const float * __restrict__ b, float * row, double * red) {
+// Split in two so that a fused kernel can issue the row's loads FIRST, then its weight-stream loads, and only then
+// wait for the row (vmcnt counts in order: loads issued after the row do not delay it).
+struct ln_row_regs { float4 t[8]; };
+
+__device__ __forceinline__ void layer_norm_issue(const float * __restrict__ x, int64_t n, ln_row_regs & r) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t nv = n >> 2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * nt + tid; r.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
+}
+
+__device__ __forceinline__ void layer_norm_finish(const ln_row_regs & r, const float * __restrict__ x, int64_t n,
+                                                  const float * __restrict__ w, const float * __restrict__ b, float * row, double * red) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t nv = n >> 2;
     double s = 0.0;
-    for (int64_t base = 0; base < nv; base += 8 * nt) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = (int64_t) k * nt + tid;
+        if (i < nv) { ((float4 *) row)[i] = r.t[k]; s += (double) r.t[k].x; s += (double) r.t[k].y; s += (double) r.t[k].z; s += (double) r.t[k].w; }
+    }
+    for (int64_t base = 8 * nt; base < nv; base += 8 * nt) {           // rows longer than 8192 floats (Falcon-180B)
         float4 t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t) k * nt + tid; t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
@@ -125,4 +140,11 @@ __device__ __forceinline__ void layer_norm_row_block(const float * __restrict__ 
         ((float4 *) row)[i] = v;
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void layer_norm_row_block(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
+                                                     const float * __restrict__ b, float * row, double * red) {
+    ln_row_regs r;
+    layer_norm_issue(x, n, r);
+    layer_norm_finish(r, x, n, w, b, row, red);
 }

@@ -204,6 +204,19 @@ extern "C" void ggml_hip_profile_end(int64_t * n_launches, double * total_us, do
     g_prof_ev.clear();
 }
 
+// bracket one launch (used by the fused decode path in falcon_hip.hip)
+bool fq_prof_active() { return g_prof_on; }
+void fq_prof_open(hipStream_t st) {
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, st));
+    g_prof_ev.emplace_back(e0, e1);
+}
+void fq_prof_close(hipStream_t st, double bytes) {
+    HIP_CHECK(hipEventRecord(g_prof_ev.back().second, st));
+    g_prof_bytes += bytes;
+}
+
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {
     hip_context & c = fq_ctx();
     if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }

@@ -19,16 +19,39 @@
 template <int TYPE> struct act_of { static constexpr int value =
     (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1) ? FQ_Q8_1 : ((TYPE == FQ_Q4_0 || TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0) ? FQ_Q8_0 : FQ_Q8_K); };
 
-// R rows x all units of one weight matrix against one activation image in LDS; loads of a chunk issued back to back
-template <int TYPE, int R, int UNROLL>
-__device__ __forceinline__ void rows_dot(const fq_weight & w, int64_t row0, const fq_actcol & col, float (&acc)[R]) {
-    constexpr int ELEMS = fq_unit<TYPE>::ELEMS;
-    const int lane = threadIdx.x & 63;
-    const int units = (int)(w.K / ELEMS);
-    fq_wrow rows[R];
+// ---- weight streaming helpers. Lane l owns units l, l+64, ... of each of R rows (fq_units.h). The first NPRE
+// unit-columns are ISSUED before the workgroup's prologue (so HBM streams while the LayerNorm / quantizer runs),
+// consumed after it; longer rows continue with a chunked loop. Per-lane accumulation order is u ascending on every
+// path, so the result does not depend on NPRE / UNROLL.
+template <int TYPE, int R>
+__device__ __forceinline__ void rows_ptrs(const fq_weight & w, int64_t row0, fq_wrow (&rows)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int64_t row = row0 + r; rows[r] = fq_row<TYPE>(w, row < w.M ? row : w.M - 1); }
-    for (int u0 = 0; u0 < units; u0 += 64 * UNROLL) {
+}
+template <int TYPE, int R, int NPRE>
+__device__ __forceinline__ void rows_issue(const fq_wrow (&rows)[R], int units, fq_unit_regs (&regs)[NPRE][R]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        const int u = i * 64 + lane; const int uc = u < units ? u : units - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
+    }
+}
+template <int TYPE, int R, int NPRE>
+__device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        const int u = i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); acc[r] += ok ? v : 0.0f; }
+    }
+}
+template <int TYPE, int R, int UNROLL>
+__device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int units, int u_begin, const fq_actcol & col, float (&acc)[R]) {
+    const int lane = threadIdx.x & 63;
+    for (int u0 = u_begin; u0 < units; u0 += 64 * UNROLL) {
         fq_unit_regs regs[UNROLL][R];
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) {
@@ -44,6 +67,17 @@ __device__ __forceinline__ void rows_dot(const fq_weight & w, int64_t row0, cons
         }
     }
 }
+
+// per-format shape of the fused GEMVs: R rows per pass and NPRE pre-issued unit columns, sized so that the
+// kernels keep >= 4 waves per SIMD (<= 128 VGPRs): all 714 / 568 workgroups of a Falcon-7B launch are then resident at
+// once (fq_unit_regs is 5 dwords for Q4_0 ... 12 for Q5_K)
+template <int TYPE> struct decode_cfg {
+    static constexpr bool four_bit = (TYPE == FQ_Q4_0 || TYPE == FQ_Q4_1 || TYPE == FQ_Q5_0 || TYPE == FQ_Q5_1);
+    static constexpr int LN_R     = 4;                                  // rows per pass in k_gemv_ln (8 rows per wave in total)
+    static constexpr int LN_NPRE  = four_bit ? 3 : 2;
+    static constexpr int OUT_NPRE_D = four_bit ? 4 : 2;                 // k_gemv_out, down projection (R = 2)
+    static constexpr int OUT_NPRE_O = four_bit ? 3 : 1;                 // k_gemv_out, attention projection
+};
 
 __device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_type, int64_t K) {
     return { (const int8_t *) base, (const float *)(base + fq_act_d_off(act_type, K)), (const void *)(base + fq_act_aux_off(act_type, K)) };
@@ -67,20 +101,37 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
     float   * out32 = (float *)(image + fq_act_col_bytes(ACT, E));
     double  * red   = (double *)(out32 + 32);
 
-    layer_norm_row_block(a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
-    quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));       // identical to k_quantize_q8 / q8K
+    constexpr int R = decode_cfg<TYPE>::LN_R, NPRE = decode_cfg<TYPE>::LN_NPRE, PASSES = 8 / R;
+    const int units = (int)(E / fq_unit<TYPE>::ELEMS);
+    // 1. the residual row's loads, 2. the first pass's weight loads, 3. LayerNorm + Q8 image while the weights stream
+    ln_row_regs xr;
+    layer_norm_issue(a.x, E, xr);
+    fq_wrow rows[R];
+    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows);
+    fq_unit_regs pre[NPRE][R];
+    rows_issue<TYPE, R, NPRE>(rows, units, pre);
+    layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
+    quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));        // identical to k_quantize_q8 / q8K
     __syncthreads();
     const fq_actcol col = actcol_at(image, ACT, E);
 
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        rows_dot<TYPE, 4, 2>(sg.w, row0 + 8 * wid + 4 * pass, col, acc);
+    for (int pass = 0; pass < PASSES; ++pass) {
+        float acc[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]);
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+        if (pass == 0) {
+            rows_consume<TYPE, R, NPRE>(pre, units, col, acc);
+            rows_dot_from<TYPE, R, 2>(rows, units, 64 * NPRE, col, acc);
+        } else {
+            rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R * pass, rows);
+            rows_dot_from<TYPE, R, (NPRE > 3 ? 4 : NPRE)>(rows, units, 0, col, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out32[8 * wid + 4 * pass + r] = acc[r];
+            for (int r = 0; r < R; ++r) out32[8 * wid + R * pass + r] = acc[r];
         }
     }
     __syncthreads();
@@ -148,26 +199,43 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     uint8_t * img_ff  = smem;                                           // image of gelu(up), already quantized
     uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
 
-    // stage the FF image (flat 16-byte copy, loads batched) and quantize the attention output into its image
-    {
-        const int64_t nvec = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
-        const fq_u4 * src = (const fq_u4 *) a.act_ff_image;
-        fq_u4 * dst = (fq_u4 *) img_ff;
-        for (int64_t base = 0; base < nvec; base += 8 * 256) {
-            fq_u4 t[8];
+    constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
+    const int units_d = (int)(FF / fq_unit<TYPE>::ELEMS), units_o = (int)(E / fq_unit<TYPE>::ELEMS);
+    const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
+    // 1. prologue loads (quantized gelu(up) image: flat 16-byte vectors; attention output: f32 row)
+    const int64_t nvec = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
+    const int64_t nq = E >> 2;
+    fq_u4  tf[8];
+    float4 ta[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + tid; t[k] = src[i < nvec ? i : nvec - 1]; }
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; tf[k] = ((const fq_u4 *) a.act_ff_image)[i < nvec ? i : nvec - 1]; }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + tid; if (i < nvec) dst[i] = t[k]; }
-        }
-    }
-    quantize_row_block<ACT>(a.att, E, act_image_at(img_att, ACT, E));
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; ta[k] = ((const float4 *) a.att)[i < nq ? i : nq - 1]; }
+    // 2. weight loads for both sources
+    fq_wrow rd[2], ro[2];
+    rows_ptrs<TYPE, 2>(a.w_down, row0, rd);
+    rows_ptrs<TYPE, 2>(a.w_wo, row0, ro);
+    fq_unit_regs pd[NPD][2], po[NPO][2];
+    rows_issue<TYPE, 2, NPD>(rd, units_d, pd);
+    rows_issue<TYPE, 2, NPO>(ro, units_o, po);
+    // 3. finish the prologue while the weights stream
+    float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));          // f32 copy of the attention row
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec) ((fq_u4 *) img_ff)[i] = tf[k]; }
+    for (int64_t i = 8 * 256 + tid; i < nvec; i += 256) ((fq_u4 *) img_ff)[i] = ((const fq_u4 *) a.act_ff_image)[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nq) ((float4 *) att_f)[i] = ta[k]; }
+    for (int64_t i = 8 * 256 + tid; i < nq; i += 256) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
+    __syncthreads();
+    quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
     __syncthreads();
 
-    const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
     float acc_d[2] = {0.0f, 0.0f}, acc_o[2] = {0.0f, 0.0f};
-    rows_dot<TYPE, 2, 4>(a.w_down, row0, actcol_at(img_ff, ACT, FF), acc_d);
-    rows_dot<TYPE, 2, 2>(a.w_wo,   row0, actcol_at(img_att, ACT, E), acc_o);
+    const fq_actcol col_d = actcol_at(img_ff, ACT, FF), col_o = actcol_at(img_att, ACT, E);
+    rows_consume<TYPE, 2, NPD>(pd, units_d, col_d, acc_d);
+    rows_dot_from<TYPE, 2, 4>(rd, units_d, 64 * NPD, col_d, acc_d);
+    rows_consume<TYPE, 2, NPO>(po, units_o, col_o, acc_o);
+    rows_dot_from<TYPE, 2, 2>(ro, units_o, 64 * NPO, col_o, acc_o);
 #pragma unroll
     for (int r = 0; r < 2; ++r) { acc_d[r] = wave_sum(acc_d[r]); acc_o[r] = wave_sum(acc_o[r]); }
     if (lane == 0) {
@@ -182,7 +250,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
 void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
-    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K);
+    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (size_t) a.w_wo.K * 4 + 16;
     const unsigned blocks = (unsigned)((a.w_wo.M + 7) / 8);
 #define FQ_CASE(T) case T: { \
         if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
