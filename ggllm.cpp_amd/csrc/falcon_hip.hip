@@ -249,7 +249,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             const int ff_act = fq_desc(L.down.type).act_type;
             const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
             fq_gemv_ln_args ga{};
-            ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table;
+            ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table; ga.dbg = hc.dbg_stamps;
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, (int)((QKV + 31) / 32) };
             const bool prof = fq_prof_active();
@@ -260,7 +260,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table, c->att, st);
-            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, c->x, c->x };
+            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, c->x, c->x, hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (prof) fq_prof_open(st);
             fq_launch_gemv_out(go, st);
             if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));

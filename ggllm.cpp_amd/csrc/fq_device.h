@@ -19,15 +19,53 @@
 #define FQ_WAVE 64
 
 #if defined(__HIPCC__)
-__device__ __forceinline__ float  wave_sum(float v)  {
+// ---- wave64 butterfly reductions, pairing order xor 1, 2, 4, 8, 16, 32 (ascending; oracle knob orc_set_sum_order(1)
+// uses the same association). Steps 1..8 stay inside a 16-lane row and use DPP (register-to-register, no LDS
+// crossbar): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after the first two steps every
+// lane of a quad holds the quad's value, so mirror pairings combine exactly the operands xor 4 / xor 8 would. Steps
+// 16 and 32 combine the four row results through v_readlane: (r0 + r1) + (r2 + r3).
+// FQ_SHFL_REDUCE selects plain __shfl_xor for every step (same association; used by the self-test as the reference).
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ float  dpp_mov(float v)  { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+template <int CTRL> __device__ __forceinline__ int    dpp_mov(int v)    { return dpp_i32<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned) dpp_i32<CTRL>((int)(unsigned) b), hi = (unsigned) dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, (long long)(((unsigned long long) hi << 32) | lo));
+}
+__device__ __forceinline__ float  lane_get(float v, int l)  { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ int    lane_get(int v, int l)    { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_get(double v, int l) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int)(unsigned) b, l), hi = (unsigned) __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long) hi << 32) | lo));
+}
+struct op_add { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct op_max { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+template <typename T, typename OP>
+__device__ __forceinline__ T wave_reduce_shfl(T v, OP op) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ __forceinline__ float  wave_max(float v)  {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+    for (int o = 1; o < 64; o <<= 1) v = op(v, __shfl_xor(v, o));
+    return v;
+}
+template <typename T, typename OP>
+__device__ __forceinline__ T wave_reduce(T v, OP op) {
+#if defined(FQ_SHFL_REDUCE)
+    return wave_reduce_shfl(v, op);
+#else
+    v = op(v, dpp_mov<0xB1>(v));        // quad_perm [1,0,3,2]  == xor 1
+    v = op(v, dpp_mov<0x4E>(v));        // quad_perm [2,3,0,1]  == xor 2
+    v = op(v, dpp_mov<0x141>(v));       // row_half_mirror      (pairs quad q with quad q^1)
+    v = op(v, dpp_mov<0x140>(v));       // row_mirror           (pairs 8-lane half with the other half)
+    const T r0 = lane_get(v, 0), r1 = lane_get(v, 16), r2 = lane_get(v, 32), r3 = lane_get(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+#endif
+}
+__device__ __forceinline__ float  wave_sum(float v)  { return wave_reduce(v, op_add()); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, op_add()); }
+__device__ __forceinline__ int    wave_sum(int v)    { return wave_reduce(v, op_add()); }
+__device__ __forceinline__ float  wave_max(float v)  { return wave_reduce(v, op_max()); }
 
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16) f); }   // RNE, keeps subnormals
 __device__ __forceinline__ float    h2f_bits(uint16_t h) { return (float) __builtin_bit_cast(_Float16, h); }

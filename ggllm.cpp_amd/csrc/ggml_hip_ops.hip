@@ -66,6 +66,17 @@ extern "C" int ggml_hip_init(int device) {
     return g_ctx.n_devices;
 }
 
+// phase stamps of the fused decode kernels: enable -> allocate/zero the buffer; read -> copy 2*4096*8 int64 to the host
+extern "C" void ggml_hip_debug_stamps(int enable, long long * out_host) {
+    hip_context & c = fq_ctx();
+    const size_t n = 2 * 4096 * 8 * sizeof(long long);
+    if (enable && !c.dbg_stamps) { HIP_CHECK(hipMalloc((void **) &c.dbg_stamps, n)); HIP_CHECK(hipMemset(c.dbg_stamps, 0, n)); }
+    if (out_host && c.dbg_stamps) { HIP_CHECK(hipStreamSynchronize(c.stream)); HIP_CHECK(hipMemcpy(out_host, c.dbg_stamps, n, hipMemcpyDeviceToHost)); }
+    if (!enable && c.dbg_stamps) { HIP_CHECK(hipFree(c.dbg_stamps)); c.dbg_stamps = nullptr; }
+}
+
+extern "C" int ggml_hip_selftest(void) { return fq_selftest_reduce(fq_ctx().stream); }
+
 extern "C" void * ggml_hip_stream(void) { return (void *) fq_ctx().stream; }
 
 extern "C" void * ggml_hip_malloc(size_t bytes) {

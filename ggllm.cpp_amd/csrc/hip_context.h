@@ -17,6 +17,7 @@ struct hip_context {
     uint16_t *  gelu_table = nullptr;     // device, 65536 x fp16
     uint16_t *  exp_table = nullptr;      // device, 65536 x fp16
     int *       scalar_i32 = nullptr;     // device scratch scalar for the op-level API
+    long long * dbg_stamps = nullptr;     // optional phase-stamp buffer (ggml_hip_debug_stamps), 2 x 4096 x 8 entries
 };
 
 hip_context & fq_ctx();

@@ -36,6 +36,8 @@ void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * 
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                            const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);
 
+int    fq_selftest_reduce(hipStream_t st);   // 0 = DPP wave reductions agree with the __shfl_xor butterfly
+
 // kernels_decode.hip -- fused N = 1 decode kernels
 enum { FQ_LNEPI_STORE = 0, FQ_LNEPI_GELU_QUANT = 1, FQ_LNEPI_GELU_STORE = 2 };
 struct fq_gemv_ln_seg {
@@ -47,13 +49,14 @@ struct fq_gemv_ln_seg {
     int           next_act_type;
     int           block_begin;     // first workgroup of the segment (32 rows per workgroup)
 };
-struct fq_gemv_ln_args { const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; };
+struct fq_gemv_ln_args { const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg; };
 struct fq_gemv_out_args {
     fq_weight w_down, w_wo;
     const uint8_t * act_ff_image;  // quantized gelu(up), image of length w_down.K
     const float *   att;           // f32 attention output, quantized in the prologue
     const float *   resid;         // residual stream (may alias dst)
     float *         dst;
+    long long *     dbg;           // optional phase stamps (wall_clock64), 8 per workgroup
 };
 size_t fq_gemv_ln_lds(int type, int64_t E);
 void   fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st);

@@ -147,3 +147,37 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     hipLaunchKernelGGL(k_attention, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
 }
+
+// ------------------------------------------------------------------------------------------------ self-test
+// DPP/readlane wave reductions against the plain __shfl_xor butterfly (same pairing order): must agree bit for bit.
+__global__ void k_selftest_reduce(int * __restrict__ mismatches, unsigned seed) {
+    const int lane = threadIdx.x & 63;
+    unsigned h = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    for (int it = 0; it < 64; ++it) {
+        h = h * 1664525u + 1013904223u;
+        const float  f = __builtin_bit_cast(float, (h & 0x007FFFFFu) | 0x3F800000u) * ((h >> 24) & 1 ? -3.7f : 1.3f) * (float)(1 + (h >> 28));
+        const double d = (double) f * 1.000000119 + 1e-9 * (double)(h & 1023);
+        const int    i = (int)(h >> 7) - (1 << 23);
+        const float  fa = wave_reduce(f, op_add()), fb = wave_reduce_shfl(f, op_add());
+        const double da = wave_reduce(d, op_add()), db = wave_reduce_shfl(d, op_add());
+        const int    ia = wave_reduce(i, op_add()), ib = wave_reduce_shfl(i, op_add());
+        const float  ma = wave_reduce(f, op_max()), mb = wave_reduce_shfl(f, op_max());
+        int bad = 0;
+        bad += __builtin_bit_cast(int, fa) != __builtin_bit_cast(int, fb);
+        bad += __builtin_bit_cast(long long, da) != __builtin_bit_cast(long long, db);
+        bad += ia != ib;
+        bad += __builtin_bit_cast(int, ma) != __builtin_bit_cast(int, mb);
+        if (bad) atomicAdd(mismatches, bad);
+        (void) lane;
+    }
+}
+int fq_selftest_reduce(hipStream_t st) {
+    int * dev = nullptr; int host = -1;
+    HIP_CHECK(hipMalloc((void **) &dev, 4));
+    HIP_CHECK(hipMemsetAsync(dev, 0, 4, st));
+    hipLaunchKernelGGL(k_selftest_reduce, dim3(64), dim3(256), 0, st, dev, 12345u);
+    HIP_CHECK(hipMemcpyAsync(&host, dev, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(dev));
+    return host;
+}

@@ -16,6 +16,8 @@
 #include "fq_block_dev.h"
 #include "kernels.h"
 
+#define FQ_STAMP(dbg, slot) do { if ((dbg) && threadIdx.x == 0) (dbg)[(size_t) blockIdx.x * 8 + (slot)] = (long long) wall_clock64(); } while (0)
+
 template <int TYPE> struct act_of { static constexpr int value =
     (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1) ? FQ_Q8_1 : ((TYPE == FQ_Q4_0 || TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0) ? FQ_Q8_0 : FQ_Q8_K); };
 
@@ -104,15 +106,19 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
     constexpr int R = decode_cfg<TYPE>::LN_R, NPRE = decode_cfg<TYPE>::LN_NPRE, PASSES = 8 / R;
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
     // 1. the residual row's loads, 2. the first pass's weight loads, 3. LayerNorm + Q8 image while the weights stream
+    FQ_STAMP(a.dbg, 0);
     ln_row_regs xr;
     layer_norm_issue(a.x, E, xr);
     fq_wrow rows[R];
     rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows);
     fq_unit_regs pre[NPRE][R];
     rows_issue<TYPE, R, NPRE>(rows, units, pre);
+    FQ_STAMP(a.dbg, 1);
     layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
+    FQ_STAMP(a.dbg, 2);
     quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));        // identical to k_quantize_q8 / q8K
     __syncthreads();
+    FQ_STAMP(a.dbg, 3);
     const fq_actcol col = actcol_at(image, ACT, E);
 
 #pragma unroll
@@ -133,6 +139,7 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) out32[8 * wid + R * pass + r] = acc[r];
         }
+        FQ_STAMP(a.dbg, 4 + pass);
     }
     __syncthreads();
     if (tid < 64) {                                   // wave 0 finishes the 32 rows (lanes 32..63 mirror 0..31)
@@ -165,6 +172,7 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
             }
         }
     }
+    FQ_STAMP(a.dbg, 7);
 }
 
 size_t fq_gemv_ln_lds(int type, int64_t E) {
@@ -202,6 +210,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
     const int units_d = (int)(FF / fq_unit<TYPE>::ELEMS), units_o = (int)(E / fq_unit<TYPE>::ELEMS);
     const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
+    FQ_STAMP(a.dbg, 0);
     // 1. prologue loads (quantized gelu(up) image: flat 16-byte vectors; attention output: f32 row)
     const int64_t nvec = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
     const int64_t nq = E >> 2;
@@ -219,6 +228,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     rows_issue<TYPE, 2, NPD>(rd, units_d, pd);
     rows_issue<TYPE, 2, NPO>(ro, units_o, po);
     // 3. finish the prologue while the weights stream
+    FQ_STAMP(a.dbg, 1);
     float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));          // f32 copy of the attention row
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec) ((fq_u4 *) img_ff)[i] = tf[k]; }
@@ -227,13 +237,17 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nq) ((float4 *) att_f)[i] = ta[k]; }
     for (int64_t i = 8 * 256 + tid; i < nq; i += 256) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
     __syncthreads();
+    FQ_STAMP(a.dbg, 2);
     quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
     __syncthreads();
+    FQ_STAMP(a.dbg, 3);
 
     float acc_d[2] = {0.0f, 0.0f}, acc_o[2] = {0.0f, 0.0f};
     const fq_actcol col_d = actcol_at(img_ff, ACT, FF), col_o = actcol_at(img_att, ACT, E);
     rows_consume<TYPE, 2, NPD>(pd, units_d, col_d, acc_d);
+    FQ_STAMP(a.dbg, 4);
     rows_dot_from<TYPE, 2, 4>(rd, units_d, 64 * NPD, col_d, acc_d);
+    FQ_STAMP(a.dbg, 5);
     rows_consume<TYPE, 2, NPO>(po, units_o, col_o, acc_o);
     rows_dot_from<TYPE, 2, 2>(ro, units_o, 64 * NPO, col_o, acc_o);
 #pragma unroll
@@ -245,6 +259,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
             if (row < a.w_wo.M) a.dst[row] = (acc_d[r] + acc_o[r]) + a.resid[row];                  // libfalcon.cpp:2399-2400
         }
     }
+    FQ_STAMP(a.dbg, 7);
 }
 
 void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {

@@ -22,6 +22,9 @@ typedef struct ggml_hip_acts   ggml_hip_acts;     /* quantized activations (Q8_0
 /* ---- device / memory plumbing (reference: ggml_init_cublas ggml-cuda.cu:1982-2041, pool 1738-1853) ---- */
 int     ggml_hip_init(int device);                /* idempotent; returns number of visible HIP devices        */
 int     ggml_hip_device_count(void);
+/* tuning aid: wall_clock64 phase stamps (8 per workgroup) of the last k_gemv_ln [0,4096) and k_gemv_out [4096,8192) */
+void    ggml_hip_debug_stamps(int enable, long long * out_host);
+int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
 void *  ggml_hip_stream(void);                    /* hipStream_t used for every launch of this library        */
 void *  ggml_hip_malloc(size_t bytes);
 void    ggml_hip_free(void * dev);

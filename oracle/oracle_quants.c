@@ -372,7 +372,7 @@ void orc_dequantize_row(int type, const void * in, float * y, int64_t k) {
 
 /* ------------------------------------------------------------------ integer dot products */
 /* Test knob: association of the f32 sum over blocks. 0 = the reference's scalar left-to-right loop; 1 = 64 strided
- * partial sums + butterfly (what a 64-lane wave does). Used only to MEASURE how far a legitimate re-association moves
+ * partial sums + xor butterfly in the order 1,2,4,..,32 (what the kernels' 64-lane wave reduction does). Used only to MEASURE how far a legitimate re-association moves
  * the logits of a whole model (tests/test_oracle_spread.py); the oracle proper always runs with 0. */
 static int g_sum_order = 0;
 void orc_set_sum_order(int mode) { g_sum_order = mode; }
@@ -388,7 +388,8 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
             const float one = orc_vec_dot(wtype, 32, w + i * orc_type_size(wtype), a + i * orc_type_size(at));
             lane[i & 63] += one;
         }
-        for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; ++l) lane[l] = lane[l] + lane[l + o];
+        /* xor butterfly, pairing order 1, 2, 4, ..., 32 (every lane ends with the total; lane 0 is returned) */
+        for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
         return lane[0];
     }
     if (orc_blck_size(wtype) == 32) {

@@ -17,6 +17,11 @@ def relrms(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
 
 
+def test_wave_reductions_selftest():
+    """DPP / readlane wave reductions == plain __shfl_xor butterfly, bit for bit (f32, f64, i32 sums and f32 max)"""
+    assert g.load().ggml_hip_selftest() == 0
+
+
 def test_tables_match_reference(oracle, golden):
     """the fp16 GELU / EXP tables the kernels index are the reference's (ggml.c:4276-4290), bit for bit"""
     L = g.load()
