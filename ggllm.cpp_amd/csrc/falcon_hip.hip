@@ -259,8 +259,12 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
-            fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table, c->att, st);
-            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, c->x, c->x, hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
+            const int att_act = fq_desc(L.wo.type).act_type;
+            const bool att_q = (att_act == FQ_Q8_0 || att_act == FQ_Q8_1);      // the head's 64 outputs = two 32-blocks
+            fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table,
+                                  att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
+            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, att_q ? c->act_att.base : nullptr, c->x, c->x,
+                                 hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (prof) fq_prof_open(st);
             fq_launch_gemv_out(go, st);
             if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));

@@ -16,12 +16,12 @@ __device__ __forceinline__ act_image_ptr act_image_at(uint8_t * base, int act_ty
 template <int ACT>
 __device__ __forceinline__ void quant_q8_quad(const float4 v, int64_t q4, const act_image_ptr & o, bool live) {
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    amax = reduce8(amax, op_max());
     const float d  = amax / 127.0f;                       // ggml.c:1116 / 1302
     const float id = d ? 1.0f / d : 0.0f;
     const int q0 = (int) roundf(v.x * id), q1 = (int) roundf(v.y * id), q2 = (int) roundf(v.z * id), q3 = (int) roundf(v.w * id);
     int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    s = reduce8(s, op_add());
     if (live) {
         *(uint32_t *)(o.qs + 4 * q4) = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
         if ((q4 & 7) == 0) {
@@ -44,11 +44,16 @@ __device__ __forceinline__ void quant_q8K_wave(const float4 v, int lane, int64_t
     if (fabsf(v.y) > ax) { ax = fabsf(v.y); mx = v.y; idx = 4 * lane + 1; }
     if (fabsf(v.z) > ax) { ax = fabsf(v.z); mx = v.z; idx = 4 * lane + 2; }
     if (fabsf(v.w) > ax) { ax = fabsf(v.w); mx = v.w; idx = 4 * lane + 3; }
-#pragma unroll
-    for (int o2 = 1; o2 < 64; o2 <<= 1) {
-        const float oax = __shfl_xor(ax, o2), omx = __shfl_xor(mx, o2); const int oidx = __shfl_xor(idx, o2);
-        if (oax > ax || (oax == ax && oidx < idx)) { ax = oax; mx = omx; idx = oidx; }
-    }
+    // butterfly over the 64 lanes; the winner rule is symmetric, so paired lanes always agree afterwards
+#define FQ_Q8K_STEP(oax, omx, oidx) do { const float a_ = (oax), m_ = (omx); const int i_ = (oidx); \
+        if (a_ > ax || (a_ == ax && i_ < idx)) { ax = a_; mx = m_; idx = i_; } } while (0)
+    FQ_Q8K_STEP(dpp_mov<0xB1>(ax),  dpp_mov<0xB1>(mx),  dpp_mov<0xB1>(idx));
+    FQ_Q8K_STEP(dpp_mov<0x4E>(ax),  dpp_mov<0x4E>(mx),  dpp_mov<0x4E>(idx));
+    FQ_Q8K_STEP(dpp_mov<0x141>(ax), dpp_mov<0x141>(mx), dpp_mov<0x141>(idx));
+    FQ_Q8K_STEP(dpp_mov<0x140>(ax), dpp_mov<0x140>(mx), dpp_mov<0x140>(idx));
+    FQ_Q8K_STEP(__shfl_xor(ax, 16), __shfl_xor(mx, 16), __shfl_xor(idx, 16));
+    FQ_Q8K_STEP(__shfl_xor(ax, 32), __shfl_xor(mx, 32), __shfl_xor(idx, 32));
+#undef FQ_Q8K_STEP
     int8_t  * qo = o.qs + 256 * sb + 4 * lane;
     int16_t * bs = (int16_t *) o.aux + 16 * sb;
     if (ax == 0.0f) {
@@ -63,7 +68,7 @@ __device__ __forceinline__ void quant_q8K_wave(const float4 v, int lane, int64_t
     q0 = q0 > 127 ? 127 : q0; q1 = q1 > 127 ? 127 : q1; q2 = q2 > 127 ? 127 : q2; q3 = q3 > 127 ? 127 : q3;
     *(uint32_t *) qo = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
     int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s);
     if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
     if (lane == 0) o.d[sb] = 1.0f / iscale;
 }

@@ -62,6 +62,12 @@ __device__ __forceinline__ T wave_reduce(T v, OP op) {
     return op(op(r0, r1), op(r2, r3));
 #endif
 }
+// butterflies over aligned groups of 8 / 16 / 32 lanes (every lane of the group ends with the group's result)
+template <typename T, typename OP> __device__ __forceinline__ T reduce8(T v, OP op) {
+    v = op(v, dpp_mov<0xB1>(v)); v = op(v, dpp_mov<0x4E>(v)); return op(v, dpp_mov<0x141>(v));
+}
+template <typename T, typename OP> __device__ __forceinline__ T reduce16(T v, OP op) { v = reduce8(v, op); return op(v, dpp_mov<0x140>(v)); }
+template <typename T, typename OP> __device__ __forceinline__ T reduce32(T v, OP op) { v = reduce16(v, op); return op(v, __shfl_xor(v, 16)); }
 __device__ __forceinline__ float  wave_sum(float v)  { return wave_reduce(v, op_add()); }
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, op_add()); }
 __device__ __forceinline__ int    wave_sum(int v)    { return wave_reduce(v, op_add()); }

@@ -53,7 +53,8 @@ struct fq_gemv_ln_args { const float * x; int64_t E; int nseg; fq_gemv_ln_seg se
 struct fq_gemv_out_args {
     fq_weight w_down, w_wo;
     const uint8_t * act_ff_image;  // quantized gelu(up), image of length w_down.K
-    const float *   att;           // f32 attention output, quantized in the prologue
+    const float *   att;           // f32 attention output, quantized in the prologue (used when att_image == nullptr)
+    const uint8_t * att_image;     // attention output already quantized by k_attn_decode (Q8_0 / Q8_1), or nullptr
     const float *   resid;         // residual stream (may alias dst)
     float *         dst;
     long long *     dbg;           // optional phase stamps (wall_clock64), 8 per workgroup
@@ -62,4 +63,5 @@ size_t fq_gemv_ln_lds(int type, int64_t E);
 void   fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st);
 void   fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st);
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
-                             float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);
+                             float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
+                             int att_act_type, hipStream_t st);

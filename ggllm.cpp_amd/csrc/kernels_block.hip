@@ -11,6 +11,7 @@
 //               soft_max with the fp16 exp table and an f64 sum (ggml.c:12389-12456), V.P
 // Built with -ffp-contract=off.
 #include "fq_block_dev.h"
+#include "fq_attn_dev.h"
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------ layer norm
@@ -82,12 +83,8 @@ void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// One 256-thread workgroup per (head, token). D = 64 (every Falcon). n_kv = n_past + t + 1 keys are visible.
-//   phase 1: 16 lanes per key row (one float4 each), f32 products accumulated in f64 -> score * 1/sqrt(D) -> LDS
-//   phase 2: max, exp via the fp16 table, f64 sum, scale by (float)(1/sum)
-//   phase 3: out[d] = sum_j V[j][d] * p[j], thread = (d, j mod 4), f64 accumulation
-// f64 accumulation of f32 products reproduces the reference's portable ggml_vec_dot_f32 (ggml.c:2296-2300) up to
-// the association of an f64 sum, i.e. bit-exact after the final rounding except with probability ~1e-9.
+// One 256-thread workgroup per (head, token); n_kv = n_past + t + 1 keys are visible, all read from the KV cache
+// (k_rope_kv has already appended this launch's keys). The arithmetic lives in fq_attn_dev.h.
 __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                    const float * __restrict__ kc, const float * __restrict__ vc,
                                                    const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
@@ -95,56 +92,19 @@ __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qk
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int h = blockIdx.x, t = blockIdx.y;
     const int n_kv = *n_past_ptr + t + 1;
-    float  * p    = (float *) smem;                                      // n_kv scores
-    double * red  = (double *)(smem + (((size_t) n_kv * 4 + 15) & ~(size_t) 15));   // 4 x 64 doubles
-    float  * redf = (float *)(red + 4 * 64);
     const int heads = H + 2 * HKV;
     const int hk = h / (H / HKV);
-    const float * q = qkv + ((int64_t) t * heads + h) * D;
-    const int tid = threadIdx.x, sub = tid & 15, rowi = tid >> 4;
-    const float4 q4 = *(const float4 *)(q + 4 * sub);
-
-    float lmax = -INFINITY;
-    for (int j0 = 0; j0 < n_kv; j0 += 16) {
-        const int j = j0 + rowi;
-        const int jc = j < n_kv ? j : n_kv - 1;
-        const float4 k4 = *(const float4 *)(kc + ((int64_t) jc * HKV + hk) * D + 4 * sub);
-        double s = (double)(k4.x * q4.x); s += (double)(k4.y * q4.y); s += (double)(k4.z * q4.z); s += (double)(k4.w * q4.w);
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        const float sc = (float) s * 0.125f;                             // 1/sqrt(64), libfalcon.cpp:2313-2317
-        if (sub == 0 && j < n_kv) p[j] = sc;
-        if (j < n_kv) lmax = fmaxf(lmax, sc);
-    }
-    const float mx = block_max(lmax, redf);
-    __syncthreads();
-    double lsum = 0.0;
-    for (int j = tid; j < n_kv; j += blockDim.x) {
-        const float e = h2f_bits(exp_tab[f2h_bits(p[j] - mx)]);          // ggml.c:12436-12442
-        p[j] = e;
-        lsum += (double) e;
-    }
-    const double sum = block_sum(lsum, red);
-    const float inv = (float)(1.0 / sum);
-    __syncthreads();
-    for (int j = tid; j < n_kv; j += blockDim.x) p[j] *= inv;
-    __syncthreads();
-
-    const int d = tid & 63, part = tid >> 6;
-    double acc = 0.0;
-    for (int j = part; j < n_kv; j += 4) acc += (double)(vc[((int64_t) j * HKV + hk) * D + d] * p[j]);
-    red[part * 64 + d] = acc;
-    __syncthreads();
-    if (tid < 64) {
-        const double o = ((red[d] + red[64 + d]) + red[128 + d]) + red[192 + d];
-        att[(int64_t) t * H * D + (int64_t) h * D + d] = (float) o;
-    }
+    const attn_lds L = attn_lds_carve(smem);
+    const float o = attn_head_block(qkv + ((int64_t) t * heads + h) * D, kc, vc, HKV, hk, n_kv, nullptr, nullptr, exp_tab, L);
+    if (threadIdx.x < 64) att[(int64_t) t * H * D + (int64_t) h * D + threadIdx.x] = o;
 }
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                          const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
     if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
-    const size_t lds = (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15) + 4 * 64 * 8 + 64;    // sized for the largest n_past + N the launch may see
+    const size_t lds = 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15);    // sized for the largest n_past + N the launch may see
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
+    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     hipLaunchKernelGGL(k_attention, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
 }
 

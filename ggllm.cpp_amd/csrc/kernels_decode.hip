@@ -14,6 +14,7 @@
 // Arithmetic is the stand-alone kernels' arithmetic (same device functions, same per-lane unit order, same reductions):
 // logits are bit-identical to the unfused path, which the tests check.
 #include "fq_block_dev.h"
+#include "fq_attn_dev.h"
 #include "kernels.h"
 
 #define FQ_STAMP(dbg, slot) do { if ((dbg) && threadIdx.x == 0) (dbg)[(size_t) blockIdx.x * 8 + (slot)] = (long long) wall_clock64(); } while (0)
@@ -103,16 +104,18 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
     float   * out32 = (float *)(image + fq_act_col_bytes(ACT, E));
     double  * red   = (double *)(out32 + 32);
 
-    constexpr int R = decode_cfg<TYPE>::LN_R, NPRE = decode_cfg<TYPE>::LN_NPRE, PASSES = 8 / R;
+    constexpr int R = 4, NPRE = decode_cfg<TYPE>::LN_NPRE;              // 8 rows per wave = two passes of 4
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
-    // 1. the residual row's loads, 2. the first pass's weight loads, 3. LayerNorm + Q8 image while the weights stream
+    // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
+    //    5. pass 1 (its loads overlap other workgroups' dots)
     FQ_STAMP(a.dbg, 0);
     ln_row_regs xr;
     layer_norm_issue(a.x, E, xr);
-    fq_wrow rows[R];
-    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows);
-    fq_unit_regs pre[NPRE][R];
-    rows_issue<TYPE, R, NPRE>(rows, units, pre);
+    fq_wrow rows0[R], rows1[R];
+    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
+    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
+    fq_unit_regs pre0[NPRE][R];
+    rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
     FQ_STAMP(a.dbg, 1);
     layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
     FQ_STAMP(a.dbg, 2);
@@ -120,26 +123,32 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
     __syncthreads();
     FQ_STAMP(a.dbg, 3);
     const fq_actcol col = actcol_at(image, ACT, E);
-
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
+    {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-        if (pass == 0) {
-            rows_consume<TYPE, R, NPRE>(pre, units, col, acc);
-            rows_dot_from<TYPE, R, 2>(rows, units, 64 * NPRE, col, acc);
-        } else {
-            rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R * pass, rows);
-            rows_dot_from<TYPE, R, (NPRE > 3 ? 4 : NPRE)>(rows, units, 0, col, acc);
-        }
+        rows_consume<TYPE, R, NPRE>(pre0, units, col, acc);
+        rows_dot_from<TYPE, R, 2>(rows0, units, 64 * NPRE, col, acc);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) out32[8 * wid + R * pass + r] = acc[r];
+            for (int r = 0; r < R; ++r) out32[8 * wid + r] = acc[r];
         }
-        FQ_STAMP(a.dbg, 4 + pass);
+        FQ_STAMP(a.dbg, 4);
+    }
+    {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+        rows_dot_from<TYPE, R, NPRE>(rows1, units, 0, col, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out32[8 * wid + R + r] = acc[r];
+        }
+        FQ_STAMP(a.dbg, 5);
     }
     __syncthreads();
     if (tid < 64) {                                   // wave 0 finishes the 32 rows (lanes 32..63 mirror 0..31)
@@ -153,15 +162,11 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
             if (sg.epi == FQ_LNEPI_GELU_STORE) {
                 if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
             } else {                                                                  // GELU -> Q8_0 / Q8_1 block of 32
-                float amax = fabsf(v);
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+                const float amax = reduce32(fabsf(v), op_max());
                 const float d  = amax / 127.0f;
                 const float id = d ? 1.0f / d : 0.0f;
                 const int q = (int) roundf(v * id);
-                int s = q;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+                const int s = reduce32(q, op_add());
                 const act_image_ptr o = act_image_at(sg.dst_image, sg.next_act_type, sg.w.M);
                 if (lane < 32) o.qs[row] = (int8_t) q;
                 if (lane == 0) {
@@ -210,16 +215,22 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
     const int units_d = (int)(FF / fq_unit<TYPE>::ELEMS), units_o = (int)(E / fq_unit<TYPE>::ELEMS);
     const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
+    (void) lane;
     FQ_STAMP(a.dbg, 0);
-    // 1. prologue loads (quantized gelu(up) image: flat 16-byte vectors; attention output: f32 row)
-    const int64_t nvec = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
-    const int64_t nq = E >> 2;
-    fq_u4  tf[8];
-    float4 ta[8];
+    // 1. prologue loads: the quantized gelu(up) image and either the already-quantized attention image (flat 16-byte
+    //    vectors, img_att directly follows img_ff in LDS) or the f32 attention row (Q8_K: quantized here)
+    const int64_t nvec_ff = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
+    const int64_t nvec_at = a.att_image ? (int64_t)(fq_act_col_bytes(ACT, E) >> 4) : 0;
+    const int64_t nq = a.att_image ? 0 : (E >> 2);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 * src_ff = (const u32x4 *) a.act_ff_image;
+    const u32x4 * src_at = (const u32x4 *) (a.att_image ? a.att_image : a.act_ff_image);
+    u32x4 tf[8], tq[3];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; tf[k] = ((const fq_u4 *) a.act_ff_image)[i < nvec ? i : nvec - 1]; }
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; ta[k] = ((const float4 *) a.att)[i < nq ? i : nq - 1]; }
+    for (int k = 0; k < 3; ++k) { const int64_t i = (int64_t) k * 256 + tid; tq[k] = src_at[i < nvec_at ? i : 0]; }
+    __builtin_amdgcn_sched_barrier(0);
     // 2. weight loads for both sources
     fq_wrow rd[2], ro[2];
     rows_ptrs<TYPE, 2>(a.w_down, row0, rd);
@@ -227,18 +238,21 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     fq_unit_regs pd[NPD][2], po[NPO][2];
     rows_issue<TYPE, 2, NPD>(rd, units_d, pd);
     rows_issue<TYPE, 2, NPO>(ro, units_o, po);
-    // 3. finish the prologue while the weights stream
     FQ_STAMP(a.dbg, 1);
-    float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));          // f32 copy of the attention row
+    // 3. finish the prologue while the weights stream
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec) ((fq_u4 *) img_ff)[i] = tf[k]; }
-    for (int64_t i = 8 * 256 + tid; i < nvec; i += 256) ((fq_u4 *) img_ff)[i] = ((const fq_u4 *) a.act_ff_image)[i];
+    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec_ff) ((u32x4 *) img_ff)[i] = tf[k]; }
+    for (int64_t i = 8 * 256 + tid; i < nvec_ff; i += 256) ((u32x4 *) img_ff)[i] = src_ff[i];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nq) ((float4 *) att_f)[i] = ta[k]; }
-    for (int64_t i = 8 * 256 + tid; i < nq; i += 256) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
-    __syncthreads();
-    FQ_STAMP(a.dbg, 2);
-    quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
+    for (int k = 0; k < 3; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec_at) ((u32x4 *) img_att)[i] = tq[k]; }
+    for (int64_t i = 3 * 256 + tid; i < nvec_at; i += 256) ((u32x4 *) img_att)[i] = src_at[i];
+    if (nq) {
+        float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));      // f32 copy of the attention row
+        for (int64_t i = tid; i < nq; i += 256) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
+        __syncthreads();
+        FQ_STAMP(a.dbg, 2);
+        quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
+    }
     __syncthreads();
     FQ_STAMP(a.dbg, 3);
 
@@ -265,7 +279,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
 void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
-    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (size_t) a.w_wo.K * 4 + 16;
+    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (a.att_image ? 0 : (size_t) a.w_wo.K * 4) + 16;
     const unsigned blocks = (unsigned)((a.w_wo.M + 7) / 8);
 #define FQ_CASE(T) case T: { \
         if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
@@ -280,22 +294,22 @@ void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {
 
 // =============================================================================================== k_attn_decode
 // one workgroup per query head, N = 1. Rotates q and the new k itself (ggml.c:12957-12978), appends k/v to the cache
-// (first head of each kv group), then K.Q / soft_max / V.P exactly as k_attention (kernels_block.hip) with the key at
-// position n_past taken from LDS instead of the cache. Loads are issued in batches of 4 (scores) / 8 (values).
+// (first head of each kv group), runs fq_attn_dev.h with the newest key/value taken from LDS, and -- when the output
+// projection's activation format is Q8_0 / Q8_1 -- quantizes its 64 outputs (two 32-blocks) straight into the
+// activation image k_gemv_out stages, so no separate quantizer pass or f32 round trip is needed.
 __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                      const float * __restrict__ cs, float * __restrict__ kc, float * __restrict__ vc,
-                                                     const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
+                                                     const uint16_t * __restrict__ exp_tab, float * __restrict__ att,
+                                                     uint8_t * __restrict__ att_image, int att_act_type) {
     constexpr int D = 64, HALF = 32;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int h = blockIdx.x, tid = threadIdx.x;
-    const int np = *n_past_ptr, n_kv = np + 1;
+    const int np = *n_past_ptr;
     const int group = H / HKV, hk = h / group;
-    float  * qr   = (float *) smem;                 // rotated q [64]
-    float  * kr   = qr + D;                         // rotated new k [64]
-    float  * vn   = kr + D;                         // new v [64]
-    float  * redf = vn + D;                         // 16 floats
-    double * red  = (double *)(redf + 16);          // 4 x 64 doubles
-    float  * p    = (float *)(red + 4 * D);         // n_kv scores
+    float * qr = (float *) smem;                    // rotated q [64]
+    float * kr = qr + D;                            // rotated new k [64]
+    float * vn = kr + D;                            // new v [64]
+    const attn_lds L = attn_lds_carve(smem + 3 * D * 4);
     const float * qh = qkv + (int64_t) h * D;
     const float * kh = qkv + (int64_t)(H + hk) * D;
     const float * vh = qkv + (int64_t)(H + HKV + hk) * D;
@@ -315,64 +329,31 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
         if (h % group == 0) vc[((int64_t) np * HKV + hk) * D + d] = v;
     }
     __syncthreads();
-
-    const int sub = tid & 15, rowi = tid >> 4;
-    const float4 q4 = *(const float4 *)(qr + 4 * sub);
-    float lmax = -INFINITY;
-    for (int j0 = 0; j0 < n_kv; j0 += 64) {
-        float4 k4[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            const int jc = j < np ? j : (np > 0 ? np - 1 : 0);
-            k4[b] = (np > 0) ? *(const float4 *)(kc + ((int64_t) jc * HKV + hk) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            if (j == np) k4[b] = *(const float4 *)(kr + 4 * sub);                     // the new key lives in LDS
-            double s = (double)(k4[b].x * q4.x); s += (double)(k4[b].y * q4.y); s += (double)(k4[b].z * q4.z); s += (double)(k4[b].w * q4.w);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            const float sc = (float) s * 0.125f;                                      // 1/sqrt(64), libfalcon.cpp:2313-2317
-            if (j < n_kv) { if (sub == 0) p[j] = sc; lmax = fmaxf(lmax, sc); }
-        }
-    }
-    const float mx = block_max(lmax, redf);
-    __syncthreads();
-    double lsum = 0.0;
-    for (int j = tid; j < n_kv; j += 256) {
-        const float e = h2f_bits(exp_tab[f2h_bits(p[j] - mx)]);                       // ggml.c:12436-12442
-        p[j] = e;
-        lsum += (double) e;
-    }
-    const double sum = block_sum(lsum, red);
-    const float inv = (float)(1.0 / sum);
-    __syncthreads();
-    for (int j = tid; j < n_kv; j += 256) p[j] *= inv;
-    __syncthreads();
-
-    const int d = tid & 63, part = tid >> 6;
-    double acc = 0.0;
-    for (int j0 = part; j0 < np; j0 += 32) {
-        float v[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) { const int j = j0 + 4 * b; v[b] = vc[((int64_t)(j < np ? j : np - 1) * HKV + hk) * D + d]; }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) { const int j = j0 + 4 * b; if (j < np) acc += (double)(v[b] * p[j]); }
-    }
-    if ((np & 3) == part) acc += (double)(vn[d] * p[np]);                             // the new value, last of its residue class
-    red[part * 64 + d] = acc;
-    __syncthreads();
+    const float o = attn_head_block(qr, kc, vc, HKV, hk, np, kr, vn, exp_tab, L);
     if (tid < 64) {
-        const double o = ((red[d] + red[64 + d]) + red[128 + d]) + red[192 + d];
-        att[(int64_t) h * D + d] = (float) o;
+        if (att) att[(int64_t) h * D + tid] = o;
+        if (att_image) {                                                             // lanes 0-31 / 32-63 = the head's two 32-blocks
+            const float amax = reduce32(fabsf(o), op_max());
+            const float d  = amax / 127.0f;
+            const float id = d ? 1.0f / d : 0.0f;
+            const int q = (int) roundf(o * id);
+            const int s = reduce32(q, op_add());
+            const int64_t E = (int64_t) H * D;
+            const act_image_ptr im = act_image_at(att_image, att_act_type, E);
+            im.qs[(int64_t) h * D + tid] = (int8_t) q;
+            if ((tid & 31) == 0) {
+                const int64_t b = 2 * (int64_t) h + (tid >> 5);
+                if (att_act_type == FQ_Q8_0) { im.d[b] = h2f_bits(f2h_bits(d)); ((int32_t *) im.aux)[b] = s; }
+                else                         { im.d[b] = d; ((float *) im.aux)[b] = (float) s * d; }
+            }
+        }
     }
 }
 
 void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
-                           float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
-    const size_t lds = (64 * 3 + 16) * 4 + 4 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15) + 64;
+                           float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st) {
+    const size_t lds = 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
-    hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att);
+    hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type);
 }
