@@ -46,11 +46,16 @@ struct falcon_hip_context {
     int * n_past_dev = nullptr;
     int32_t * tokens_dev = nullptr, * out_tokens_dev = nullptr;
     float * hidden_dev = nullptr;
+    float * argmax_val = nullptr;              // per-workgroup greedy candidates written by the lm_head kernel
+    int   * argmax_idx = nullptr;
     bool keep_hidden = false;
     int  hidden_tokens = 0;
     std::vector<float> logits_host;
     std::vector<void *> allocs;
     bool use_graph = false;
+    bool dual_stream = true;                   // fused decode: MLP-up GEMV on a side stream, concurrent with QKV GEMV + attention
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_fork, ev_join;  // one pair per local layer
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
     hipGraphExec_t decode_graph = nullptr;
     int  graph_base = -1;                      // n_past the captured graph was built for
@@ -203,12 +208,21 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->n_past_dev     = (int *) dev_alloc(c->allocs, 256);
     c->tokens_dev     = (int32_t *) dev_alloc(c->allocs, (size_t) B * 4 + 256);
     c->out_tokens_dev = (int32_t *) dev_alloc(c->allocs, (size_t) n_ctx * 4 + 256);
+    HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    c->ev_fork.resize((size_t) nl); c->ev_join.resize((size_t) nl);
+    for (int64_t i = 0; i < nl; ++i) { HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); }
+    if (const char * e = getenv("FALCON_HIP_DUAL")) c->dual_stream = atoi(e) != 0;
+    c->argmax_val     = (float *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 2) * 4);
+    c->argmax_idx     = (int *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 2) * 4);
     return c;
 }
 
 extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (!c) return;
     if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
+    for (hipEvent_t e : c->ev_fork) HIP_CHECK(hipEventDestroy(e));
+    for (hipEvent_t e : c->ev_join) HIP_CHECK(hipEventDestroy(e));
+    if (c->side) HIP_CHECK(hipStreamDestroy(c->side));
     for (void * p : c->allocs) HIP_CHECK(hipFree(p));
     delete c;
 }
@@ -253,10 +267,23 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, (int)((QKV + 31) / 32) };
             const bool prof = fq_prof_active();
-            if (prof) fq_prof_open(st);
-            fq_launch_gemv_ln(ga, st);
-            if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
-            if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
+            const bool dual = c->dual_stream && !prof;
+            if (dual) {
+                // the MLP-up mat-vec only needs x: run it on the side stream while QKV + attention run on the main one
+                fq_gemv_ln_args gu = ga; gu.nseg = 1; gu.seg[0] = ga.seg[1]; gu.seg[0].block_begin = 0;
+                fq_gemv_ln_args gq = ga; gq.nseg = 1;
+                HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
+                HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
+                fq_launch_gemv_ln(gu, c->side);
+                if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), c->side);
+                HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
+                fq_launch_gemv_ln(gq, st);
+            } else {
+                if (prof) fq_prof_open(st);
+                fq_launch_gemv_ln(ga, st);
+                if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
+                if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
+            }
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             const int att_act = fq_desc(L.wo.type).act_type;
@@ -265,6 +292,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                                   att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
             fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, att_q ? c->act_att.base : nullptr, c->x, c->x,
                                  hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
+            if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
             if (prof) fq_prof_open(st);
             fq_launch_gemv_out(go, st);
             if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
@@ -277,6 +305,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_gemv_ln_args ga{};
             ga.x = c->x; ga.E = E; ga.nseg = 1; ga.gelu_table = hc.gelu_table;
             ga.seg[0] = { m->lm_head, m->out_norm_w, m->out_norm_b, FQ_LNEPI_STORE, c->logits_dev, nullptr, 0, 0 };
+            ga.argmax_val = c->argmax_val; ga.argmax_idx = c->argmax_idx;
             const bool prof = fq_prof_active();
             if (prof) fq_prof_open(st);
             fq_launch_gemv_ln(ga, st);
@@ -358,13 +387,21 @@ extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) { return 
 
 // ------------------------------------------------------------------------------------------------ greedy decode
 // argmax with first-maximum tie-break (std::max_element in llama_sample_token_greedy, libfalcon.cpp:3440-3450);
-// also advances the device-side loop state: next token id, n_past + 1, output slot.
-__global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restrict__ logits, int n, int32_t * __restrict__ token,
-                                                         int * __restrict__ n_past, int32_t * __restrict__ out, int n_past0) {
+// also advances the device-side loop state: next token id, n_past + 1, output slot. `vals`/`idxs` are either the
+// logits themselves (idxs == nullptr: candidate i has index i) or the per-workgroup candidates written by the
+// lm_head kernel (fused decode path) -- the single-workgroup scan then covers 2032 instead of 65024 entries.
+__global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restrict__ vals, const int * __restrict__ idxs, int n,
+                                                         int32_t * __restrict__ token, int * __restrict__ n_past, int32_t * __restrict__ out, int n_past0) {
     __shared__ float bv[16];
     __shared__ int   bi[16];
     float best = -INFINITY; int idx = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = logits[i]; if (v > best || (v == best && i < idx)) { best = v; idx = i; } }
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {            // 4 independent loads per step
+        float v[4]; int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + k * blockDim.x; const int ic = i < n ? i : n - 1; v[k] = vals[ic]; id[k] = idxs ? idxs[ic] : ic; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + k * blockDim.x; if (i < n && (v[k] > best || (v[k] == best && id[k] < idx))) { best = v[k]; idx = id[k]; } }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(idx, o);
@@ -395,7 +432,10 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
     c->keep_hidden = false;
     auto one_step = [&](hipStream_t s, int max_kv) {
         launch_stage(c, 1, max_kv, s);
-        hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+        if (c->fused_decode)
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, s, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+        else
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
     };
     if (c->use_graph) {
         // the graph bakes n_past0 into k_argmax_advance's arguments: re-capture when the base position changes

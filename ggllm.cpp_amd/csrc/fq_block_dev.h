@@ -11,6 +11,12 @@ __device__ __forceinline__ act_image_ptr act_image_at(uint8_t * base, int act_ty
     return { (int8_t *) base, (float *)(base + fq_act_d_off(act_type, K)), base + fq_act_aux_off(act_type, K) };
 }
 
+// roundf (round half away from zero) in 4 VALU ops: v - trunc(v) is exact, so the comparison with 0.5 is exact too
+__device__ __forceinline__ int round_half_away(float v) {
+    const float t = truncf(v);
+    return (int) t + (fabsf(v - t) >= 0.5f ? (v < 0.0f ? -1 : 1) : 0);
+}
+
 // ---- Q8_0 / Q8_1 (ggml.c:1106-1129, 1292-1325): one thread = 4 consecutive elements (quad q4 of the row), the 8
 // threads of a 32-block are 8 consecutive lanes. All 8 lanes of a group must call together.
 template <int ACT>
@@ -19,7 +25,7 @@ __device__ __forceinline__ void quant_q8_quad(const float4 v, int64_t q4, const 
     amax = reduce8(amax, op_max());
     const float d  = amax / 127.0f;                       // ggml.c:1116 / 1302
     const float id = d ? 1.0f / d : 0.0f;
-    const int q0 = (int) roundf(v.x * id), q1 = (int) roundf(v.y * id), q2 = (int) roundf(v.z * id), q3 = (int) roundf(v.w * id);
+    const int q0 = round_half_away(v.x * id), q1 = round_half_away(v.y * id), q2 = round_half_away(v.z * id), q3 = round_half_away(v.w * id);
     int s = q0 + q1 + q2 + q3;
     s = reduce8(s, op_add());
     if (live) {

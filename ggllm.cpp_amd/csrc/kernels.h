@@ -49,7 +49,10 @@ struct fq_gemv_ln_seg {
     int           next_act_type;
     int           block_begin;     // first workgroup of the segment (32 rows per workgroup)
 };
-struct fq_gemv_ln_args { const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg; };
+struct fq_gemv_ln_args {
+    const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg;
+    float * argmax_val; int * argmax_idx;      // optional (lm_head): per-workgroup best logit and its row, for greedy sampling
+};
 struct fq_gemv_out_args {
     fq_weight w_down, w_wo;
     const uint8_t * act_ff_image;  // quantized gelu(up), image of length w_down.K

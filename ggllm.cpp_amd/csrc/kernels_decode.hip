@@ -157,6 +157,15 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
         float v = out32[j];
         if (sg.epi == FQ_LNEPI_STORE) {
             if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
+            if (a.argmax_val) {                       // first stage of the greedy sampler: this workgroup's best (value, row)
+                float bv = row < sg.w.M ? v : -INFINITY; int bi = (int) row;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { a.argmax_val[blockIdx.x] = bv; a.argmax_idx[blockIdx.x] = bi; }
+            }
         } else {
             v = h2f_bits(a.gelu_table[f2h_bits(v)]);                                  // ggml.c:3477-3484
             if (sg.epi == FQ_LNEPI_GELU_STORE) {
@@ -165,7 +174,7 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
                 const float amax = reduce32(fabsf(v), op_max());
                 const float d  = amax / 127.0f;
                 const float id = d ? 1.0f / d : 0.0f;
-                const int q = (int) roundf(v * id);
+                const int q = round_half_away(v * id);
                 const int s = reduce32(q, op_add());
                 const act_image_ptr o = act_image_at(sg.dst_image, sg.next_act_type, sg.w.M);
                 if (lane < 32) o.qs[row] = (int8_t) q;
@@ -260,7 +269,7 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     const fq_actcol col_d = actcol_at(img_ff, ACT, FF), col_o = actcol_at(img_att, ACT, E);
     rows_consume<TYPE, 2, NPD>(pd, units_d, col_d, acc_d);
     FQ_STAMP(a.dbg, 4);
-    rows_dot_from<TYPE, 2, 4>(rd, units_d, 64 * NPD, col_d, acc_d);
+    rows_dot_from<TYPE, 2, (decode_cfg<TYPE>::four_bit ? 5 : 2)>(rd, units_d, 64 * NPD, col_d, acc_d);      // 7B: the remaining 5 columns in one round trip
     FQ_STAMP(a.dbg, 5);
     rows_consume<TYPE, 2, NPO>(po, units_o, col_o, acc_o);
     rows_dot_from<TYPE, 2, 2>(ro, units_o, 64 * NPO, col_o, acc_o);
@@ -336,7 +345,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
             const float amax = reduce32(fabsf(o), op_max());
             const float d  = amax / 127.0f;
             const float id = d ? 1.0f / d : 0.0f;
-            const int q = (int) roundf(o * id);
+            const int q = round_half_away(o * id);
             const int s = reduce32(q, op_add());
             const int64_t E = (int64_t) H * D;
             const act_image_ptr im = act_image_at(att_image, att_act_type, E);
