@@ -53,7 +53,10 @@ struct falcon_hip_context {
     std::vector<float> logits_host;
     std::vector<void *> allocs;
     bool use_graph = false;
-    bool dual_stream = true;                   // fused decode: MLP-up GEMV on a side stream, concurrent with QKV GEMV + attention
+    // fused decode: MLP-up GEMV on a side stream, concurrent with QKV GEMV + attention. Measured on MI355X (Falcon-7B
+    // Q4_0, hipGraph): 555 tok/s with the fork/join vs 674 tok/s in stream order -- the cross-stream dependencies cost
+    // more than the ~8 us of attention they hide, so it is OFF by default (FALCON_HIP_DUAL=1 turns it on).
+    bool dual_stream = false;
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;  // one pair per local layer
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
