@@ -144,9 +144,12 @@ def main():
         nl, us, by = C.c_int64(), C.c_double(), C.c_double()
         L.ggml_hip_profile_end(C.byref(nl), C.byref(us), C.byref(by))
         if nl.value:
-            ach = by.value / (us.value * 1e-6) / 1e9
+            # an event bracket adds a fixed dispatch cost to what it encloses: measure an EMPTY bracket and subtract it
+            ovh = L.ggml_hip_profile_bracket_overhead_us()
+            avg_us = us.value / nl.value - ovh
+            ach = (by.value / nl.value) / (avg_us * 1e-6) / 1e9
             roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln + k_gemv_out (fused quantized mat-vec)", launches=nl.value,
-                        avg_launch_us=us.value / nl.value, bytes_per_launch=by.value / nl.value)
+                        avg_launch_us=avg_us, raw_bracket_us=us.value / nl.value, empty_bracket_us=ovh, bytes_per_launch=by.value / nl.value)
     step_gbs = b_tok * tok_s / 1e9
     roof.update(step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok)
 

@@ -23,7 +23,7 @@ VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_
 
 EXPORTS_OPS = """ggml_hip_init ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
-ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
+ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
 ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_acts_alloc ggml_hip_acts_free
 ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
@@ -65,7 +65,7 @@ def load():
         "ggml_hip_memcpy_h2d": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2h": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2d": (None, [vp, vp, sz]),
         "ggml_hip_memset": (None, [vp, C.c_int, sz]), "ggml_hip_synchronize": (None, []),
         "ggml_hip_event_create": (vp, []), "ggml_hip_event_record": (None, [vp]), "ggml_hip_event_elapsed_ms": (C.c_float, [vp, vp]),
-        "ggml_hip_profile_begin": (None, []), "ggml_hip_profile_end": (None, [vp, vp, vp]),
+        "ggml_hip_profile_begin": (None, []), "ggml_hip_profile_bracket_overhead_us": (C.c_double, []), "ggml_hip_profile_end": (None, [vp, vp, vp]),
         "ggml_hip_event_destroy": (None, [vp]), "ggml_hip_gelu_table_dev": (vp, []), "ggml_hip_exp_table_dev": (vp, []),
         "ggml_hip_weight_upload": (vp, [C.c_int, vp, i64, i64]), "ggml_hip_weight_free": (None, [vp]), "ggml_hip_weight_nbytes": (sz, [vp]),
         "ggml_hip_dequantize_rows": (None, [vp, vp, i64, vp]),

@@ -215,6 +215,21 @@ extern "C" void ggml_hip_profile_end(int64_t * n_launches, double * total_us, do
     g_prof_ev.clear();
 }
 
+// cost of an empty hipEvent bracket on the launch stream (subtracted from bracketed kernel times by bench.py)
+extern "C" double ggml_hip_profile_bracket_overhead_us(void) {
+    hip_context & c = fq_ctx();
+    const int n = 64;
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto & e : ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipStreamSynchronize(c.stream));
+    for (int i = 0; i < n; ++i) { HIP_CHECK(hipEventRecord(ev[2 * i], c.stream)); HIP_CHECK(hipEventRecord(ev[2 * i + 1], c.stream)); }
+    HIP_CHECK(hipStreamSynchronize(c.stream));
+    double us = 0.0;
+    for (int i = 0; i < n; ++i) { float ms = 0.0f; HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); us += 1e3 * (double) ms; }
+    for (auto & e : ev) HIP_CHECK(hipEventDestroy(e));
+    return us / n;
+}
+
 // bracket one launch (used by the fused decode path in falcon_hip.hip)
 bool fq_prof_active() { return g_prof_on; }
 void fq_prof_open(hipStream_t st) {

@@ -43,6 +43,7 @@ void    ggml_hip_event_destroy(void * ev);
  * algorithmic bytes (the weight matrix of each launch, read once)                                            */
 void    ggml_hip_profile_begin(void);
 void    ggml_hip_profile_end(int64_t * n_launches, double * total_us, double * total_bytes);
+double  ggml_hip_profile_bracket_overhead_us(void);   /* duration an EMPTY event bracket reports on this stream */
 const uint16_t * ggml_hip_gelu_table_dev(void);   /* 65536 fp16 entries, built like ggml.c:4276-4290 */
 const uint16_t * ggml_hip_exp_table_dev(void);
 
