@@ -63,6 +63,11 @@ FQ_HD fq_type_desc fq_desc(int type) {
     }
 }
 
+// vec_dot_type of a weight format as a compile-time constant (ggml.c:1627-1718)
+constexpr int fq_act_of(int type) {
+    return (type == FQ_Q4_1 || type == FQ_Q5_1) ? FQ_Q8_1 : ((type == FQ_Q4_0 || type == FQ_Q5_0 || type == FQ_Q8_0) ? FQ_Q8_0 : FQ_Q8_K);
+}
+
 // A weight matrix on the device: K inputs (ne00), M output rows (ne01).
 struct fq_weight {
     int     type;

@@ -196,6 +196,9 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
     return v;
 }
 
+static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
+extern "C" void ggml_hip_debug_force_gemv(int on) { g_force_gemv = on != 0; }
+
 // ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
@@ -246,6 +249,10 @@ void fq_prof_close(hipStream_t st, double bytes) {
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {
     hip_context & c = fq_ctx();
     if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }
+    if (N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv) {      // prefill: int8 MFMA GEMM
+        fq_launch_gemm(w, a, N, dst, ldd, ep0, c.n_cu, st);
+        return;
+    }
     const int max_blocks = c.n_cu * 4;
     int64_t n0 = 0;
     while (n0 < N) {

@@ -25,6 +25,11 @@ size_t fq_gemv_lds_bytes(int act_type, int64_t K, int ncols);
 void   fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float * dst, int64_t ldd,
                       const fq_gemv_epi & ep, int max_blocks, hipStream_t st);
 
+// kernels_gemm.hip -- int8 MFMA mat-mul for N > 4 columns
+bool   fq_gemm_supported(int type);
+void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd,
+                      const fq_gemv_epi & ep, int n_cu, hipStream_t st);
+
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
 void   fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st);

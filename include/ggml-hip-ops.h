@@ -24,6 +24,7 @@ int     ggml_hip_init(int device);                /* idempotent; returns number 
 int     ggml_hip_device_count(void);
 /* tuning aid: wall_clock64 phase stamps (8 per workgroup) of the last k_gemv_ln [0,4096) and k_gemv_out [4096,8192) */
 void    ggml_hip_debug_stamps(int enable, long long * out_host);
+void    ggml_hip_debug_force_gemv(int on);        /* tests: N > 4 through column-chunked mat-vec instead of the MFMA GEMM */
 int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
 void *  ggml_hip_stream(void);                    /* hipStream_t used for every launch of this library        */
 void *  ggml_hip_malloc(size_t bytes);

@@ -374,8 +374,9 @@ void orc_dequantize_row(int type, const void * in, float * y, int64_t k) {
 /* Test knob: association of the f32 sum over blocks. 0 = the reference's scalar left-to-right loop; 1 = 64 strided
  * partial sums + xor butterfly in the order 1,2,4,..,32 (what the kernels' 64-lane wave reduction does). Used only to MEASURE how far a legitimate re-association moves
  * the logits of a whole model (tests/test_oracle_spread.py); the oracle proper always runs with 0. */
-static int g_sum_order = 0;
-void orc_set_sum_order(int mode) { g_sum_order = mode; }
+static int g_sum_order = 0;       /* effective order for the current mat-mul */
+static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend: wave for N <= 4 columns, scalar (MFMA GEMM, block order) above */
+void orc_set_sum_order(int mode) { g_sum_mode = mode; g_sum_order = (mode == 1); }
 
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     const uint8_t * w = (const uint8_t *) wv;
@@ -502,6 +503,7 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
                    float * dst, int n_threads, int flavour) {
     const int at = orc_vec_dot_type(wtype);
     const size_t act_row = orc_row_bytes(at, K);
+    if (g_sum_mode == 2) g_sum_order = (N <= 4);
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
     /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */
     for (int64_t n = 0; n < N; ++n) orc_quantize_act(at, x + n * K, act + (size_t) n * act_row, K, flavour);

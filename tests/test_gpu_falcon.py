@@ -28,8 +28,9 @@ CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQ
 # the reference algorithm (which every vectorised build of the reference does) flips an 8-bit activation rounding now
 # and then, and one flip moves the logits by ~1e-3..1e-2 (measured: the reference's own AVX2 and scalar builds differ
 # by 2.8e-2 on gqa_q5_1 -- tests/golden/tiny_models.npz holds both). So two checks:
-#   (1) against the oracle run with the wave's association of that sum (orc_set_sum_order(1): 64 strided partial sums +
-#       butterfly): TIGHT -- this pins every kernel of the stack;
+#   (1) against the oracle run with the backend's association of that sum (orc_set_sum_order(2): 64 strided partial
+#       sums + xor butterfly for N <= 4 columns = the mat-vec kernels, block order for N > 4 = the MFMA GEMM): TIGHT --
+#       this pins every kernel of the stack;
 #   (2) against the logits captured from the reference itself: within 1e-3, or within 2x the reference's own
 #       build-to-build spread when that is larger.
 TIGHT = 1e-4
@@ -45,7 +46,7 @@ def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t):
     dec = np.concatenate([m.eval(toks[i:i + 1], i, logits_all=True) for i in range(8, 12)])
     m.free()
     if t in ob.LEGACY:
-        oracle.lib.orc_set_sum_order(1)
+        oracle.lib.orc_set_sum_order(2)
         try:
             mo = oracle.model(w, 64)
             lo, ho = mo.eval(toks[:8], 0, 2, want_hidden=True)
@@ -70,7 +71,7 @@ def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
     toks = synth.tokens(10, hp["n_vocab"], seed=5)
     m = g.FalconModel(w, n_ctx=32, n_batch=6)
     if t in ob.LEGACY:
-        oracle.lib.orc_set_sum_order(1)
+        oracle.lib.orc_set_sum_order(2)
     try:
         mo = oracle.model(w, 32)
         lo, ho = mo.eval(toks[:6], 0, 4, want_hidden=True)
@@ -114,9 +115,14 @@ def test_prefill_equals_incremental_and_graph(oracle):
     w = synth.make_model(oracle, hp, ob.Q4_0, seed=3)
     toks = synth.tokens(9, hp["n_vocab"], seed=8)
     m = g.FalconModel(w, n_ctx=64, n_batch=9)
-    full = m.eval(toks, 0)
-    inc = np.concatenate([m.eval(toks[i:i + 1], i) for i in range(9)])
+    g.load().ggml_hip_debug_force_gemv(1)          # same kernel family for both -> bit-identical
+    try:
+        full = m.eval(toks, 0)
+        inc = np.concatenate([m.eval(toks[i:i + 1], i) for i in range(9)])
+    finally:
+        g.load().ggml_hip_debug_force_gemv(0)
     assert np.array_equal(full, inc)
+    assert relrms(m.eval(toks, 0), full) <= TIGHT    # the MFMA GEMM prefill: other association, same values
     first = int(full[-1].argmax())
     plain = m.decode_greedy(first, 9, 12, use_graph=False)
     m.eval(toks, 0)                                   # rewind the KV cache to the same state
@@ -138,7 +144,7 @@ def test_falcon7b_shaped_layer_vs_oracle(oracle):
     w = synth.make_model(oracle, hp, ob.Q4_0, seed=9)
     toks = synth.tokens(4, 1024, seed=2)
     m = g.FalconModel(w, n_ctx=16, n_batch=3)
-    oracle.lib.orc_set_sum_order(1)
+    oracle.lib.orc_set_sum_order(2)
     try:
         mo = oracle.model(w, 16)
         lo, ho = mo.eval(toks[:3], 0, 8, want_hidden=True)

@@ -83,6 +83,36 @@ def test_integer_dot_bit_exact(oracle, t, K):
     assert np.array_equal(got.astype(np.int64), x.astype(np.int64) @ deq.T)
 
 
+GEMM_TYPES = [ob.Q4_0, ob.Q4_1, ob.Q5_0, ob.Q5_1, ob.Q8_0, ob.Q4_K, ob.Q5_K]
+
+
+@pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
+@pytest.mark.parametrize("K,M,N", [(512, 37, 9), (4544, 200, 33), (8192, 129, 128), (1024, 300, 257), (18176, 70, 40)])
+def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
+    """N > 4 columns: int8 MFMA GEMM (legacy formats + Q4_K/Q5_K) or column-chunked mat-vec (Q2_K/Q3_K/Q6_K).
+    Legacy formats through the GEMM add the per-block terms in block order with the reference's scalar expression:
+    BIT-EXACT against the oracle (= the reference's scalar vec_dot)."""
+    if K % ob.BLCK[t]:
+        pytest.skip("k-quants need K % 256 == 0")
+    rng = np.random.default_rng(K + M + N + t)
+    w = synth.quantized_matrix(oracle, t, M, K, rng)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    dw = g.Weight(t, w, K, M)
+    got = dw.mul_mat(x)
+    exp = oracle.mul_mat(t, w, K, M, x, 8)
+    if t in ob.LEGACY:
+        assert np.array_equal(got, exp)
+    assert relrms(got, exp) <= TOL
+    # and the same columns through the mat-vec kernel agree within the association tolerance
+    g.load().ggml_hip_debug_force_gemv(1)
+    try:
+        via_gemv = dw.mul_mat(x)
+    finally:
+        g.load().ggml_hip_debug_force_gemv(0)
+    dw.free()
+    assert relrms(got, via_gemv) <= TOL
+
+
 def test_epilogues(oracle):
     L = g.load()
     rng = np.random.default_rng(5)
