@@ -122,7 +122,8 @@ def test_prefill_equals_incremental_and_graph(oracle):
     finally:
         g.load().ggml_hip_debug_force_gemv(0)
     assert np.array_equal(full, inc)
-    assert relrms(m.eval(toks, 0), full) <= TIGHT    # the MFMA GEMM prefill: other association, same values
+    # (the MFMA GEMM prefill associates the block sum differently; that path is pinned bit-exactly against the oracle in
+    #  test_tiny_falcon_vs_reference_fixture -- comparing the two associations with each other only measures the chaos)
     first = int(full[-1].argmax())
     plain = m.decode_greedy(first, 9, 12, use_graph=False)
     m.eval(toks, 0)                                   # rewind the KV cache to the same state
