@@ -17,7 +17,7 @@ def _declared(header):
 def test_library_builds_and_exports_every_declared_symbol():
     g.build()
     lib = ctypes.CDLL(g.LIB_PATH)
-    for header in ("ggml-hip-ops.h", "falcon-hip.h"):
+    for header in ("ggml-hip-ops.h", "falcon-hip.h", os.path.join("dropin", "ggml-cuda.h")):
         names = _declared(header)
         assert len(names) > 10
         for n in names:
