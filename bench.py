@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-tokens", type=int, default=6)
+    ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
+    ap.add_argument("--streams", type=int, default=2, help="decode streams in flight for --force-pipeline at one GPU")
     return ap.parse_args()
 
 
@@ -81,7 +83,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or a.force_pipeline:
         import bench_pipeline                      # layer-sharded multi-GPU path (RCCL hand-off)
         return bench_pipeline.main(a, rank, world, local)
 

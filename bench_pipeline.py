@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Layer-pipelined multi-GPU decode: one process per GPU, rank r owns a contiguous range of Falcon blocks,
+the ONLY exchange is the residual row [n_embd] f32 between neighbouring stages (RCCL send/recv over xGMI, one link per
+hop) plus the 4-byte greedy-sampled token from the last stage back to stage 0. No all-reduce, no all-gather.
+
+A single decode stream is serial through the stages (capacity scaling only), so S = 2 x world independent decode streams
+are kept in flight, each with its own KV cache on every stage; a ROUND advances every stream by one token:
+
+    stage 0     :  token_s (from the last stage)  -> embed + blocks                          -> hidden_s to stage 1
+    stage r     :  hidden_s from stage r-1        -> blocks                                  -> hidden_s to stage r+1
+    last stage  :  hidden_s                       -> blocks + ln_f + lm_head + greedy argmax -> token_s to stage 0
+(slot schedule and deadlock-freedom: see PipelineRunner)
+
+Everything is enqueued asynchronously on the library's HIP stream (falcon_hip_stage_step has no host sync; the RCCL calls
+are torch.distributed P2P ops issued with that stream current), so stage r works on stream s+1 while stage r+1 works on s.
+
+bench.py --gpus N (N > 1) lands here: W warm-up rounds, K timed rounds, value = K * S / time (tokens/s over all GPUs).
+The host logic (partition, schedule, token ring) is backend-agnostic and is tested on CPU with gloo and a mock stage
+(tests/test_pipeline_gloo.py).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def partition(n_layer, world):
+    """contiguous, balanced block ranges: [(begin, end)] per rank (40B: 60 -> 15/15/15/15 or 8,8,8,8,7,7,7,7)"""
+    base, extra = divmod(n_layer, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < extra else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+class PipelineRunner:
+    """Backend-agnostic schedule. `engine.step(stream, n_past)` runs this stage for one stream on pre-bound buffers;
+    `comm.exchange(send, recv)` performs one grouped P2P exchange. Both may be asynchronous w.r.t. the host.
+
+    The ranks form a ring (stage P-1 returns the sampled token to stage 0). Work item w = k*S + s is stream s in round
+    k; rank r computes item t - r in slot t. At the START of slot t every rank does ONE grouped exchange
+        send  the result of its slot t-1 (item t-1-r) to the next rank      (last rank: the token, to rank 0)
+        recv  the input of item t-r from the previous rank                  (rank 0: the token of item t-P, into the
+                                                                             token buffer of that item's stream)
+    then computes. Send and receive are posted together (ncclGroup / async gloo ops), so the ring cannot deadlock, and
+    in steady state all P stages compute concurrently on P different streams. S >= P keeps stage 0 from waiting for
+    a token that is still in flight.
+    """
+
+    def __init__(self, rank, world, n_streams, engine, comm):
+        self.rank, self.world, self.S, self.engine, self.comm = rank, world, n_streams, engine, comm
+        self.first, self.last = rank == 0, rank == world - 1
+        assert world == 1 or n_streams >= world, "need at least one decode stream per stage"
+
+    def run(self, rounds, n_past0):
+        """advance every stream by `rounds` tokens starting at position n_past0 (initial tokens are in engine.tok_in)"""
+        P, S, r = self.world, self.S, self.rank
+        W = rounds * S
+        if P == 1:
+            for w in range(W):
+                self.engine.step(w % S, n_past0 + w // S)
+                self.engine.feed_back_token(w % S)
+            return
+        for t in range(W + P):
+            sends, recvs = [], []
+            w_prev = t - 1 - r                              # item computed in the previous slot
+            if 0 <= w_prev < W:
+                sends.append(("token", w_prev % S, 0) if self.last else ("hidden", w_prev % S, r + 1))
+            w = t - r                                       # item to compute now
+            if self.first:
+                if 0 <= t - P < W:
+                    recvs.append(("token", (t - P) % S, P - 1))
+            elif 0 <= w < W:
+                recvs.append(("hidden", w % S, r - 1))
+            if sends or recvs:
+                self.comm.exchange(sends, recvs)
+            if 0 <= w < W:
+                self.engine.step(w % S, n_past0 + w // S)
+
+
+# ------------------------------------------------------------------------------------------------ GPU backend
+class HipEngine:
+    def __init__(self, g, model, n_streams, n_ctx, torch, device):
+        self.g, self.L, self.model, self.torch = g, g.load(), model, torch
+        E = model.hp["n_embd"]
+        self.ctx = [model.ctx] + [model.new_context(n_ctx) for _ in range(n_streams - 1)]
+        z = dict(device=device)
+        self.hidden_in = [torch.zeros(E, dtype=torch.float32, **z) for _ in range(n_streams)]
+        self.hidden_out = [torch.zeros(E, dtype=torch.float32, **z) for _ in range(n_streams)]
+        self.tok_in = [torch.zeros(1, dtype=torch.int32, **z) for _ in range(n_streams)]
+        self.tok_out = [torch.zeros(1, dtype=torch.int32, **z) for _ in range(n_streams)]
+
+    def set_initial_tokens(self, toks):
+        for s, t in enumerate(toks):
+            self.tok_in[s].fill_(int(t))
+
+    def step(self, s, n_past):
+        self.L.falcon_hip_stage_step(self.ctx[s], self.tok_in[s].data_ptr(), self.hidden_in[s].data_ptr(), n_past,
+                                     self.hidden_out[s].data_ptr(), self.tok_out[s].data_ptr())
+
+    def feed_back_token(self, s):
+        self.tok_in[s].copy_(self.tok_out[s], non_blocking=True)
+
+
+class TorchComm:
+    """torch.distributed P2P (backend nccl = RCCL on ROCm, or gloo on CPU) on the engine's buffers; one grouped
+    batch_isend_irecv per slot"""
+
+    def __init__(self, dist, engine):
+        self.dist, self.e = dist, engine
+
+    def exchange(self, sends, recvs):
+        ops = []
+        for kind, s, peer in sends:
+            ops.append(self.dist.P2POp(self.dist.isend, self.e.tok_out[s] if kind == "token" else self.e.hidden_out[s], peer))
+        for kind, s, peer in recvs:
+            ops.append(self.dist.P2POp(self.dist.irecv, self.e.tok_in[s] if kind == "token" else self.e.hidden_in[s], peer))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def main(a, rank, world, local):
+    import torch
+    import torch.distributed as dist
+    import ggllm_cpp_amd as g
+    import synth
+    from oracle import binding as ob
+
+    tname = {v: k for k, v in ob.TYPE_NAME.items()}
+    wtype = tname[a.quant if a.quant in tname else a.quant.replace("_k", "_K")]
+    hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B, "tiny": synth.HP_TINY_MQA}[a.model])
+    if a.layers:
+        hp["n_layer"] = a.layers
+    if not os.path.exists(g.LIB_PATH):
+        g.build()
+    torch.cuda.set_device(local)
+    g.init(local)
+    L = g.load()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    lb, le = partition(hp["n_layer"], world)[rank]
+    S = max(2 * world, 2) if world > 1 else getattr(a, "streams", 1)
+    n_ctx = min(a.n_ctx, 512)
+
+    t0 = time.time()
+    weights = synth.make_model_fast(hp, wtype, seed=1234, layers=range(lb, le))
+    model = g.FalconModel(weights, n_ctx=n_ctx, n_batch=1, layer_begin=lb, layer_end=le)
+    del weights
+    t_setup = time.time() - t0
+
+    ext = torch.cuda.ExternalStream(L.ggml_hip_stream(), device=torch.device("cuda", local))
+    with torch.cuda.stream(ext):                     # torch allocations / P2P ops are ordered with the library's kernels
+        engine = HipEngine(g, model, S, n_ctx, torch, torch.device("cuda", local))
+        comm = TorchComm(dist, engine)
+        runner = PipelineRunner(rank, world, S, engine, comm)
+        engine.set_initial_tokens(synth.tokens(S, hp["n_vocab"], seed=42))
+        n_past = 0
+        wr = max(a.warmup, 1)
+        runner.run(wr, n_past)                       # warm-up rounds (also build the RCCL P2P channels)
+        n_past += wr
+        L.ggml_hip_synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run(a.steps, n_past)                  # K rounds = K * S tokens, including pipeline fill and drain
+        n_past += a.steps
+        L.ggml_hip_synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local))
+    wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=torch.device("cuda", local))
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wb_t, op=dist.ReduceOp.SUM)
+    dt = float(dt_t.item())
+    if rank == 0:
+        tok_s = a.steps * S / dt
+        wbytes = float(wb_t.item())
+        from bench import kv_bytes_per_token, HBM_PEAK_GBS
+        b_tok = wbytes + kv_bytes_per_token(hp, n_past - a.steps // 2)
+        gbs = b_tok * tok_s / 1e9
+        print(json.dumps({
+            "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
+                      else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
+            "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
+            "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPUs "
+                                   f"({[e - b for b, e in partition(hp['n_layer'], world)]} blocks per stage), {S} greedy decode streams in flight, "
+                                   f"a step = one round (one token per stream); hidden-state hand-off by RCCL send/recv",
+                       "streams": S, "weight_bytes_per_token": wbytes, "n_past_timed": [n_past - a.steps, n_past]},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
+                         "traffic": None, "note": "whole-job view: bytes per token x tokens/s over the summed peak of all GPUs"},
+            "cpu_baseline": None, "setup_s": t_setup,
+        }))
+    model.free()
+    if world > 1:
+        dist.destroy_process_group()

@@ -28,7 +28,7 @@ ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_ac
 ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
-falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_decode_greedy
+falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
 falcon_hip_context_set_fused""".split()
 
@@ -84,6 +84,7 @@ def load():
         "falcon_hip_eval": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_eval_stage": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_decode_greedy": (C.c_int, [vp, i32, C.c_int, C.c_int, vp]),
+        "falcon_hip_stage_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]),
@@ -218,6 +219,10 @@ class FalconModel:
                 put(p + leaf, F32, lw[k], E, 1)
         self.ctx = L.falcon_hip_context_create(self.m, n_ctx, n_batch, rope_n_ctx)
         self.n_local = (layer_end or hp["n_layer"]) - layer_begin
+
+    def new_context(self, n_ctx, n_batch=1, rope_n_ctx=0):
+        """another context (own KV cache / scratch) over the same device weights: one per concurrent decode stream"""
+        return load().falcon_hip_context_create(self.m, n_ctx, n_batch, rope_n_ctx)
 
     def eval(self, tokens, n_past, logits_all=True, want_hidden=False):
         L = load()

@@ -422,6 +422,40 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pipeline step
+__global__ void k_set_i32(int * p, int v) { *p = v; }
+__global__ void k_copy_i32(int32_t * dst, const int32_t * src) { *dst = *src; }
+
+// One decode step of one pipeline stage, fully stream-ordered (no host synchronisation, no host memory): the token id
+// (first stage) / residual row (other stages) are read from device memory, the residual row (inner stages) / the
+// greedy-sampled next token (last stage) are written to device memory. The caller moves them between ranks (RCCL).
+extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * token_dev, const float * hidden_in_dev, int n_past,
+                                     float * hidden_out_dev, int32_t * next_token_dev) {
+    hip_context & hc = fq_ctx();
+    falcon_hip_model * m = c->m;
+    hipStream_t st = hc.stream;
+    if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: stage step at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); exit(1); }
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
+    if (m->first_stage()) hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(1), 0, st, c->tokens_dev, token_dev);
+    else HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+    const bool was_keep = c->keep_hidden;
+    c->keep_hidden = false;
+    launch_stage(c, 1, n_past + 1, st);
+    c->keep_hidden = was_keep;
+    if (m->last_stage()) {
+        if (next_token_dev) {
+            // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
+            if (c->fused_decode)
+                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+            else
+                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+        }
+    } else if (hidden_out_dev) {
+        HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
 extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens) {
     hip_context & hc = fq_ctx();
     falcon_hip_model * m = c->m;

@@ -55,6 +55,11 @@ int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, int n_tokens
  * embeds tokens / produces logits).                                                                             */
 int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tokens, const float * hidden_in_dev, int n_tokens,
                           int n_past, int logits_all, float * hidden_out_dev);
+/* One decode step (N = 1) of a pipeline stage with device-resident inputs/outputs, asynchronous on the library stream:
+ * token_dev (stage 0) or hidden_in_dev [n_embd] (other stages) -> hidden_out_dev [n_embd] (not the last stage) or the
+ * greedy-sampled next_token_dev (last stage). The caller exchanges them with RCCL send/recv (bench_pipeline.py).      */
+int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * token_dev, const float * hidden_in_dev, int n_past,
+                          float * hidden_out_dev, int32_t * next_token_dev);
 /* Greedy decode loop entirely stream-ordered: evaluates `first_token` at n_past, then n_steps-1 more argmax-sampled
  * tokens (falcon_main --temp 0, falcon_main.cpp:958-960); out_tokens receives n_steps ids. No host sync per step. */
 int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens);
