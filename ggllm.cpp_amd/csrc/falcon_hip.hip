@@ -215,8 +215,8 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->ev_fork.resize((size_t) nl); c->ev_join.resize((size_t) nl);
     for (int64_t i = 0; i < nl; ++i) { HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); }
     if (const char * e = getenv("FALCON_HIP_DUAL")) c->dual_stream = atoi(e) != 0;
-    c->argmax_val     = (float *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 2) * 4);
-    c->argmax_idx     = (int *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 2) * 4);
+    c->argmax_val     = (float *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 8) * 4);
+    c->argmax_idx     = (int *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 8) * 4);
     return c;
 }
 
@@ -268,7 +268,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_gemv_ln_args ga{};
             ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table; ga.dbg = hc.dbg_stamps;
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
-            ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, (int)((QKV + 31) / 32) };
+            ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, 0 };
             const bool prof = fq_prof_active();
             const bool dual = c->dual_stream && !prof;
             if (dual) {
@@ -277,13 +277,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 fq_gemv_ln_args gq = ga; gq.nseg = 1;
                 HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
                 HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
-                fq_launch_gemv_ln(gu, c->side);
+                fq_launch_gemv_ln(gu, hc.n_cu, c->side);
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), c->side);
                 HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
-                fq_launch_gemv_ln(gq, st);
+                fq_launch_gemv_ln(gq, hc.n_cu, st);
             } else {
                 if (prof) fq_prof_open(st);
-                fq_launch_gemv_ln(ga, st);
+                fq_launch_gemv_ln(ga, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
             }
@@ -297,7 +297,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                                  hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
             if (prof) fq_prof_open(st);
-            fq_launch_gemv_out(go, st);
+            fq_launch_gemv_out(go, hc.n_cu, st);
             if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
         }
         if (c->keep_hidden) {
@@ -311,7 +311,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             ga.argmax_val = c->argmax_val; ga.argmax_idx = c->argmax_idx;
             const bool prof = fq_prof_active();
             if (prof) fq_prof_open(st);
-            fq_launch_gemv_ln(ga, st);
+            fq_launch_gemv_ln(ga, hc.n_cu, st);
             if (prof) fq_prof_close(st, (double) m->lm_head.bytes);
         }
         return;

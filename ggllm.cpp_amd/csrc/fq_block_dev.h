@@ -100,26 +100,28 @@ __device__ __forceinline__ void quantize_row_block(const float * __restrict__ ro
 // x: global, n % 4 == 0. Result (norm * w + b, or plain norm when w == nullptr) is left in `row` (LDS, n floats).
 // Split in two so that a fused kernel can issue the row's loads FIRST, then its weight-stream loads, and only then
 // wait for the row (vmcnt counts in order: loads issued after the row do not delay it).
-struct ln_row_regs { float4 t[8]; };
+template <int NLN> struct ln_row_regs { float4 t[NLN]; };       // NLN * blockDim float4 of the row live in registers
 
-__device__ __forceinline__ void layer_norm_issue(const float * __restrict__ x, int64_t n, ln_row_regs & r) {
+template <int NLN>
+__device__ __forceinline__ void layer_norm_issue(const float * __restrict__ x, int64_t n, ln_row_regs<NLN> & r) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t nv = n >> 2;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * nt + tid; r.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
+    for (int k = 0; k < NLN; ++k) { const int64_t i = (int64_t) k * nt + tid; r.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
 }
 
-__device__ __forceinline__ void layer_norm_finish(const ln_row_regs & r, const float * __restrict__ x, int64_t n,
+template <int NLN>
+__device__ __forceinline__ void layer_norm_finish(const ln_row_regs<NLN> & r, const float * __restrict__ x, int64_t n,
                                                   const float * __restrict__ w, const float * __restrict__ b, float * row, double * red) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t nv = n >> 2;
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NLN; ++k) {
         const int64_t i = (int64_t) k * nt + tid;
         if (i < nv) { ((float4 *) row)[i] = r.t[k]; s += (double) r.t[k].x; s += (double) r.t[k].y; s += (double) r.t[k].z; s += (double) r.t[k].w; }
     }
-    for (int64_t base = 8 * nt; base < nv; base += 8 * nt) {           // rows longer than 8192 floats (Falcon-180B)
+    for (int64_t base = (int64_t) NLN * nt; base < nv; base += 8 * nt) {   // the part of the row that did not fit the registers
         float4 t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t) k * nt + tid; t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
@@ -153,9 +155,90 @@ __device__ __forceinline__ void layer_norm_finish(const ln_row_regs & r, const f
     __syncthreads();
 }
 
+// ---- LayerNorm + activation quantizer of one row entirely in registers (the fused decode prologue), run by the first
+// LNW waves of the workgroup only (one per SIMD for Falcon-7B: the prologue is instruction-issue bound, and the other
+// waves are busy requesting weights). Thread t < nt = 64 LNW holds float4 number k*nt + t of the row (k < NLN), so the
+// 8 lanes of a Q8 block / the wave of a Q8_K super-block already sit next to each other and the f32 row never visits
+// LDS. Same arithmetic and per-thread order as layer_norm_finish + quantize_row_block. Requires n/4 <= NLN * nt.
+// Three stages, the CALLER puts a workgroup barrier between them (every wave must reach it). red: 32 doubles of LDS.
+template <int NLN>
+__device__ __forceinline__ void ln_regs_issue(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b,
+                                              int64_t n, int nt, ln_row_regs<NLN> & xr, ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) { const int64_t i = (int64_t) k * nt + tid; xr.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t i = (int64_t) k * nt + tid, j = i < nv ? i : nv - 1;
+        wr.t[k] = ((const float4 *) w)[j]; br.t[k] = ((const float4 *) b)[j];
+    }
+}
+template <typename T, typename OP>
+__device__ __forceinline__ T waves_combine(const T * scratch, int nw, OP op) {      // partials of waves 0..nw-1, in wave order
+    const int lane = threadIdx.x & 63;
+    const T mine = scratch[lane < nw ? lane : 0];
+    T t = lane_get(mine, 0);
+    for (int i = 1; i < nw; ++i) t = op(t, lane_get(mine, i));
+    return t;
+}
+template <int NLN>
+__device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t i = (int64_t) k * nt + tid;
+        if (i < nv) { s += (double) r.t[k].x; s += (double) r.t[k].y; s += (double) r.t[k].z; s += (double) r.t[k].w; }
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+}
+template <int NLN>
+__device__ __forceinline__ void ln_regs_stage2(ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+    const double s = waves_combine(red, nt >> 6, op_add());
+    const float mean = (float)(s / (double) n);
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t i = (int64_t) k * nt + tid;
+        float4 v = r.t[k];
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        r.t[k] = v;
+        if (i < nv) { s2 += (double)(v.x * v.x); s2 += (double)(v.y * v.y); s2 += (double)(v.z * v.z); s2 += (double)(v.w * v.w); }
+    }
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) red[16 + (tid >> 6)] = s2;
+}
+template <int ACT, int NLN>
+__device__ __forceinline__ void ln_regs_stage3(const ln_row_regs<NLN> & r, const ln_row_regs<NLN> & wr, const ln_row_regs<NLN> & br,
+                                               int64_t n, int nt, const act_image_ptr & o, const double * red) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+    const double s2 = waves_combine(red + 16, nt >> 6, op_add());
+    const float variance = (float)(s2 / (double) n);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t q4 = (int64_t) k * nt + tid;
+        float4 v = r.t[k];
+        const float4 ww = wr.t[k], bb = br.t[k];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
+        if constexpr (ACT == FQ_Q8_K) {
+            if ((q4 >> 6) < (n >> 8)) quant_q8K_wave(v, tid & 63, q4 >> 6, o);             // wave-uniform
+        } else {
+            if ((q4 & ~(int64_t) 63) < nv) { const bool live = q4 < nv; quant_q8_quad<ACT>(v, live ? q4 : nv - 1, o, live); }
+        }
+    }
+}
+
 __device__ __forceinline__ void layer_norm_row_block(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
                                                      const float * __restrict__ b, float * row, double * red) {
-    ln_row_regs r;
+    ln_row_regs<8> r;
     layer_norm_issue(x, n, r);
     layer_norm_finish(r, x, n, w, b, row, red);
 }

@@ -76,26 +76,32 @@ __device__ __forceinline__ float  wave_max(float v)  { return wave_reduce(v, op_
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16) f); }   // RNE, keeps subnormals
 __device__ __forceinline__ float    h2f_bits(uint16_t h) { return (float) __builtin_bit_cast(_Float16, h); }
 
-// block-wide reductions for 256-thread blocks (4 waves); `scratch` = >= 4 elements of LDS
+// block-wide reductions (<= 16 waves); `scratch` = >= 16 elements of LDS. The per-wave partials are combined in wave
+// order 0, 1, 2, ... : each lane fetches one partial with a single LDS read and the chain runs over v_readlane (a loop of
+// dependent LDS reads costs ~70 ns per wave, which is most of a LayerNorm at 12 waves).
+template <typename T, typename OP>
+__device__ __forceinline__ T block_combine(const T * scratch, OP op) {
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const T mine = scratch[lane < nw ? lane : 0];
+    T t = lane_get(mine, 0);
+    for (int i = 1; i < nw; ++i) t = op(t, lane_get(mine, i));
+    return t;
+}
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T * scratch) {
     v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) scratch[wid] = v;
     __syncthreads();
-    T t = scratch[0];
-    for (int i = 1; i < nw; ++i) t += scratch[i];
-    return t;
+    return block_combine(scratch, op_add());
 }
 __device__ __forceinline__ float block_max(float v, float * scratch) {
     v = wave_max(v);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) scratch[wid] = v;
     __syncthreads();
-    float t = scratch[0];
-    for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
-    return t;
+    return block_combine(scratch, op_max());
 }
 #endif

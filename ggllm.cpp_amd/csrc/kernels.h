@@ -52,7 +52,7 @@ struct fq_gemv_ln_seg {
     float *       dst;             // f32 output (STORE / GELU_STORE)
     uint8_t *     dst_image;       // Q8_0 / Q8_1 activation image of length w.M (GELU_QUANT)
     int           next_act_type;
-    int           block_begin;     // first workgroup of the segment (32 rows per workgroup)
+    int           block_begin;     // first workgroup of the segment (set by the launcher)
 };
 struct fq_gemv_ln_args {
     const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg;
@@ -68,8 +68,8 @@ struct fq_gemv_out_args {
     long long *     dbg;           // optional phase stamps (wall_clock64), 8 per workgroup
 };
 size_t fq_gemv_ln_lds(int type, int64_t E);
-void   fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st);
-void   fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st);
+void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st);       // fills seg[].block_begin
+void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
                              int att_act_type, hipStream_t st);

@@ -31,11 +31,11 @@ __device__ __forceinline__ void rows_ptrs(const fq_weight & w, int64_t row0, fq_
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int64_t row = row0 + r; rows[r] = fq_row<TYPE>(w, row < w.M ? row : w.M - 1); }
 }
-template <int TYPE, int R, int NPRE>
+template <int TYPE, int R, int NPRE, int C0 = 0, int C1 = NPRE>            // unit columns [C0, C1) of the NPRE pre-issued ones
 __device__ __forceinline__ void rows_issue(const fq_wrow (&rows)[R], int units, fq_unit_regs (&regs)[NPRE][R]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
+    for (int i = C0; i < C1; ++i) {
         const int u = i * 64 + lane; const int uc = u < units ? u : units - 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
@@ -77,7 +77,8 @@ __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int unit
 template <int TYPE> struct decode_cfg {
     static constexpr bool four_bit = (TYPE == FQ_Q4_0 || TYPE == FQ_Q4_1 || TYPE == FQ_Q5_0 || TYPE == FQ_Q5_1);
     static constexpr int LN_R     = 4;                                  // rows per pass in k_gemv_ln (8 rows per wave in total)
-    static constexpr int LN_NPRE  = four_bit ? 3 : 2;
+    static constexpr int LN_NPRE  = four_bit ? 3 : 2;                   // 4-wave workgroups (small models)
+    static constexpr int LN_NPRE_BIG = 1;                               // 12-wave workgroups, see k_gemv_ln
     static constexpr int OUT_NPRE_D = four_bit ? 4 : 2;                 // k_gemv_out, down projection (R = 2)
     static constexpr int OUT_NPRE_O = four_bit ? 3 : 1;                 // k_gemv_out, attention projection
 };
@@ -87,40 +88,64 @@ __device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_typ
 }
 
 // =============================================================================================== k_gemv_ln
-// one workgroup = 32 consecutive rows of one segment; wave w owns rows 8w..8w+7 (two passes of 4)
-template <int TYPE>
-__global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
+// one workgroup = NW waves = 8*NW consecutive rows of one segment (NW = blockDim/64, chosen by the launcher so that the
+// grid is about one workgroup per CU: the LayerNorm + Q8 prologue is then computed ~n_cu times per launch instead of
+// once per 32 rows); wave w owns rows 8w..8w+7 (two passes of 4)
+template <int TYPE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = act_of<TYPE>::value;
     const int64_t E = a.E;
     const int sidx = (a.nseg > 1 && (int) blockIdx.x >= a.seg[1].block_begin) ? 1 : 0;
     const fq_gemv_ln_seg sg = sidx ? a.seg[1] : a.seg[0];       // whole-struct select: no runtime-indexed kernarg array
-    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * (8 * nw);
 
-    // LDS: f32 row [E] | image | out32 | reduction scratch
+    // LDS: f32 row [E] | image | out rows (<= 128) | reduction scratch
     float   * rowf  = (float *) smem;
     uint8_t * image = smem + (((size_t) E * 4 + 15) & ~(size_t) 15);
     float   * out32 = (float *)(image + fq_act_col_bytes(ACT, E));
-    double  * red   = (double *)(out32 + 32);
+    double  * red   = (double *)(out32 + 128);
 
-    constexpr int R = 4, NPRE = decode_cfg<TYPE>::LN_NPRE;              // 8 rows per wave = two passes of 4
+    constexpr int R = 4, NPRE = MAXT > 256 ? decode_cfg<TYPE>::LN_NPRE_BIG : decode_cfg<TYPE>::LN_NPRE;              // 8 rows per wave = two passes of 4
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
     // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
     //    5. pass 1 (its loads overlap other workgroups' dots)
     FQ_STAMP(a.dbg, 0);
-    ln_row_regs xr;
-    layer_norm_issue(a.x, E, xr);
+    // LayerNorm + Q8 image in registers (NLN float4 of the row per thread) when the row fits, through LDS otherwise
+    constexpr int NLN = MAXT > 256 ? 2 : 5;
+    const bool in_regs = (E >> 2) <= (int64_t) NLN * blockDim.x;        // Falcon-7B/40B/180B with 12 waves: yes
     fq_wrow rows0[R], rows1[R];
-    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
-    rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
     fq_unit_regs pre0[NPRE][R];
-    rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
-    FQ_STAMP(a.dbg, 1);
-    layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);          // identical to k_layer_norm
-    FQ_STAMP(a.dbg, 2);
-    quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));        // identical to k_quantize_q8 / q8K
-    __syncthreads();
+    if (in_regs) {
+        ln_row_regs<NLN> xr, wr, br;
+        ln_regs_issue(a.x, sg.ln_w, sg.ln_b, E, blockDim.x, xr, wr, br);
+        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
+        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
+        ln_regs_stage1(xr, E, blockDim.x, red);                          // waits for the row only
+        // only NPRE (12 waves: ONE) unit column per row is requested ahead of the LayerNorm (48 KB per CU): a CU keeps
+        // only so many requests in flight, more makes the later waves' loads block at issue, and a wave that cannot
+        // issue cannot reach the LN's barriers either (measured: +3 us with 3 columns)
+        rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
+        FQ_STAMP(a.dbg, 1);
+        __syncthreads();
+        ln_regs_stage2(xr, E, blockDim.x, red);
+        __syncthreads();
+        ln_regs_stage3<ACT>(xr, wr, br, E, blockDim.x, act_image_at(image, ACT, E), red);
+        FQ_STAMP(a.dbg, 2);
+        __syncthreads();
+    } else {
+        ln_row_regs<8> xr;
+        layer_norm_issue(a.x, E, xr);
+        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
+        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
+        rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
+        FQ_STAMP(a.dbg, 1);
+        layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);      // identical to k_layer_norm
+        FQ_STAMP(a.dbg, 2);
+        quantize_row_block<ACT>(rowf, E, act_image_at(image, ACT, E));    // identical to k_quantize_q8 / q8K
+        __syncthreads();
+    }
     FQ_STAMP(a.dbg, 3);
     const fq_actcol col = actcol_at(image, ACT, E);
     {
@@ -151,26 +176,26 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
         FQ_STAMP(a.dbg, 5);
     }
     __syncthreads();
-    if (tid < 64) {                                   // wave 0 finishes the 32 rows (lanes 32..63 mirror 0..31)
+    for (int grp = wid; grp < nw / 4; grp += nw) {     // wave grp finishes rows [32*grp, 32*grp+32) (lanes 32..63 mirror 0..31)
         const int j = lane & 31;
-        const int64_t row = row0 + j;
-        float v = out32[j];
+        const int64_t row = row0 + 32 * grp + j;
+        float v = out32[32 * grp + j];
         if (sg.epi == FQ_LNEPI_STORE) {
             if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
-            if (a.argmax_val) {                       // first stage of the greedy sampler: this workgroup's best (value, row)
+            if (a.argmax_val) {                       // first stage of the greedy sampler: best (value, row) of these 32 rows
                 float bv = row < sg.w.M ? v : -INFINITY; int bi = (int) row;
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) {
                     const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
                     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                 }
-                if (lane == 0) { a.argmax_val[blockIdx.x] = bv; a.argmax_idx[blockIdx.x] = bi; }
+                if (lane == 0 && row0 + 32 * grp < sg.w.M) { a.argmax_val[(row0 >> 5) + grp] = bv; a.argmax_idx[(row0 >> 5) + grp] = bi; }
             }
         } else {
             v = h2f_bits(a.gelu_table[f2h_bits(v)]);                                  // ggml.c:3477-3484
             if (sg.epi == FQ_LNEPI_GELU_STORE) {
                 if (lane < 32 && row < sg.w.M) sg.dst[row] = v;
-            } else {                                                                  // GELU -> Q8_0 / Q8_1 block of 32
+            } else if (row0 + 32 * grp < sg.w.M) {                                    // GELU -> Q8_0 / Q8_1 block of 32 (M % 32 == 0)
                 const float amax = reduce32(fabsf(v), op_max());
                 const float d  = amax / 127.0f;
                 const float id = d ? 1.0f / d : 0.0f;
@@ -179,7 +204,7 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
                 const act_image_ptr o = act_image_at(sg.dst_image, sg.next_act_type, sg.w.M);
                 if (lane < 32) o.qs[row] = (int8_t) q;
                 if (lane == 0) {
-                    const int64_t b = row0 >> 5;
+                    const int64_t b = (row0 >> 5) + grp;
                     if (sg.next_act_type == FQ_Q8_0) { o.d[b] = h2f_bits(f2h_bits(d)); ((int32_t *) o.aux)[b] = s; }
                     else                             { o.d[b] = d; ((float *) o.aux)[b] = (float) s * d; }
                 }
@@ -191,29 +216,49 @@ __global__ void __launch_bounds__(256) k_gemv_ln(fq_gemv_ln_args a) {
 
 size_t fq_gemv_ln_lds(int type, int64_t E) {
     const int act = fq_desc(type).act_type;
-    return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 32 * 4 + 64;
+    return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 128 * 4 + 32 * 8;
 }
 
-void fq_launch_gemv_ln(const fq_gemv_ln_args & a, hipStream_t st) {
+// waves per workgroup (8 rows per wave; 4, 8 or 12 so that a workgroup is whole 32-row groups): the one that needs the
+// fewest rounds x rows-per-workgroup over the chip's CUs, ties to the larger workgroup (fewer LN + Q8 prologues)
+int fq_gemv_ln_waves(const fq_gemv_ln_args & a, int n_cu) {
+    int best = 4; int64_t best_cost = INT64_MAX;
+    for (int nw = 4; nw <= 12; nw += 4) {
+        int64_t blocks = 0;
+        for (int s = 0; s < a.nseg; ++s) blocks += (a.seg[s].w.M + 8 * nw - 1) / (8 * nw);
+        const int64_t cost = ((blocks + n_cu - 1) / n_cu) * nw;
+        if (cost <= best_cost) { best_cost = cost; best = nw; }
+    }
+    return best;
+}
+
+void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
+    const int nw = fq_gemv_ln_waves(a, n_cu);
     int blocks = 0;
-    for (int s = 0; s < a.nseg; ++s) blocks = a.seg[s].block_begin + (int)((a.seg[s].w.M + 31) / 32);
+    for (int s = 0; s < a.nseg; ++s) { a.seg[s].block_begin = blocks; blocks += (int)((a.seg[s].w.M + 8 * nw - 1) / (8 * nw)); }
     const int type = a.seg[0].w.type;
-    const size_t lds = fq_gemv_ln_lds(type, a.E);
-#define FQ_CASE(T) case T: { \
-        if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
-        hipLaunchKernelGGL(k_gemv_ln<T>, dim3((unsigned) blocks), dim3(256), lds, st, a); } break;
+    size_t lds = fq_gemv_ln_lds(type, a.E);
+    // a grid that fits the chip gets one workgroup per CU: claim more than half of the 160 KiB LDS so that the dispatcher
+    // cannot co-locate two of them while other CUs stay empty
+    if (blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;
+#define FQ_LAUNCH(T, MAXT) { \
+        static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
+        hipLaunchKernelGGL((k_gemv_ln<T, MAXT>), dim3((unsigned) blocks), dim3(64 * nw), lds, st, a); }
+#define FQ_CASE(T) case T: if (nw <= 4) FQ_LAUNCH(T, 256) else FQ_LAUNCH(T, 768) break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
         default: fprintf(stderr, "ggml-hip: gemv_ln: unsupported weight type %d\n", type); exit(1);
     }
 #undef FQ_CASE
+#undef FQ_LAUNCH
 }
 
 // =============================================================================================== k_gemv_out
-// one workgroup = 8 consecutive output rows (wave w: rows 2w, 2w+1); x[row] = (down + wo) + x[row]
-template <int TYPE>
-__global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
+// one workgroup = NW waves = 2*NW consecutive output rows (wave w: rows 2w, 2w+1), NW chosen by the launcher for about
+// one workgroup per CU; x[row] = (down + wo) + x[row]
+template <int TYPE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = act_of<TYPE>::value;
     const int64_t E = a.w_wo.K, FF = a.w_down.K;
@@ -223,7 +268,8 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
 
     constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
     const int units_d = (int)(FF / fq_unit<TYPE>::ELEMS), units_o = (int)(E / fq_unit<TYPE>::ELEMS);
-    const int64_t row0 = (int64_t) blockIdx.x * 8 + 2 * wid;
+    const int nt = blockDim.x;
+    const int64_t row0 = (int64_t) blockIdx.x * (2 * (nt >> 6)) + 2 * wid;
     (void) lane;
     FQ_STAMP(a.dbg, 0);
     // 1. prologue loads: the quantized gelu(up) image and either the already-quantized attention image (flat 16-byte
@@ -234,11 +280,12 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 * src_ff = (const u32x4 *) a.act_ff_image;
     const u32x4 * src_at = (const u32x4 *) (a.att_image ? a.att_image : a.act_ff_image);
-    u32x4 tf[8], tq[3];
+    constexpr int NTF = MAXT > 256 ? 4 : 8, NTQ = MAXT > 256 ? 1 : 3;       // prologue vectors held in registers per thread
+    u32x4 tf[NTF], tq[NTQ];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int64_t i = (int64_t) k * 256 + tid; tq[k] = src_at[i < nvec_at ? i : 0]; }
+    for (int k = 0; k < NTQ; ++k) { const int64_t i = (int64_t) k * nt + tid; tq[k] = src_at[i < nvec_at ? i : 0]; }
     __builtin_amdgcn_sched_barrier(0);
     // 2. weight loads for both sources
     fq_wrow rd[2], ro[2];
@@ -250,14 +297,14 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     FQ_STAMP(a.dbg, 1);
     // 3. finish the prologue while the weights stream
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec_ff) ((u32x4 *) img_ff)[i] = tf[k]; }
-    for (int64_t i = 8 * 256 + tid; i < nvec_ff; i += 256) ((u32x4 *) img_ff)[i] = src_ff[i];
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; if (i < nvec_ff) ((u32x4 *) img_ff)[i] = tf[k]; }
+    for (int64_t i = (int64_t) NTF * nt + tid; i < nvec_ff; i += nt) ((u32x4 *) img_ff)[i] = src_ff[i];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int64_t i = (int64_t) k * 256 + tid; if (i < nvec_at) ((u32x4 *) img_att)[i] = tq[k]; }
-    for (int64_t i = 3 * 256 + tid; i < nvec_at; i += 256) ((u32x4 *) img_att)[i] = src_at[i];
+    for (int k = 0; k < NTQ; ++k) { const int64_t i = (int64_t) k * nt + tid; if (i < nvec_at) ((u32x4 *) img_att)[i] = tq[k]; }
+    for (int64_t i = (int64_t) NTQ * nt + tid; i < nvec_at; i += nt) ((u32x4 *) img_att)[i] = src_at[i];
     if (nq) {
         float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));      // f32 copy of the attention row
-        for (int64_t i = tid; i < nq; i += 256) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
+        for (int64_t i = tid; i < nq; i += nt) ((float4 *) att_f)[i] = ((const float4 *) a.att)[i];
         __syncthreads();
         FQ_STAMP(a.dbg, 2);
         quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
@@ -285,20 +332,30 @@ __global__ void __launch_bounds__(256) k_gemv_out(fq_gemv_out_args a) {
     FQ_STAMP(a.dbg, 7);
 }
 
-void fq_launch_gemv_out(const fq_gemv_out_args & a, hipStream_t st) {
+void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
-    const size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (a.att_image ? 0 : (size_t) a.w_wo.K * 4) + 16;
-    const unsigned blocks = (unsigned)((a.w_wo.M + 7) / 8);
-#define FQ_CASE(T) case T: { \
-        if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } } \
-        hipLaunchKernelGGL(k_gemv_out<T>, dim3(blocks), dim3(256), lds, st, a); } break;
+    size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (a.att_image ? 0 : (size_t) a.w_wo.K * 4) + 16;
+    // 2 rows per wave; 4..12 waves per workgroup, the count with the fewest rounds x rows-per-workgroup over the CUs
+    int nw = 4; int64_t best_cost = INT64_MAX;
+    for (int c = 4; c <= 12; ++c) {
+        const int64_t nb = (a.w_wo.M + 2 * c - 1) / (2 * c);
+        const int64_t cost = ((nb + n_cu - 1) / n_cu) * c;
+        if (cost <= best_cost) { best_cost = cost; nw = c; }
+    }
+    const unsigned blocks = (unsigned)((a.w_wo.M + 2 * nw - 1) / (2 * nw));
+    if ((int) blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;       // one workgroup per CU (see fq_launch_gemv_ln)
+#define FQ_LAUNCH(T, MAXT) { \
+        static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
+        hipLaunchKernelGGL((k_gemv_out<T, MAXT>), dim3(blocks), dim3(64 * nw), lds, st, a); }
+#define FQ_CASE(T) case T: if (nw <= 4) FQ_LAUNCH(T, 256) else FQ_LAUNCH(T, 768) break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
         default: fprintf(stderr, "ggml-hip: gemv_out: unsupported weight type %d\n", type); exit(1);
     }
 #undef FQ_CASE
+#undef FQ_LAUNCH
 }
 
 // =============================================================================================== k_attn_decode

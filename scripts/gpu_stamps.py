@@ -17,7 +17,7 @@ m.decode_greedy(int(out[-1]), 158, 4)
 st = np.zeros(2 * 4096 * 8, np.int64)
 L.ggml_hip_debug_stamps(1, st.ctypes.data)
 st = st.reshape(2, 4096, 8)
-for name, k, nb in (("k_gemv_ln", 0, 714), ("k_gemv_out", 1, 568)):
+for name, k, nb in (("k_gemv_ln", 0, 239), ("k_gemv_out", 1, 253)):
     s = st[k, :nb].astype(np.float64)
     t0 = s[:, 0].min()
     rel = (s - t0) / 100.0          # wall clock = 100 MHz -> us
