@@ -30,7 +30,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error""".split()
 
 
 def build(verbose=False):
@@ -87,7 +87,7 @@ def load():
         "falcon_hip_stage_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)          # AttributeError here = an include/*.h symbol is not exported
@@ -247,8 +247,12 @@ class FalconModel:
         L.falcon_hip_decode_greedy(self.ctx, int(first_token), n_past, n_steps, out.ctypes.data)
         return out
 
-    def set_fused(self, on):
-        load().falcon_hip_context_set_fused(self.ctx, 1 if on else 0)
+    def set_fused(self, mode):
+        """0 = op list, 1 = three launches per block, 2 (True) = two launches per block (default)"""
+        load().falcon_hip_context_set_fused(self.ctx, 2 if mode is True else int(mode))
+
+    def sync_error(self):
+        return load().falcon_hip_context_sync_error(self.ctx)
 
     def weight_bytes(self):
         return load().falcon_hip_model_weight_bytes(self.m)

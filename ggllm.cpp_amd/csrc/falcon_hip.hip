@@ -60,6 +60,8 @@ struct falcon_hip_context {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;  // one pair per local layer
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
+    bool merged_attn_out = true;               // ... with attention and the output mat-vec in one launch (k_attn_out) when the grid fits the chip
+    unsigned * sync_words = nullptr;           // [0] arrival counter of k_attn_out, [1] its time-out flag
     hipGraphExec_t decode_graph = nullptr;
     int  graph_base = -1;                      // n_past the captured graph was built for
 };
@@ -217,6 +219,9 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     if (const char * e = getenv("FALCON_HIP_DUAL")) c->dual_stream = atoi(e) != 0;
     c->argmax_val     = (float *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 8) * 4);
     c->argmax_idx     = (int *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 8) * 4);
+    c->sync_words     = (unsigned *) dev_alloc(c->allocs, 64 + 256);        // + the rope table row of the current position
+    HIP_CHECK(hipMemset(c->sync_words, 0, 64 + 256));
+    if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     return c;
 }
 
@@ -240,9 +245,16 @@ extern "C" void falcon_hip_get_hidden(falcon_hip_context * c, float * dst) {
     HIP_CHECK(hipMemcpy(dst, c->hidden_dev, (size_t)(c->m->layers.size() + 1) * c->hidden_tokens * c->m->hp.n_embd * 4, hipMemcpyDeviceToHost));
 }
 extern "C" void falcon_hip_context_use_graph(falcon_hip_context * c, int enable) { c->use_graph = enable != 0; }
-extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int enable) {
-    if (c->fused_decode != (enable != 0) && c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
-    c->fused_decode = enable != 0;
+extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1 if a k_attn_out poll ever timed out (results invalid)
+    unsigned w[2] = {0, 0};
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(w, c->sync_words, sizeof w, hipMemcpyDeviceToHost));
+    return (int) w[1];
+}
+extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default)
+    if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
+    c->fused_decode = mode != 0;
+    c->merged_attn_out = mode >= 2;
 }
 
 // ------------------------------------------------------------------------------------------------ one eval
@@ -267,6 +279,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
             fq_gemv_ln_args ga{};
             ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table; ga.dbg = hc.dbg_stamps;
+            ga.zero_word = c->sync_words;
+            if (c->merged_attn_out) { ga.n_past_ptr = c->n_past_dev; ga.rope_cs = c->rope_cs; ga.rope_cur = (float *)(c->sync_words + 16); }
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, 0 };
             const bool prof = fq_prof_active();
@@ -291,13 +305,21 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             const int att_act = fq_desc(L.wo.type).act_type;
             const bool att_q = (att_act == FQ_Q8_0 || att_act == FQ_Q8_1);      // the head's 64 outputs = two 32-blocks
-            fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table,
-                                  att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
             fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, att_q ? c->act_att.base : nullptr, c->x, c->x,
                                  hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
-            if (prof) fq_prof_open(st);
-            fq_launch_gemv_out(go, hc.n_cu, st);
+            bool merged = false;
+            if (c->merged_attn_out && !dual) {
+                if (prof) fq_prof_open(st);
+                merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
+                                            kc, vc, hc.exp_table, att_act, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+            }
+            if (!merged) {
+                fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table,
+                                      att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
+                if (prof) fq_prof_open(st);
+                fq_launch_gemv_out(go, hc.n_cu, st);
+            }
             if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
         }
         if (c->keep_hidden) {

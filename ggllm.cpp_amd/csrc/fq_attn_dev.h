@@ -1,18 +1,24 @@
-// fq_attn_dev.h -- one (head, token) of Falcon attention by a 256-thread workgroup; shared by k_attention (prefill /
+// fq_attn_dev.h -- one (head, token) of Falcon attention by 256 threads (a workgroup, or one of several lockstep
+// 256-thread groups of a larger workgroup: tid = index in the group, every barrier is a workgroup barrier); shared by k_attention (prefill /
 // op-by-op path) and k_attn_decode (fused N = 1 path) so that both produce the same bits.
 //
 //   scores  K.Q (ggml.c:11049-11088) * 1/sqrt(64) (libfalcon.cpp:2313-2317); keys j >= n_kv are masked (ggml.c:12341)
 //   softmax max, exp through the fp16 table, f64 sum, scale by (float)(1/sum)  (ggml.c:12389-12456)
 //   V.P     out[d] = sum_j V[j][d] * p[j]
 // f32 products are accumulated in f64 like the reference's portable ggml_vec_dot_f32 (ggml.c:2296-2300); the f64 sums
-// are associated differently (16 lanes / 16 row classes), which changes the f32 result with probability ~1e-9.
+// are associated differently (8 lanes x 8 dims / waves / 16 row classes), which changes the f32 result with probability ~1e-9.
+// (One thread per key row would reproduce the reference's order exactly and needs a third of the instructions, but its
+// 64 scattered 16-byte requests per load instruction cost more than they save: measured +3 us per decode attention.)
 //
 // Keys/values [0, n_cached) come from the cache ([pos][HKV][64] f32); an optional newest key/value (index n_cached)
 // comes from LDS (the fused decode kernel has not written it to HBM for other workgroups to see).
-// Thread map: sub = tid & 15 owns 4 consecutive head dims, rowi = tid >> 4 owns key rows j == rowi (mod 16); global
-// loads are issued in batches of 8 rows per thread (128 rows per workgroup step).
+// Thread map. Scores: 8 lanes per key row (lane s8 owns dims 4 s8.. and 32 + 4 s8..: every load instruction reads runs of
+// 128 contiguous bytes), 3 DPP steps per row. V.P: sub = tid & 15 owns 4 consecutive head dims, rowi = tid >> 4 owns
+// value rows j == rowi (mod 16). Loads in steps of 128 rows per workgroup, one step ahead of their use.
 #pragma once
 #include "fq_device.h"
+
+#define FQ_ATTN_STAMP(dbg, slot) do { if ((dbg) && threadIdx.x == 0) (dbg)[(size_t) blockIdx.x * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
 struct attn_lds {
     float  * redf;     // >= 16 floats
@@ -30,65 +36,122 @@ __device__ __forceinline__ attn_lds attn_lds_carve(uint8_t * base) {       // ba
     return a;
 }
 
+// The first 128 key rows and the first 128 value rows (8 per thread each) can be requested before q is known (the decode
+// kernel issues them together with the q/k/v loads of the rope, one memory round trip earlier); later batches are
+// requested one batch ahead of their use. The arithmetic does not depend on any of this.
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // (arrays of HIP's float4 struct are not promoted to registers)
+// Loads run TWO steps (of 128 rows) ahead of their use: decode attention at a few hundred keys is a chain of memory round
+// trips (each 1.5-2 us while the rest of the chip streams weights), so keys [0, 256) and values [0, 128) are requested
+// before q is even known (the decode kernel issues them first thing), values [128, 256) as soon as the scores are done.
+struct attn_pre { f32x4 k[16], v[8]; };                       // k[8 s + ..]: step s (s = 0, 1)
+
+__device__ __forceinline__ void attn_load_k(const float * __restrict__ kc, int HKV, int hk, int row_limit, int j0, int tid, f32x4 * k8) {
+    const int s8 = tid & 7, rowg = tid >> 3, last = row_limit > 0 ? row_limit - 1 : 0;      // 8 lanes per row: float4 s8 and s8 + 8
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int j = j0 + 32 * b + rowg;
+        const f32x4 * r = (const f32x4 *)(kc + ((int64_t)(j < row_limit ? j : last) * HKV + hk) * 64);
+        k8[2 * b] = r[s8]; k8[2 * b + 1] = r[s8 + 8];
+    }
+}
+__device__ __forceinline__ void attn_load_v(const float * __restrict__ vc, int HKV, int hk, int row_limit, int j0, int tid, f32x4 * v8) {
+    const int sub = tid & 15, rowi = tid >> 4, last = row_limit > 0 ? row_limit - 1 : 0;    // 16 lanes per row: float4 sub
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int j = j0 + 16 * b + rowi;
+        v8[b] = *(const f32x4 *)(vc + ((int64_t)(j < row_limit ? j : last) * HKV + hk) * 64 + 4 * sub);
+    }
+}
+// row_limit: rows [0, row_limit) exist in the cache (the cache's length when n_cached is not known yet, else n_cached)
+__device__ __forceinline__ void attn_prefetch(const float * __restrict__ kc, const float * __restrict__ vc, int HKV, int hk, int row_limit,
+                                              int tid, attn_pre & P) {
+    attn_load_k(kc, HKV, hk, row_limit, 0, tid, P.k);
+    attn_load_v(vc, HKV, hk, row_limit, 0, tid, P.v);
+    attn_load_k(kc, HKV, hk, row_limit, 128, tid, P.k + 8);
+}
+
+// scores of the 128 rows [j0, j0 + 128) held in k8
+__device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_cached, int n_kv, const float * new_k, const f32x4 qa, const f32x4 qb,
+                                                int tid, float * p, float & lmax) {
+    const int s8 = tid & 7, rowg = tid >> 3;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int j = j0 + 32 * b + rowg;
+        f32x4 ka = k8[2 * b], kb = k8[2 * b + 1];
+        if (new_k && j == n_cached) { ka = *(const f32x4 *)(new_k + 4 * s8); kb = *(const f32x4 *)(new_k + 32 + 4 * s8); }
+        double s = (double)(ka.x * qa.x); s += (double)(ka.y * qa.y); s += (double)(ka.z * qa.z); s += (double)(ka.w * qa.w);
+        s += (double)(kb.x * qb.x); s += (double)(kb.y * qb.y); s += (double)(kb.z * qb.z); s += (double)(kb.w * qb.w);
+        s = reduce8(s, op_add());
+        const float sc = (float) s * 0.125f;
+        if (j < n_kv) { if (s8 == 0) p[j] = sc; lmax = fmaxf(lmax, sc); }
+    }
+}
+__device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cached, int tid, const float * p, double & a0, double & a1, double & a2, double & a3) {
+    const int rowi = tid >> 4;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int j = j0 + 16 * b + rowi;
+        if (j < n_cached) {
+            const float pj = p[j];
+            const f32x4 v4 = v8[b];
+            a0 += (double)(v4.x * pj); a1 += (double)(v4.y * pj); a2 += (double)(v4.z * pj); a3 += (double)(v4.w * pj);
+        }
+    }
+}
+
 // q: 64 floats (rotated) in LDS or global; returns out[d] for d = tid (valid for tid < 64)
 __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, const float * __restrict__ kc, const float * __restrict__ vc,
                                                  int HKV, int hk, int n_cached, const float * new_k, const float * new_v,
-                                                 const uint16_t * __restrict__ exp_tab, const attn_lds & L) {
-    constexpr int D = 64;
-    const int tid = threadIdx.x, sub = tid & 15, rowi = tid >> 4;
+                                                 const uint16_t * __restrict__ exp_tab, const attn_lds & L, const int tid, attn_pre & P,
+                                                 long long * dbg = nullptr) {
+    constexpr int NT = 256;
+    const int sub = tid & 15, rowi = tid >> 4;
     const int n_kv = n_cached + (new_k ? 1 : 0);
-    const float4 q4 = *(const float4 *)(q + 4 * sub);
-    const int last = n_cached > 0 ? n_cached - 1 : 0;
 
-    // ---- scores
+    // ---- scores: 8 lanes per key row (two float4 each), 4 rows per thread and step, 128 rows per step
     float lmax = -INFINITY;
-    for (int j0 = 0; j0 < n_kv; j0 += 128) {
-        float4 k4[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            k4[b] = *(const float4 *)(kc + ((int64_t)(j < n_cached ? j : last) * HKV + hk) * D + 4 * sub);
-        }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            if (new_k && j == n_cached) k4[b] = *(const float4 *)(new_k + 4 * sub);
-            double s = (double)(k4[b].x * q4.x); s += (double)(k4[b].y * q4.y); s += (double)(k4[b].z * q4.z); s += (double)(k4[b].w * q4.w);
-            s = reduce16(s, op_add());
-            const float sc = (float) s * 0.125f;
-            if (j < n_kv) { if (sub == 0) L.p[j] = sc; lmax = fmaxf(lmax, sc); }
+    {
+        const int s8 = tid & 7;
+        const f32x4 qa = *(const f32x4 *)(q + 4 * s8), qb = *(const f32x4 *)(q + 32 + 4 * s8);
+        for (int j0 = 0; j0 < n_kv; j0 += 256) {
+            attn_score_step(P.k, j0, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+            if (j0 + 256 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 256, tid, P.k);
+            if (j0 + 128 < n_kv) {
+                attn_score_step(P.k + 8, j0 + 128, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+                if (j0 + 384 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 384, tid, P.k + 8);
+            }
         }
     }
-    const float mx = block_max(lmax, L.redf);
+    f32x4 v1[8];                                                   // values of the odd steps (the key registers are free now)
+    if (128 < n_cached) attn_load_v(vc, HKV, hk, n_cached, 128, tid, v1);
+    FQ_ATTN_STAMP(dbg, 3);
+    // ---- soft_max (three barriers: scores + maxima visible, sums visible, probabilities visible)
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) L.redf[tid >> 6] = lmax;
     __syncthreads();
-    // ---- soft_max
+    const float mx = waves_combine(L.redf, NT >> 6, op_max());
     double lsum = 0.0;
-    for (int j = tid; j < n_kv; j += blockDim.x) {
+    for (int j = tid; j < n_kv; j += NT) {
         const float e = h2f_bits(exp_tab[f2h_bits(L.p[j] - mx)]);
         L.p[j] = e;
         lsum += (double) e;
     }
-    const double sum = block_sum(lsum, L.red);
+    lsum = wave_sum(lsum);
+    if ((tid & 63) == 0) L.red[tid >> 6] = lsum;
+    __syncthreads();
+    const double sum = waves_combine(L.red, NT >> 6, op_add());
     const float inv = (float)(1.0 / sum);
+    for (int j = tid; j < n_kv; j += NT) L.p[j] *= inv;
     __syncthreads();
-    for (int j = tid; j < n_kv; j += blockDim.x) L.p[j] *= inv;
-    __syncthreads();
+    FQ_ATTN_STAMP(dbg, 4);
     // ---- V.P
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int j0 = 0; j0 < n_cached; j0 += 128) {
-        float4 v4[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            v4[b] = *(const float4 *)(vc + ((int64_t)(j < n_cached ? j : last) * HKV + hk) * D + 4 * sub);
-        }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = j0 + 16 * b + rowi;
-            if (j < n_cached) {
-                const float pj = L.p[j];
-                a0 += (double)(v4[b].x * pj); a1 += (double)(v4[b].y * pj); a2 += (double)(v4[b].z * pj); a3 += (double)(v4[b].w * pj);
-            }
+    for (int j0 = 0; j0 < n_cached; j0 += 256) {
+        attn_pv_step(P.v, j0, n_cached, tid, L.p, a0, a1, a2, a3);
+        if (j0 + 256 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 256, tid, P.v);
+        if (j0 + 128 < n_cached) {
+            attn_pv_step(v1, j0 + 128, n_cached, tid, L.p, a0, a1, a2, a3);
+            if (j0 + 384 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 384, tid, v1);
         }
     }
     if (new_v && rowi == (n_cached & 15)) {
@@ -96,6 +159,7 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
         const float pj = L.p[n_cached];
         a0 += (double)(v.x * pj); a1 += (double)(v.y * pj); a2 += (double)(v.z * pj); a3 += (double)(v.w * pj);
     }
+    FQ_ATTN_STAMP(dbg, 5);
     L.red[rowi * 64 + 4 * sub + 0] = a0; L.red[rowi * 64 + 4 * sub + 1] = a1;
     L.red[rowi * 64 + 4 * sub + 2] = a2; L.red[rowi * 64 + 4 * sub + 3] = a3;
     __syncthreads();
@@ -107,4 +171,11 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
         out = (float) o;
     }
     return out;
+}
+__device__ __forceinline__ float attn_head_block(const float * __restrict__ q, const float * __restrict__ kc, const float * __restrict__ vc,
+                                                 int HKV, int hk, int n_cached, const float * new_k, const float * new_v,
+                                                 const uint16_t * __restrict__ exp_tab, const attn_lds & L) {
+    attn_pre P;
+    attn_prefetch(kc, vc, HKV, hk, n_cached, (int) threadIdx.x, P);
+    return attn_head_block(q, kc, vc, HKV, hk, n_cached, new_k, new_v, exp_tab, L, (int) threadIdx.x, P);
 }

@@ -174,14 +174,6 @@ __device__ __forceinline__ void ln_regs_issue(const float * __restrict__ x, cons
         wr.t[k] = ((const float4 *) w)[j]; br.t[k] = ((const float4 *) b)[j];
     }
 }
-template <typename T, typename OP>
-__device__ __forceinline__ T waves_combine(const T * scratch, int nw, OP op) {      // partials of waves 0..nw-1, in wave order
-    const int lane = threadIdx.x & 63;
-    const T mine = scratch[lane < nw ? lane : 0];
-    T t = lane_get(mine, 0);
-    for (int i = 1; i < nw; ++i) t = op(t, lane_get(mine, i));
-    return t;
-}
 template <int NLN>
 __device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
     const int tid = threadIdx.x;

@@ -80,12 +80,30 @@ __device__ __forceinline__ float    h2f_bits(uint16_t h) { return (float) __buil
 // order 0, 1, 2, ... : each lane fetches one partial with a single LDS read and the chain runs over v_readlane (a loop of
 // dependent LDS reads costs ~70 ns per wave, which is most of a LayerNorm at 12 waves).
 template <typename T, typename OP>
-__device__ __forceinline__ T block_combine(const T * scratch, OP op) {
-    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+__device__ __forceinline__ T waves_combine(const T * scratch, int nw, OP op) {      // partials of waves 0..nw-1, in wave order
+    const int lane = threadIdx.x & 63;
     const T mine = scratch[lane < nw ? lane : 0];
     T t = lane_get(mine, 0);
     for (int i = 1; i < nw; ++i) t = op(t, lane_get(mine, i));
     return t;
+}
+template <typename T, typename OP>
+__device__ __forceinline__ T block_combine(const T * scratch, OP op) { return waves_combine(scratch, (int)(blockDim.x >> 6), op); }
+// the same over a GROUP of gnt threads (a multiple of 64) of a larger workgroup whose groups run in lockstep: gtid is the
+// thread's index in its group, scratch the group's own LDS words; the barriers are workgroup barriers
+__device__ __forceinline__ double group_sum(double v, double * scratch, int gtid, int gnt) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((gtid & 63) == 0) scratch[gtid >> 6] = v;
+    __syncthreads();
+    return waves_combine(scratch, gnt >> 6, op_add());
+}
+__device__ __forceinline__ float group_max(float v, float * scratch, int gtid, int gnt) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((gtid & 63) == 0) scratch[gtid >> 6] = v;
+    __syncthreads();
+    return waves_combine(scratch, gnt >> 6, op_max());
 }
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T * scratch) {

@@ -111,6 +111,8 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
     // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
     //    5. pass 1 (its loads overlap other workgroups' dots)
+    if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+    if (a.rope_cur && blockIdx.x == gridDim.x - 1 && tid < 64) a.rope_cur[tid] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + tid];
     FQ_STAMP(a.dbg, 0);
     // LayerNorm + Q8 image in registers (NLN float4 of the row per thread) when the row fits, through LDS otherwise
     constexpr int NLN = MAXT > 256 ? 2 : 5;
@@ -359,67 +361,245 @@ void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
 }
 
 // =============================================================================================== k_attn_decode
-// one workgroup per query head, N = 1. Rotates q and the new k itself (ggml.c:12957-12978), appends k/v to the cache
-// (first head of each kv group), runs fq_attn_dev.h with the newest key/value taken from LDS, and -- when the output
-// projection's activation format is Q8_0 / Q8_1 -- quantizes its 64 outputs (two 32-blocks) straight into the
-// activation image k_gemv_out stages, so no separate quantizer pass or f32 round trip is needed.
-__global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
-                                                     const float * __restrict__ cs, float * __restrict__ kc, float * __restrict__ vc,
-                                                     const uint16_t * __restrict__ exp_tab, float * __restrict__ att,
-                                                     uint8_t * __restrict__ att_image, int att_act_type) {
+// one query head, N = 1, by a group of 256 threads (tid = index in the group; barriers are workgroup barriers, every
+// group of a workgroup runs this in lockstep). Rotates q and the new k itself (ggml.c:12957-12978), appends k/v to the
+// cache (first head of each kv group), runs fq_attn_dev.h with the newest key/value taken from LDS, and -- when the
+// output projection's activation format is Q8_0 / Q8_1 -- quantizes its 64 outputs (two 32-blocks) straight into the
+// activation image the output mat-vec stages, so no separate quantizer pass or f32 round trip is needed.
+// PUBLISH: the results are consumed by other workgroups of the SAME launch (k_attn_out): agent-scope write-through
+// stores. live = false: a padding group (no head left) computes head H-1 again and stores nothing.
+struct fq_attn_decode_args {
+    const float * qkv; int H, HKV; const int * n_past_ptr; const float * cs; float * kc, * vc; const uint16_t * exp_tab;
+    float * att; uint8_t * att_image; int att_act_type;
+    int cache_rows;                 // key/value rows [0, cache_rows) are allocated (>= n_past + 1): prefetch bound before n_past is known
+    const float * cs_cur;           // optional: the rope table's row for n_past, prepared by the preceding k_gemv_ln
+};
+template <bool PUBLISH, typename T> __device__ __forceinline__ void out_store(T * p, T v) {
+    if constexpr (PUBLISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool PUBLISH>
+__device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr) {
     constexpr int D = 64, HALF = 32;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    const int np = *n_past_ptr;
+    const int H = a.H, HKV = a.HKV;
     const int group = H / HKV, hk = h / group;
     float * qr = (float *) smem;                    // rotated q [64]
     float * kr = qr + D;                            // rotated new k [64]
     float * vn = kr + D;                            // new v [64]
     const attn_lds L = attn_lds_carve(smem + 3 * D * 4);
-    const float * qh = qkv + (int64_t) h * D;
-    const float * kh = qkv + (int64_t)(H + hk) * D;
-    const float * vh = qkv + (int64_t)(H + HKV + hk) * D;
+    const float * qh = a.qkv + (int64_t) h * D;
+    const float * kh = a.qkv + (int64_t)(H + hk) * D;
+    const float * vh = a.qkv + (int64_t)(H + HKV + hk) * D;
+    // requests in the order they are needed: n_past, the rope's inputs (every thread asks, 128 use them), then the first
+    // 256 key / 128 value rows (whatever n_past is: rows beyond it are never used)
+    const int np = *a.n_past_ptr;
+    const int k = tid & (HALF - 1);
+    const float * src = tid < HALF ? qh : kh;
+    const float * csr = a.cs_cur ? a.cs_cur : a.cs + (int64_t) np * HALF * 2;
+    const float x0 = src[k], x1 = src[k + HALF];
+    const float c = csr[2 * k], s = csr[2 * k + 1];
+    const float vnew = vh[tid & (D - 1)];
+    attn_pre P;
+    attn_prefetch(a.kc, a.vc, HKV, hk, a.cache_rows, tid, P);
+    FQ_STAMP(dbg, 1);
+    const bool append = live && h % group == 0;
     if (tid < 2 * HALF) {
-        const int k = tid & (HALF - 1);
-        const float * src = tid < HALF ? qh : kh;
-        const float c = cs[((int64_t) np * HALF + k) * 2], s = cs[((int64_t) np * HALF + k) * 2 + 1];
-        const float x0 = src[k], x1 = src[k + HALF];
         const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;                      // ggml.c:12974-12975
         float * dst = tid < HALF ? qr : kr;
         dst[k] = r0; dst[k + HALF] = r1;
-        if (tid >= HALF && h % group == 0) { float * o = kc + ((int64_t) np * HKV + hk) * D; o[k] = r0; o[k + HALF] = r1; }
+        if (tid >= HALF && append) { float * o = a.kc + ((int64_t) np * HKV + hk) * D; o[k] = r0; o[k + HALF] = r1; }
     } else if (tid < 2 * HALF + D) {
         const int d = tid - 2 * HALF;
-        const float v = vh[d];
-        vn[d] = v;
-        if (h % group == 0) vc[((int64_t) np * HKV + hk) * D + d] = v;
+        vn[d] = vnew;
+        if (append) a.vc[((int64_t) np * HKV + hk) * D + d] = vnew;
     }
     __syncthreads();
-    const float o = attn_head_block(qr, kc, vc, HKV, hk, np, kr, vn, exp_tab, L);
+    FQ_STAMP(dbg, 2);
+    const float o = attn_head_block(qr, a.kc, a.vc, HKV, hk, np, kr, vn, a.exp_tab, L, tid, P, dbg);
+    FQ_STAMP(dbg, 6);
     if (tid < 64) {
-        if (att) att[(int64_t) h * D + tid] = o;
-        if (att_image) {                                                             // lanes 0-31 / 32-63 = the head's two 32-blocks
+        if (a.att && live) out_store<PUBLISH>(a.att + (int64_t) h * D + tid, o);
+        if (a.att_image) {                                                           // lanes 0-31 / 32-63 = the head's two 32-blocks
             const float amax = reduce32(fabsf(o), op_max());
             const float d  = amax / 127.0f;
             const float id = d ? 1.0f / d : 0.0f;
             const int q = round_half_away(o * id);
             const int s = reduce32(q, op_add());
             const int64_t E = (int64_t) H * D;
-            const act_image_ptr im = act_image_at(att_image, att_act_type, E);
-            im.qs[(int64_t) h * D + tid] = (int8_t) q;
-            if ((tid & 31) == 0) {
+            const act_image_ptr im = act_image_at(a.att_image, a.att_act_type, E);
+            unsigned w = (unsigned) q & 0xFFu;                                       // 4 lanes -> one 32-bit store
+            w |= ((unsigned) __shfl_down((int) w, 1) & 0xFFu) << 8;
+            w |= ((unsigned) __shfl_down((int) w, 2) & 0xFFFFu) << 16;
+            if (live && (tid & 3) == 0) out_store<PUBLISH>((unsigned *)(im.qs + (int64_t) h * D + tid), w);
+            if (live && (tid & 31) == 0) {
                 const int64_t b = 2 * (int64_t) h + (tid >> 5);
-                if (att_act_type == FQ_Q8_0) { im.d[b] = h2f_bits(f2h_bits(d)); ((int32_t *) im.aux)[b] = s; }
-                else                         { im.d[b] = d; ((float *) im.aux)[b] = (float) s * d; }
+                if (a.att_act_type == FQ_Q8_0) { out_store<PUBLISH>(im.d + b, h2f_bits(f2h_bits(d))); out_store<PUBLISH>((int32_t *) im.aux + b, (int32_t) s); }
+                else                           { out_store<PUBLISH>(im.d + b, d); out_store<PUBLISH>((float *) im.aux + b, (float) s * d); }
             }
         }
     }
 }
 
+__global__ void __launch_bounds__(256) k_attn_decode(fq_attn_decode_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    attn_decode_group<false>(a, (int) blockIdx.x, true, (int) threadIdx.x, smem);
+}
+
+static size_t attn_decode_lds(int max_n_kv) { return 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15); }
+
 void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                            float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st) {
-    const size_t lds = 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15);
+    const size_t lds = attn_decode_lds(max_n_kv);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
-    hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type);
+    const fq_attn_decode_args a{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type, max_n_kv, nullptr };
+    hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, a);
 }
+
+// =============================================================================================== k_attn_out
+// Attention and the output mat-vec of one block in ONE launch, one workgroup of 12 waves per CU:
+//   workgroups [0, n_attn)      3 query heads each (three lockstep 256-thread groups running attn_decode_group), results
+//                               PUBLISHED to the others: agent-scope write-through stores, every storing wave drains
+//                               (s_waitcnt vmcnt(0)), barrier, one agent-scope counter increment per workgroup
+//   workgroups [n_attn, grid)   24 rows of x = (Wdown . q8(gelu(up)) + Wo . q8(att)) + x each: the Wdown part (80 % of
+//                               the bytes) does not need the attention output and streams while the attention runs;
+//                               then ONE lane polls the counter (relaxed, s_sleep), barrier, the attention image is read
+//                               with agent-scope loads (the producers stored write-through: no acquire fence needed),
+//                               and the pre-fetched Wo rows are finished.
+// ~190 streaming CUs already saturate HBM (scripts/microbench/mb_stream.hip), so lending 24 CUs to the latency-bound
+// attention costs the stream nothing and removes a launch boundary plus the attention's 8 us from every block.
+// Requires every workgroup to be resident at once (grid <= CUs; the launcher checks) -- or at least the attention
+// workgroups to start first, which in-order dispatch gives; the poll is bounded and reports through a.err.
+// The arithmetic is k_attn_decode's and k_gemv_out's: bit-identical results.
+struct fq_attn_out_args {
+    fq_gemv_out_args g;             // g.att / g.att_image are what the attention role writes
+    fq_attn_decode_args at;
+    unsigned * counter;             // zeroed by the preceding k_gemv_ln launch
+    unsigned * err;                 // set to 1 if the poll gave up
+    int n_attn, heads_per_wg, attn_lds_group;
+};
+
+template <int TYPE>
+__global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x;
+    if ((int) blockIdx.x < a.n_attn) {
+        // ------------------------------------------------------------------------------------ attention role
+        const int grp = tid >> 8, gtid = tid & 255;
+        if (grp >= a.heads_per_wg) return;                       // (blockDim = 768: never; keeps a smaller blockDim legal)
+        int h = (int) blockIdx.x * a.heads_per_wg + grp;
+        const bool live = h < a.at.H;
+        if (!live) h = a.at.H - 1;
+        long long * dbg = a.g.dbg ? a.g.dbg + 2048 * 8 : nullptr;
+        FQ_STAMP(dbg, 0);
+        attn_decode_group<true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, dbg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FQ_STAMP(dbg, 7);
+        return;
+    }
+    // ---------------------------------------------------------------------------------------- mat-vec role
+    constexpr int ACT = act_of<TYPE>::value;
+    const fq_gemv_out_args & g = a.g;
+    const int64_t E = g.w_wo.K, FF = g.w_down.K;
+    uint8_t * img_ff  = smem;
+    uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
+    constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
+    const int units_d = (int)(FF / fq_unit<TYPE>::ELEMS), units_o = (int)(E / fq_unit<TYPE>::ELEMS);
+    const int64_t row0 = (int64_t)((int) blockIdx.x - a.n_attn) * (2 * (nt >> 6)) + 2 * wid;
+    long long * dbg = g.dbg ? g.dbg - (size_t) a.n_attn * 8 : nullptr;         // stamps indexed by mat-vec workgroup
+    FQ_STAMP(dbg, 0);
+    const int64_t nvec_ff = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 * src_ff = (const u32x4 *) g.act_ff_image;
+    constexpr int NTF = 4;
+    u32x4 tf[NTF];
+#pragma unroll
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
+    __builtin_amdgcn_sched_barrier(0);
+    fq_wrow rd[2], ro[2];
+    rows_ptrs<TYPE, 2>(g.w_down, row0, rd);
+    rows_ptrs<TYPE, 2>(g.w_wo, row0, ro);
+    fq_unit_regs pd[NPD][2], po[NPO][2];
+    rows_issue<TYPE, 2, NPD>(rd, units_d, pd);
+    rows_issue<TYPE, 2, NPO>(ro, units_o, po);
+    FQ_STAMP(dbg, 1);
+#pragma unroll
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; if (i < nvec_ff) ((u32x4 *) img_ff)[i] = tf[k]; }
+    for (int64_t i = (int64_t) NTF * nt + tid; i < nvec_ff; i += nt) ((u32x4 *) img_ff)[i] = src_ff[i];
+    __syncthreads();
+    FQ_STAMP(dbg, 3);
+    float acc_d[2] = {0.0f, 0.0f}, acc_o[2] = {0.0f, 0.0f};
+    const fq_actcol col_d = actcol_at(img_ff, ACT, FF), col_o = actcol_at(img_att, ACT, E);
+    rows_consume<TYPE, 2, NPD>(pd, units_d, col_d, acc_d);
+    FQ_STAMP(dbg, 4);
+    rows_dot_from<TYPE, 2, (decode_cfg<TYPE>::four_bit ? 5 : 2)>(rd, units_d, 64 * NPD, col_d, acc_d);
+    FQ_STAMP(dbg, 5);
+    // ---- the attention output: wait for every attention workgroup, then read it past the (stale) caches
+    if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) a.n_attn) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    FQ_STAMP(dbg, 6);
+    if (g.att_image) {
+        const int64_t n8 = (int64_t)(fq_act_col_bytes(ACT, E) >> 3);
+        const unsigned long long * src = (const unsigned long long *) g.att_image;
+        for (int64_t i = tid; i < n8; i += nt)
+            ((unsigned long long *) img_att)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));          // f32 copy of the attention row, quantized here
+        const unsigned long long * src = (const unsigned long long *) g.att;
+        for (int64_t i = tid; i < (E >> 1); i += nt)
+            ((unsigned long long *) att_f)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
+    }
+    __syncthreads();
+    rows_consume<TYPE, 2, NPO>(po, units_o, col_o, acc_o);
+    rows_dot_from<TYPE, 2, 2>(ro, units_o, 64 * NPO, col_o, acc_o);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { acc_d[r] = wave_sum(acc_d[r]); acc_o[r] = wave_sum(acc_o[r]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t row = row0 + r;
+            if (row < g.w_wo.M) g.dst[row] = (acc_d[r] + acc_o[r]) + g.resid[row];                  // libfalcon.cpp:2399-2400
+        }
+    }
+    FQ_STAMP(dbg, 7);
+}
+
+// true (and launched) when the merged form applies: every workgroup resident at once
+bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
+                        const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
+                        int att_act_type, unsigned * counter, unsigned * err, int n_cu, hipStream_t st) {
+    const int type = g.w_wo.type, act = fq_desc(type).act_type;
+    const int nw = 12, hpw = 2;             // 2 heads per attention workgroup: the attention is instruction-issue bound per SIMD
+    const int n_attn = (H + hpw - 1) / hpw;
+    const int n_mv = (int)((g.w_wo.M + 2 * nw - 1) / (2 * nw));
+    const size_t lds_group = (attn_decode_lds(max_n_kv) + 15) & ~(size_t) 15;
+    const size_t lds_mv = fq_act_col_bytes(act, g.w_down.K) + fq_act_col_bytes(act, g.w_wo.K) + (g.att_image ? 0 : (size_t) g.w_wo.K * 4) + 16;
+    size_t lds = lds_group * hpw > lds_mv ? lds_group * hpw : lds_mv;
+    if (n_attn + n_mv > n_cu || lds > 160 * 1024) return false;
+    if (lds < 84 * 1024) lds = 84 * 1024;                                 // one workgroup per CU
+    fq_attn_out_args a{};
+    a.g = g;
+    a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, const_cast<float *>(g.att_image ? nullptr : g.att),
+                                const_cast<uint8_t *>(g.att_image), att_act_type, max_n_kv, rope_cur };
+    a.counter = counter; a.err = err; a.n_attn = n_attn; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
+#define FQ_CASE(T) case T: { \
+        static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
+        hipLaunchKernelGGL((k_attn_out<T>), dim3((unsigned)(n_attn + n_mv)), dim3(64 * nw), lds, st, a); } break;
+    switch (type) {
+        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
+        FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
+        default: fprintf(stderr, "ggml-hip: attn_out: unsupported weight type %d\n", type); exit(1);
+    }
+#undef FQ_CASE
+    return true;
+}
+

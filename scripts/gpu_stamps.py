@@ -17,8 +17,8 @@ m.decode_greedy(int(out[-1]), 158, 4)
 st = np.zeros(2 * 4096 * 8, np.int64)
 L.ggml_hip_debug_stamps(1, st.ctypes.data)
 st = st.reshape(2, 4096, 8)
-for name, k, nb in (("k_gemv_ln", 0, 239), ("k_gemv_out", 1, 253)):
-    s = st[k, :nb].astype(np.float64)
+for name, k, b0, nb in (("k_gemv_ln", 0, 0, 239), ("k_attn_out mat-vec role", 1, 0, 190), ("k_attn_out attention role", 1, 2048, 36)):
+    s = st[k, b0:b0 + nb].astype(np.float64)
     t0 = s[:, 0].min()
     rel = (s - t0) / 100.0          # wall clock = 100 MHz -> us
     print(name, "blocks", nb, "start spread us: min %.2f med %.2f max %.2f" % (rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max()))

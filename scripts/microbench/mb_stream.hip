@@ -68,6 +68,31 @@ int main(int argc, char ** argv) {
     timeit("empty kernel", [&](u32x4 *) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, out); });
 #define LIN(U, G, B) { char n[64]; snprintf(n, 64, "linear U=%d grid=%d x %d", U, G, B); timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_linear<U>), dim3(G), dim3(B), 0, st, b, nvec, out); }); }
 #define CHK(U, G, B) { char n[64]; snprintf(n, 64, "chunk  U=%d grid=%d x %d", U, G, B); timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_chunk<U>), dim3(G), dim3(B), 0, st, b, nvec, out); }); }
+    if (argc > 2 && argv[2][0] == 'm') {   // Infinity-Cache (MALL) residency: the SAME 58 MB again right after a read of it, with
+                                           // 0 / 58 / 117 / 234 MB of other traffic in between
+        auto pair = [&](const char * name, int between) {
+            float tot = 0; const int R = 20;
+            for (int r = 0; r < R; ++r) {
+                for (int i = 0; i < 8; ++i) hipLaunchKernelGGL((k_linear<8>), dim3(256), dim3(768), 0, st, bufs[8 + i], nvec, out);   // flush
+                hipLaunchKernelGGL((k_linear<8>), dim3(256), dim3(768), 0, st, bufs[0], nvec, out);
+                for (int i = 0; i < between; ++i) hipLaunchKernelGGL((k_linear<8>), dim3(256), dim3(768), 0, st, bufs[1 + i], nvec, out);
+                CK(hipEventRecord(e0, st));
+                hipLaunchKernelGGL((k_linear<8>), dim3(256), dim3(768), 0, st, bufs[0], nvec, out);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+            }
+            printf("%-40s %8.2f us (event-bracketed single launch)\n", name, tot * 1e3 / R);
+        };
+        pair("re-read, nothing in between", 0); pair("re-read, 58 MB in between", 1); pair("re-read, 117 MB in between", 2);
+        pair("re-read, 234 MB in between", 4); pair("re-read, 350 MB in between", 6);
+        return 0;
+    }
+    if (argc > 2) {     // CU-count sweep: how many streaming CUs does the chip need?
+        LIN(8, 128, 768) LIN(8, 160, 768) LIN(8, 190, 768) LIN(8, 207, 704) LIN(8, 228, 640) LIN(8, 240, 640) LIN(8, 256, 640) LIN(8, 256, 768)
+        LIN(4, 190, 768) LIN(4, 228, 640) LIN(16, 190, 768) LIN(12, 228, 640)
+        return 0;
+    }
     LIN(4, 256, 1024) LIN(8, 256, 1024) LIN(4, 512, 512) LIN(8, 512, 512) LIN(4, 1024, 256) LIN(8, 1024, 256) LIN(4, 2048, 256) LIN(8, 2048, 256) LIN(2, 4096, 256) LIN(4, 4096, 256)
     LIN(8, 256, 768) LIN(16, 256, 768) LIN(8, 256, 512) LIN(16, 256, 512) LIN(16, 256, 256) LIN(1, 8192, 256) LIN(1, 16384, 256)
     CHK(4, 256, 768) CHK(8, 256, 768) CHK(16, 256, 768) CHK(8, 256, 1024) CHK(8, 512, 512) CHK(8, 1024, 256) CHK(4, 2048, 256) CHK(8, 714, 256) CHK(8, 239, 768)

@@ -92,20 +92,47 @@ def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
                                        ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K)])
 def test_fused_decode_bit_identical_to_op_list(oracle, name, hp, t):
-    """the 3-launch fused decode kernels reproduce the op-by-op launch list bit for bit (logits, hidden, KV cache)"""
+    """the fused decode kernels -- 3 launches per block, and 2 (attention + output mat-vec in one launch with an
+    in-launch hand-off) -- reproduce the op-by-op launch list bit for bit (logits, hidden, KV cache)"""
     w = synth.make_model(oracle, hp, t, seed=21)
     toks = synth.tokens(9, hp["n_vocab"], seed=6)
     outs = []
-    for fused in (False, True):
+    for mode in (0, 1, 2):
         m = g.FalconModel(w, n_ctx=32, n_batch=4)
-        m.set_fused(fused)
-        m.eval(toks[:4], 0)                                       # prefill is the same code on both
+        m.set_fused(mode)
+        m.eval(toks[:4], 0)                                       # prefill is the same code on all
         r = [m.eval(toks[i:i + 1], i, want_hidden=True) for i in range(4, 9)]
+        assert m.sync_error() == 0
         outs.append(r)
         m.free()
-    for (la, ha), (lb, hb) in zip(*outs):
-        assert np.array_equal(ha, hb)
-        assert np.array_equal(la, lb)
+    for other in outs[1:]:
+        for (la, ha), (lb, hb) in zip(outs[0], other):
+            assert np.array_equal(ha, hb)
+            assert np.array_equal(la, lb)
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q5_1, ob.Q4_K])
+def test_in_launch_handoff_full_width(oracle, t):
+    """k_attn_out at Falcon-7B width (214 workgroups, 24 of them attention producers, every CU streaming weights while
+    the consumers poll): 96 greedy steps through the hipGraph give the same tokens and the same final logits as the
+    3-launch form, and no poll ever timed out"""
+    hp = dict(synth.HP_7B); hp["n_layer"] = 3; hp["n_vocab"] = 4096
+    if t in ob.KQUANTS:                                 # super-blocks of 256: 72 heads, two norms, 2 kv heads
+        hp.update(n_embd=4608, n_head=72, n_head_kv=2, n_ff=18432, two_norms=True)
+    w = synth.make_model_fast(hp, t, seed=5)
+    toks = synth.tokens(16, hp["n_vocab"], seed=9)
+    res = []
+    for mode in (1, 2):
+        m = g.FalconModel(w, n_ctx=256, n_batch=16)
+        m.set_fused(mode)
+        m.eval(toks, 0)
+        out = m.decode_greedy(int(toks[-1]), 16, 96, use_graph=True)
+        lg = m.eval(out[-1:], 16 + 96)
+        assert m.sync_error() == 0
+        res.append((out, lg))
+        m.free()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
 
 
 def test_prefill_equals_incremental_and_graph(oracle):
