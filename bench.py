@@ -8,9 +8,11 @@ A STEP is one decoded token = one pass of the whole hot path (32 blocks + ln_f +
 of one token, everything resident in HBM. W untimed warm-up tokens, then exactly K timed tokens between
 barrier + device synchronise; `value` = K / time (tokens/s); prefill tok/s of the 128-token prompt is reported beside it.
 
-  roofline     dominant kernel = the quantized GEMV (k_gemv): achieved = algorithmic weight bytes per launch / average
-               launch duration, both measured live with hipEvents around every GEMV launch of an instrumented repeat
-               of the timed decode steps (same stream); `step` = whole-token view B_tok * tok/s of the timed region.
+  roofline     dominant kernels = the two fused quantized mat-vec launches of a block (k_gemv_ln: LayerNorm + [Wqkv | Wup];
+               k_attn_out: attention + [Wdown, Wo] + residual): achieved = algorithmic weight bytes per launch / average
+               launch duration, both measured live with hipEvents (stamped by the dispatch itself) on every such launch of an instrumented repeat of
+               the timed decode steps (same stream, plain launches); `step_*` = whole-token view B_tok * tok/s of the timed
+               (hipGraph) region. profiles/ holds the rocprofv3 kernel-trace summary of the same command.
   cpu_baseline the same decode step on the host cores, bounded sample: oracle/_ref (the real reference, "reference")
                when its .so travelled, else the oracle port.
 """
@@ -146,12 +148,22 @@ def main():
         nl, us, by = C.c_int64(), C.c_double(), C.c_double()
         L.ggml_hip_profile_end(C.byref(nl), C.byref(us), C.byref(by))
         if nl.value:
-            # an event bracket adds a fixed dispatch cost to what it encloses: measure an EMPTY bracket and subtract it
+            # the two events of a launch are handed to hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's own
+            # begin / end (the clock rocprofv3's kernel trace reads) -- no marker packets, nothing to subtract
             ovh = L.ggml_hip_profile_bracket_overhead_us()
-            avg_us = us.value / nl.value - ovh
+            avg_us = us.value / nl.value
             ach = (by.value / nl.value) / (avg_us * 1e-6) / 1e9
-            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln + k_gemv_out (fused quantized mat-vec)", launches=nl.value,
-                        avg_launch_us=avg_us, raw_bracket_us=us.value / nl.value, empty_bracket_us=ovh, bytes_per_launch=by.value / nl.value)
+            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln + k_attn_out (fused quantized mat-vec launches; lm_head included)",
+                        launches=nl.value, avg_launch_us=avg_us, empty_event_pair_us=ovh, bytes_per_launch=by.value / nl.value)
+    # HBM traffic per launch from the PMC counters: collected off-line (scripts/gpu_pmc.sh: one rocprofv3 --pmc pass per
+    # counter over this same command, corrected by scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes) and committed
+    pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if pmc and a.model == "7b" and a.quant == "q4_0" and a.layers == 0:
+        d = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+        ks = [v for k, v in d.items() if k.startswith("k_gemv_ln") or k.startswith("k_attn_out") or k.startswith("k_gemv_out")]
+        if ks:
+            roof["traffic"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / sum(v["launches"] for v in ks)
+            roof["traffic_source"] = "profiles/" + pmc[-1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH_SIZE per the gfx950 note; bytes per launch, same launch mix)"
     step_gbs = b_tok * tok_s / 1e9
     roof.update(step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok)
 

@@ -312,10 +312,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (c->merged_attn_out && !dual) {
                 if (prof) fq_prof_open(st);
                 merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
-                                            kc, vc, hc.exp_table, att_act, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                                            kc, vc, hc.exp_table_attn, att_act, c->sync_words, c->sync_words + 1, hc.n_cu, st);
             }
             if (!merged) {
-                fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table,
+                fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,
                                       att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
                 if (prof) fq_prof_open(st);
                 fq_launch_gemv_out(go, hc.n_cu, st);
@@ -353,7 +353,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
         float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
         fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st);
-        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table, c->att, st);
+        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st);
         fq_launch_quantize_act(c->att, E, acts(c->act_att, N), st);
         fq_mul_mat_q_acts(L.wo, acts(c->act_att, N), N, c->wo_out, E, store, st);
         const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };

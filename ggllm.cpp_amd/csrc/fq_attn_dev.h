@@ -132,7 +132,7 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
     const float mx = waves_combine(L.redf, NT >> 6, op_max());
     double lsum = 0.0;
     for (int j = tid; j < n_kv; j += NT) {
-        const float e = h2f_bits(exp_tab[f2h_bits(L.p[j] - mx)]);
+        const float e = soft_max_exp(exp_tab, L.p[j] - mx);
         L.p[j] = e;
         lsum += (double) e;
     }

@@ -76,6 +76,16 @@ __device__ __forceinline__ float  wave_max(float v)  { return wave_reduce(v, op_
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16) f); }   // RNE, keeps subnormals
 __device__ __forceinline__ float    h2f_bits(uint16_t h) { return (float) __builtin_bit_cast(_Float16, h); }
 
+// fp16 EXP "table" without the table: table_exp_f16[h] = fp16(expf(fp32(h))) (ggml.c:4276-4290) recomputed as
+// fp16((float) exp((double) fp32(h))). ggml_hip_init compares this against the host-built table for all 63488 non-NaN
+// inputs and only then lets the attention kernels use it (a dependent gather costs a memory round trip, 1-2 us while the
+// chip streams weights; this costs ~60 instructions).
+__device__ __forceinline__ uint16_t exp_f16_formula(uint16_t hbits) { return f2h_bits((float) exp((double) h2f_bits(hbits))); }
+__device__ __forceinline__ float soft_max_exp(const uint16_t * __restrict__ exp_tab, float x) {      // exp_tab == nullptr: verified formula
+    const uint16_t hb = f2h_bits(x);
+    return h2f_bits(exp_tab ? exp_tab[hb] : exp_f16_formula(hb));
+}
+
 // block-wide reductions (<= 16 waves); `scratch` = >= 16 elements of LDS. The per-wave partials are combined in wave
 // order 0, 1, 2, ... : each lane fetches one partial with a single LDS read and the chain runs over v_readlane (a loop of
 // dependent LDS reads costs ~70 ns per wave, which is most of a LayerNorm at 12 waves).

@@ -60,6 +60,10 @@ extern "C" int ggml_hip_init(int device) {
         g_ctx.n_cu = prop.multiProcessorCount;
         snprintf(g_ctx.name, sizeof(g_ctx.name), "%s", prop.name);
         build_tables(g_ctx);
+        // the attention kernels recompute the EXP table's entries instead of gathering them -- only if the recomputation
+        // reproduces the host-built table for every input (GGML_HIP_EXP_TABLE=1 forces the gather)
+        g_ctx.exp_table_attn = g_ctx.exp_table;
+        if (!getenv("GGML_HIP_EXP_TABLE") && fq_verify_exp_formula(g_ctx.exp_table, g_ctx.stream) == 0) g_ctx.exp_table_attn = nullptr;
         HIP_CHECK(hipMalloc((void **) &g_ctx.scalar_i32, 256));
         g_ctx.ready = true;
     });
@@ -76,6 +80,11 @@ extern "C" void ggml_hip_debug_stamps(int enable, long long * out_host) {
 }
 
 extern "C" int ggml_hip_selftest(void) { return fq_selftest_reduce(fq_ctx().stream); }
+// 0 = the fp16 EXP table is recomputed in-kernel (verified identical at init), else the number of mismatching inputs / -1 forced gather
+extern "C" int ggml_hip_exp_formula_mismatches(void) {
+    if (getenv("GGML_HIP_EXP_TABLE")) return -1;
+    return fq_verify_exp_formula(fq_ctx().exp_table, fq_ctx().stream);
+}
 
 extern "C" void * ggml_hip_stream(void) { return (void *) fq_ctx().stream; }
 
@@ -218,7 +227,7 @@ extern "C" void ggml_hip_profile_end(int64_t * n_launches, double * total_us, do
     g_prof_ev.clear();
 }
 
-// cost of an empty hipEvent bracket on the launch stream (subtracted from bracketed kernel times by bench.py)
+// cost of an empty hipEventRecord pair on the launch stream (information only: the profile brackets do not record markers)
 extern "C" double ggml_hip_profile_bracket_overhead_us(void) {
     hip_context & c = fq_ctx();
     const int n = 64;
@@ -235,14 +244,19 @@ extern "C" double ggml_hip_profile_bracket_overhead_us(void) {
 
 // bracket one launch (used by the fused decode path in falcon_hip.hip)
 bool fq_prof_active() { return g_prof_on; }
-void fq_prof_open(hipStream_t st) {
+// A profile bracket = the pair of events the NEXT fused mat-vec launch hands to hipExtLaunchKernelGGL: the runtime stamps
+// them with the dispatch's own begin / end times (the clock rocprofv3's kernel trace reads), so the elapsed time is the
+// kernel's duration without the cost of two extra marker packets (~4.6 us for an empty hipEventRecord pair).
+static hipEvent_t g_prof_pending[2] = { nullptr, nullptr };
+void fq_prof_open(hipStream_t) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-    HIP_CHECK(hipEventRecord(e0, st));
     g_prof_ev.emplace_back(e0, e1);
+    g_prof_pending[0] = e0; g_prof_pending[1] = e1;
 }
-void fq_prof_close(hipStream_t st, double bytes) {
-    HIP_CHECK(hipEventRecord(g_prof_ev.back().second, st));
+void fq_prof_events(hipEvent_t * start, hipEvent_t * stop) { *start = g_prof_pending[0]; *stop = g_prof_pending[1]; }
+void fq_prof_close(hipStream_t, double bytes) {
+    g_prof_pending[0] = g_prof_pending[1] = nullptr;
     g_prof_bytes += bytes;
 }
 
@@ -334,5 +348,5 @@ extern "C" void ggml_hip_rope_kv_store(float * qkv, int N, int H, int HKV, int D
     fq_launch_rope_kv(qkv, N, H, HKV, D, upload_n_past(n_past), rope_table, kc, vc, fq_ctx().stream);
 }
 extern "C" void ggml_hip_attention(const float * qkv, int N, int H, int HKV, int D, int n_past, const float * kc, const float * vc, float * att) {
-    fq_launch_attention(qkv, N, H, HKV, D, upload_n_past(n_past), n_past + N, kc, vc, fq_ctx().exp_table, att, fq_ctx().stream);
+    fq_launch_attention(qkv, N, H, HKV, D, upload_n_past(n_past), n_past + N, kc, vc, fq_ctx().exp_table_attn, att, fq_ctx().stream);
 }

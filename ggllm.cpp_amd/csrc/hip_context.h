@@ -16,6 +16,7 @@ struct hip_context {
     hipStream_t stream = nullptr;
     uint16_t *  gelu_table = nullptr;     // device, 65536 x fp16
     uint16_t *  exp_table = nullptr;      // device, 65536 x fp16
+    const uint16_t * exp_table_attn = nullptr;   // what the attention kernels get: nullptr once exp_f16_formula is verified == exp_table
     int *       scalar_i32 = nullptr;     // device scratch scalar for the op-level API
     long long * dbg_stamps = nullptr;     // optional phase-stamp buffer (ggml_hip_debug_stamps), 2 x 4096 x 8 entries
 };
@@ -29,3 +30,4 @@ std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_prof_active();
 void      fq_prof_open(hipStream_t st);
 void      fq_prof_close(hipStream_t st, double bytes);
+void      fq_prof_events(hipEvent_t * start, hipEvent_t * stop);   // the open bracket's events (nullptr, nullptr when none)

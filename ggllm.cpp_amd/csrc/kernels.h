@@ -41,7 +41,8 @@ void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * 
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                            const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);
 
-int    fq_selftest_reduce(hipStream_t st);   // 0 = DPP wave reductions agree with the __shfl_xor butterfly
+int    fq_selftest_reduce(hipStream_t st);
+int    fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st);   // number of non-NaN inputs where the formula != table   // 0 = DPP wave reductions agree with the __shfl_xor butterfly
 
 // kernels_decode.hip -- fused N = 1 decode kernels
 enum { FQ_LNEPI_STORE = 0, FQ_LNEPI_GELU_QUANT = 1, FQ_LNEPI_GELU_STORE = 2 };

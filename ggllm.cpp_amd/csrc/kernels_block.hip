@@ -141,3 +141,21 @@ int fq_selftest_reduce(hipStream_t st) {
     HIP_CHECK(hipFree(dev));
     return host;
 }
+
+// ---- exp_f16_formula (fq_device.h) against the host-built table, every non-NaN fp16 input
+__global__ void k_verify_exp_formula(const uint16_t * __restrict__ table, int * mismatches) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536u) return;
+    if ((i & 0x7C00u) == 0x7C00u && (i & 0x03FFu)) return;      // NaN in: NaN out either way, payloads are not compared
+    if (exp_f16_formula((uint16_t) i) != table[i]) atomicAdd(mismatches, 1);
+}
+int fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st) {
+    int * d = nullptr; int h = -1;
+    HIP_CHECK(hipMalloc((void **) &d, 4));
+    HIP_CHECK(hipMemsetAsync(d, 0, 4, st));
+    hipLaunchKernelGGL(k_verify_exp_formula, dim3(256), dim3(256), 0, st, exp_table, d);
+    HIP_CHECK(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(d));
+    return h;
+}

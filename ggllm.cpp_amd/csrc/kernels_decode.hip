@@ -16,6 +16,14 @@
 #include "fq_block_dev.h"
 #include "fq_attn_dev.h"
 #include "kernels.h"
+#include "hip_context.h"
+#include <hip/hip_ext.h>
+
+// launch, handing the open profile bracket's events (if any) to the dispatch
+#define FQ_LAUNCH_PROF(kern, grid, block, lds, st, ...) do { \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_); \
+        if (e0_) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0_, e1_, 0, __VA_ARGS__); \
+        else     hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__); } while (0)
 
 #define FQ_STAMP(dbg, slot) do { if ((dbg) && threadIdx.x == 0) (dbg)[(size_t) blockIdx.x * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
@@ -245,7 +253,7 @@ void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
     if (blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;
 #define FQ_LAUNCH(T, MAXT) { \
         static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
-        hipLaunchKernelGGL((k_gemv_ln<T, MAXT>), dim3((unsigned) blocks), dim3(64 * nw), lds, st, a); }
+        FQ_LAUNCH_PROF((k_gemv_ln<T, MAXT>), dim3((unsigned) blocks), dim3(64 * nw), lds, st, a); }
 #define FQ_CASE(T) case T: if (nw <= 4) FQ_LAUNCH(T, 256) else FQ_LAUNCH(T, 768) break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
@@ -349,7 +357,7 @@ void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
     if ((int) blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;       // one workgroup per CU (see fq_launch_gemv_ln)
 #define FQ_LAUNCH(T, MAXT) { \
         static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
-        hipLaunchKernelGGL((k_gemv_out<T, MAXT>), dim3(blocks), dim3(64 * nw), lds, st, a); }
+        FQ_LAUNCH_PROF((k_gemv_out<T, MAXT>), dim3(blocks), dim3(64 * nw), lds, st, a); }
 #define FQ_CASE(T) case T: if (nw <= 4) FQ_LAUNCH(T, 256) else FQ_LAUNCH(T, 768) break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
@@ -593,7 +601,7 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
     a.counter = counter; a.err = err; a.n_attn = n_attn; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
 #define FQ_CASE(T) case T: { \
         static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
-        hipLaunchKernelGGL((k_attn_out<T>), dim3((unsigned)(n_attn + n_mv)), dim3(64 * nw), lds, st, a); } break;
+        FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned)(n_attn + n_mv)), dim3(64 * nw), lds, st, a); } break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)

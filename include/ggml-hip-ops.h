@@ -26,6 +26,10 @@ int     ggml_hip_device_count(void);
 void    ggml_hip_debug_stamps(int enable, long long * out_host);
 void    ggml_hip_debug_force_gemv(int on);        /* tests: N > 4 through column-chunked mat-vec instead of the MFMA GEMM */
 int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
+/* soft_max's fp16 EXP table entries are recomputed in the attention kernels instead of gathered when -- checked at init, for
+ * every non-NaN fp16 input -- the recomputation equals the host-built table. Returns the number of mismatching inputs (0 = in
+ * use), -1 when GGML_HIP_EXP_TABLE=1 forces the gather. */
+int     ggml_hip_exp_formula_mismatches(void);
 void *  ggml_hip_stream(void);                    /* hipStream_t used for every launch of this library        */
 void *  ggml_hip_malloc(size_t bytes);
 void    ggml_hip_free(void * dev);

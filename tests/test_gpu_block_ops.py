@@ -22,6 +22,12 @@ def test_wave_reductions_selftest():
     assert g.load().ggml_hip_selftest() == 0
 
 
+def test_exp_formula_reproduces_table():
+    """the in-kernel recomputation of soft_max's EXP table entry (fp16(exp(fp32(h))) through f64) equals the host-built
+    table for every non-NaN fp16 input -- the condition under which the attention kernels use it instead of a gather"""
+    assert g.load().ggml_hip_exp_formula_mismatches() == 0
+
+
 def test_tables_match_reference(oracle, golden):
     """the fp16 GELU / EXP tables the kernels index are the reference's (ggml.c:4276-4290), bit for bit"""
     L = g.load()
