@@ -79,6 +79,7 @@ extern "C" void ggml_hip_debug_stamps(int enable, long long * out_host) {
     if (!enable && c.dbg_stamps) { HIP_CHECK(hipFree(c.dbg_stamps)); c.dbg_stamps = nullptr; }
 }
 
+extern "C" void ggml_hip_debug_gemm_mode(int m) { fq_gemm_debug_mode(m); }
 extern "C" int ggml_hip_selftest(void) { return fq_selftest_reduce(fq_ctx().stream); }
 // 0 = the fp16 EXP table is recomputed in-kernel (verified identical at init), else the number of mismatching inputs / -1 forced gather
 extern "C" int ggml_hip_exp_formula_mismatches(void) {

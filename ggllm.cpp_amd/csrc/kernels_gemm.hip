@@ -8,230 +8,323 @@
 // (The reference's fp16 GEMM path does NOT reproduce its own CPU results -- SURVEY hard part 1; this does, up to the
 // association of the f32 sum over groups.)
 //
-// Tiling: workgroup = 4 waves = 128 tokens x (32*J) weight rows; wave w owns tokens [32w, 32w+32) x all 32*J rows
-// (J accumulator tiles of 16 VGPRs). Per K-stage of 128 (4 groups):
+// What bounds it. The exact per-group scaling costs ~3-4 VALU operations per (token, row, group): 16 values per lane and
+// MFMA, ~50 VALU instructions (200 cycles) against the MFMA's 32 -- the kernel is VALU-issue bound, the matrix pipe is
+// nearly free, and the f32 sum over groups is sequential per output (no split-K). The design therefore spends MFMAs to
+// buy parallelism: a workgroup is 128 tokens x 32 weight rows; wave w owns the 32 tokens of tile w & 3, and S waves share
+// each tile -- all S issue the tile's MFMA, each applies the scales to its own 16/S of the 16 result registers (S = 4 for
+// the 4544-row matrices of Falcon-7B: 142 workgroups of 16 waves; S = 1 for the 18176-row one: 568 workgroups of 4).
+// Per K-stage of 128 (4 groups), software-pipelined: the next stage's global loads are in flight while this stage's
+// MFMAs + scaling run out of the current LDS buffer (two buffers, one barrier per stage):
 //   weights  : 16-byte quant groups -> registers -> sign-corrected int8 -> LDS  Wq[row][144] (+ dW, minW per group)
 //   tokens   : int8 image rows                                        -> LDS  Xq[tok][144] (+ dX, sX per group)
-//   per group: A = ds_read_b128 Xq (tokens), B = ds_read_b128 Wq (rows), MFMA, 16 cvt + 16 mul + 16 fma per tile
+//   per group: A = ds_read_b128 Xq (tokens), B = ds_read_b128 Wq (rows), MFMA, cvt + mul + mul + add per value
 // MFMA operand convention used: A lane l -> (row i = l & 31, 16 consecutive k bytes of half l >> 5), B likewise for
 // column j; any k permutation is harmless as long as A and B agree. C: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 // Row stride 144 B (128 + 16 pad) makes the 16-lane groups of ds_read_b128 conflict-free.
 #include "fq_block_dev.h"
 #include "kernels.h"
+#include <type_traits>
 
 typedef int v4i  __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-#define GQ_TN      128          // tokens per workgroup
+#define GQ_TM      32           // weight rows per workgroup
 #define GQ_STRIDE  144          // LDS bytes per staged row (128 payload + 16 pad)
 #define GQ_GROUPS  4            // 32-element groups per K stage
 
 __device__ __forceinline__ uint32_t bytes_sub(uint32_t x, uint32_t c4) { return ((x | 0x80808080u) - c4) ^ 0x80808080u; }   // per-byte x - c, x in [0,127], c <= 64
 
-// one 32-element group of a weight row -> 32 int8 (lo = elements 0..15, hi = 16..31), f32 scale, f32 min term
+// one 32-element group of a weight row: load() only issues the global loads (so that they can fly during the previous
+// stage's MFMAs), finish() turns them into 32 int8 (lo = elements 0..15, hi = 16..31), an f32 scale and an f32 min term
+struct gemm_raw { fq_u4 a, b; uint32_t s0, s1, s2, s3; };
 template <int TYPE> struct gemm_group;
 
 template <> struct gemm_group<FQ_Q4_0> {            // ggml.c:1509-1527
     static constexpr bool HAS_MIN = false;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const fq_u4 q = ld_u4(r.p0 + 16 * (size_t) g);
-        const uint32_t v[4] = { q.x, q.y, q.z, q.w };
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u16(r.p1 + 2 * (size_t) g); }
+    __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
+        const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
         for (int i = 0; i < 4; ++i) { lo[i] = (int) bytes_sub(v[i] & 0x0F0F0F0Fu, 0x08080808u); hi[i] = (int) bytes_sub((v[i] >> 4) & 0x0F0F0F0Fu, 0x08080808u); }
-        sc = fq_h2f(ld_u16(r.p1 + 2 * (size_t) g)); mn = 0.0f;
+        sc = fq_h2f((uint16_t) w.s0); mn = 0.0f;
     }
 };
 template <> struct gemm_group<FQ_Q4_1> {            // ggml.c:1529-1548
     static constexpr bool HAS_MIN = true;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const fq_u4 q = ld_u4(r.p0 + 16 * (size_t) g);
-        const uint32_t v[4] = { q.x, q.y, q.z, q.w };
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); }
+    __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
+        const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
         for (int i = 0; i < 4; ++i) { lo[i] = (int)(v[i] & 0x0F0F0F0Fu); hi[i] = (int)((v[i] >> 4) & 0x0F0F0F0Fu); }
-        const uint32_t dm = ld_u32(r.p1 + 4 * (size_t) g);
-        sc = fq_h2f((uint16_t) dm); mn = fq_h2f((uint16_t)(dm >> 16));
+        sc = fq_h2f((uint16_t) w.s0); mn = fq_h2f((uint16_t)(w.s0 >> 16));
     }
 };
 template <> struct gemm_group<FQ_Q5_0> {            // ggml.c:1550-1574
     static constexpr bool HAS_MIN = false;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const fq_u4 q = ld_u4(r.p0 + 16 * (size_t) g);
-        const uint32_t qh = ld_u32(r.p1 + 4 * (size_t) g);
-        const uint32_t v[4] = { q.x, q.y, q.z, q.w };
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u16(r.p2 + 2 * (size_t) g);
+    }
+    __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
+        const uint32_t qh = w.s0;
+        const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             lo[i] = (int) bytes_sub((v[i] & 0x0F0F0F0Fu) | (spread4(qh >> (4 * i)) << 4), 0x10101010u);
             hi[i] = (int) bytes_sub(((v[i] >> 4) & 0x0F0F0F0Fu) | (spread4(qh >> (16 + 4 * i)) << 4), 0x10101010u);
         }
-        sc = fq_h2f(ld_u16(r.p2 + 2 * (size_t) g)); mn = 0.0f;
+        sc = fq_h2f((uint16_t) w.s1); mn = 0.0f;
     }
 };
 template <> struct gemm_group<FQ_Q5_1> {            // ggml.c:1576-1601
     static constexpr bool HAS_MIN = true;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const fq_u4 q = ld_u4(r.p0 + 16 * (size_t) g);
-        const uint32_t qh = ld_u32(r.p1 + 4 * (size_t) g);
-        const uint32_t v[4] = { q.x, q.y, q.z, q.w };
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u32(r.p2 + 4 * (size_t) g);
+    }
+    __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
+        const uint32_t qh = w.s0;
+        const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             lo[i] = (int)((v[i] & 0x0F0F0F0Fu) | (spread4(qh >> (4 * i)) << 4));
             hi[i] = (int)(((v[i] >> 4) & 0x0F0F0F0Fu) | (spread4(qh >> (16 + 4 * i)) << 4));
         }
-        const uint32_t dm = ld_u32(r.p2 + 4 * (size_t) g);
-        sc = fq_h2f((uint16_t) dm); mn = fq_h2f((uint16_t)(dm >> 16));
+        sc = fq_h2f((uint16_t) w.s1); mn = fq_h2f((uint16_t)(w.s1 >> 16));
     }
 };
 template <> struct gemm_group<FQ_Q8_0> {            // ggml.c:1603-1619
     static constexpr bool HAS_MIN = false;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const fq_u4 a = ld_u4(r.p0 + 32 * (size_t) g), b = ld_u4(r.p0 + 32 * (size_t) g + 16);
-        lo = v4i{ (int) a.x, (int) a.y, (int) a.z, (int) a.w }; hi = v4i{ (int) b.x, (int) b.y, (int) b.z, (int) b.w };
-        sc = fq_h2f(ld_u16(r.p1 + 2 * (size_t) g)); mn = 0.0f;
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        w.a = ld_u4(r.p0 + 32 * (size_t) g); w.b = ld_u4(r.p0 + 32 * (size_t) g + 16); w.s0 = ld_u16(r.p1 + 2 * (size_t) g);
+    }
+    __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
+        lo = v4i{ (int) w.a.x, (int) w.a.y, (int) w.a.z, (int) w.a.w }; hi = v4i{ (int) w.b.x, (int) w.b.y, (int) w.b.z, (int) w.b.w };
+        sc = fq_h2f((uint16_t) w.s0); mn = 0.0f;
     }
 };
 // Q4_K / Q5_K: group g = sub-block j = g % 8 of super-block g / 8 (k_quants.c:607-631, 734-760); w = (d*sc)*q - dmin*m
 template <int TYPE> struct gemm_group_k45 {
     static constexpr bool HAS_MIN = true;
-    __device__ static void get(const fq_wrow & r, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
-        const size_t sb = (size_t)(g >> 3); const int j = g & 7, c = j >> 1, up = j & 1;
-        const fq_u4 a = ld_u4(r.p0 + 128 * sb + 32 * c), b = ld_u4(r.p0 + 128 * sb + 32 * c + 16);
-        const uint32_t va[4] = { a.x, a.y, a.z, a.w }, vb[4] = { b.x, b.y, b.z, b.w };
-        uint32_t ha[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0};
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        const size_t sb = (size_t)(g >> 3); const int j = g & 7, c = j >> 1;
+        const uint8_t * q = r.p0 + 128 * sb + 32 * c;
         if constexpr (TYPE == FQ_Q5_K) {
+            // only the 16 bytes of each half that carry this sub-block's 5th bits are kept: bit j of every byte
             const fq_u4 qa = ld_u4(r.p1 + 32 * sb), qb = ld_u4(r.p1 + 32 * sb + 16);
+            const fq_u4 a = ld_u4(q), b = ld_u4(q + 16);
             const uint32_t xa[4] = { qa.x, qa.y, qa.z, qa.w }, xb[4] = { qb.x, qb.y, qb.z, qb.w };
+            uint32_t ha[4], hb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ha[i] = ((xa[i] >> j) & 0x01010101u) << 4; hb[i] = ((xb[i] >> j) & 0x01010101u) << 4; }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lo[i] = (int)(((up ? (va[i] >> 4) : va[i]) & 0x0F0F0F0Fu) | ha[i]);
-            hi[i] = (int)(((up ? (vb[i] >> 4) : vb[i]) & 0x0F0F0F0Fu) | hb[i]);
+            const int sh = (j & 1) ? 4 : 0;
+            w.a = fq_u4{ ((a.x >> sh) & 0x0F0F0F0Fu) | ha[0], ((a.y >> sh) & 0x0F0F0F0Fu) | ha[1], ((a.z >> sh) & 0x0F0F0F0Fu) | ha[2], ((a.w >> sh) & 0x0F0F0F0Fu) | ha[3] };
+            w.b = fq_u4{ ((b.x >> sh) & 0x0F0F0F0Fu) | hb[0], ((b.y >> sh) & 0x0F0F0F0Fu) | hb[1], ((b.z >> sh) & 0x0F0F0F0Fu) | hb[2], ((b.w >> sh) & 0x0F0F0F0Fu) | hb[3] };
+        } else {
+            w.a = ld_u4(q); w.b = ld_u4(q + 16);
         }
         const uint8_t * scp = (TYPE == FQ_Q4_K ? r.p1 : r.p2) + 12 * sb;
-        int s6, m6; k4_scale_min(ld_u32(scp), ld_u32(scp + 4), ld_u32(scp + 8), j, s6, m6);
-        const uint32_t dm = ld_u32((TYPE == FQ_Q4_K ? r.p2 : r.p3) + 4 * sb);
-        sc = fq_h2f((uint16_t) dm) * (float) s6;
-        mn = -(fq_h2f((uint16_t)(dm >> 16)) * (float) m6);
+        w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
+        w.s3 = ld_u32((TYPE == FQ_Q4_K ? r.p2 : r.p3) + 4 * sb);
+    }
+    __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
+        const int j = g & 7;
+        if constexpr (TYPE == FQ_Q5_K) {
+            lo = v4i{ (int) w.a.x, (int) w.a.y, (int) w.a.z, (int) w.a.w }; hi = v4i{ (int) w.b.x, (int) w.b.y, (int) w.b.z, (int) w.b.w };
+        } else {
+            const int sh = (j & 1) ? 4 : 0;
+            lo = v4i{ (int)((w.a.x >> sh) & 0x0F0F0F0Fu), (int)((w.a.y >> sh) & 0x0F0F0F0Fu), (int)((w.a.z >> sh) & 0x0F0F0F0Fu), (int)((w.a.w >> sh) & 0x0F0F0F0Fu) };
+            hi = v4i{ (int)((w.b.x >> sh) & 0x0F0F0F0Fu), (int)((w.b.y >> sh) & 0x0F0F0F0Fu), (int)((w.b.z >> sh) & 0x0F0F0F0Fu), (int)((w.b.w >> sh) & 0x0F0F0F0Fu) };
+        }
+        int s6, m6; k4_scale_min(w.s0, w.s1, w.s2, j, s6, m6);
+        sc = fq_h2f((uint16_t) w.s3) * (float) s6;
+        mn = -(fq_h2f((uint16_t)(w.s3 >> 16)) * (float) m6);
     }
 };
 template <> struct gemm_group<FQ_Q4_K> : gemm_group_k45<FQ_Q4_K> {};
 template <> struct gemm_group<FQ_Q5_K> : gemm_group_k45<FQ_Q5_K> {};
 
-template <int TYPE, int J>
-__global__ void __launch_bounds__(256) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
+// tuning aid (ggml_hip_debug_gemm_mode): bit 0 = no global loads after the first stage, bit 1 = no MFMA / scaling (timing only)
+__device__ int g_gemm_dbg = 0;
+void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
+
+// LDS buffer of one K stage
+template <bool HAS_MIN, int TN> struct gemm_lds {                    // TN = tokens per workgroup
+    static constexpr int XQ = 0, WQ = TN * GQ_STRIDE, DX = WQ + GQ_TM * GQ_STRIDE, SX = DX + GQ_GROUPS * TN * 4,
+                         DW = SX + (HAS_MIN ? GQ_GROUPS * TN * 4 : 0), MW = DW + GQ_GROUPS * GQ_TM * 4,
+                         BYTES = MW + (HAS_MIN ? GQ_GROUPS * GQ_TM * 4 : 0);
+};
+
+// S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves
+template <int TYPE, int S, int TT>
+__global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = fq_act_of(TYPE);
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
-    constexpr int TM = 32 * J;
+    constexpr int TN = 32 * TT;
+    typedef gemm_lds<HAS_MIN, TN> LB;
+    constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16 / S;     // threads, token vectors per thread and stage, results per lane
+    static_assert(NT >= GQ_TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t m0 = (int64_t) blockIdx.x * TM, n0 = (int64_t) blockIdx.y * GQ_TN;
+    const int tt = wid % TT, sw = wid / TT;                               // token tile, share of the tile's 16 result registers
+    const int64_t m0 = (int64_t) blockIdx.x * GQ_TM, n0 = (int64_t) blockIdx.y * TN;
     const int64_t K = w.K, M = w.M;
     const int ngroups = (int)(K >> 5);
-
-    uint8_t * Xq = smem;                                        // [128][144]
-    uint8_t * Wq = Xq + GQ_TN * GQ_STRIDE;                      // [TM][144]
-    float   * dxs = (float *)(Wq + TM * GQ_STRIDE);            // [4][128]
-    float   * sxs = dxs + GQ_GROUPS * GQ_TN;                    // [4][128]   (min formats)
-    float   * dws = sxs + (HAS_MIN ? GQ_GROUPS * GQ_TN : 0);    // [4][TM]
-    float   * mws = dws + GQ_GROUPS * TM;                       // [4][TM]    (min formats)
-
     const size_t img = fq_act_col_bytes(ACT, K);
-    float acc[J][16];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    for (int g0 = 0; g0 < ngroups; g0 += GQ_GROUPS) {
-        __syncthreads();
-        // ---- stage weights: (row, group) tasks
-        for (int t = tid; t < TM * GQ_GROUPS; t += 256) {
-            const int row = t >> 2, gg = t & 3, g = g0 + gg;
-            v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; float sc = 0.0f, mn = 0.0f;
-            if (g < ngroups && m0 + row < M) gemm_group<TYPE>::get(fq_row<TYPE>(w, m0 + row), g, lo, hi, sc, mn);
-            *(v4i *)(Wq + row * GQ_STRIDE + 32 * gg)      = lo;
-            *(v4i *)(Wq + row * GQ_STRIDE + 32 * gg + 16) = hi;
-            dws[gg * TM + row] = sc;
-            if constexpr (HAS_MIN) mws[gg * TM + row] = mn;
+    // ---- what this thread stages per K stage: weights = (row, group) tasks of threads < 128; tokens = 16-byte vectors
+    // of all threads; token scales = the 4 groups' d (and s / bsums) of token tid, threads < 128
+    const bool has_w = tid < GQ_TM * GQ_GROUPS;
+    const int w_row = (tid >> 2) & (GQ_TM - 1), w_gg = tid & 3;
+    const fq_wrow wrow = fq_row<TYPE>(w, m0 + w_row < M ? m0 + w_row : M - 1);
+    const bool has_sc = tid < TN;
+    const int sc_tok = tid & (TN - 1);
+    const uint8_t * sc_col = act.base + (size_t)(n0 + sc_tok < N ? n0 + sc_tok : N - 1) * img;
+
+    struct stage_regs { gemm_raw w; v4i x[VT]; float4 d4; float2 sa, sb; uint2 ba, bb; };
+    auto issue = [&](int g0, stage_regs & R) {
+        if (has_w) { const int g = g0 + w_gg; gemm_group<TYPE>::load(wrow, g < ngroups ? g : ngroups - 1, R.w); }
+#pragma unroll
+        for (int i = 0; i < VT; ++i) {
+            const int t = tid + i * NT, tok = t >> 3, part = t & 7;
+            const int64_t n = n0 + tok < N ? n0 + tok : N - 1;
+            const int64_t kb = (int64_t) g0 * 32 + 16 * part;
+            R.x[i] = *(const v4i *)(act.base + (size_t) n * img + (size_t)(kb < K ? kb : 0));
         }
-        // ---- stage tokens: 8 x 16 B per token row, then the per-group scales
-        for (int t = tid; t < GQ_TN * 8; t += 256) {
-            const int tok = t >> 3, part = t & 7;
-            const int64_t n = n0 + tok;
-            v4i v = {0, 0, 0, 0};
-            if (n < N && g0 * 32 + 16 * part < K) v = *(const v4i *)(act.base + (size_t) n * img + (size_t) g0 * 32 + 16 * part);
-            *(v4i *)(Xq + tok * GQ_STRIDE + 16 * part) = v;
-        }
-        for (int t = tid; t < GQ_TN * GQ_GROUPS; t += 256) {
-            const int tok = t & (GQ_TN - 1), gg = t >> 7, g = g0 + gg;
-            const int64_t n = n0 + tok;
-            float dx = 0.0f, sx = 0.0f;
-            if (n < N && g < ngroups) {
-                const uint8_t * col = act.base + (size_t) n * img;
-                if constexpr (ACT == FQ_Q8_K) {
-                    dx = ((const float *)(col + fq_act_d_off(ACT, K)))[g >> 3];
-                    const int16_t * bs = (const int16_t *)(col + fq_act_aux_off(ACT, K)) + 2 * g;
-                    sx = dx * (float)((int) bs[0] + (int) bs[1]);
-                } else {
-                    dx = ((const float *)(col + fq_act_d_off(ACT, K)))[g];
-                    if constexpr (ACT == FQ_Q8_1) sx = ((const float *)(col + fq_act_aux_off(ACT, K)))[g];
+        if (has_sc) {
+            const int gc = g0 + 3 < ngroups ? g0 : (ngroups >= 4 ? ngroups - 4 : 0);     // (K % 128 != 0: the tail stage re-reads valid groups)
+            if constexpr (ACT == FQ_Q8_K) {
+                R.d4.x = ((const float *)(sc_col + fq_act_d_off(ACT, K)))[g0 >> 3];
+                const uint2 * bs = (const uint2 *)(sc_col + fq_act_aux_off(ACT, K) + 4 * (size_t) gc);       // 8 x int16
+                R.ba = bs[0]; R.bb = bs[1];
+            } else {
+                R.d4 = *(const float4 *)(sc_col + fq_act_d_off(ACT, K) + 4 * (size_t) gc);
+                if constexpr (ACT == FQ_Q8_1) {
+                    const float2 * sp = (const float2 *)(sc_col + fq_act_aux_off(ACT, K) + 4 * (size_t) gc);
+                    R.sa = sp[0]; R.sb = sp[1];
                 }
             }
-            dxs[gg * GQ_TN + tok] = dx;
-            if constexpr (HAS_MIN) sxs[gg * GQ_TN + tok] = sx;
         }
-        __syncthreads();
-        // ---- 4 groups x J tiles
-        const int half = lane >> 5, l31 = lane & 31;
+    };
+    auto commit = [&](int g0, const stage_regs & R, uint8_t * B) {        // registers -> LDS buffer B (zeros beyond K / N / M)
+        if (has_w) {
+            const int g = g0 + w_gg;
+            v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; float sc = 0.0f, mn = 0.0f;
+            if (g < ngroups && m0 + w_row < M) gemm_group<TYPE>::finish(R.w, g, lo, hi, sc, mn);
+            *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg)      = lo;
+            *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg + 16) = hi;
+            ((float *)(B + LB::DW))[w_gg * GQ_TM + w_row] = sc;
+            if constexpr (HAS_MIN) ((float *)(B + LB::MW))[w_gg * GQ_TM + w_row] = mn;
+        }
 #pragma unroll
-        for (int gg = 0; gg < GQ_GROUPS; ++gg) {
-            const v4i a = *(const v4i *)(Xq + (32 * wid + l31) * GQ_STRIDE + 32 * gg + 16 * half);
-            float dxv[16], sxv[16];
+        for (int i = 0; i < VT; ++i) {
+            const int t = tid + i * NT, tok = t >> 3, part = t & 7;
+            const bool ok = n0 + tok < N && (int64_t) g0 * 32 + 16 * part < K;
+            *(v4i *)(B + LB::XQ + tok * GQ_STRIDE + 16 * part) = ok ? R.x[i] : v4i{0, 0, 0, 0};
+        }
+        if (has_sc) {
+            float dx[4], sx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const bool full = g0 + 3 < ngroups;
+            if constexpr (ACT == FQ_Q8_K) {
+                const uint32_t bw[4] = { R.ba.x, R.ba.y, R.bb.x, R.bb.y };
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t = *(const float4 *)(dxs + gg * GQ_TN + 32 * wid + 8 * q + 4 * half);
+                for (int i = 0; i < 4; ++i) { dx[i] = R.d4.x; sx[i] = R.d4.x * (float)((int)(int16_t) bw[i] + (int)(int16_t)(bw[i] >> 16)); }
+            } else {
+                dx[0] = R.d4.x; dx[1] = R.d4.y; dx[2] = R.d4.z; dx[3] = R.d4.w;
+                if constexpr (ACT == FQ_Q8_1) { sx[0] = R.sa.x; sx[1] = R.sa.y; sx[2] = R.sb.x; sx[3] = R.sb.y; }
+            }
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                // a tail stage (fewer than 4 groups left) re-read the LAST four groups: shift them back into place
+                const int src = full ? gg : gg + (g0 - (ngroups >= 4 ? ngroups - 4 : 0));
+                const bool ok = n0 + tid < N && g0 + gg < ngroups && src < 4;
+                float dv = 0.0f, sv = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q == src) { dv = dx[q]; sv = sx[q]; }
+                ((float *)(B + LB::DX))[gg * TN + tid] = ok ? dv : 0.0f;
+                if constexpr (HAS_MIN) ((float *)(B + LB::SX))[gg * TN + tid] = ok ? sv : 0.0f;
+            }
+        }
+    };
+
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
+    const int half = lane >> 5, l31 = lane & 31;
+    // the S waves of a tile feed the MFMA the tile's tokens ROTATED by (32 / S) sw rows, so that each finds its own share of
+    // the results in the first 16 / S result registers (a run-time register index would cost a select chain per value)
+    const int rot = (32 / S) * sw, arow = (l31 + rot) & 31;
+
+    const int dbgm = g_gemm_dbg;
+    // ---- software pipeline, prefetch distance TWO stages (a stage's math, ~0.7 us, is shorter than a load round trip):
+    // while stage s is computed out of LDS buffer s & 1, stage s+1 sits in one register set and stage s+2 is in flight
+    // into the other
+    auto compute = [&](const uint8_t * B) {
+#pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
+        for (int gg = 0; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); ++gg) {
+            const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
+            const v4i b = *(const v4i *)(B + LB::WQ + l31 * GQ_STRIDE + 32 * gg + 16 * half);
+            const float dw = ((const float *)(B + LB::DW))[gg * GQ_TM + l31];
+            const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[gg * GQ_TM + l31] : 0.0f;
+            // the lane's result i  <->  token 32 tt + rot + (i & 3) + 8 (i >> 2) + 4 half: runs of 4 consecutive tokens
+            float dxv[NR], sxv[NR];
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+                const int tok = 32 * tt + rot + 8 * q + 4 * half;
+                const float4 t = *(const float4 *)(B + LB::DX + (gg * TN + tok) * 4);
                 dxv[4 * q] = t.x; dxv[4 * q + 1] = t.y; dxv[4 * q + 2] = t.z; dxv[4 * q + 3] = t.w;
                 if constexpr (HAS_MIN) {
-                    const float4 u = *(const float4 *)(sxs + gg * GQ_TN + 32 * wid + 8 * q + 4 * half);
+                    const float4 u = *(const float4 *)(B + LB::SX + (gg * TN + tok) * 4);
                     sxv[4 * q] = u.x; sxv[4 * q + 1] = u.y; sxv[4 * q + 2] = u.z; sxv[4 * q + 3] = u.w;
                 }
             }
+            v16i c = {0};
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+            // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
+            // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const v4i b = *(const v4i *)(Wq + (32 * j + l31) * GQ_STRIDE + 32 * gg + 16 * half);
-                const float dw = dws[gg * TM + 32 * j + l31];
-                v16i c = {0};
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
-                // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
-                // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
-                const float mw = HAS_MIN ? mws[gg * TM + 32 * j + l31] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ci = (float) c[r];
-                    float t;
-                    if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[r];                    // ggml.c:2606
-                    else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[r]) * ci;                    // ggml.c:2972, 3325
-                    else                                                    t = (dw * dxv[r]) * ci + mw * sxv[r];      // ggml.c:2731, 3227; k-quants
-                    acc[j][r] = acc[j][r] + t;
-                }
+            for (int i = 0; i < NR; ++i) {
+                const float ci = (float) c[i];
+                float t;
+                if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
+                else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
+                else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
+                acc[i] = acc[i] + t;
             }
         }
+    };
+    const int nstages = (ngroups + GQ_GROUPS - 1) / GQ_GROUPS;
+    const int last_g0 = (nstages - 1) * GQ_GROUPS;
+    auto g0_of = [&](int st) { return st < nstages ? st * GQ_GROUPS : last_g0; };      // beyond the end: re-read the last stage (unused)
+    stage_regs R0, R1;
+    issue(0, R0);
+    issue(g0_of(1), R1);
+    commit(0, R0, smem);
+    __syncthreads();
+    // (measured: the kernel is instruction-issue bound -- ~28 issue slots per group and wave in the MFMA loop, ~50 per stage
+    // for issue + commit, 4 waves per SIMD; making the idle threads' loads unconditional so that the waits become countable
+    // vmcnt(N) instead of vmcnt(0) costs more in extra load instructions than the deeper prefetch gains)
+    for (int st = 0; st < nstages; st += 2) {
+        // even stage st out of buffer 0; R1 holds st + 1; st + 2 goes into R0
+        issue(g0_of(st + 2), R0);
+        compute(smem);
+        commit(g0_of(st + 1), R1, smem + LB::BYTES);
+        __syncthreads();
+        // odd stage st + 1 out of buffer 1; R0 holds st + 2; st + 3 goes into R1
+        issue(g0_of(st + 3), R1);
+        if (st + 1 < nstages) compute(smem + LB::BYTES);
+        commit(g0_of(st + 2), R0, smem);
+        __syncthreads();
     }
-    // ---- epilogue: token n = n0 + 32*wid + (r&3) + 8*(r>>2) + 4*(lane>>5), row m = m0 + 32*j + (lane&31)
-    const int half = lane >> 5, l31 = lane & 31;
+    // ---- epilogue: token n = n0 + 32*tt + rot + (i&3) + 8*(i>>2) + 4*half, row m = m0 + (lane&31)
+    const int64_t m = m0 + l31;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int64_t m = m0 + 32 * j + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t n = n0 + 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (n < N && m < M) {
-                float v = acc[j][r];
-                if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
-                else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
-                dst[n * ldd + m] = v;
-            }
+    for (int i = 0; i < NR; ++i) {
+        const int64_t n = n0 + 32 * tt + rot + (i & 3) + 8 * (i >> 2) + 4 * half;
+        if (n < N && m < M) {
+            float v = acc[i];
+            if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+            else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+            dst[n * ldd + m] = v;
         }
     }
 }
@@ -240,20 +333,27 @@ bool fq_gemm_supported(int type) {
     return type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0 || type == FQ_Q4_K || type == FQ_Q5_K;
 }
 
-template <int TYPE, int J>
+template <int TYPE, int S, int TT>
 static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
-    constexpr int TM = 32 * J;
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
-    const size_t lds = (size_t)(GQ_TN + TM) * GQ_STRIDE + (size_t) GQ_GROUPS * (GQ_TN + TM) * 4 * (HAS_MIN ? 2 : 1);
-    const dim3 grid((unsigned)((w.M + TM - 1) / TM), (unsigned)((N + GQ_TN - 1) / GQ_TN));
-    hipLaunchKernelGGL((k_gemm_q<TYPE, J>), grid, dim3(256), lds, st, w, act, N, dst, ldd, ep);
+    constexpr int TN = 32 * TT;
+    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN>::BYTES;
+    const dim3 grid((unsigned)((w.M + GQ_TM - 1) / GQ_TM), (unsigned)((N + TN - 1) / TN));
+    hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
 }
 
 // dst[n*ldd + m], n < N; act holds N quantized columns
 void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int n_cu, hipStream_t st) {
-    const int64_t tiles128 = ((w.M + 127) / 128) * ((N + GQ_TN - 1) / GQ_TN);
-    const bool small = tiles128 < 2 * (int64_t) n_cu;            // few workgroups: halve the row tile to fill the chip
-#define FQ_CASE(T) case T: if (small) launch_gemm_t<T, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 4>(w, act, N, dst, ldd, ep, st); break;
+    // The unit of parallelism is a 32-token x 32-row tile (568 of them for a 4544-row matrix and 128 tokens); the scaling
+    // epilogue is instruction-issue bound. Measured on MI355X, Falcon-7B shapes, 128 tokens, Q4_0 (scripts/gpu_gemm_prof.sh):
+    //   <S = 1, 4 tiles per workgroup>   up 18176 x 4544: 92 us     wo 4544 x 4544: 60 us    down 4544 x 18176: 216 us
+    //   <S = 4, 4 tiles per workgroup>   up: 101-123 us             wo: 45 us                down: 161 us
+    //   <S = 4, 1 tile per workgroup>    (all CUs busy, but 4 x the weight staging)  wo: 52 us   down: 181 us
+    const int64_t tiles = ((w.M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
+    int cfg = tiles >= 8 * (int64_t) n_cu ? 0 : 2;
+    if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>
+#define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
+                           else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); break;
     switch (w.type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K)
         default: fprintf(stderr, "ggml-hip: gemm: unsupported weight type %d\n", w.type); exit(1);
