@@ -128,6 +128,30 @@ class TorchComm:
             w.wait()
 
 
+class HostStagedComm:
+    """debug transport (FALCON_PIPE_DEBUG_SHARED_GPU=1): the same exchange through host buffers and gloo, so that the
+    whole multi-process path (partition, schedule, stage API, stream ordering) can be exercised with every rank on ONE GPU
+    (RCCL refuses two ranks on one device)"""
+
+    def __init__(self, dist, engine, torch):
+        self.dist, self.e, self.torch = dist, engine, torch
+
+    def exchange(self, sends, recvs):
+        works, pend = [], []
+        for kind, s, peer in sends:
+            t = (self.e.tok_out[s] if kind == "token" else self.e.hidden_out[s]).cpu()
+            works.append(self.dist.isend(t, peer))
+        for kind, s, peer in recvs:
+            dst = self.e.tok_in[s] if kind == "token" else self.e.hidden_in[s]
+            buf = self.torch.empty(dst.shape, dtype=dst.dtype)
+            works.append(self.dist.irecv(buf, peer))
+            pend.append((dst, buf))
+        for w in works:
+            w.wait()
+        for dst, buf in pend:
+            dst.copy_(buf)
+
+
 def main(a, rank, world, local):
     import torch
     import torch.distributed as dist
@@ -142,12 +166,18 @@ def main(a, rank, world, local):
         hp["n_layer"] = a.layers
     if not os.path.exists(g.LIB_PATH):
         g.build()
+    shared = os.environ.get("FALCON_PIPE_DEBUG_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     g.init(local)
     L = g.load()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     lb, le = partition(hp["n_layer"], world)[rank]
     S = max(2 * world, 2) if world > 1 else getattr(a, "streams", 1)
     n_ctx = min(a.n_ctx, 512)
@@ -161,7 +191,7 @@ def main(a, rank, world, local):
     ext = torch.cuda.ExternalStream(L.ggml_hip_stream(), device=torch.device("cuda", local))
     with torch.cuda.stream(ext):                     # torch allocations / P2P ops are ordered with the library's kernels
         engine = HipEngine(g, model, S, n_ctx, torch, torch.device("cuda", local))
-        comm = TorchComm(dist, engine)
+        comm = HostStagedComm(dist, engine, torch) if shared else TorchComm(dist, engine)
         runner = PipelineRunner(rank, world, S, engine, comm)
         engine.set_initial_tokens(synth.tokens(S, hp["n_vocab"], seed=42))
         n_past = 0
@@ -179,8 +209,9 @@ def main(a, rank, world, local):
         L.ggml_hip_synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local))
-    wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=torch.device("cuda", local))
+    red_dev = torch.device("cpu") if shared else torch.device("cuda", local)
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(wb_t, op=dist.ReduceOp.SUM)
