@@ -257,6 +257,11 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     c->merged_attn_out = mode >= 2;
 }
 
+static bool stage_uniform(const falcon_hip_model * m) {
+    for (const layer_weights & L : m->layers) if (L.qkv.type != L.up.type || L.down.type != L.wo.type) return false;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
@@ -270,7 +275,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     if (m->first_stage()) fq_launch_dequant_rows(m->tok_emb, c->tokens_dev, N, c->x, st);    // ggml_get_rows, libfalcon.cpp:2120
 
     auto acts = [&](const fq_act & a, int64_t n) { fq_act v = a; v.ncols = n; return v; };
-    if (N == 1 && c->fused_decode) {
+    // the fused kernels are instantiated per weight format: a model that mixes formats inside a block (e.g. the reference's
+    // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
+    const bool fused = c->fused_decode && stage_uniform(m);
+    if (N == 1 && fused) {
         // ---- fused single-token path: 3 launches per block (kernels_decode.hip), bit-identical to the list below
         for (size_t li = 0; li < m->layers.size(); ++li) {
             const layer_weights & L = m->layers[li];
@@ -467,7 +475,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     if (m->last_stage()) {
         if (next_token_dev) {
             // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
-            if (c->fused_decode)
+            if (c->fused_decode && stage_uniform(m))
                 hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
             else
                 hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
@@ -491,7 +499,7 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
     c->keep_hidden = false;
     auto one_step = [&](hipStream_t s, int max_kv) {
         launch_stage(c, 1, max_kv, s);
-        if (c->fused_decode)
+        if (c->fused_decode && stage_uniform(m))
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, s, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
         else
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
