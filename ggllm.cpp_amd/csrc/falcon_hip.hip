@@ -61,7 +61,8 @@ struct falcon_hip_context {
     std::vector<hipEvent_t> ev_fork, ev_join;  // one pair per local layer
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
     bool merged_attn_out = true;               // ... with attention and the output mat-vec in one launch (k_attn_out) when the grid fits the chip
-    unsigned * sync_words = nullptr;           // [0] arrival counter of k_attn_out, [1] its time-out flag
+    unsigned * sync_words = nullptr;           // [0] hand-off epoch of k_attn_out, [1] its time-out flag, [16..80) rope row of the position
+    unsigned long long * att_gran = nullptr;   // hand-off granules of k_attn_out: one per 32-bit word of the attention image / row
     hipGraphExec_t decode_graph = nullptr;
     int  graph_base = -1;                      // n_past the captured graph was built for
 };
@@ -221,6 +222,8 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->argmax_idx     = (int *) dev_alloc(c->allocs, (size_t)(hp.n_vocab / 32 + 8) * 4);
     c->sync_words     = (unsigned *) dev_alloc(c->allocs, 64 + 256);        // + the rope table row of the current position
     HIP_CHECK(hipMemset(c->sync_words, 0, 64 + 256));
+    c->att_gran       = (unsigned long long *) dev_alloc(c->allocs, (size_t) hp.n_embd * 8 + 64);
+    HIP_CHECK(hipMemset(c->att_gran, 0, (size_t) hp.n_embd * 8 + 64));
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     return c;
 }
@@ -287,7 +290,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
             fq_gemv_ln_args ga{};
             ga.x = c->x; ga.E = E; ga.nseg = 2; ga.gelu_table = hc.gelu_table; ga.dbg = hc.dbg_stamps;
-            ga.zero_word = c->sync_words;
+            ga.epoch_word = c->merged_attn_out ? c->sync_words : nullptr;
             if (c->merged_attn_out) { ga.n_past_ptr = c->n_past_dev; ga.rope_cs = c->rope_cs; ga.rope_cur = (float *)(c->sync_words + 16); }
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, 0 };
@@ -320,7 +323,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (c->merged_attn_out && !dual) {
                 if (prof) fq_prof_open(st);
                 merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
-                                            kc, vc, hc.exp_table_attn, att_act, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                                            kc, vc, hc.exp_table_attn, att_act, c->att_gran, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                if (!merged && prof) fq_prof_cancel();
             }
             if (!merged) {
                 fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,

@@ -255,6 +255,12 @@ void fq_prof_open(hipStream_t) {
     g_prof_ev.emplace_back(e0, e1);
     g_prof_pending[0] = e0; g_prof_pending[1] = e1;
 }
+void fq_prof_cancel() {                                             // the bracket just opened enclosed no launch after all
+    if (g_prof_ev.empty()) return;
+    (void) hipEventDestroy(g_prof_ev.back().first); (void) hipEventDestroy(g_prof_ev.back().second);
+    g_prof_ev.pop_back();
+    g_prof_pending[0] = g_prof_pending[1] = nullptr;
+}
 void fq_prof_events(hipEvent_t * start, hipEvent_t * stop) { *start = g_prof_pending[0]; *stop = g_prof_pending[1]; }
 void fq_prof_close(hipStream_t, double bytes) {
     g_prof_pending[0] = g_prof_pending[1] = nullptr;

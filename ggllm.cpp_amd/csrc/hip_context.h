@@ -30,4 +30,5 @@ std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_prof_active();
 void      fq_prof_open(hipStream_t st);
 void      fq_prof_close(hipStream_t st, double bytes);
+void      fq_prof_cancel();
 void      fq_prof_events(hipEvent_t * start, hipEvent_t * stop);   // the open bracket's events (nullptr, nullptr when none)

@@ -59,7 +59,7 @@ struct fq_gemv_ln_seg {
 struct fq_gemv_ln_args {
     const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg;
     float * argmax_val; int * argmax_idx;      // optional (lm_head): per-workgroup best logit and its row, for greedy sampling
-    unsigned * zero_word;                      // optional: a word this launch resets (the arrival counter of the next k_attn_out)
+    unsigned * epoch_word;                     // optional: the hand-off tag of the k_attn_out that follows; this launch increments it (never 0)
     // optional: copy the rope table's row of the current position (cos/sin pairs, 64 floats) to rope_cur, so that the
     // attention that follows does not have to wait for n_past before it can ask for them
     const int * n_past_ptr; const float * rope_cs; float * rope_cur;
@@ -77,10 +77,11 @@ size_t fq_gemv_ln_lds(int type, int64_t E);
 void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st);       // fills seg[].block_begin
 void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
 // attention + output mat-vec in one launch (k_attn_out); returns false (nothing launched) when the grid would not be
-// resident at once -- the caller then uses fq_launch_attn_decode + fq_launch_gemv_out. counter must be 0 at launch.
+// resident at once -- the caller then uses fq_launch_attn_decode + fq_launch_gemv_out. gran: >= n_embd granules (8 bytes
+// each), zero-filled once; epoch_word: incremented by the k_gemv_ln launch before it.
 bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
                           const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
-                          int att_act_type, unsigned * counter, unsigned * err, int n_cu, hipStream_t st);
+                          int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st);
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
                              int att_act_type, hipStream_t st);

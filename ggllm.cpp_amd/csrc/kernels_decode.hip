@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
     // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
     //    5. pass 1 (its loads overlap other workgroups' dots)
-    if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+    if (a.epoch_word && blockIdx.x == 0 && tid == 0) { const unsigned e = *a.epoch_word + 1u; *a.epoch_word = e ? e : 1u; }
     if (a.rope_cur && blockIdx.x == gridDim.x - 1 && tid < 64) a.rope_cur[tid] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + tid];
     FQ_STAMP(a.dbg, 0);
     // LayerNorm + Q8 image in registers (NLN float4 of the row per thread) when the row fits, through LDS otherwise
@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
         ln_regs_stage1(xr, E, blockDim.x, red);                          // waits for the row only
         // only NPRE (12 waves: ONE) unit column per row is requested ahead of the LayerNorm (48 KB per CU): a CU keeps
         // only so many requests in flight, more makes the later waves' loads block at issue, and a wave that cannot
-        // issue cannot reach the LN's barriers either (measured: +3 us with 3 columns)
+        // issue cannot reach the LN's barriers either (measured: +3 us with 3 columns; requesting the other columns
+        // right after the last statistics barrier, ahead of the quantizer, moves the image 1.4 us later and the end of
+        // the kernel nowhere)
         rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
         FQ_STAMP(a.dbg, 1);
         __syncthreads();
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-        rows_dot_from<TYPE, R, NPRE>(rows1, units, 0, col, acc);
+        rows_dot_from<TYPE, R, decode_cfg<TYPE>::LN_NPRE>(rows1, units, 0, col, acc);      // pass 1: 3 (2) unit columns in flight per row
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
@@ -298,6 +300,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
     for (int k = 0; k < NTQ; ++k) { const int64_t i = (int64_t) k * nt + tid; tq[k] = src_at[i < nvec_at ? i : 0]; }
     __builtin_amdgcn_sched_barrier(0);
     // 2. weight loads for both sources
+    const float res0 = a.resid[row0 < a.w_wo.M ? row0 : 0], res1 = a.resid[row0 + 1 < a.w_wo.M ? row0 + 1 : 0];
     fq_wrow rd[2], ro[2];
     rows_ptrs<TYPE, 2>(a.w_down, row0, rd);
     rows_ptrs<TYPE, 2>(a.w_wo, row0, ro);
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t row = row0 + r;
-            if (row < a.w_wo.M) a.dst[row] = (acc_d[r] + acc_o[r]) + a.resid[row];                  // libfalcon.cpp:2399-2400
+            if (row < a.w_wo.M) a.dst[row] = (acc_d[r] + acc_o[r]) + (r ? res1 : res0);            // libfalcon.cpp:2399-2400
         }
     }
     FQ_STAMP(a.dbg, 7);
@@ -382,11 +385,18 @@ struct fq_attn_decode_args {
     int cache_rows;                 // key/value rows [0, cache_rows) are allocated (>= n_past + 1): prefetch bound before n_past is known
     const float * cs_cur;           // optional: the rope table's row for n_past, prepared by the preceding k_gemv_ln
 };
-template <bool PUBLISH, typename T> __device__ __forceinline__ void out_store(T * p, T v) {
-    if constexpr (PUBLISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+// PUBLISH: the 32-bit word `word` of the image / f32 row goes out as ONE 8-byte granule {tag = epoch, value}, a single
+// agent-scope (write-through) store: the data is its own flag (the consumer re-reads a granule until its tag is this
+// launch's epoch), so no drain, no barrier and no counter are needed on the producing side.
+struct fq_publish { unsigned long long * gran; unsigned epoch; };
+template <bool PUBLISH, typename T> __device__ __forceinline__ void out_store(T * base, int64_t word, T v, const fq_publish & pub) {
+    static_assert(sizeof(T) == 4, "32-bit words");
+    if constexpr (PUBLISH) __hip_atomic_store(pub.gran + word, ((unsigned long long) pub.epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else base[word] = v;
 }
 template <bool PUBLISH>
-__device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr) {
+__device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr,
+                                                  const fq_publish pub = fq_publish{ nullptr, 0u }) {
     constexpr int D = 64, HALF = 32;
     const int H = a.H, HKV = a.HKV;
     const int group = H / HKV, hk = h / group;
@@ -425,7 +435,7 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
     const float o = attn_head_block(qr, a.kc, a.vc, HKV, hk, np, kr, vn, a.exp_tab, L, tid, P, dbg);
     FQ_STAMP(dbg, 6);
     if (tid < 64) {
-        if (a.att && live) out_store<PUBLISH>(a.att + (int64_t) h * D + tid, o);
+        if (a.att && live) out_store<PUBLISH>(a.att, (int64_t) h * D + tid, o, pub);
         if (a.att_image) {                                                           // lanes 0-31 / 32-63 = the head's two 32-blocks
             const float amax = reduce32(fabsf(o), op_max());
             const float d  = amax / 127.0f;
@@ -433,15 +443,20 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
             const int q = round_half_away(o * id);
             const int s = reduce32(q, op_add());
             const int64_t E = (int64_t) H * D;
-            const act_image_ptr im = act_image_at(a.att_image, a.att_act_type, E);
-            unsigned w = (unsigned) q & 0xFFu;                                       // 4 lanes -> one 32-bit store
+            // the image as 32-bit words: [qs E/4 | d E/32 | aux E/32]
+            unsigned w = (unsigned) q & 0xFFu;                                       // 4 lanes -> one word of qs
             w |= ((unsigned) __shfl_down((int) w, 1) & 0xFFu) << 8;
             w |= ((unsigned) __shfl_down((int) w, 2) & 0xFFFFu) << 16;
-            if (live && (tid & 3) == 0) out_store<PUBLISH>((unsigned *)(im.qs + (int64_t) h * D + tid), w);
+            if (live && (tid & 3) == 0) out_store<PUBLISH>((unsigned *) a.att_image, ((int64_t) h * D + tid) >> 2, w, pub);
             if (live && (tid & 31) == 0) {
-                const int64_t b = 2 * (int64_t) h + (tid >> 5);
-                if (a.att_act_type == FQ_Q8_0) { out_store<PUBLISH>(im.d + b, h2f_bits(f2h_bits(d))); out_store<PUBLISH>((int32_t *) im.aux + b, (int32_t) s); }
-                else                           { out_store<PUBLISH>(im.d + b, d); out_store<PUBLISH>((float *) im.aux + b, (float) s * d); }
+                const int64_t wd = (E >> 2) + 2 * (int64_t) h + (tid >> 5), wa = wd + (E >> 5);      // words of d and aux
+                if (a.att_act_type == FQ_Q8_0) {
+                    out_store<PUBLISH>((float *) a.att_image, wd, h2f_bits(f2h_bits(d)), pub);
+                    out_store<PUBLISH>((int32_t *) a.att_image, wa, (int32_t) s, pub);
+                } else {
+                    out_store<PUBLISH>((float *) a.att_image, wd, d, pub);
+                    out_store<PUBLISH>((float *) a.att_image, wa, (float) s * d, pub);
+                }
             }
         }
     }
@@ -481,8 +496,9 @@ void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past
 struct fq_attn_out_args {
     fq_gemv_out_args g;             // g.att / g.att_image are what the attention role writes
     fq_attn_decode_args at;
-    unsigned * counter;             // zeroed by the preceding k_gemv_ln launch
-    unsigned * err;                 // set to 1 if the poll gave up
+    unsigned long long * gran;      // hand-off buffer: one granule per 32-bit word of the attention image (or f32 row)
+    const unsigned * epoch_word;    // this launch's tag (incremented by the preceding k_gemv_ln launch, never 0)
+    unsigned * err;                 // set to 1 if a sweep gave up
     int n_attn, heads_per_wg, attn_lds_group;
 };
 
@@ -499,10 +515,7 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
         if (!live) h = a.at.H - 1;
         long long * dbg = a.g.dbg ? a.g.dbg + 2048 * 8 : nullptr;
         FQ_STAMP(dbg, 0);
-        attn_decode_group<true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, dbg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        attn_decode_group<true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, dbg, fq_publish{ a.gran, *a.epoch_word });
         FQ_STAMP(dbg, 7);
         return;
     }
@@ -525,6 +538,8 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
 #pragma unroll
     for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
     __builtin_amdgcn_sched_barrier(0);
+    // (the residual is asked for now: as a dependent load at the very end it would add a memory round trip to the tail)
+    const float res0 = g.resid[row0 < g.w_wo.M ? row0 : 0], res1 = g.resid[row0 + 1 < g.w_wo.M ? row0 + 1 : 0];
     fq_wrow rd[2], ro[2];
     rows_ptrs<TYPE, 2>(g.w_down, row0, rd);
     rows_ptrs<TYPE, 2>(g.w_wo, row0, ro);
@@ -543,28 +558,35 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
     FQ_STAMP(dbg, 4);
     rows_dot_from<TYPE, 2, (decode_cfg<TYPE>::four_bit ? 5 : 2)>(rd, units_d, 64 * NPD, col_d, acc_d);
     FQ_STAMP(dbg, 5);
-    // ---- the attention output: wait for every attention workgroup, then read it past the (stale) caches
-    if (tid == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) a.n_attn) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    // ---- the attention output: every wave re-reads its share of the granules (agent-scope loads, past the caches) until
+    // all of them carry this launch's tag, and drops the values into the image in LDS
+    {
+        const unsigned epoch = *a.epoch_word;
+        const int64_t nwords = g.att_image ? (E >> 2) + 2 * (E >> 5) : E;      // published words: [qs | d | aux] of Q8_0 / Q8_1, or the f32 row
+        unsigned * dstw = g.att_image ? (unsigned *) img_att : (unsigned *)(img_att + fq_act_col_bytes(ACT, E));
+        constexpr int NG = 3;                                        // granules per thread and sweep (768 threads: 2304 words)
+        for (int64_t base = 0; base < nwords; base += (int64_t) NG * nt) {
+            unsigned v[NG];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const int64_t i = base + (int64_t) k * nt + tid;
+                    const unsigned long long x = __hip_atomic_load(a.gran + (i < nwords ? i : nwords - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[k] = (unsigned) x; ok = ok && (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if (spins > (1u << 20)) { if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { const int64_t i = base + (int64_t) k * nt + tid; if (i < nwords) dstw[i] = v[k]; }
         }
     }
-    __syncthreads();
     FQ_STAMP(dbg, 6);
-    if (g.att_image) {
-        const int64_t n8 = (int64_t)(fq_act_col_bytes(ACT, E) >> 3);
-        const unsigned long long * src = (const unsigned long long *) g.att_image;
-        for (int64_t i = tid; i < n8; i += nt)
-            ((unsigned long long *) img_att)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        float * att_f = (float *)(img_att + fq_act_col_bytes(ACT, E));          // f32 copy of the attention row, quantized here
-        const unsigned long long * src = (const unsigned long long *) g.att;
-        for (int64_t i = tid; i < (E >> 1); i += nt)
-            ((unsigned long long *) att_f)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!g.att_image) {
         __syncthreads();
-        quantize_row_block<ACT>(att_f, E, act_image_at(img_att, ACT, E));
+        quantize_row_block<ACT>((const float *)(img_att + fq_act_col_bytes(ACT, E)), E, act_image_at(img_att, ACT, E));
     }
     __syncthreads();
     rows_consume<TYPE, 2, NPO>(po, units_o, col_o, acc_o);
@@ -575,7 +597,7 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t row = row0 + r;
-            if (row < g.w_wo.M) g.dst[row] = (acc_d[r] + acc_o[r]) + g.resid[row];                  // libfalcon.cpp:2399-2400
+            if (row < g.w_wo.M) g.dst[row] = (acc_d[r] + acc_o[r]) + (r ? res1 : res0);            // libfalcon.cpp:2399-2400
         }
     }
     FQ_STAMP(dbg, 7);
@@ -584,7 +606,7 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
 // true (and launched) when the merged form applies: every workgroup resident at once
 bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
                         const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
-                        int att_act_type, unsigned * counter, unsigned * err, int n_cu, hipStream_t st) {
+                        int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st) {
     const int type = g.w_wo.type, act = fq_desc(type).act_type;
     const int nw = 12, hpw = 2;             // 2 heads per attention workgroup: the attention is instruction-issue bound per SIMD
     const int n_attn = (H + hpw - 1) / hpw;
@@ -598,7 +620,7 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
     a.g = g;
     a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, const_cast<float *>(g.att_image ? nullptr : g.att),
                                 const_cast<uint8_t *>(g.att_image), att_act_type, max_n_kv, rope_cur };
-    a.counter = counter; a.err = err; a.n_attn = n_attn; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
+    a.gran = gran; a.epoch_word = epoch_word; a.err = err; a.n_attn = n_attn; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
 #define FQ_CASE(T) case T: { \
         static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
         FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned)(n_attn + n_mv)), dim3(64 * nw), lds, st, a); } break;
