@@ -59,6 +59,7 @@ struct fq_gemv_ln_seg {
 struct fq_gemv_ln_args {
     const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg;
     float * argmax_val; int * argmax_idx;      // optional (lm_head): per-workgroup best logit and its row, for greedy sampling
+    int npass;                                 // 4-row passes per wave (set by the launcher)
     unsigned * epoch_word;                     // optional: the hand-off tag of the k_attn_out that follows; this launch increments it (never 0)
     // optional: copy the rope table's row of the current position (cos/sin pairs, 64 floats) to rope_cur, so that the
     // attention that follows does not have to wait for n_past before it can ask for them

@@ -96,9 +96,9 @@ __device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_typ
 }
 
 // =============================================================================================== k_gemv_ln
-// one workgroup = NW waves = 8*NW consecutive rows of one segment (NW = blockDim/64, chosen by the launcher so that the
-// grid is about one workgroup per CU: the LayerNorm + Q8 prologue is then computed ~n_cu times per launch instead of
-// once per 32 rows); wave w owns rows 8w..8w+7 (two passes of 4)
+// one workgroup = NW waves = RW*NW consecutive rows of one segment (NW = blockDim/64 and RW = 4 * a.npass rows per wave,
+// chosen by the launcher so that the grid is about one workgroup per CU: the LayerNorm + Q8 prologue is then computed
+// ~n_cu times per launch instead of once per 32 rows); wave w owns rows RW*w .. RW*w + RW - 1 (npass passes of 4)
 template <int TYPE, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -107,13 +107,14 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     const int sidx = (a.nseg > 1 && (int) blockIdx.x >= a.seg[1].block_begin) ? 1 : 0;
     const fq_gemv_ln_seg sg = sidx ? a.seg[1] : a.seg[0];       // whole-struct select: no runtime-indexed kernarg array
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * (8 * nw);
+    const int RW = 4 * a.npass;
+    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * (RW * nw);
 
-    // LDS: f32 row [E] | image | out rows (<= 128) | reduction scratch
+    // LDS: f32 row [E] | image | out rows (<= 384) | reduction scratch
     float   * rowf  = (float *) smem;
     uint8_t * image = smem + (((size_t) E * 4 + 15) & ~(size_t) 15);
     float   * out32 = (float *)(image + fq_act_col_bytes(ACT, E));
-    double  * red   = (double *)(out32 + 128);
+    double  * red   = (double *)(out32 + 384);
 
     constexpr int R = 4, NPRE = MAXT > 256 ? decode_cfg<TYPE>::LN_NPRE_BIG : decode_cfg<TYPE>::LN_NPRE;              // 8 rows per wave = two passes of 4
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
@@ -123,15 +124,14 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     if (a.rope_cur && blockIdx.x == gridDim.x - 1 && tid < 64) a.rope_cur[tid] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + tid];
     FQ_STAMP(a.dbg, 0);
     // LayerNorm + Q8 image in registers (NLN float4 of the row per thread) when the row fits, through LDS otherwise
-    constexpr int NLN = MAXT > 256 ? 2 : 5;
-    const bool in_regs = (E >> 2) <= (int64_t) NLN * blockDim.x;        // Falcon-7B/40B/180B with 12 waves: yes
-    fq_wrow rows0[R], rows1[R];
+    constexpr int NLN = MAXT > 256 ? 3 : 5;
+    const bool in_regs = (E >> 2) <= (int64_t) NLN * blockDim.x;        // Falcon-7B (1136 float4) and 40B (2048) with 12 waves: yes
+    fq_wrow rows0[R];
     fq_unit_regs pre0[NPRE][R];
     if (in_regs) {
         ln_row_regs<NLN> xr, wr, br;
         ln_regs_issue(a.x, sg.ln_w, sg.ln_b, E, blockDim.x, xr, wr, br);
-        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
-        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
+        rows_ptrs<TYPE, R>(sg.w, row0 + RW * wid, rows0);
         ln_regs_stage1(xr, E, blockDim.x, red);                          // waits for the row only
         // only NPRE (12 waves: ONE) unit column per row is requested ahead of the LayerNorm (48 KB per CU): a CU keeps
         // only so many requests in flight, more makes the later waves' loads block at issue, and a wave that cannot
@@ -149,8 +149,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     } else {
         ln_row_regs<8> xr;
         layer_norm_issue(a.x, E, xr);
-        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid, rows0);
-        rows_ptrs<TYPE, R>(sg.w, row0 + 8 * wid + R, rows1);
+        rows_ptrs<TYPE, R>(sg.w, row0 + RW * wid, rows0);
         rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
         FQ_STAMP(a.dbg, 1);
         layer_norm_finish(xr, a.x, E, sg.ln_w, sg.ln_b, rowf, red);      // identical to k_layer_norm
@@ -170,25 +169,30 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) out32[8 * wid + r] = acc[r];
+            for (int r = 0; r < R; ++r) out32[RW * wid + r] = acc[r];
         }
         FQ_STAMP(a.dbg, 4);
     }
-    {
+    for (int p = 1; p < a.npass; ++p) {                // later passes: all unit columns of the 4 rows in flight at once
+        fq_wrow rowsp[R];
+        rows_ptrs<TYPE, R>(sg.w, row0 + RW * wid + R * p, rowsp);
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-        rows_dot_from<TYPE, R, decode_cfg<TYPE>::LN_NPRE>(rows1, units, 0, col, acc);      // pass 1: 3 (2) unit columns in flight per row
+        // (rows of <= 192 units -- Falcon-7B: 142 -- in one trip of LN_NPRE columns; longer rows two columns at a time, so
+        // that the last trip does not re-request clamped columns)
+        if (units <= 64 * decode_cfg<TYPE>::LN_NPRE) rows_dot_from<TYPE, R, decode_cfg<TYPE>::LN_NPRE>(rowsp, units, 0, col, acc);
+        else                                         rows_dot_from<TYPE, R, 2>(rowsp, units, 0, col, acc);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) out32[8 * wid + R + r] = acc[r];
+            for (int r = 0; r < R; ++r) out32[RW * wid + R * p + r] = acc[r];
         }
-        FQ_STAMP(a.dbg, 5);
     }
+    FQ_STAMP(a.dbg, 5);
     __syncthreads();
-    for (int grp = wid; grp < nw / 4; grp += nw) {     // wave grp finishes rows [32*grp, 32*grp+32) (lanes 32..63 mirror 0..31)
+    for (int grp = wid; grp < (RW * nw) / 32; grp += nw) {     // a wave finishes rows [32*grp, 32*grp+32) (lanes 32..63 mirror 0..31)
         const int j = lane & 31;
         const int64_t row = row0 + 32 * grp + j;
         float v = out32[32 * grp + j];
@@ -228,26 +232,38 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
 
 size_t fq_gemv_ln_lds(int type, int64_t E) {
     const int act = fq_desc(type).act_type;
-    return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 128 * 4 + 32 * 8;
+    return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 384 * 4 + 32 * 8;
 }
 
-// waves per workgroup (8 rows per wave; 4, 8 or 12 so that a workgroup is whole 32-row groups): the one that needs the
-// fewest rounds x rows-per-workgroup over the chip's CUs, ties to the larger workgroup (fewer LN + Q8 prologues)
-int fq_gemv_ln_waves(const fq_gemv_ln_args & a, int n_cu) {
-    int best = 4; int64_t best_cost = INT64_MAX;
+// workgroup shape: nw waves (4, 8 or 12) x 4*npass rows per wave (npass even, so that a workgroup is whole 32-row groups;
+// at most 8 passes = 384 rows).
+//   nw    : with 8 rows per wave, the count that needs the fewest rounds x rows-per-workgroup over the chip's CUs, ties
+//           to the larger workgroup (fewer LN + Q8 prologues): 12 for Falcon-7B (239 workgroups) and 40B (438, two rounds)
+//   npass : 2, except for the single-segment lm_head launch, which takes as many passes as it needs to fit the chip in
+//           one round (12 x 6 rows, 226 workgroups: one prologue per CU, measured -8 us on Falcon-7B). A block's
+//           two-segment launch does NOT gain from that at Falcon-40B width (measured 8 % slower than two rounds of
+//           96-row workgroups, whose second-round prologues fall into the first round's stream).
+static void gemv_ln_shape(const fq_gemv_ln_args & a, int n_cu, int & nw_out, int & npass_out) {
+    int64_t best_cost = INT64_MAX;
     for (int nw = 4; nw <= 12; nw += 4) {
         int64_t blocks = 0;
         for (int s = 0; s < a.nseg; ++s) blocks += (a.seg[s].w.M + 8 * nw - 1) / (8 * nw);
         const int64_t cost = ((blocks + n_cu - 1) / n_cu) * nw;
-        if (cost <= best_cost) { best_cost = cost; best = nw; }
+        if (cost <= best_cost) { best_cost = cost; nw_out = nw; }
     }
-    return best;
+    npass_out = 2;
+    // (only where the prologue is a large share of a 96-row workgroup: < 384 KB of weights per workgroup, i.e. Falcon-7B width)
+    if (a.nseg == 1 && a.seg[0].w.bytes / (size_t)(a.seg[0].w.M ? a.seg[0].w.M : 1) * 8 * nw_out < 384 * 1024)
+        while (npass_out < 8 && (a.seg[0].w.M + 4 * npass_out * nw_out - 1) / (4 * npass_out * nw_out) > n_cu) npass_out += 2;
 }
 
 void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
-    const int nw = fq_gemv_ln_waves(a, n_cu);
+    int nw = 4, npass = 2;
+    gemv_ln_shape(a, n_cu, nw, npass);
+    a.npass = npass;
+    const int rows = 4 * npass * nw;
     int blocks = 0;
-    for (int s = 0; s < a.nseg; ++s) { a.seg[s].block_begin = blocks; blocks += (int)((a.seg[s].w.M + 8 * nw - 1) / (8 * nw)); }
+    for (int s = 0; s < a.nseg; ++s) { a.seg[s].block_begin = blocks; blocks += (int)((a.seg[s].w.M + rows - 1) / rows); }
     const int type = a.seg[0].w.type;
     size_t lds = fq_gemv_ln_lds(type, a.E);
     // a grid that fits the chip gets one workgroup per CU: claim more than half of the 160 KiB LDS so that the dispatcher
