@@ -30,7 +30,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_sync_error""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan""".split()
 
 
 def build(verbose=False):
@@ -88,6 +88,7 @@ def load():
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
+        "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)          # AttributeError here = an include/*.h symbol is not exported
@@ -164,6 +165,23 @@ class Weight:
             self.h = None
 
 
+def ggcc_scan(path):
+    """host-only parse of a GGCC v10 file: (hparams dict, ftype, [(name, ggml type, ne0, ne1, offset, bytes)])"""
+    L = load()
+    hp, ft = HParams(), C.c_int(0)
+    buf = C.create_string_buffer(1 << 20)
+    n = L.falcon_hip_ggcc_scan(os.fsencode(path), C.byref(hp), C.byref(ft), buf, len(buf))
+    if n < 0:
+        raise RuntimeError("not a readable GGCC v10 file: %s" % path)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, t, ne0, ne1, off, sz = line.rsplit(" ", 5)
+        rows.append((name, int(t), int(ne0), int(ne1), int(off), int(sz)))
+    assert len(rows) == n
+    d = dict(n_vocab=hp.n_vocab, n_embd=hp.n_embd, n_head=hp.n_head, n_head_kv=hp.n_head_kv, n_layer=hp.n_layer, n_ff=hp.n_ff, two_norms=bool(hp.two_norms))
+    return d, ft.value, rows
+
+
 def quantize_acts(act_type, x):
     """x: [N, K] f32 -> ggml block bytes [N, K/blck*tsize] produced on the device"""
     L = load()
@@ -219,6 +237,21 @@ class FalconModel:
                 put(p + leaf, F32, lw[k], E, 1)
         self.ctx = L.falcon_hip_context_create(self.m, n_ctx, n_batch, rope_n_ctx)
         self.n_local = (layer_end or hp["n_layer"]) - layer_begin
+
+    @classmethod
+    def from_ggcc(cls, path, n_ctx, n_batch, rope_n_ctx=0, layer_begin=0, layer_end=0):
+        """load a GGCC v10 model file (the reference's format) through falcon_hip_model_load_ggcc"""
+        L = load()
+        self = cls.__new__(cls)
+        self.c_hp = HParams()
+        self.m = L.falcon_hip_model_load_ggcc(os.fsencode(path), layer_begin, layer_end, C.byref(self.c_hp))
+        if not self.m:
+            raise RuntimeError("cannot load %s" % path)
+        self.hp = dict(n_vocab=self.c_hp.n_vocab, n_embd=self.c_hp.n_embd, n_head=self.c_hp.n_head, n_head_kv=self.c_hp.n_head_kv,
+                       n_layer=self.c_hp.n_layer, n_ff=self.c_hp.n_ff, two_norms=bool(self.c_hp.two_norms))
+        self.ctx = L.falcon_hip_context_create(self.m, n_ctx, n_batch, rope_n_ctx)
+        self.n_local = self.c_hp.layer_end - self.c_hp.layer_begin
+        return self
 
     def new_context(self, n_ctx, n_batch=1, rope_n_ctx=0):
         """another context (own KV cache / scratch) over the same device weights: one per concurrent decode stream"""

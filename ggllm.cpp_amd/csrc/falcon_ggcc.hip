@@ -1,0 +1,150 @@
+// falcon_ggcc.hip -- the reference's model file format, GGCC v10 (libfalcon.cpp:770-973: falcon_file_loader::read_magic /
+// read_hparams / read_vocab / read_tensor_metadata), read straight into a device-resident falcon_hip_model.
+//
+//   u32 magic 0x67676363 'ggcc', u32 version 10
+//   u32 n_vocab, n_embd, n_head, n_head_kv, n_layer, n_falcon_type (7 | 40), ftype, n_bpe_merges
+//   n_vocab x { u32 len, bytes, f32 score }                 (skipped: the tokenizer is not on this path)
+//   u32 n_merges, n_merges x { u32 len, bytes, u32 len, bytes }   (skipped)
+//   until EOF: u32 n_dims (1 | 2), u32 name_len, u32 ggml_type, u32 ne[n_dims], name, pad to 32 bytes, data
+// n_ff is not stored: 4 * n_embd (libfalcon.cpp:1598). Two LayerNorms per block <=> Falcon-40B layout: n_layer 60 / 80,
+// else n_falcon_type == 40 (libfalcon.cpp:1578-1592). The file is mmap'ed; tensors outside the requested block range
+// are never touched (a pipeline stage reads only its own blocks). Host-only code except for the uploads it triggers.
+#include <hip/hip_runtime.h>
+#include "../../include/falcon-hip.h"
+#include "fq_types.h"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+struct ggcc_tensor { std::string name; int type; int n_dims; int64_t ne[2]; size_t offset, size; };
+struct ggcc_file {
+    int fd = -1; const uint8_t * base = nullptr; size_t size = 0;
+    falcon_hip_hparams hp{}; int ftype = 0, falcon_type = 0, n_merges = 0;
+    std::vector<ggcc_tensor> tensors;
+    std::string error;
+    ~ggcc_file() { if (base) munmap((void *) base, size); if (fd >= 0) close(fd); }
+};
+
+size_t tensor_bytes(int type, int64_t ne0, int64_t ne1) {
+    if (type == FQ_F32) return (size_t) ne0 * ne1 * 4;
+    if (type == 1 /* GGML_TYPE_F16 */) return (size_t) ne0 * ne1 * 2;
+    const fq_type_desc d = fq_desc(type);
+    if (!d.blck || ne0 % d.blck) return 0;
+    return (size_t)(ne0 / d.blck) * d.tsize * (size_t) ne1;
+}
+
+bool ggcc_open(const char * path, ggcc_file & f) {
+    f.fd = open(path, O_RDONLY);
+    if (f.fd < 0) { f.error = std::string("cannot open ") + path; return false; }
+    struct stat st;
+    if (fstat(f.fd, &st) != 0 || st.st_size < 40) { f.error = "file too small"; return false; }
+    f.size = (size_t) st.st_size;
+    void * p = mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
+    if (p == MAP_FAILED) { f.error = "mmap failed"; return false; }
+    f.base = (const uint8_t *) p;
+    size_t pos = 0;
+    auto u32 = [&](uint32_t & v) { if (pos + 4 > f.size) return false; memcpy(&v, f.base + pos, 4); pos += 4; return true; };
+    auto skip = [&](size_t n) { if (pos + n > f.size) return false; pos += n; return true; };
+    uint32_t magic = 0, version = 0;
+    if (!u32(magic) || !u32(version)) { f.error = "truncated header"; return false; }
+    if (magic != 0x67676363u || version != 10u) {
+        char b[128]; snprintf(b, sizeof b, "not a GGCC v10 file (magic %08x, version %u): re-convert with falcon_quantize", magic, version);
+        f.error = b; return false;
+    }
+    uint32_t h[8];
+    for (uint32_t & v : h) if (!u32(v)) { f.error = "truncated hparams"; return false; }
+    f.hp.n_vocab = (int32_t) h[0]; f.hp.n_embd = (int32_t) h[1]; f.hp.n_head = (int32_t) h[2]; f.hp.n_head_kv = (int32_t) h[3];
+    f.hp.n_layer = (int32_t) h[4]; f.falcon_type = (int) h[5]; f.ftype = (int) h[6];
+    f.hp.n_ff = 4 * f.hp.n_embd;
+    f.hp.two_norms = (f.hp.n_layer == 60 || f.hp.n_layer == 80) ? 1 : (f.hp.n_layer == 32 ? 0 : (f.falcon_type == 40 ? 1 : 0));
+    f.hp.layer_begin = 0; f.hp.layer_end = f.hp.n_layer;
+    if (f.hp.n_embd <= 0 || f.hp.n_head <= 0 || f.hp.n_embd != 64 * f.hp.n_head || f.hp.n_head_kv <= 0 || f.hp.n_head % f.hp.n_head_kv) {
+        f.error = "implausible hparams (head_dim must be 64)"; return false;
+    }
+    for (int i = 0; i < f.hp.n_vocab; ++i) {                     // vocabulary: len, bytes, f32 score
+        uint32_t len = 0;
+        if (!u32(len) || !skip((size_t) len + 4)) { f.error = "truncated vocabulary"; return false; }
+    }
+    uint32_t nm = 0;
+    if (!u32(nm)) { f.error = "truncated merges"; return false; }
+    f.n_merges = (int) nm;
+    for (uint32_t i = 0; i < nm; ++i) {
+        uint32_t l1 = 0, l2 = 0;
+        if (!u32(l1) || !skip(l1) || !u32(l2) || !skip(l2)) { f.error = "truncated merges"; return false; }
+    }
+    while (pos < f.size) {
+        uint32_t n_dims = 0, name_len = 0, type = 0, ne[2] = {1, 1};
+        if (!u32(n_dims) || !u32(name_len) || !u32(type)) { f.error = "truncated tensor record"; return false; }
+        if (n_dims < 1 || n_dims > 2) { f.error = "tensor with " + std::to_string(n_dims) + " dimensions"; return false; }
+        for (uint32_t d = 0; d < n_dims; ++d) if (!u32(ne[d])) { f.error = "truncated tensor record"; return false; }
+        if (pos + name_len > f.size) { f.error = "truncated tensor name"; return false; }
+        ggcc_tensor t;
+        t.name.assign((const char *) f.base + pos, name_len); pos += name_len;
+        pos += (size_t)(-(int64_t) pos & 31);                    // data starts at the next multiple of 32 (libfalcon.cpp:949-952)
+        t.type = (int) type; t.n_dims = (int) n_dims; t.ne[0] = ne[0]; t.ne[1] = ne[1];
+        t.size = tensor_bytes(t.type, t.ne[0], t.ne[1]);
+        if (!t.size) { f.error = "tensor " + t.name + ": unsupported type " + std::to_string(type) + " / row length"; return false; }
+        t.offset = pos;
+        if (pos + t.size > f.size) { f.error = "tensor " + t.name + " runs past the end of the file"; return false; }
+        pos += t.size;
+        f.tensors.push_back(std::move(t));
+    }
+    return true;
+}
+}   // namespace
+
+// Host-only: header + tensor directory (no device needed). Returns the number of tensors, or -1 (message on stderr).
+// If dir_out != NULL, up to dir_cap bytes of a text directory are written: one line per tensor "name type ne0 ne1 offset size".
+extern "C" int falcon_hip_ggcc_scan(const char * path, falcon_hip_hparams * hp_out, int * ftype_out, char * dir_out, size_t dir_cap) {
+    ggcc_file f;
+    if (!ggcc_open(path, f)) { fprintf(stderr, "falcon-hip: %s: %s\n", path, f.error.c_str()); return -1; }
+    if (hp_out) *hp_out = f.hp;
+    if (ftype_out) *ftype_out = f.ftype;
+    if (dir_out && dir_cap) {
+        std::string s;
+        for (const ggcc_tensor & t : f.tensors) {
+            char b[512];
+            snprintf(b, sizeof b, "%s %d %lld %lld %zu %zu\n", t.name.c_str(), t.type, (long long) t.ne[0], (long long) t.ne[1], t.offset, t.size);
+            s += b;
+        }
+        snprintf(dir_out, dir_cap, "%s", s.c_str());
+    }
+    return (int) f.tensors.size();
+}
+
+// Loads blocks [layer_begin, layer_end) (layer_end <= 0: all) of a GGCC v10 file into a new device-resident model.
+// hp_out (optional) receives the hyper-parameters. NULL on error (message on stderr).
+extern "C" falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int layer_begin, int layer_end, falcon_hip_hparams * hp_out) {
+    ggcc_file f;
+    if (!ggcc_open(path, f)) { fprintf(stderr, "falcon-hip: %s: %s\n", path, f.error.c_str()); return nullptr; }
+    falcon_hip_hparams hp = f.hp;
+    hp.layer_begin = layer_begin > 0 ? layer_begin : 0;
+    hp.layer_end = (layer_end > 0 && layer_end <= hp.n_layer) ? layer_end : hp.n_layer;
+    if (hp.layer_begin >= hp.layer_end) { fprintf(stderr, "falcon-hip: %s: empty block range [%d, %d)\n", path, hp.layer_begin, hp.layer_end); return nullptr; }
+    falcon_hip_model * m = falcon_hip_model_create(&hp);
+    int used = 0;
+    for (const ggcc_tensor & t : f.tensors) {
+        if (t.type == 1) {                                       // f16 tensors (unquantized output / embedding matrices) are not on this path
+            const bool mine = (t.name == "lm_head.weight" && hp.layer_end == hp.n_layer) || (t.name == "transformer.word_embeddings.weight" && hp.layer_begin == 0);
+            if (mine) { fprintf(stderr, "falcon-hip: %s: %s is f16; quantize it (falcon_quantize quantizes the output tensor by default)\n", path, t.name.c_str()); falcon_hip_model_free(m); return nullptr; }
+            continue;
+        }
+        if (falcon_hip_model_set_tensor(m, t.name.c_str(), t.type, f.base + t.offset, t.ne[0], t.n_dims > 1 ? t.ne[1] : 1) == 0) ++used;
+    }
+    const int per_block = hp.two_norms ? 8 : 6;
+    const int want = per_block * (hp.layer_end - hp.layer_begin) + (hp.layer_begin == 0 ? 1 : 0) + (hp.layer_end == hp.n_layer ? 3 : 0);
+    if (used != want) {
+        fprintf(stderr, "falcon-hip: %s: %d of the %d tensors of blocks [%d, %d) found\n", path, used, want, hp.layer_begin, hp.layer_end);
+        falcon_hip_model_free(m);
+        return nullptr;
+    }
+    if (hp_out) *hp_out = hp;
+    return m;
+}

@@ -353,7 +353,8 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     int cfg = tiles >= 8 * (int64_t) n_cu ? 0 : 2;
     if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>
 #define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
-                           else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); break;
+                           else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
+                           else if (cfg == 4) launch_gemm_t<T, 4, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 2, 2>(w, act, N, dst, ldd, ep, st); break;
     switch (w.type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K)
         default: fprintf(stderr, "ggml-hip: gemm: unsupported weight type %d\n", w.type); exit(1);

@@ -43,6 +43,15 @@ void               falcon_hip_model_free(falcon_hip_model * m);
 int  falcon_hip_model_set_tensor(falcon_hip_model * m, const char * name, int type, const void * data, int64_t ne0, int64_t ne1);
 size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m);   /* quantized bytes read per decoded token */
 
+/* The reference's model file format, GGCC v10 (what falcon_quantize writes and falcon_main loads; libfalcon.cpp:770-973).
+ * falcon_hip_model_load_ggcc maps the file and uploads blocks [layer_begin, layer_end) (layer_end <= 0: all; a pipeline
+ * stage passes its own range) plus the embedding (first stage) and ln_f + lm_head (last stage); the vocabulary and BPE
+ * merges are skipped (the tokenizer is not on this path). Returns NULL on error (message on stderr).
+ * falcon_hip_ggcc_scan is the host-only part (no device needed): header + tensor directory (one text line per tensor:
+ * "name ggml_type ne0 ne1 file_offset bytes"); returns the number of tensors or -1.                                  */
+falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int layer_begin, int layer_end, falcon_hip_hparams * hp_out);
+int  falcon_hip_ggcc_scan(const char * path, falcon_hip_hparams * hp_out, int * ftype_out, char * dir_out, size_t dir_cap);
+
 /* n_ctx: KV capacity; n_batch: largest N of one eval; rope_n_ctx: the n_ctx handed to ggml_rope
  * (n_max_real_ctx or n_ctx, libfalcon.cpp:2229-2230)                                                           */
 falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx);

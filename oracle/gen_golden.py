@@ -34,6 +34,48 @@ def weights_digest(w):
     return h.hexdigest()
 
 
+def gen_ggcc(O):
+    """5. the reference's MODEL path on model FILES: synthetic GGCC v10 files (tests/ggcc_writer.py) loaded and evaluated
+    by the real libfalcon.cpp (falcon_init_from_file -> its loader, graph builder, falcon_eval; scalar build,
+    oracle/_ref/libfalcon_ref.so). The fixture holds the file's sha256 (the writer is deterministic), the tokens and the
+    reference's logits for a 9-token prompt and 3 single-token steps."""
+    import ctypes as C
+    import tempfile
+    import ggcc_writer
+    so = os.path.join(ROOT, "oracle", "_ref", "libfalcon_ref.so")
+    if not os.path.exists(so):
+        print("oracle/_ref/libfalcon_ref.so not built (make -C oracle ref_falcon): ggcc_models.npz not regenerated")
+        return
+    L = C.CDLL(so)
+    L.reff_load.restype = C.c_void_p; L.reff_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.reff_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.reff_free.argtypes = [C.c_void_p]
+    d = {}
+    for name, hp, t in (("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+                        ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)):
+        w = synth.make_model(O, hp, t, seed=4321)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, name + ".ggcc")
+            ggcc_writer.write_ggcc(path, w)
+            d[f"{name}_sha256"] = np.frombuffer(hashlib.sha256(open(path, "rb").read()).digest(), np.uint8)
+            d[f"{name}_bytes"] = np.int64(os.path.getsize(path))
+            ctx = L.reff_load(path.encode(), 64, 16)
+            assert ctx, name
+            toks = synth.tokens(12, hp["n_vocab"], seed=77)
+            d[f"{name}_tokens"] = toks
+            lg = np.zeros((9, hp["n_vocab"]), np.float32)
+            assert L.reff_eval(ctx, toks[:9].ctypes.data, 9, 0, 1, lg.ctypes.data) == 0
+            d[f"{name}_prefill_logits"] = lg
+            dec = []
+            for i in range(9, 12):
+                one = np.zeros((1, hp["n_vocab"]), np.float32)
+                assert L.reff_eval(ctx, toks[i:i + 1].ctypes.data, 1, i, 1, one.ctypes.data) == 0
+                dec.append(one)
+            d[f"{name}_decode_logits"] = np.concatenate(dec)
+            L.reff_free(ctx)
+    np.savez_compressed(os.path.join(OUT, "ggcc_models.npz"), **d)
+
+
 def main():
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
@@ -133,6 +175,7 @@ def main():
             dec = [m.eval(toks[i:i + 1], i, 2) for i in range(8, 12)]
             d[f"{name}_decode_logits_{tag}"] = np.concatenate(dec)
     np.savez_compressed(os.path.join(OUT, "tiny_models.npz"), **d)
+    gen_ggcc(O)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

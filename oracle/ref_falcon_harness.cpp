@@ -1,0 +1,33 @@
+// ref_falcon_harness.cpp -- TEST INFRASTRUCTURE. A few C entry points over the REAL reference's model path
+// (libfalcon.cpp: falcon_init_from_file -> GGCC loader -> falcon_eval -> falcon_get_logits), compiled by oracle/Makefile
+// together with the reference's own sources where they lie under /root/reference into oracle/_ref/libfalcon_ref.so.
+// Used by oracle/gen_golden.py in the build container to capture logits of synthetic GGCC files written by
+// tests/ggcc_writer.py (which pins the writer, our loader and our graph restatement against the reference itself).
+#include "libfalcon.h"
+#include <cstring>
+#include <cstdio>
+
+extern "C" {
+
+void * reff_load(const char * path, int n_ctx, int n_batch) {
+    static bool once = false;
+    if (!once) { falcon_init_backend(); once = true; }
+    falcon_context_params p = falcon_context_default_params();
+    p.n_ctx = n_ctx; p.n_batch = n_batch; p.n_gpu_layers = 0; p.logits_all = true; p.f16_kv = false; p.use_mmap = true; p.seed = 1;
+    return (void *) falcon_init_from_file(path, p);
+}
+
+// logits_out: n * n_vocab floats (logits_all). Returns 0 on success.
+int reff_eval(void * ctx, const int * tokens, int n, int n_past, int n_threads, float * logits_out) {
+    falcon_evaluation_config cfg;
+    cfg.n_tokens = n; cfg.n_past = n_past; cfg.n_threads = n_threads; cfg.n_max_real_ctx = falcon_n_ctx((falcon_context *) ctx);
+    const int rc = falcon_eval((falcon_context *) ctx, (const falcon_token *) tokens, cfg);
+    if (rc) return rc;
+    std::memcpy(logits_out, falcon_get_logits((falcon_context *) ctx), sizeof(float) * (size_t) n * falcon_n_vocab((falcon_context *) ctx));
+    return 0;
+}
+
+int reff_n_vocab(void * ctx) { return falcon_n_vocab((falcon_context *) ctx); }
+void reff_free(void * ctx) { llama_free((falcon_context *) ctx); }
+
+}

@@ -199,3 +199,38 @@ def test_falcon40b_shaped_layer_vs_oracle(oracle):
     m.free()
     print("40B-shaped block: logits %.2e decode %.2e" % (relrms(lg, lo), relrms(d, do)))
     assert relrms(lg, lo) <= 5e-2 and relrms(d, do) <= 5e-2       # one k-quant block + lm_head, see the note above
+
+
+@pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+                                       ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)])
+def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
+    """falcon_hip_model_load_ggcc on a GGCC v10 file (the reference's model format; the file is byte-identical to the one
+    the real libfalcon.cpp loaded when tests/golden/ggcc_models.npz was captured): same logits as the in-memory upload of
+    the same weights, bit for bit; for the legacy formats the prefill logits (MFMA GEMM, scalar block order) are the
+    REFERENCE's own logits bit for bit; a pipeline stage loads only its own blocks"""
+    import ggcc_writer
+    gg = golden["ggcc_models"]
+    w = synth.make_model(oracle, hp, t, seed=4321)
+    path = str(tmp_path / (name + ".ggcc"))
+    ggcc_writer.write_ggcc(path, w)
+    toks = gg[f"{name}_tokens"]
+    a = g.FalconModel.from_ggcc(path, n_ctx=64, n_batch=16)
+    b = g.FalconModel(w, n_ctx=64, n_batch=16)
+    assert a.hp["n_embd"] == hp["n_embd"] and a.hp["two_norms"] == bool(hp.get("two_norms"))
+    la, lb = a.eval(toks[:9], 0), b.eval(toks[:9], 0)
+    assert np.array_equal(la, lb)
+    da = np.concatenate([a.eval(toks[i:i + 1], i) for i in range(9, 12)])
+    db = np.concatenate([b.eval(toks[i:i + 1], i) for i in range(9, 12)])
+    assert np.array_equal(da, db)
+    ref_pre, ref_dec = gg[f"{name}_prefill_logits"], gg[f"{name}_decode_logits"]
+    if t in ob.LEGACY:
+        assert np.array_equal(la, ref_pre)
+        assert relrms(da, ref_dec) <= max(1e-3, 2 * 2.8e-2)          # decode: wave-order association, see DESIGN.md section 2
+    else:
+        assert relrms(la, ref_pre) <= 5e-2 and relrms(da, ref_dec) <= 5e-2
+    assert a.weight_bytes() == b.weight_bytes()
+    a.free(); b.free()
+    # second pipeline stage: block 1 only (+ ln_f, lm_head)
+    s1 = g.FalconModel.from_ggcc(path, n_ctx=64, n_batch=16, layer_begin=1, layer_end=hp["n_layer"])
+    assert s1.n_local == hp["n_layer"] - 1
+    s1.free()
