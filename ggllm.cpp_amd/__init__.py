@@ -30,7 +30,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_perplexity""".split()
 
 
 def build(verbose=False):
@@ -89,6 +89,7 @@ def load():
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
+        "falcon_hip_perplexity": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)          # AttributeError here = an include/*.h symbol is not exported
@@ -279,6 +280,13 @@ class FalconModel:
         out = np.zeros(n_steps, np.int32)
         L.falcon_hip_decode_greedy(self.ctx, int(first_token), n_past, n_steps, out.ctypes.data)
         return out
+
+    def perplexity(self, tokens, n_ctx, n_batch):
+        """(summed NLL, scored tokens) of the reference's perplexity loop over a token stream"""
+        tok = np.ascontiguousarray(tokens, np.int32)
+        nll = C.c_double(0.0)
+        n = load().falcon_hip_perplexity(self.ctx, tok.ctypes.data, tok.size, n_ctx, n_batch, C.byref(nll))
+        return nll.value, n
 
     def set_fused(self, mode):
         """0 = op list, 1 = three launches per block, 2 (True) = two launches per block (default)"""

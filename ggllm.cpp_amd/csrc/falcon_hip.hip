@@ -14,6 +14,8 @@
 #include "kernels.h"
 #include "hip_context.h"
 #include "../../include/falcon-hip.h"
+#include <cmath>
+#include <cstring>
 
 #include <string>
 #include <string.h>
@@ -421,6 +423,44 @@ extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, i
 }
 
 extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) { return c->logits_host.data(); }
+
+// ------------------------------------------------------------------------------------------------ perplexity
+// The reference's perplexity loop (examples/falcon_perplexity/falcon_perplexity.cpp:28-124), same chunking and the same
+// host arithmetic: the token stream is cut into chunks of n_ctx tokens, each chunk is evaluated from an empty context in
+// batches of n_batch (logits of every position), and the negative log-likelihood of token j+1 is added for
+// j in [min(512, n_ctx/2), n_ctx-1) with soft_max as in :12-27 (float expf of logit - max, double sum, float division).
+// Returns the number of scored tokens; *nll_out = their summed NLL (perplexity = exp(nll / count)).
+extern "C" int falcon_hip_perplexity(falcon_hip_context * c, const int32_t * tokens, int64_t n_tokens, int n_ctx, int n_batch, double * nll_out) {
+    if (n_ctx < 2 || n_ctx > c->n_ctx || n_batch < 1 || n_batch > c->n_batch) {
+        fprintf(stderr, "falcon-hip: perplexity: n_ctx %d / n_batch %d exceed the context's (%d / %d)\n", n_ctx, n_batch, c->n_ctx, c->n_batch); exit(1);
+    }
+    const int64_t n_chunk = n_tokens / n_ctx;
+    const int V = c->m->hp.n_vocab;
+    double nll = 0.0; int count = 0;
+    std::vector<float> logits((size_t) n_ctx * V), probs((size_t) V);
+    for (int64_t i = 0; i < n_chunk; ++i) {
+        const int64_t start = i * n_ctx, end = start + n_ctx;
+        const int num_batches = (n_ctx + n_batch - 1) / n_batch;
+        for (int j = 0; j < num_batches; ++j) {
+            const int64_t batch_start = start + (int64_t) j * n_batch;
+            const int batch_size = (int)(end - batch_start < n_batch ? end - batch_start : n_batch);
+            if (falcon_hip_eval(c, tokens + batch_start, batch_size, j * n_batch, 1)) return -1;
+            memcpy(logits.data() + (size_t) j * n_batch * V, falcon_hip_get_logits(c), (size_t) batch_size * V * sizeof(float));
+        }
+        for (int j = (512 < n_ctx / 2 ? 512 : n_ctx / 2); j < n_ctx - 1; ++j) {
+            const float * l = logits.data() + (size_t) j * V;
+            float max_logit = l[0];
+            for (int v = 0; v < V; ++v) max_logit = l[v] > max_logit ? l[v] : max_logit;
+            double sum_exp = 0.0;
+            for (int v = 0; v < V; ++v) { const float e = expf(l[v] - max_logit); sum_exp += e; probs[v] = e; }
+            const float prob = (float)(probs[tokens[start + j + 1]] / sum_exp);
+            nll += -std::log(prob);
+            ++count;
+        }
+    }
+    if (nll_out) *nll_out = nll;
+    return count;
+}
 
 // ------------------------------------------------------------------------------------------------ greedy decode
 // argmax with first-maximum tie-break (std::max_element in llama_sample_token_greedy, libfalcon.cpp:3440-3450);

@@ -74,6 +74,10 @@ int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * token_dev, con
 int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens);
 
 const float * falcon_hip_get_logits(falcon_hip_context * c);        /* host, n_vocab (or n_tokens*n_vocab) floats */
+/* The reference's perplexity loop (falcon_perplexity.cpp:28-124) over a token stream: chunks of n_ctx tokens evaluated
+ * from an empty context in batches of n_batch, NLL of the second half of every chunk (host soft_max as in :12-27).
+ * Returns the number of scored tokens and their summed NLL (perplexity = exp(nll / count)).                            */
+int   falcon_hip_perplexity(falcon_hip_context * c, const int32_t * tokens, int64_t n_tokens, int n_ctx, int n_batch, double * nll_out);
 /* test hook: residual stream entering each local layer (+ leaving the last), device->host, after an eval with
  * falcon_hip_context_keep_hidden(c, 1): (n_local_layers + 1) * n_tokens * n_embd floats                          */
 void  falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep);

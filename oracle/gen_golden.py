@@ -50,6 +50,7 @@ def gen_ggcc(O):
     L.reff_load.restype = C.c_void_p; L.reff_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.reff_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.reff_free.argtypes = [C.c_void_p]
+    L.reff_token_nll.restype = C.c_double; L.reff_token_nll.argtypes = [C.c_void_p, C.c_int, C.c_int]
     d = {}
     for name, hp, t in (("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
                         ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)):
@@ -72,6 +73,26 @@ def gen_ggcc(O):
                 assert L.reff_eval(ctx, toks[i:i + 1].ctypes.data, 1, i, 1, one.ctypes.data) == 0
                 dec.append(one)
             d[f"{name}_decode_logits"] = np.concatenate(dec)
+            if name in ("mqa_q4_0", "gqa_q5_1"):
+                # the perplexity loop (falcon_perplexity.cpp:28-124) driven by hand over the reference's falcon_eval:
+                # 3 chunks of n_ctx 32 in batches of 8, NLL of positions 16..30 of every chunk
+                n_ctx, n_batch = 32, 8
+                stream = synth.tokens(3 * n_ctx + 5, hp["n_vocab"], seed=99)
+                nll, count = 0.0, 0
+                for i in range(len(stream) // n_ctx):
+                    start = i * n_ctx
+                    lgs = np.zeros((n_ctx, hp["n_vocab"]), np.float32)
+                    for j in range(n_ctx // n_batch):
+                        b0 = start + j * n_batch
+                        part = np.zeros((n_batch, hp["n_vocab"]), np.float32)
+                        assert L.reff_eval(ctx, stream[b0:b0 + n_batch].ctypes.data, n_batch, j * n_batch, 1, part.ctypes.data) == 0
+                        lgs[j * n_batch:(j + 1) * n_batch] = part
+                    for j in range(min(512, n_ctx // 2), n_ctx - 1):
+                        nll += L.reff_token_nll(lgs[j].ctypes.data, hp["n_vocab"], int(stream[start + j + 1]))
+                        count += 1
+                d[f"{name}_ppl_tokens"] = stream
+                d[f"{name}_ppl_nll"] = np.float64(nll)
+                d[f"{name}_ppl_count"] = np.int64(count)
             L.reff_free(ctx)
     np.savez_compressed(os.path.join(OUT, "ggcc_models.npz"), **d)
 

@@ -4,8 +4,11 @@
 // Used by oracle/gen_golden.py in the build container to capture logits of synthetic GGCC files written by
 // tests/ggcc_writer.py (which pins the writer, our loader and our graph restatement against the reference itself).
 #include "libfalcon.h"
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <cstdio>
+#include <vector>
 
 extern "C" {
 
@@ -25,6 +28,19 @@ int reff_eval(void * ctx, const int * tokens, int n, int n_past, int n_threads, 
     if (rc) return rc;
     std::memcpy(logits_out, falcon_get_logits((falcon_context *) ctx), sizeof(float) * (size_t) n * falcon_n_vocab((falcon_context *) ctx));
     return 0;
+}
+
+// NLL of `target` under the logits of one position, as the reference's perplexity example computes it
+// (examples/falcon_perplexity/falcon_perplexity.cpp:12-27 soft_max + :115-117), with this build's libm
+double reff_token_nll(const float * logits, int n_vocab, int target) {
+    float max_logit = logits[0];
+    for (int i = 0; i < n_vocab; ++i) max_logit = std::max(max_logit, logits[i]);
+    double sum_exp = 0.0;
+    std::vector<float> probs((size_t) n_vocab);
+    for (int i = 0; i < n_vocab; ++i) { const float e = expf(logits[i] - max_logit); sum_exp += e; probs[i] = e; }
+    for (int i = 0; i < n_vocab; ++i) probs[i] /= sum_exp;
+    const float prob = probs[target];
+    return (double) -std::log(prob);
 }
 
 int reff_n_vocab(void * ctx) { return falcon_n_vocab((falcon_context *) ctx); }

@@ -234,3 +234,17 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     s1 = g.FalconModel.from_ggcc(path, n_ctx=64, n_batch=16, layer_begin=1, layer_end=hp["n_layer"])
     assert s1.n_local == hp["n_layer"] - 1
     s1.free()
+
+
+@pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1)])
+def test_perplexity_loop(oracle, golden, name, hp, t):
+    """falcon_hip_perplexity = the reference's perplexity loop (falcon_perplexity.cpp:28-124): chunks of n_ctx 32 in batches
+    of 8, NLL of the second half of every chunk. The fixture was produced by driving the same loop over the REAL reference's
+    falcon_eval (oracle/gen_golden.py); the prefill logits are bit-identical to the reference's, so the NLL is too (same libm)"""
+    gg = golden["ggcc_models"]
+    w = synth.make_model(oracle, hp, t, seed=4321)
+    m = g.FalconModel(w, n_ctx=64, n_batch=16)
+    nll, count = m.perplexity(gg[f"{name}_ppl_tokens"], n_ctx=32, n_batch=8)
+    m.free()
+    assert count == int(gg[f"{name}_ppl_count"]) == 45
+    assert abs(nll - float(gg[f"{name}_ppl_nll"])) <= 1e-9 * abs(nll)
