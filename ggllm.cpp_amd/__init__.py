@@ -289,7 +289,7 @@ class FalconModel:
         return nll.value, n
 
     def set_fused(self, mode):
-        """0 = op list, 1 = three launches per block, 2 (True) = two launches per block (default)"""
+        """0 = op list, 1 = three launches per block, 2 (True) = two (default), 3 = one launch per block"""
         load().falcon_hip_context_set_fused(self.ctx, 2 if mode is True else int(mode))
 
     def sync_error(self):

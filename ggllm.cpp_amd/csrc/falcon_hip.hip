@@ -63,6 +63,13 @@ struct falcon_hip_context {
     std::vector<hipEvent_t> ev_fork, ev_join;  // one pair per local layer
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
     bool merged_attn_out = true;               // ... with attention and the output mat-vec in one launch (k_attn_out) when the grid fits the chip
+    // ... and the next block's k_gemv_ln as a second phase of that launch (k_attn_out_ln): one launch per block. Measured on
+    // MI355X (Falcon-7B Q4_0): 867 tok/s against 934 with two launches -- the second phase starts 4.3 us after the last
+    // residual value is published (every workgroup sweeps the 36 KB row out of the hand-off buffer, the early finishers
+    // keep polling it) and the launch boundary it removes costs less than that. OFF by default; set_fused(3) /
+    // FALCON_HIP_TWO_PHASE=1 turn it on.
+    bool two_phase = false;
+    unsigned long long * x_gran = nullptr;     // hand-off granules of the residual row between the two phases
     unsigned * sync_words = nullptr;           // [0] hand-off epoch of k_attn_out, [1] its time-out flag, [16..80) rope row of the position
     unsigned long long * att_gran = nullptr;   // hand-off granules of k_attn_out: one per 32-bit word of the attention image / row
     hipGraphExec_t decode_graph = nullptr;
@@ -226,6 +233,9 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     HIP_CHECK(hipMemset(c->sync_words, 0, 64 + 256));
     c->att_gran       = (unsigned long long *) dev_alloc(c->allocs, (size_t) hp.n_embd * 8 + 64);
     HIP_CHECK(hipMemset(c->att_gran, 0, (size_t) hp.n_embd * 8 + 64));
+    c->x_gran         = (unsigned long long *) dev_alloc(c->allocs, (size_t) hp.n_embd * 8 + 64);
+    HIP_CHECK(hipMemset(c->x_gran, 0, (size_t) hp.n_embd * 8 + 64));
+    if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     return c;
 }
@@ -256,10 +266,11 @@ extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1
     HIP_CHECK(hipMemcpy(w, c->sync_words, sizeof w, hipMemcpyDeviceToHost));
     return (int) w[1];
 }
-extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default)
+extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
+    c->two_phase = mode >= 3;
 }
 
 static bool stage_uniform(const falcon_hip_model * m) {
@@ -284,10 +295,14 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
     const bool fused = c->fused_decode && stage_uniform(m);
     if (N == 1 && fused) {
-        // ---- fused single-token path: 3 launches per block (kernels_decode.hip), bit-identical to the list below
-        for (size_t li = 0; li < m->layers.size(); ++li) {
+        // ---- fused single-token path (kernels_decode.hip), bit-identical to the op list below. Per block, by mode:
+        //   3 launches  k_gemv_ln | k_attn_decode | k_gemv_out
+        //   2 launches  k_gemv_ln | k_attn_out                        (attention inside the output mat-vec launch)
+        //   1 launch    k_attn_out_ln = k_attn_out of block l + k_gemv_ln of block l+1 (or ln_f + lm_head) as a second phase
+        const bool prof = fq_prof_active();
+        const bool dual = c->dual_stream && !prof;
+        auto ln_args = [&](size_t li) {
             const layer_weights & L = m->layers[li];
-            if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
             const int ff_act = fq_desc(L.down.type).act_type;
             const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
             fq_gemv_ln_args ga{};
@@ -296,8 +311,24 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (c->merged_attn_out) { ga.n_past_ptr = c->n_past_dev; ga.rope_cs = c->rope_cs; ga.rope_cur = (float *)(c->sync_words + 16); }
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
             ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, 0 };
-            const bool prof = fq_prof_active();
-            const bool dual = c->dual_stream && !prof;
+            return ga;
+        };
+        auto head_args = [&]() {
+            fq_gemv_ln_args ga{};
+            ga.x = c->x; ga.E = E; ga.nseg = 1; ga.gelu_table = hc.gelu_table;
+            ga.epoch_word = c->merged_attn_out ? c->sync_words : nullptr;
+            ga.seg[0] = { m->lm_head, m->out_norm_w, m->out_norm_b, FQ_LNEPI_STORE, c->logits_dev, nullptr, 0, 0 };
+            ga.argmax_val = c->argmax_val; ga.argmax_idx = c->argmax_idx;
+            return ga;
+        };
+        bool ln_done = false;                                   // this block's k_gemv_ln already ran as the previous launch's second phase
+        bool head_done = false;
+        for (size_t li = 0; li < m->layers.size(); ++li) {
+            const layer_weights & L = m->layers[li];
+            if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
+            const int ff_act = fq_desc(L.down.type).act_type;
+            const bool quant_epi = (ff_act == FQ_Q8_0 || ff_act == FQ_Q8_1);
+            const fq_gemv_ln_args ga = ln_args(li);
             if (dual) {
                 // the MLP-up mat-vec only needs x: run it on the side stream while QKV + attention run on the main one
                 fq_gemv_ln_args gu = ga; gu.nseg = 1; gu.seg[0] = ga.seg[1]; gu.seg[0].block_begin = 0;
@@ -308,12 +339,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), c->side);
                 HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
                 fq_launch_gemv_ln(gq, hc.n_cu, st);
-            } else {
+            } else if (!ln_done) {
                 if (prof) fq_prof_open(st);
                 fq_launch_gemv_ln(ga, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
             }
+            ln_done = false;
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             const int att_act = fq_desc(L.wo.type).act_type;
@@ -323,9 +355,30 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
             bool merged = false;
             if (c->merged_attn_out && !dual) {
+                // second phase: the next block's k_gemv_ln (its GELU output must be quantized in its epilogue: a separate
+                // quantizer launch cannot sit between the phases), or ln_f + lm_head after the last block
+                fq_gemv_ln_args next{}; bool have_next = false; double next_bytes = 0.0;
+                if (c->two_phase && !c->keep_hidden) {
+                    if (li + 1 < m->layers.size()) {
+                        const layer_weights & Ln = m->layers[li + 1];
+                        const int a2 = fq_desc(Ln.down.type).act_type;
+                        if (a2 == FQ_Q8_0 || a2 == FQ_Q8_1) { next = ln_args(li + 1); have_next = true; next_bytes = (double)(Ln.qkv.bytes + Ln.up.bytes); }
+                    } else if (m->last_stage()) { next = head_args(); have_next = true; next_bytes = (double) m->lm_head.bytes; }
+                }
                 if (prof) fq_prof_open(st);
-                merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
-                                            kc, vc, hc.exp_table_attn, att_act, c->att_gran, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                if (have_next) {
+                    merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
+                                                kc, vc, hc.exp_table_attn, att_act, c->att_gran, c->sync_words, c->sync_words + 1, hc.n_cu, st, &next, c->x_gran);
+                    if (merged) {
+                        if (li + 1 < m->layers.size()) ln_done = true; else head_done = true;
+                        if (prof) { fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes) + next_bytes); }
+                    }
+                }
+                if (!merged) {
+                    merged = fq_launch_attn_out(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
+                                                kc, vc, hc.exp_table_attn, att_act, c->att_gran, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                    if (merged && prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
+                }
                 if (!merged && prof) fq_prof_cancel();
             }
             if (!merged) {
@@ -333,19 +386,15 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                                       att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
                 if (prof) fq_prof_open(st);
                 fq_launch_gemv_out(go, hc.n_cu, st);
+                if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
             }
-            if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
         }
         if (c->keep_hidden) {
             HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) E, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
             c->hidden_tokens = 1;
         }
-        if (m->last_stage()) {
-            fq_gemv_ln_args ga{};
-            ga.x = c->x; ga.E = E; ga.nseg = 1; ga.gelu_table = hc.gelu_table;
-            ga.seg[0] = { m->lm_head, m->out_norm_w, m->out_norm_b, FQ_LNEPI_STORE, c->logits_dev, nullptr, 0, 0 };
-            ga.argmax_val = c->argmax_val; ga.argmax_idx = c->argmax_idx;
-            const bool prof = fq_prof_active();
+        if (m->last_stage() && !head_done) {
+            const fq_gemv_ln_args ga = head_args();
             if (prof) fq_prof_open(st);
             fq_launch_gemv_ln(ga, hc.n_cu, st);
             if (prof) fq_prof_close(st, (double) m->lm_head.bytes);

@@ -20,6 +20,10 @@
 
 #define FQ_ATTN_STAMP(dbg, slot) do { if ((dbg) && threadIdx.x == 0) (dbg)[(size_t) blockIdx.x * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
+// workgroup barriers attn_head_block executes (scores+maxima, sums, probabilities, V.P partials): waves of the workgroup that
+// do NOT take part in an attention group must execute as many (k_attn_out_ln), see attn_decode_group_idle
+#define FQ_ATTN_HEAD_BARRIERS 4
+
 struct attn_lds {
     float  * redf;     // >= 16 floats
     double * red;      // 16 x 64 doubles

@@ -174,6 +174,42 @@ __device__ __forceinline__ void ln_regs_issue(const float * __restrict__ x, cons
         wr.t[k] = ((const float4 *) w)[j]; br.t[k] = ((const float4 *) b)[j];
     }
 }
+// the same row fetched from a hand-off buffer instead: one 8-byte {epoch tag, f32 bits} granule per element, written by
+// other workgroups of the SAME launch with agent-scope stores; every wave re-reads its granules until all carry `epoch`
+// (bounded; *err is set if it gives up). w and b are plain loads and can be requested before this.
+template <int NLN>
+__device__ __forceinline__ void ln_regs_issue_wb(const float * __restrict__ w, const float * __restrict__ b, int64_t n, int nt,
+                                                 ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t i = (int64_t) k * nt + tid, j = i < nv ? i : nv - 1;
+        wr.t[k] = ((const float4 *) w)[j]; br.t[k] = ((const float4 *) b)[j];
+    }
+}
+template <int NLN>
+__device__ __forceinline__ void ln_regs_sweep_x(const unsigned long long * gran, unsigned epoch, int64_t n, int nt, ln_row_regs<NLN> & xr, unsigned * err) {
+    const int tid = threadIdx.x;
+    const int64_t nv = n >> 2;
+#pragma unroll
+    for (int k = 0; k < NLN; ++k) {
+        const int64_t i = (int64_t) k * nt + tid, j = i < nv ? i : nv - 1;
+        const unsigned long long * g = gran + 4 * j;
+        unsigned v0, v1, v2, v3;
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned long long a0 = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long a2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v0 = (unsigned) a0; v1 = (unsigned) a1; v2 = (unsigned) a2; v3 = (unsigned) a3;
+            const bool ok = (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch && (unsigned)(a2 >> 32) == epoch && (unsigned)(a3 >> 32) == epoch;
+            if (__all(ok)) break;
+            if (spins > (1u << 20)) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        xr.t[k] = make_float4(__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1), __builtin_bit_cast(float, v2), __builtin_bit_cast(float, v3));
+    }
+}
+
 template <int NLN>
 __device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
     const int tid = threadIdx.x;

@@ -60,6 +60,7 @@ struct fq_gemv_ln_args {
     const float * x; int64_t E; int nseg; fq_gemv_ln_seg seg[2]; const uint16_t * gelu_table; long long * dbg;
     float * argmax_val; int * argmax_idx;      // optional (lm_head): per-workgroup best logit and its row, for greedy sampling
     int npass;                                 // 4-row passes per wave (set by the launcher)
+    int n_blocks;                              // workgroups of this launch (set by the launcher)
     unsigned * epoch_word;                     // optional: the hand-off tag of the k_attn_out that follows; this launch increments it (never 0)
     // optional: copy the rope table's row of the current position (cos/sin pairs, 64 floats) to rope_cur, so that the
     // attention that follows does not have to wait for n_past before it can ask for them
@@ -79,10 +80,13 @@ void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st);       // 
 void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
 // attention + output mat-vec in one launch (k_attn_out); returns false (nothing launched) when the grid would not be
 // resident at once -- the caller then uses fq_launch_attn_decode + fq_launch_gemv_out. gran: >= n_embd granules (8 bytes
-// each), zero-filled once; epoch_word: incremented by the k_gemv_ln launch before it.
+// each), zero-filled once; epoch_word: incremented by the k_gemv_ln launch (or phase) before it. With ln != nullptr the launch
+// is k_attn_out_ln: *ln (the next block's k_gemv_ln, or ln_f + lm_head) runs as a second phase of the same launch and takes
+// the residual row from xgran (>= n_embd granules, zero-filled once) instead of memory.
 bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
                           const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
-                          int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st);
+                          int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st,
+                          const fq_gemv_ln_args * ln = nullptr, unsigned long long * xgran = nullptr);
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
                              int att_act_type, hipStream_t st);

@@ -99,16 +99,18 @@ __device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_typ
 // one workgroup = NW waves = RW*NW consecutive rows of one segment (NW = blockDim/64 and RW = 4 * a.npass rows per wave,
 // chosen by the launcher so that the grid is about one workgroup per CU: the LayerNorm + Q8 prologue is then computed
 // ~n_cu times per launch instead of once per 32 rows); wave w owns rows RW*w .. RW*w + RW - 1 (npass passes of 4)
+// xs.gran != nullptr: the residual row arrives through a hand-off buffer of the same launch (k_attn_out_ln), see fq_block_dev.h
+struct fq_xsrc { const unsigned long long * gran; unsigned epoch; unsigned * err; };
+
 template <int TYPE, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const int bid, uint8_t * smem, const fq_xsrc xs) {
     constexpr int ACT = act_of<TYPE>::value;
     const int64_t E = a.E;
-    const int sidx = (a.nseg > 1 && (int) blockIdx.x >= a.seg[1].block_begin) ? 1 : 0;
+    const int sidx = (a.nseg > 1 && bid >= a.seg[1].block_begin) ? 1 : 0;
     const fq_gemv_ln_seg sg = sidx ? a.seg[1] : a.seg[0];       // whole-struct select: no runtime-indexed kernarg array
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
     const int RW = 4 * a.npass;
-    const int64_t row0 = (int64_t)((int) blockIdx.x - sg.block_begin) * (RW * nw);
+    const int64_t row0 = (int64_t)(bid - sg.block_begin) * (RW * nw);
 
     // LDS: f32 row [E] | image | out rows (<= 384) | reduction scratch
     float   * rowf  = (float *) smem;
@@ -120,8 +122,9 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
     // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
     //    5. pass 1 (its loads overlap other workgroups' dots)
-    if (a.epoch_word && blockIdx.x == 0 && tid == 0) { const unsigned e = *a.epoch_word + 1u; *a.epoch_word = e ? e : 1u; }
-    if (a.rope_cur && blockIdx.x == gridDim.x - 1 && tid < 64) a.rope_cur[tid] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + tid];
+    // the hand-off tag of the launch that follows (in the two-phase kernel: after the row has been read with the current one)
+    if (!xs.gran && a.epoch_word && bid == 0 && tid == 0) { const unsigned e = *a.epoch_word + 1u; *a.epoch_word = e ? e : 1u; }
+    if (a.rope_cur && bid == a.n_blocks - 1 && tid < 64) a.rope_cur[tid] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + tid];
     FQ_STAMP(a.dbg, 0);
     // LayerNorm + Q8 image in registers (NLN float4 of the row per thread) when the row fits, through LDS otherwise
     constexpr int NLN = MAXT > 256 ? 3 : 5;
@@ -130,15 +133,23 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     fq_unit_regs pre0[NPRE][R];
     if (in_regs) {
         ln_row_regs<NLN> xr, wr, br;
-        ln_regs_issue(a.x, sg.ln_w, sg.ln_b, E, blockDim.x, xr, wr, br);
+        if (xs.gran) ln_regs_issue_wb(sg.ln_w, sg.ln_b, E, blockDim.x, wr, br);
+        else         ln_regs_issue(a.x, sg.ln_w, sg.ln_b, E, blockDim.x, xr, wr, br);
         rows_ptrs<TYPE, R>(sg.w, row0 + RW * wid, rows0);
+        if (xs.gran) {
+            // two-phase kernel: the first unit column is requested BEFORE the row exists (it streams while the producers
+            // finish), then the row is swept out of the hand-off buffer
+            rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
+            ln_regs_sweep_x(xs.gran, xs.epoch, E, blockDim.x, xr, xs.err);
+            if (a.epoch_word && bid == 0 && tid == 0) { const unsigned e = xs.epoch + 1u; *a.epoch_word = e ? e : 1u; }
+        }
         ln_regs_stage1(xr, E, blockDim.x, red);                          // waits for the row only
         // only NPRE (12 waves: ONE) unit column per row is requested ahead of the LayerNorm (48 KB per CU): a CU keeps
         // only so many requests in flight, more makes the later waves' loads block at issue, and a wave that cannot
         // issue cannot reach the LN's barriers either (measured: +3 us with 3 columns; requesting the other columns
         // right after the last statistics barrier, ahead of the quantizer, moves the image 1.4 us later and the end of
         // the kernel nowhere)
-        rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
+        if (!xs.gran) rows_issue<TYPE, R, NPRE>(rows0, units, pre0);
         FQ_STAMP(a.dbg, 1);
         __syncthreads();
         ln_regs_stage2(xr, E, blockDim.x, red);
@@ -230,6 +241,12 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     FQ_STAMP(a.dbg, 7);
 }
 
+template <int TYPE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    gemv_ln_body<TYPE, MAXT>(a, (int) blockIdx.x, smem, fq_xsrc{ nullptr, 0u, nullptr });
+}
+
 size_t fq_gemv_ln_lds(int type, int64_t E) {
     const int act = fq_desc(type).act_type;
     return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 384 * 4 + 32 * 8;
@@ -264,6 +281,7 @@ void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
     const int rows = 4 * npass * nw;
     int blocks = 0;
     for (int s = 0; s < a.nseg; ++s) { a.seg[s].block_begin = blocks; blocks += (int)((a.seg[s].w.M + rows - 1) / rows); }
+    a.n_blocks = blocks;
     const int type = a.seg[0].w.type;
     size_t lds = fq_gemv_ln_lds(type, a.E);
     // a grid that fits the chip gets one workgroup per CU: claim more than half of the 160 KiB LDS so that the dispatcher
@@ -478,6 +496,12 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
     }
 }
 
+// the barriers of attn_decode_group (1 after the rope + attn_head_block's), for waves of the same workgroup that sit a group out
+__device__ __forceinline__ void attn_decode_group_idle() {
+#pragma unroll
+    for (int i = 0; i < 1 + FQ_ATTN_HEAD_BARRIERS; ++i) __syncthreads();
+}
+
 __global__ void __launch_bounds__(256) k_attn_decode(fq_attn_decode_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     attn_decode_group<false>(a, (int) blockIdx.x, true, (int) threadIdx.x, smem);
@@ -515,23 +539,24 @@ struct fq_attn_out_args {
     unsigned long long * gran;      // hand-off buffer: one granule per 32-bit word of the attention image (or f32 row)
     const unsigned * epoch_word;    // this launch's tag (incremented by the preceding k_gemv_ln launch, never 0)
     unsigned * err;                 // set to 1 if a sweep gave up
-    int n_attn, heads_per_wg, attn_lds_group;
+    int n_attn, n_mv, heads_per_wg, attn_lds_group;
 };
 
+// xpub.gran != nullptr: the new residual values are ALSO published as granules for the LayerNorm phase of the same launch
 template <int TYPE>
-__global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void attn_out_body(const fq_attn_out_args & a, uint8_t * smem, const unsigned epoch, const fq_publish xpub) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x;
+    if ((int) blockIdx.x >= a.n_attn + a.n_mv) return;             // (two-phase kernel: workgroups that only have a second phase)
     if ((int) blockIdx.x < a.n_attn) {
         // ------------------------------------------------------------------------------------ attention role
         const int grp = tid >> 8, gtid = tid & 255;
-        if (grp >= a.heads_per_wg) return;                       // (blockDim = 768: never; keeps a smaller blockDim legal)
+        if (grp >= a.heads_per_wg) { if (xpub.gran) attn_decode_group_idle(); return; }   // two-phase kernel: these waves come back for phase 2
         int h = (int) blockIdx.x * a.heads_per_wg + grp;
         const bool live = h < a.at.H;
         if (!live) h = a.at.H - 1;
         long long * dbg = a.g.dbg ? a.g.dbg + 2048 * 8 : nullptr;
         FQ_STAMP(dbg, 0);
-        attn_decode_group<true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, dbg, fq_publish{ a.gran, *a.epoch_word });
+        attn_decode_group<true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, dbg, fq_publish{ a.gran, epoch });
         FQ_STAMP(dbg, 7);
         return;
     }
@@ -577,7 +602,6 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
     // ---- the attention output: every wave re-reads its share of the granules (agent-scope loads, past the caches) until
     // all of them carry this launch's tag, and drops the values into the image in LDS
     {
-        const unsigned epoch = *a.epoch_word;
         const int64_t nwords = g.att_image ? (E >> 2) + 2 * (E >> 5) : E;      // published words: [qs | d | aux] of Q8_0 / Q8_1, or the f32 row
         unsigned * dstw = g.att_image ? (unsigned *) img_att : (unsigned *)(img_att + fq_act_col_bytes(ACT, E));
         constexpr int NG = 3;                                        // granules per thread and sweep (768 threads: 2304 words)
@@ -613,16 +637,43 @@ __global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t row = row0 + r;
-            if (row < g.w_wo.M) g.dst[row] = (acc_d[r] + acc_o[r]) + (r ? res1 : res0);            // libfalcon.cpp:2399-2400
+            if (row < g.w_wo.M) {
+                const float v = (acc_d[r] + acc_o[r]) + (r ? res1 : res0);                          // libfalcon.cpp:2399-2400
+                g.dst[row] = v;
+                if (xpub.gran) __hip_atomic_store(xpub.gran + row, ((unsigned long long) xpub.epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     FQ_STAMP(dbg, 7);
 }
 
+template <int TYPE>
+__global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    attn_out_body<TYPE>(a, smem, *a.epoch_word, fq_publish{ nullptr, 0u });
+}
+
+// =============================================================================================== k_attn_out_ln
+// TWO phases in one launch (256 workgroups of 12 waves, one per CU): phase 1 = k_attn_out of block l, phase 2 = k_gemv_ln
+// of block l+1 (or ln_f + lm_head after the last block). The new residual row crosses from the 190 mat-vec workgroups to
+// all phase-2 workgroups through tagged granules, like the attention output inside phase 1: no launch boundary, no kernel
+// start between the two, and a workgroup that finished phase 1 already has its LayerNorm weights and its first weight
+// column in flight while it waits for the row.
+template <int TYPE>
+__global__ void __launch_bounds__(768) k_attn_out_ln(fq_attn_out_args a, fq_gemv_ln_args b, unsigned long long * xgran) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned epoch = *a.epoch_word;
+    attn_out_body<TYPE>(a, smem, epoch, fq_publish{ xgran, epoch });
+    __syncthreads();
+    if ((int) blockIdx.x < b.n_blocks) gemv_ln_body<TYPE, 768>(b, (int) blockIdx.x, smem, fq_xsrc{ xgran, epoch, a.err });
+}
+
 // true (and launched) when the merged form applies: every workgroup resident at once
+// ln == nullptr: k_attn_out. ln != nullptr: k_attn_out_ln with *ln as the second phase (xgran: >= n_embd granules).
 bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
                         const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
-                        int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st) {
+                        int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st,
+                        const fq_gemv_ln_args * ln, unsigned long long * xgran) {
     const int type = g.w_wo.type, act = fq_desc(type).act_type;
     const int nw = 12, hpw = 2;             // 2 heads per attention workgroup: the attention is instruction-issue bound per SIMD
     const int n_attn = (H + hpw - 1) / hpw;
@@ -631,15 +682,38 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
     const size_t lds_mv = fq_act_col_bytes(act, g.w_down.K) + fq_act_col_bytes(act, g.w_wo.K) + (g.att_image ? 0 : (size_t) g.w_wo.K * 4) + 16;
     size_t lds = lds_group * hpw > lds_mv ? lds_group * hpw : lds_mv;
     if (n_attn + n_mv > n_cu || lds > 160 * 1024) return false;
-    if (lds < 84 * 1024) lds = 84 * 1024;                                 // one workgroup per CU
     fq_attn_out_args a{};
     a.g = g;
     a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, const_cast<float *>(g.att_image ? nullptr : g.att),
                                 const_cast<uint8_t *>(g.att_image), att_act_type, max_n_kv, rope_cur };
-    a.gran = gran; a.epoch_word = epoch_word; a.err = err; a.n_attn = n_attn; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
-#define FQ_CASE(T) case T: { \
+    a.gran = gran; a.epoch_word = epoch_word; a.err = err; a.n_attn = n_attn; a.n_mv = n_mv; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
+    int grid = n_attn + n_mv;
+    fq_gemv_ln_args b{};
+    if (ln) {
+        // second phase: same format, 12-wave workgroups, the row in registers, everything resident at once
+        b = *ln;
+        for (int s = 0; s < b.nseg; ++s) if (b.seg[s].w.type != type) return false;
+        int lnw = 4, npass = 2;
+        gemv_ln_shape(b, n_cu, lnw, npass);
+        if (lnw != nw || (b.E >> 2) > 3 * 64 * nw) return false;
+        b.npass = npass;
+        const int rows = 4 * npass * nw;
+        int blocks = 0;
+        for (int s = 0; s < b.nseg; ++s) { b.seg[s].block_begin = blocks; blocks += (int)((b.seg[s].w.M + rows - 1) / rows); }
+        b.n_blocks = blocks;
+        if (blocks > n_cu) return false;
+        const size_t lds_ln = fq_gemv_ln_lds(type, b.E);
+        if (lds_ln > lds) lds = lds_ln;
+        if (blocks > grid) grid = blocks;
+    }
+    if (lds < 84 * 1024) lds = 84 * 1024;                                 // one workgroup per CU
+    if (lds > 160 * 1024) return false;
+#define FQ_CASE(T) case T: if (ln) { \
+        static size_t gmax2 = 0; if (lds > gmax2) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out_ln<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax2 = lds; } \
+        FQ_LAUNCH_PROF((k_attn_out_ln<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a, b, xgran); \
+    } else { \
         static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
-        FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned)(n_attn + n_mv)), dim3(64 * nw), lds, st, a); } break;
+        FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a); } break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
@@ -648,4 +722,3 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
 #undef FQ_CASE
     return true;
 }
-

@@ -83,9 +83,9 @@ int   falcon_hip_perplexity(falcon_hip_context * c, const int32_t * tokens, int6
 void  falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep);
 void  falcon_hip_get_hidden(falcon_hip_context * c, float * dst_host);
 void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* capture decode steps into a hipGraph */
-/* N == 1 evals: 2 (default) = fused decode kernels, attention + output mat-vec in one launch (2 launches per block, when the
- * grid fits the chip), 1 = fused decode kernels (3 launches per block), 0 = one launch per graph op (A/B, tests).
- * All three produce the same bits. */
+/* N == 1 evals: 2 (default) = fused decode kernels, two launches per block (LayerNorm mat-vec | attention + output mat-vec,
+ * when the grid fits the chip), 3 = one launch per block (the next block's LayerNorm mat-vec as a second phase of the same
+ * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests). All produce the same bits. */
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
