@@ -37,10 +37,13 @@ __device__ __forceinline__ uint32_t bytes_sub(uint32_t x, uint32_t c4) { return 
 
 // one 32-element group of a weight row: load() only issues the global loads (so that they can fly during the previous
 // stage's MFMAs), finish() turns them into 32 int8 (lo = elements 0..15, hi = 16..31), an f32 scale and an f32 min term
-struct gemm_raw { fq_u4 a, b; uint32_t s0, s1, s2, s3; };
+struct gemm_raw { fq_u4 a, b, c, d; uint32_t s0, s1, s2, s3; };
+// SUB = scale sub-groups per 32-element group: 1, or 2 for the formats whose sub-blocks hold 16 elements (Q2_K, Q3_K, Q6_K:
+// the group is then TWO MFMAs, each with the other half's weight bytes zeroed, and two scalings)
 template <int TYPE> struct gemm_group;
 
-template <> struct gemm_group<FQ_Q4_0> {            // ggml.c:1509-1527
+template <> struct gemm_group<FQ_Q4_0> {
+    static constexpr int SUB = 1;            // ggml.c:1509-1527
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u16(r.p1 + 2 * (size_t) g); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
@@ -50,7 +53,8 @@ template <> struct gemm_group<FQ_Q4_0> {            // ggml.c:1509-1527
         sc = fq_h2f((uint16_t) w.s0); mn = 0.0f;
     }
 };
-template <> struct gemm_group<FQ_Q4_1> {            // ggml.c:1529-1548
+template <> struct gemm_group<FQ_Q4_1> {
+    static constexpr int SUB = 1;            // ggml.c:1529-1548
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
@@ -60,7 +64,8 @@ template <> struct gemm_group<FQ_Q4_1> {            // ggml.c:1529-1548
         sc = fq_h2f((uint16_t) w.s0); mn = fq_h2f((uint16_t)(w.s0 >> 16));
     }
 };
-template <> struct gemm_group<FQ_Q5_0> {            // ggml.c:1550-1574
+template <> struct gemm_group<FQ_Q5_0> {
+    static constexpr int SUB = 1;            // ggml.c:1550-1574
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u16(r.p2 + 2 * (size_t) g);
@@ -76,7 +81,8 @@ template <> struct gemm_group<FQ_Q5_0> {            // ggml.c:1550-1574
         sc = fq_h2f((uint16_t) w.s1); mn = 0.0f;
     }
 };
-template <> struct gemm_group<FQ_Q5_1> {            // ggml.c:1576-1601
+template <> struct gemm_group<FQ_Q5_1> {
+    static constexpr int SUB = 1;            // ggml.c:1576-1601
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u32(r.p2 + 4 * (size_t) g);
@@ -92,7 +98,8 @@ template <> struct gemm_group<FQ_Q5_1> {            // ggml.c:1576-1601
         sc = fq_h2f((uint16_t) w.s1); mn = fq_h2f((uint16_t)(w.s1 >> 16));
     }
 };
-template <> struct gemm_group<FQ_Q8_0> {            // ggml.c:1603-1619
+template <> struct gemm_group<FQ_Q8_0> {
+    static constexpr int SUB = 1;            // ggml.c:1603-1619
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         w.a = ld_u4(r.p0 + 32 * (size_t) g); w.b = ld_u4(r.p0 + 32 * (size_t) g + 16); w.s0 = ld_u16(r.p1 + 2 * (size_t) g);
@@ -104,6 +111,7 @@ template <> struct gemm_group<FQ_Q8_0> {            // ggml.c:1603-1619
 };
 // Q4_K / Q5_K: group g = sub-block j = g % 8 of super-block g / 8 (k_quants.c:607-631, 734-760); w = (d*sc)*q - dmin*m
 template <int TYPE> struct gemm_group_k45 {
+    static constexpr int SUB = 1;
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         const size_t sb = (size_t)(g >> 3); const int j = g & 7, c = j >> 1;
@@ -143,15 +151,84 @@ template <int TYPE> struct gemm_group_k45 {
 template <> struct gemm_group<FQ_Q4_K> : gemm_group_k45<FQ_Q4_K> {};
 template <> struct gemm_group<FQ_Q5_K> : gemm_group_k45<FQ_Q5_K> {};
 
+// ---- formats with 16-element sub-blocks. Group g of a row = elements [32 g, 32 g + 32) = sub-blocks 2g, 2g+1 of the row.
+static __device__ __forceinline__ v4i u4_to_v4i(const fq_u4 & x) { return v4i{ (int) x.x, (int) x.y, (int) x.z, (int) x.w }; }
+template <> struct gemm_group<FQ_Q2_K> {            // k_quants.c:344-375: w = d (sc & 15) q - dmin (sc >> 4), q = 2 bits
+    static constexpr int SUB = 2;
+    static constexpr bool HAS_MIN = true;
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1, j = g & 3;
+        w.a = ld_u4(r.p0 + 64 * sb + 32 * hf); w.b = ld_u4(r.p0 + 64 * sb + 32 * hf + 16);
+        w.s0 = ld_u16(r.p1 + 16 * sb + 8 * hf + 2 * j);                // scales[8 hf + 2 j], [.. + 1]
+        w.s1 = ld_u32(r.p2 + 4 * sb);
+    }
+    __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
+        const int sh = 2 * (g & 3);
+        lo = v4i{ (int)((w.a.x >> sh) & 0x03030303u), (int)((w.a.y >> sh) & 0x03030303u), (int)((w.a.z >> sh) & 0x03030303u), (int)((w.a.w >> sh) & 0x03030303u) };
+        hi = v4i{ (int)((w.b.x >> sh) & 0x03030303u), (int)((w.b.y >> sh) & 0x03030303u), (int)((w.b.z >> sh) & 0x03030303u), (int)((w.b.w >> sh) & 0x03030303u) };
+        const float d = fq_h2f((uint16_t) w.s1), dmin = fq_h2f((uint16_t)(w.s1 >> 16));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t b = (w.s0 >> (8 * s)) & 0xFFu;
+            sc[s] = d * (float)(int)(b & 0xFu); mn[s] = -(dmin * (float)(int)(b >> 4));
+        }
+    }
+};
+template <> struct gemm_group<FQ_Q3_K> {            // k_quants.c:472-521: w = d (sc - 32) (q - (h ? 0 : 4))
+    static constexpr int SUB = 2;
+    static constexpr bool HAS_MIN = false;
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1;
+        w.a = ld_u4(r.p0 + 64 * sb + 32 * hf); w.b = ld_u4(r.p0 + 64 * sb + 32 * hf + 16);
+        w.c = ld_u4(r.p1 + 32 * sb); w.d = ld_u4(r.p1 + 32 * sb + 16);                 // hmask bytes 0..15 / 16..31
+        w.s0 = ld_u32(r.p2 + 12 * sb); w.s1 = ld_u32(r.p2 + 12 * sb + 4); w.s2 = ld_u32(r.p2 + 12 * sb + 8);
+        w.s3 = ld_u16(r.p3 + 2 * sb);
+    }
+    __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
+        const int hf = (g >> 2) & 1, j = g & 3, sh = 2 * j, hb = 4 * hf + j;
+        auto val = [&](uint32_t q, uint32_t h) {                        // per byte: 2 bits | (high bit << 2), minus 4
+            return (int) bytes_sub(((q >> sh) & 0x03030303u) | (((h >> hb) & 0x01010101u) << 2), 0x04040404u);
+        };
+        lo = v4i{ val(w.a.x, w.c.x), val(w.a.y, w.c.y), val(w.a.z, w.c.z), val(w.a.w, w.c.w) };
+        hi = v4i{ val(w.b.x, w.d.x), val(w.b.y, w.d.y), val(w.b.z, w.d.z), val(w.b.w, w.d.w) };
+        const float d = fq_h2f((uint16_t) w.s3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { sc[s] = d * (float)(q3_scale(w.s0, w.s1, w.s2, 8 * hf + 2 * j + s) - 32); mn[s] = 0.0f; }
+    }
+};
+template <> struct gemm_group<FQ_Q6_K> {            // k_quants.c:845-876: w = d scale (q - 32), q = 4 low | 2 high bits
+    static constexpr int SUB = 2;
+    static constexpr bool HAS_MIN = false;
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
+        const size_t sb = (size_t)(g >> 3); const int h = (g >> 2) & 1, t = g & 3;
+        const uint8_t * ql = r.p0 + 128 * sb + 64 * h + 32 * (t & 1);
+        w.a = ld_u4(ql); w.b = ld_u4(ql + 16);
+        w.c = ld_u4(r.p1 + 64 * sb + 32 * h); w.d = ld_u4(r.p1 + 64 * sb + 32 * h + 16);
+        w.s0 = ld_u16(r.p2 + 16 * sb + 8 * h + 2 * t);                 // int8 scales[8 h + 2 t], [.. + 1]
+        w.s1 = ld_u16(r.p3 + 2 * sb);
+    }
+    __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
+        const int t = g & 3, nsh = (t >> 1) ? 4 : 0, hsh = 2 * t;
+        auto val = [&](uint32_t l, uint32_t h) {
+            return (int) bytes_sub(((l >> nsh) & 0x0F0F0F0Fu) | (((h >> hsh) & 0x03030303u) << 4), 0x20202020u);
+        };
+        lo = v4i{ val(w.a.x, w.c.x), val(w.a.y, w.c.y), val(w.a.z, w.c.z), val(w.a.w, w.c.w) };
+        hi = v4i{ val(w.b.x, w.d.x), val(w.b.y, w.d.y), val(w.b.z, w.d.z), val(w.b.w, w.d.w) };
+        const float d = fq_h2f((uint16_t) w.s1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { sc[s] = d * (float)(int)(int8_t)(w.s0 >> (8 * s)); mn[s] = 0.0f; }
+    }
+};
+
 // tuning aid (ggml_hip_debug_gemm_mode): bit 0 = no global loads after the first stage, bit 1 = no MFMA / scaling (timing only)
 __device__ int g_gemm_dbg = 0;
 void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
 
 // LDS buffer of one K stage
-template <bool HAS_MIN, int TN> struct gemm_lds {                    // TN = tokens per workgroup
+template <bool HAS_MIN, int TN, int SUB> struct gemm_lds {           // TN = tokens per workgroup, SUB = scale sub-groups per group
     static constexpr int XQ = 0, WQ = TN * GQ_STRIDE, DX = WQ + GQ_TM * GQ_STRIDE, SX = DX + GQ_GROUPS * TN * 4,
-                         DW = SX + (HAS_MIN ? GQ_GROUPS * TN * 4 : 0), MW = DW + GQ_GROUPS * GQ_TM * 4,
-                         BYTES = MW + (HAS_MIN ? GQ_GROUPS * GQ_TM * 4 : 0);
+                         DW = SX + (HAS_MIN ? GQ_GROUPS * SUB * TN * 4 : 0), MW = DW + GQ_GROUPS * SUB * GQ_TM * 4,
+                         BYTES = MW + (HAS_MIN ? GQ_GROUPS * SUB * GQ_TM * 4 : 0);
 };
 
 // S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves
@@ -160,8 +237,8 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = fq_act_of(TYPE);
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
-    constexpr int TN = 32 * TT;
-    typedef gemm_lds<HAS_MIN, TN> LB;
+    constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB;
+    typedef gemm_lds<HAS_MIN, TN, SUB> LB;
     constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16 / S;     // threads, token vectors per thread and stage, results per lane
     static_assert(NT >= GQ_TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -208,12 +285,18 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     auto commit = [&](int g0, const stage_regs & R, uint8_t * B) {        // registers -> LDS buffer B (zeros beyond K / N / M)
         if (has_w) {
             const int g = g0 + w_gg;
-            v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; float sc = 0.0f, mn = 0.0f;
-            if (g < ngroups && m0 + w_row < M) gemm_group<TYPE>::finish(R.w, g, lo, hi, sc, mn);
+            v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; float sc[2] = {0.0f, 0.0f}, mn[2] = {0.0f, 0.0f};
+            if (g < ngroups && m0 + w_row < M) {
+                if constexpr (SUB == 1) gemm_group<TYPE>::finish(R.w, g, lo, hi, sc[0], mn[0]);
+                else                    gemm_group<TYPE>::finish(R.w, g, lo, hi, sc, mn);
+            }
             *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg)      = lo;
             *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg + 16) = hi;
-            ((float *)(B + LB::DW))[w_gg * GQ_TM + w_row] = sc;
-            if constexpr (HAS_MIN) ((float *)(B + LB::MW))[w_gg * GQ_TM + w_row] = mn;
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss) {
+                ((float *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = sc[ss];
+                if constexpr (HAS_MIN) ((float *)(B + LB::MW))[(w_gg * SUB + ss) * GQ_TM + w_row] = mn[ss];
+            }
         }
 #pragma unroll
         for (int i = 0; i < VT; ++i) {
@@ -222,12 +305,16 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             *(v4i *)(B + LB::XQ + tok * GQ_STRIDE + 16 * part) = ok ? R.x[i] : v4i{0, 0, 0, 0};
         }
         if (has_sc) {
-            float dx[4], sx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float dx[4], sx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sx1[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // sx1: second sub-group (SUB == 2)
             const bool full = g0 + 3 < ngroups;
             if constexpr (ACT == FQ_Q8_K) {
-                const uint32_t bw[4] = { R.ba.x, R.ba.y, R.bb.x, R.bb.y };
+                const uint32_t bw[4] = { R.ba.x, R.ba.y, R.bb.x, R.bb.y };      // bsums of the group's two 16-element halves
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { dx[i] = R.d4.x; sx[i] = R.d4.x * (float)((int)(int16_t) bw[i] + (int)(int16_t)(bw[i] >> 16)); }
+                for (int i = 0; i < 4; ++i) {
+                    dx[i] = R.d4.x;
+                    if constexpr (SUB == 1) sx[i] = R.d4.x * (float)((int)(int16_t) bw[i] + (int)(int16_t)(bw[i] >> 16));
+                    else { sx[i] = R.d4.x * (float)(int)(int16_t) bw[i]; sx1[i] = R.d4.x * (float)(int)(int16_t)(bw[i] >> 16); }
+                }
             } else {
                 dx[0] = R.d4.x; dx[1] = R.d4.y; dx[2] = R.d4.z; dx[3] = R.d4.w;
                 if constexpr (ACT == FQ_Q8_1) { sx[0] = R.sa.x; sx[1] = R.sa.y; sx[2] = R.sb.x; sx[3] = R.sb.y; }
@@ -237,11 +324,14 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                 // a tail stage (fewer than 4 groups left) re-read the LAST four groups: shift them back into place
                 const int src = full ? gg : gg + (g0 - (ngroups >= 4 ? ngroups - 4 : 0));
                 const bool ok = n0 + tid < N && g0 + gg < ngroups && src < 4;
-                float dv = 0.0f, sv = 0.0f;
+                float dv = 0.0f, sv = 0.0f, sv1 = 0.0f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (q == src) { dv = dx[q]; sv = sx[q]; }
+                for (int q = 0; q < 4; ++q) if (q == src) { dv = dx[q]; sv = sx[q]; sv1 = sx1[q]; }
                 ((float *)(B + LB::DX))[gg * TN + tid] = ok ? dv : 0.0f;
-                if constexpr (HAS_MIN) ((float *)(B + LB::SX))[gg * TN + tid] = ok ? sv : 0.0f;
+                if constexpr (HAS_MIN) {
+                    ((float *)(B + LB::SX))[(gg * SUB) * TN + tid] = ok ? sv : 0.0f;
+                    if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + tid] = ok ? sv1 : 0.0f;
+                }
             }
         }
     };
@@ -263,32 +353,44 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         for (int gg = 0; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); ++gg) {
             const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
             const v4i b = *(const v4i *)(B + LB::WQ + l31 * GQ_STRIDE + 32 * gg + 16 * half);
-            const float dw = ((const float *)(B + LB::DW))[gg * GQ_TM + l31];
-            const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[gg * GQ_TM + l31] : 0.0f;
             // the lane's result i  <->  token 32 tt + rot + (i & 3) + 8 (i >> 2) + 4 half: runs of 4 consecutive tokens
-            float dxv[NR], sxv[NR];
+            float dxv[NR];
 #pragma unroll
             for (int q = 0; q < NR / 4; ++q) {
                 const int tok = 32 * tt + rot + 8 * q + 4 * half;
                 const float4 t = *(const float4 *)(B + LB::DX + (gg * TN + tok) * 4);
                 dxv[4 * q] = t.x; dxv[4 * q + 1] = t.y; dxv[4 * q + 2] = t.z; dxv[4 * q + 3] = t.w;
-                if constexpr (HAS_MIN) {
-                    const float4 u = *(const float4 *)(B + LB::SX + (gg * TN + tok) * 4);
-                    sxv[4 * q] = u.x; sxv[4 * q + 1] = u.y; sxv[4 * q + 2] = u.z; sxv[4 * q + 3] = u.w;
-                }
             }
-            v16i c = {0};
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
-            // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
-            // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const float ci = (float) c[i];
-                float t;
-                if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
-                else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
-                else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
-                acc[i] = acc[i] + t;
+            for (int ss = 0; ss < SUB; ++ss) {
+                // 16-element sub-blocks: lanes of half h hold the group's weight bytes [16 h, 16 h + 16); zeroing the other
+                // half's operand leaves exactly sub-block ss in the MFMA's sum
+                const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
+                const float dw = ((const float *)(B + LB::DW))[(gg * SUB + ss) * GQ_TM + l31];
+                const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[(gg * SUB + ss) * GQ_TM + l31] : 0.0f;
+                float sxv[NR];
+                if constexpr (HAS_MIN) {
+#pragma unroll
+                    for (int q = 0; q < NR / 4; ++q) {
+                        const int tok = 32 * tt + rot + 8 * q + 4 * half;
+                        const float4 u = *(const float4 *)(B + LB::SX + ((gg * SUB + ss) * TN + tok) * 4);
+                        sxv[4 * q] = u.x; sxv[4 * q + 1] = u.y; sxv[4 * q + 2] = u.z; sxv[4 * q + 3] = u.w;
+                    }
+                }
+                v16i c = {0};
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+                // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
+                // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const float ci = (float) c[i];
+                    float t;
+                    if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
+                    else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
+                    else if constexpr (!HAS_MIN)                            t = (dw * dxv[i]) * ci;                    // Q3_K, Q6_K
+                    else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
+                    acc[i] = acc[i] + t;
+                }
             }
         }
     };
@@ -330,14 +432,15 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 }
 
 bool fq_gemm_supported(int type) {
-    return type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0 || type == FQ_Q4_K || type == FQ_Q5_K;
+    return type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0 ||
+           type == FQ_Q2_K || type == FQ_Q3_K || type == FQ_Q4_K || type == FQ_Q5_K || type == FQ_Q6_K;
 }
 
 template <int TYPE, int S, int TT>
 static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
     constexpr int TN = 32 * TT;
-    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN>::BYTES;
+    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB>::BYTES;
     const dim3 grid((unsigned)((w.M + GQ_TM - 1) / GQ_TM), (unsigned)((N + TN - 1) / TN));
     hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
 }
@@ -356,7 +459,8 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 4) launch_gemm_t<T, 4, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 2, 2>(w, act, N, dst, ldd, ep, st); break;
     switch (w.type) {
-        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K)
+        FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
+        FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
         default: fprintf(stderr, "ggml-hip: gemm: unsupported weight type %d\n", w.type); exit(1);
     }
 #undef FQ_CASE
