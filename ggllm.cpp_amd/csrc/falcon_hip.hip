@@ -73,6 +73,11 @@ struct falcon_hip_context {
     unsigned * sync_words = nullptr;           // [0] hand-off epoch of k_attn_out, [1] its time-out flag, [16..80) rope row of the position
     unsigned long long * att_gran = nullptr;   // hand-off granules of k_attn_out: one per 32-bit word of the attention image / row
     hipGraphExec_t decode_graph = nullptr;
+    // one captured pipeline-stage step (falcon_hip_stage_step): valid for these device pointers; n_past lives on the device
+    hipGraphExec_t step_graph = nullptr;
+    const void * sg_in[2] = { nullptr, nullptr }; void * sg_out[2] = { nullptr, nullptr };
+    int step_next_n_past = -1;
+    bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
     int  graph_base = -1;                      // n_past the captured graph was built for
 };
 
@@ -236,6 +241,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->x_gran         = (unsigned long long *) dev_alloc(c->allocs, (size_t) hp.n_embd * 8 + 64);
     HIP_CHECK(hipMemset(c->x_gran, 0, (size_t) hp.n_embd * 8 + 64));
     if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
+    if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     return c;
 }
@@ -243,6 +249,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
 extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (!c) return;
     if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
+    if (c->step_graph) HIP_CHECK(hipGraphExecDestroy(c->step_graph));
     for (hipEvent_t e : c->ev_fork) HIP_CHECK(hipEventDestroy(e));
     for (hipEvent_t e : c->ev_join) HIP_CHECK(hipEventDestroy(e));
     if (c->side) HIP_CHECK(hipStreamDestroy(c->side));
@@ -268,6 +275,7 @@ extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1
 }
 extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
+    if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
     c->two_phase = mode >= 3;
@@ -539,7 +547,7 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         const int np = *n_past;
-        out[np - n_past0] = idx;
+        out[n_past0 < 0 ? 0 : np - n_past0] = idx;              // (n_past0 < 0: a pipeline stage's captured step always uses slot 0)
         token[0] = idx;
         *n_past = np + 1;
     }
@@ -548,6 +556,7 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
 // ------------------------------------------------------------------------------------------------ pipeline step
 __global__ void k_set_i32(int * p, int v) { *p = v; }
 __global__ void k_copy_i32(int32_t * dst, const int32_t * src) { *dst = *src; }
+__global__ void k_inc_i32(int * p) { *p = *p + 1; }
 
 // One decode step of one pipeline stage, fully stream-ordered (no host synchronisation, no host memory): the token id
 // (first stage) / residual row (other stages) are read from device memory, the residual row (inner stages) / the
@@ -558,24 +567,53 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     falcon_hip_model * m = c->m;
     hipStream_t st = hc.stream;
     if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: stage step at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); exit(1); }
-    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
-    if (m->first_stage()) hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(1), 0, st, c->tokens_dev, token_dev);
-    else HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
-    launch_stage(c, 1, n_past + 1, st);
-    c->keep_hidden = was_keep;
-    if (m->last_stage()) {
-        if (next_token_dev) {
-            // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
-            if (c->fused_decode && stage_uniform(m))
-                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
-            else
-                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past);
+    // body of one step; n_past_base >= 0: position baked into the launch arguments (plain launches), < 0: the position is
+    // whatever n_past_dev holds and the step leaves n_past_dev + 1 behind (captured form, replayable)
+    auto body = [&](int n_past_base, int max_kv) {
+        if (m->first_stage()) hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(1), 0, st, c->tokens_dev, token_dev);
+        else HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+        launch_stage(c, 1, max_kv, st);
+        bool advanced = false;
+        if (m->last_stage()) {
+            if (next_token_dev) {
+                // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
+                if (c->fused_decode && stage_uniform(m))
+                    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
+                else
+                    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
+                advanced = true;
+            }
+        } else if (hidden_out_dev) {
+            HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
         }
-    } else if (hidden_out_dev) {
-        HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+        if (n_past_base < 0 && !advanced) hipLaunchKernelGGL(k_inc_i32, dim3(1), dim3(1), 0, st, c->n_past_dev);
+    };
+    if (c->stage_graph && !fq_prof_active() && !fq_ctx().dbg_stamps) {
+        // one hipGraph replay per step instead of ~70 launches from the host: a stage of a deep pipeline holds few blocks,
+        // and the host side of a step would otherwise cost as much as its device side
+        const bool same = c->step_graph && c->sg_in[0] == token_dev && c->sg_in[1] == hidden_in_dev && c->sg_out[0] == hidden_out_dev && c->sg_out[1] == next_token_dev;
+        if (!same) {
+            if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
+            hipGraph_t g;
+            HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            body(-1, c->n_ctx);
+            HIP_CHECK(hipStreamEndCapture(st, &g));
+            HIP_CHECK(hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            c->sg_in[0] = token_dev; c->sg_in[1] = hidden_in_dev; c->sg_out[0] = hidden_out_dev; c->sg_out[1] = next_token_dev;
+            c->step_next_n_past = -1;
+        }
+        if (n_past != c->step_next_n_past) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
+        HIP_CHECK(hipGraphLaunch(c->step_graph, st));
+        c->step_next_n_past = n_past + 1;
+    } else {
+        hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
+        body(n_past, n_past + 1);
+        c->step_next_n_past = -1;
     }
+    c->keep_hidden = was_keep;
     return 0;
 }
 

@@ -251,3 +251,35 @@ def test_perplexity_loop(oracle, golden, name, hp, t):
     m.free()
     assert count == int(gg[f"{name}_ppl_count"]) == 45
     assert abs(nll - float(gg[f"{name}_ppl_nll"])) <= 1e-9 * abs(nll)
+
+
+@pytest.mark.parametrize("graph", [1, 0])
+@pytest.mark.parametrize("hp,t,cut", [(synth.HP_TINY_GQA, ob.Q5_1, 1), (synth.HP_TINY_MQA, ob.Q4_0, 1)])
+def test_pipeline_stage_steps_match_whole_model(oracle, monkeypatch, hp, t, cut, graph):
+    """the stage API of the layer pipeline (falcon_hip_stage_step: device-resident inputs / outputs, no host sync; captured
+    into one hipGraph per stage by default) chained over two stages in ONE process reproduces the whole-model greedy decode"""
+    monkeypatch.setenv("FALCON_HIP_STAGE_GRAPH", str(graph))
+    L = g.load()
+    w = synth.make_model(oracle, hp, t, seed=11)
+    toks = synth.tokens(6, hp["n_vocab"], seed=3)
+    whole = g.FalconModel(w, n_ctx=64, n_batch=8)
+    whole.eval(toks, 0)
+    want = whole.decode_greedy(int(toks[-1]), 6, 10)
+    whole.free()
+    s0 = g.FalconModel(w, n_ctx=64, n_batch=8, layer_begin=0, layer_end=cut)
+    s1 = g.FalconModel(w, n_ctx=64, n_batch=8, layer_begin=cut, layer_end=hp["n_layer"])
+    E = hp["n_embd"]
+    tok, hid, nxt = g.DevBuf(4), g.DevBuf(E * 4), g.DevBuf(4)
+    got = []
+    seq = list(toks) + [int(toks[-1])]                     # prompt token by token, then feed back the sampled one
+    for pos in range(6 + 10):
+        cur = np.array([seq[pos] if pos < len(seq) else got[-1]], np.int32)
+        L.ggml_hip_memcpy_h2d(tok.ptr, cur.ctypes.data, 4)
+        L.falcon_hip_stage_step(s0.ctx, tok.ptr, None, pos, hid.ptr, None)
+        L.falcon_hip_stage_step(s1.ctx, None, hid.ptr, pos, None, nxt.ptr)
+        if pos >= 6:
+            got.append(int(nxt.to_host(np.int32, (1,))[0]))
+    s0.free(); s1.free()
+    for b in (tok, hid, nxt):
+        b.free()
+    assert got == [int(x) for x in want]
