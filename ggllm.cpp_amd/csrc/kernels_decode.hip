@@ -1,15 +1,18 @@
 // kernels_decode.hip -- fused single-token (N = 1) decode kernels for a Falcon block (gfx950, wave64).
 //
-// A decode step streams ~117 MB of Q4_0 weights per block in ~18 us at HBM speed, so every extra launch (~1.5 us of
-// boundary + a few us of latency-bound prologue) costs as much as megabytes of weights. The stand-alone kernels
-// (layer norm, activation quantizer, rope, four GEMVs, attention, residual add) are therefore folded into three:
+// A decode step streams ~117 MB of Q4_0 weights per block in ~19 us at HBM speed, so every extra launch (~1.7 us of
+// boundary, ~1.2 us before its first load can be issued, a latency-bound prologue) costs as much as megabytes of weights.
+// The stand-alone kernels (layer norm, activation quantizer, rope, four GEMVs, attention, residual add) are folded into:
 //
-//   k_gemv_ln   rows [Wqkv | Wup]: every workgroup re-derives the LayerNorm of the 18 KB residual row and its Q8
-//               image in LDS (cheaper than a launch), streams 32 weight rows, and finishes with either a plain store
-//               (QKV) or GELU + Q8 quantization of its 32 outputs straight into the next mat-vec's activation image.
-//   k_attn_decode  per head: RoPE of q (and of the new k), KV append, K.Q, soft_max, V.P.
-//   k_gemv_out  x = (Wdown . q8(gelu(up)) + Wo . q8(att)) + x: two weight sources per output row, the attention
-//               output is quantized in the prologue, the residual is added in the epilogue.
+//   k_gemv_ln   rows [Wqkv | Wup]: one workgroup of 12 waves per CU; each re-derives the LayerNorm of the 18 KB residual
+//               row and its Q8 image (registers -> LDS; cheaper than a launch), streams 96 weight rows, and finishes with
+//               a plain store (QKV) or GELU + Q8 quantization straight into the next mat-vec's activation image.
+//               The same kernel is the lm_head launch (ln_f + 65 024 rows + per-32-row argmax candidates).
+//   k_attn_out  36 attention workgroups (RoPE of q and the new k, KV append, K.Q, soft_max, V.P, Q8 image; 2 heads each)
+//               next to 190 mat-vec workgroups, x = (Wdown . q8(gelu(up)) + Wo . q8(att)) + x: Wdown streams while the
+//               attention runs, its output crosses workgroups through tagged granules, the residual is added at the end.
+//   k_attn_decode, k_gemv_out   the same two roles as separate launches (models whose grid does not fit the chip at once).
+//   k_attn_out_ln               k_attn_out + the next block's k_gemv_ln as a second phase of one launch (measured slower).
 //
 // Arithmetic is the stand-alone kernels' arithmetic (same device functions, same per-lane unit order, same reductions):
 // logits are bit-identical to the unfused path, which the tests check.
@@ -79,12 +82,11 @@ __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int unit
     }
 }
 
-// per-format shape of the fused GEMVs: R rows per pass and NPRE pre-issued unit columns, sized so that the
-// kernels keep >= 4 waves per SIMD (<= 128 VGPRs): all 714 / 568 workgroups of a Falcon-7B launch are then resident at
-// once (fq_unit_regs is 5 dwords for Q4_0 ... 12 for Q5_K)
+// per-format shape of the fused GEMVs: R rows per pass and NPRE pre-issued unit columns, sized so that a 12-wave
+// workgroup stays within 168 VGPRs (3 waves per SIMD; fq_unit_regs is 5 dwords for Q4_0 ... 12 for Q5_K)
 template <int TYPE> struct decode_cfg {
     static constexpr bool four_bit = (TYPE == FQ_Q4_0 || TYPE == FQ_Q4_1 || TYPE == FQ_Q5_0 || TYPE == FQ_Q5_1);
-    static constexpr int LN_R     = 4;                                  // rows per pass in k_gemv_ln (8 rows per wave in total)
+    static constexpr int LN_R     = 4;                                  // rows per pass in k_gemv_ln
     static constexpr int LN_NPRE  = four_bit ? 3 : 2;                   // 4-wave workgroups (small models)
     static constexpr int LN_NPRE_BIG = 1;                               // 12-wave workgroups, see k_gemv_ln
     static constexpr int OUT_NPRE_D = four_bit ? 4 : 2;                 // k_gemv_out, down projection (R = 2)
