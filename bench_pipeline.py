@@ -156,10 +156,9 @@ def main(a, rank, world, local):
     import torch
     import torch.distributed as dist
     import ggllm_cpp_amd as g
-    import synth
-    from oracle import binding as ob
+    from ggllm_cpp_amd import synth
 
-    tname = {v: k for k, v in ob.TYPE_NAME.items()}
+    tname = {v: k for k, v in g.TYPE_NAME.items()}
     wtype = tname[a.quant if a.quant in tname else a.quant.replace("_k", "_K")]
     hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B, "tiny": synth.HP_TINY_MQA}[a.model])
     if a.layers:

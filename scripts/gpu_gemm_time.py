@@ -3,15 +3,15 @@ import sys, os, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import ggllm_cpp_amd as g, synth
-from oracle import binding as ob
+import ggllm_cpp_amd as g
+from ggllm_cpp_amd import synth
 g.init(0); L = g.load()
 L.ggml_hip_debug_gemm_mode.argtypes = [C.c_int]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rng = np.random.default_rng(0)
 for name, K, M in (("qkv", 4544, 4672), ("wo", 4544, 4544), ("up", 4544, 18176), ("down", 18176, 4544)):
-    blocks = synth.random_blocks(ob.Q4_0, M, K, rng)
-    w = g.Weight(ob.Q4_0, blocks, K, M)
+    blocks = synth.random_blocks(g.Q4_0, M, K, rng)
+    w = g.Weight(g.Q4_0, blocks, K, M)
     x = rng.standard_normal((N, K)).astype(np.float32)
     xb, yb = g.DevBuf(host=x), g.DevBuf(N * M * 4)
     for mode in (0, 1, 2, 3):

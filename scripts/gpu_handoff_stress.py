@@ -4,12 +4,12 @@ import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import ggllm_cpp_amd as g, synth
-from oracle import binding as ob
+import ggllm_cpp_amd as g
+from ggllm_cpp_amd import synth
 g.init(0)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 hp = dict(synth.HP_7B)
-w = synth.make_model_fast(hp, ob.Q4_0, seed=1234)
+w = synth.make_model_fast(hp, g.Q4_0, seed=1234)
 toks = synth.tokens(64, hp["n_vocab"], seed=42)
 res = {}
 for mode in (1, 2, 3):

@@ -3,11 +3,11 @@ import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import ggllm_cpp_amd as g, synth
-from oracle import binding as ob
+import ggllm_cpp_amd as g
+from ggllm_cpp_amd import synth
 g.init(0); L = g.load()
 hp = dict(synth.HP_7B); hp["n_layer"] = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-w = synth.make_model_fast(hp, ob.Q4_0)
+w = synth.make_model_fast(hp, g.Q4_0)
 m = g.FalconModel(w, n_ctx=512, n_batch=8)
 toks = synth.tokens(8, hp["n_vocab"])
 m.eval(toks, 0)
