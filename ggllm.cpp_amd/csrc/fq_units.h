@@ -53,7 +53,21 @@ FQ_HD fq_wrow fq_row(const fq_weight & w, int64_t r) {
 // one activation column as seen by the dot (LDS on the device)
 struct fq_actcol { const int8_t * qs; const float * d; const void * aux; };
 
+// weight bytes are read ONCE per token by exactly one CU: non-temporal loads keep them from displacing what IS re-read
+// (activation images, KV rows, LayerNorm inputs) -- FQ_NT_WEIGHTS=0 at compile time restores plain loads
+#ifndef FQ_NT_WEIGHTS
+#define FQ_NT_WEIGHTS 1
+#endif
 FQ_HD fq_u4    ld_u4 (const void * p) { return *(const fq_u4 *) p; }
+FQ_HD fq_u4    ld_w4 (const void * p) {            // 16 bytes of a WEIGHT plane (global memory)
+#if defined(__HIP_DEVICE_COMPILE__) && FQ_NT_WEIGHTS
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+    const u32x4_nt v = __builtin_nontemporal_load((const u32x4_nt *) p);
+    return fq_u4{ v.x, v.y, v.z, v.w };
+#else
+    return *(const fq_u4 *) p;
+#endif
+}
 FQ_HD uint32_t ld_u32(const void * p) { return *(const uint32_t *) p; }
 FQ_HD uint16_t ld_u16(const void * p) { return *(const uint16_t *) p; }
 
@@ -82,7 +96,7 @@ template <int TYPE> struct fq_unit;
 template <> struct fq_unit<FQ_Q4_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_u4(w.p0 + 16 * (size_t) u); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -95,7 +109,7 @@ template <> struct fq_unit<FQ_Q4_0> {
 template <> struct fq_unit<FQ_Q4_1> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_u4(w.p0 + 16 * (size_t) u); r.dm = ld_u32(w.p1 + 4 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.dm = ld_u32(w.p1 + 4 * (size_t) u); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -111,7 +125,7 @@ FQ_HD fq_u4 q5_hi(uint32_t qh, int base) {
 template <> struct fq_unit<FQ_Q5_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_u4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u16(w.p2 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u16(w.p2 + 2 * (size_t) u); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -124,7 +138,7 @@ template <> struct fq_unit<FQ_Q5_0> {
 template <> struct fq_unit<FQ_Q5_1> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_u4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u32(w.p2 + 4 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u32(w.p2 + 4 * (size_t) u); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -136,7 +150,7 @@ template <> struct fq_unit<FQ_Q5_1> {
 template <> struct fq_unit<FQ_Q8_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_u4(w.p0 + 32 * (size_t) u); r.q2 = ld_u4(w.p0 + 32 * (size_t) u + 16); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 32 * (size_t) u); r.q2 = ld_w4(w.p0 + 32 * (size_t) u + 16); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -150,7 +164,7 @@ template <> struct fq_unit<FQ_Q2_K> {
     static constexpr int ELEMS = 64;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
         fq_unit_regs r{}; const size_t sb = (size_t)(u >> 2); const int hf = (u >> 1) & 1;
-        r.q = ld_u4(w.p0 + 16 * (size_t) u);
+        r.q = ld_w4(w.p0 + 16 * (size_t) u);
         r.s0 = ld_u32(w.p1 + 16 * sb + 8 * hf); r.s1 = ld_u32(w.p1 + 16 * sb + 8 * hf + 4);
         r.dm = ld_u32(w.p2 + 4 * sb); return r;
     }
@@ -183,8 +197,8 @@ template <> struct fq_unit<FQ_Q3_K> {
     static constexpr int ELEMS = 64;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
         fq_unit_regs r{}; const size_t sb = (size_t)(u >> 2); const int g = u & 1;
-        r.q  = ld_u4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_u4(w.p1 + 32 * sb + 16 * g);                          // hmask bytes of this 16-byte group
+        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
+        r.q2 = ld_w4(w.p1 + 32 * sb + 16 * g);                          // hmask bytes of this 16-byte group
         r.s0 = ld_u32(w.p2 + 12 * sb); r.s1 = ld_u32(w.p2 + 12 * sb + 4); r.s2 = ld_u32(w.p2 + 12 * sb + 8);
         r.dm = ld_u16(w.p3 + 2 * sb); return r;
     }
@@ -217,7 +231,7 @@ template <> struct fq_unit<FQ_Q4_K> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
         fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3);
-        r.q = ld_u4(w.p0 + 16 * (size_t) u);
+        r.q = ld_w4(w.p0 + 16 * (size_t) u);
         r.s0 = ld_u32(w.p1 + 12 * sb); r.s1 = ld_u32(w.p1 + 12 * sb + 4); r.s2 = ld_u32(w.p1 + 12 * sb + 8);
         r.dm = ld_u32(w.p2 + 4 * sb); return r;
     }
@@ -238,8 +252,8 @@ template <> struct fq_unit<FQ_Q5_K> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
         fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3); const int g = u & 1;
-        r.q  = ld_u4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_u4(w.p1 + 32 * sb + 16 * g);                          // qh bytes of this group
+        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
+        r.q2 = ld_w4(w.p1 + 32 * sb + 16 * g);                          // qh bytes of this group
         r.s0 = ld_u32(w.p2 + 12 * sb); r.s1 = ld_u32(w.p2 + 12 * sb + 4); r.s2 = ld_u32(w.p2 + 12 * sb + 8);
         r.dm = ld_u32(w.p3 + 4 * sb); return r;
     }
@@ -263,8 +277,8 @@ template <> struct fq_unit<FQ_Q6_K> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
         fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3); const int h = (u >> 2) & 1, g = u & 1;
-        r.q  = ld_u4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_u4(w.p1 + 64 * sb + 32 * h + 16 * g);
+        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
+        r.q2 = ld_w4(w.p1 + 64 * sb + 32 * h + 16 * g);
         r.s0 = ld_u32(w.p2 + 16 * sb + 8 * h); r.s1 = ld_u32(w.p2 + 16 * sb + 8 * h + 4);   // int8 scales[8h .. 8h+7]
         r.dm = ld_u16(w.p3 + 2 * sb); return r;
     }

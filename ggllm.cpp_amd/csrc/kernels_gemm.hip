@@ -45,7 +45,7 @@ template <int TYPE> struct gemm_group;
 template <> struct gemm_group<FQ_Q4_0> {
     static constexpr int SUB = 1;            // ggml.c:1509-1527
     static constexpr bool HAS_MIN = false;
-    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u16(r.p1 + 2 * (size_t) g); }
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u16(r.p1 + 2 * (size_t) g); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
@@ -56,7 +56,7 @@ template <> struct gemm_group<FQ_Q4_0> {
 template <> struct gemm_group<FQ_Q4_1> {
     static constexpr int SUB = 1;            // ggml.c:1529-1548
     static constexpr bool HAS_MIN = true;
-    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); }
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
@@ -68,7 +68,7 @@ template <> struct gemm_group<FQ_Q5_0> {
     static constexpr int SUB = 1;            // ggml.c:1550-1574
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u16(r.p2 + 2 * (size_t) g);
+        w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u16(r.p2 + 2 * (size_t) g);
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t qh = w.s0;
@@ -85,7 +85,7 @@ template <> struct gemm_group<FQ_Q5_1> {
     static constexpr int SUB = 1;            // ggml.c:1576-1601
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_u4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u32(r.p2 + 4 * (size_t) g);
+        w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u32(r.p2 + 4 * (size_t) g);
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t qh = w.s0;
@@ -102,7 +102,7 @@ template <> struct gemm_group<FQ_Q8_0> {
     static constexpr int SUB = 1;            // ggml.c:1603-1619
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_u4(r.p0 + 32 * (size_t) g); w.b = ld_u4(r.p0 + 32 * (size_t) g + 16); w.s0 = ld_u16(r.p1 + 2 * (size_t) g);
+        w.a = ld_w4(r.p0 + 32 * (size_t) g); w.b = ld_w4(r.p0 + 32 * (size_t) g + 16); w.s0 = ld_u16(r.p1 + 2 * (size_t) g);
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         lo = v4i{ (int) w.a.x, (int) w.a.y, (int) w.a.z, (int) w.a.w }; hi = v4i{ (int) w.b.x, (int) w.b.y, (int) w.b.z, (int) w.b.w };
@@ -118,8 +118,8 @@ template <int TYPE> struct gemm_group_k45 {
         const uint8_t * q = r.p0 + 128 * sb + 32 * c;
         if constexpr (TYPE == FQ_Q5_K) {
             // only the 16 bytes of each half that carry this sub-block's 5th bits are kept: bit j of every byte
-            const fq_u4 qa = ld_u4(r.p1 + 32 * sb), qb = ld_u4(r.p1 + 32 * sb + 16);
-            const fq_u4 a = ld_u4(q), b = ld_u4(q + 16);
+            const fq_u4 qa = ld_w4(r.p1 + 32 * sb), qb = ld_w4(r.p1 + 32 * sb + 16);
+            const fq_u4 a = ld_w4(q), b = ld_w4(q + 16);
             const uint32_t xa[4] = { qa.x, qa.y, qa.z, qa.w }, xb[4] = { qb.x, qb.y, qb.z, qb.w };
             uint32_t ha[4], hb[4];
 #pragma unroll
@@ -128,7 +128,7 @@ template <int TYPE> struct gemm_group_k45 {
             w.a = fq_u4{ ((a.x >> sh) & 0x0F0F0F0Fu) | ha[0], ((a.y >> sh) & 0x0F0F0F0Fu) | ha[1], ((a.z >> sh) & 0x0F0F0F0Fu) | ha[2], ((a.w >> sh) & 0x0F0F0F0Fu) | ha[3] };
             w.b = fq_u4{ ((b.x >> sh) & 0x0F0F0F0Fu) | hb[0], ((b.y >> sh) & 0x0F0F0F0Fu) | hb[1], ((b.z >> sh) & 0x0F0F0F0Fu) | hb[2], ((b.w >> sh) & 0x0F0F0F0Fu) | hb[3] };
         } else {
-            w.a = ld_u4(q); w.b = ld_u4(q + 16);
+            w.a = ld_w4(q); w.b = ld_w4(q + 16);
         }
         const uint8_t * scp = (TYPE == FQ_Q4_K ? r.p1 : r.p2) + 12 * sb;
         w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
@@ -158,7 +158,7 @@ template <> struct gemm_group<FQ_Q2_K> {            // k_quants.c:344-375: w = d
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1, j = g & 3;
-        w.a = ld_u4(r.p0 + 64 * sb + 32 * hf); w.b = ld_u4(r.p0 + 64 * sb + 32 * hf + 16);
+        w.a = ld_w4(r.p0 + 64 * sb + 32 * hf); w.b = ld_w4(r.p0 + 64 * sb + 32 * hf + 16);
         w.s0 = ld_u16(r.p1 + 16 * sb + 8 * hf + 2 * j);                // scales[8 hf + 2 j], [.. + 1]
         w.s1 = ld_u32(r.p2 + 4 * sb);
     }
@@ -179,8 +179,8 @@ template <> struct gemm_group<FQ_Q3_K> {            // k_quants.c:472-521: w = d
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1;
-        w.a = ld_u4(r.p0 + 64 * sb + 32 * hf); w.b = ld_u4(r.p0 + 64 * sb + 32 * hf + 16);
-        w.c = ld_u4(r.p1 + 32 * sb); w.d = ld_u4(r.p1 + 32 * sb + 16);                 // hmask bytes 0..15 / 16..31
+        w.a = ld_w4(r.p0 + 64 * sb + 32 * hf); w.b = ld_w4(r.p0 + 64 * sb + 32 * hf + 16);
+        w.c = ld_w4(r.p1 + 32 * sb); w.d = ld_w4(r.p1 + 32 * sb + 16);                 // hmask bytes 0..15 / 16..31
         w.s0 = ld_u32(r.p2 + 12 * sb); w.s1 = ld_u32(r.p2 + 12 * sb + 4); w.s2 = ld_u32(r.p2 + 12 * sb + 8);
         w.s3 = ld_u16(r.p3 + 2 * sb);
     }
@@ -202,8 +202,8 @@ template <> struct gemm_group<FQ_Q6_K> {            // k_quants.c:845-876: w = d
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
         const size_t sb = (size_t)(g >> 3); const int h = (g >> 2) & 1, t = g & 3;
         const uint8_t * ql = r.p0 + 128 * sb + 64 * h + 32 * (t & 1);
-        w.a = ld_u4(ql); w.b = ld_u4(ql + 16);
-        w.c = ld_u4(r.p1 + 64 * sb + 32 * h); w.d = ld_u4(r.p1 + 64 * sb + 32 * h + 16);
+        w.a = ld_w4(ql); w.b = ld_w4(ql + 16);
+        w.c = ld_w4(r.p1 + 64 * sb + 32 * h); w.d = ld_w4(r.p1 + 64 * sb + 32 * h + 16);
         w.s0 = ld_u16(r.p2 + 16 * sb + 8 * h + 2 * t);                 // int8 scales[8 h + 2 t], [.. + 1]
         w.s1 = ld_u16(r.p3 + 2 * sb);
     }
