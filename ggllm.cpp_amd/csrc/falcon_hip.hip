@@ -125,7 +125,8 @@ static fq_weight upload_weight(falcon_hip_model * m, int type, const void * data
         HIP_CHECK(hipMemcpyAsync(stage, (const uint8_t *) data + (size_t) r0 * row_bytes, (size_t) nr * row_bytes, hipMemcpyHostToDevice, c.stream));
         fq_weight sub = w;
         sub.M = nr;
-        for (int p = 0; p < d.nplanes; ++p) sub.plane[p] = w.plane[p] + (size_t) r0 * w.nblk * d.plane[p].bytes;
+        for (int p = 0; p < d.nplanes; ++p)
+            sub.plane[p] = fq_interleaved(type) ? w.plane[0] + (size_t) r0 * w.row_stride : w.plane[p] + (size_t) r0 * w.nblk * d.plane[p].bytes;
         fq_launch_retile(stage, sub, c.stream);
         HIP_CHECK(hipStreamSynchronize(c.stream));
     }

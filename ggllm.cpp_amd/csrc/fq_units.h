@@ -36,18 +36,33 @@ FQ_HD float fq_h2f(uint16_t h) {
 #endif
 }
 
-// pointers to one weight row's planes
-struct fq_wrow { const uint8_t * p0, * p1, * p2, * p3; };
+// pointers to one weight row's planes (interleaved formats: p0 = the row, everything is addressed through fq_at)
+struct fq_wrow { const uint8_t * p0, * p1, * p2, * p3; int64_t nblk; };
 
 template <int TYPE>
 FQ_HD fq_wrow fq_row(const fq_weight & w, int64_t r) {
     const fq_type_desc d = fq_desc(TYPE);
     fq_wrow o;
+    o.nblk = w.nblk;
+    if (fq_interleaved(TYPE)) { o.p0 = w.plane[0] + (size_t) r * w.row_stride; o.p1 = o.p2 = o.p3 = nullptr; return o; }
     o.p0 = w.plane[0] + (size_t) r * w.nblk * d.plane[0].bytes;
     o.p1 = w.plane[1] + (size_t) r * w.nblk * d.plane[1].bytes;
     o.p2 = d.nplanes > 2 ? w.plane[2] + (size_t) r * w.nblk * d.plane[2].bytes : nullptr;
     o.p3 = d.nplanes > 3 ? w.plane[3] + (size_t) r * w.nblk * d.plane[3].bytes : nullptr;
     return o;
+}
+
+// plane P's chunk of block b of an INTERLEAVED row (fq_types.h)
+template <int TYPE, int P>
+FQ_HD const uint8_t * fq_at(const fq_wrow & r, int64_t b) {
+    constexpr int PB0 = (TYPE == FQ_Q8_0) ? 32 : 16;
+    constexpr int CB  = 1024 / PB0;
+    constexpr int TS  = TYPE == FQ_Q4_0 ? 18 : TYPE == FQ_Q4_1 ? 20 : TYPE == FQ_Q5_0 ? 22 : TYPE == FQ_Q5_1 ? 24 : 34;
+    constexpr int PB1 = (TYPE == FQ_Q4_0 || TYPE == FQ_Q8_0) ? 2 : 4;                 // d | d,m | qh | qh | d
+    constexpr int PB2 = TYPE == FQ_Q5_0 ? 2 : 4;                                      // d | d,m (Q5_0 / Q5_1 only)
+    constexpr int PRE = P == 0 ? 0 : (P == 1 ? PB0 : PB0 + PB1);
+    constexpr int PB  = P == 0 ? PB0 : (P == 1 ? PB1 : PB2);
+    return r.p0 + fq_il_offset(CB, TS, PRE, PB, r.nblk, b);
 }
 
 // one activation column as seen by the dot (LDS on the device)
@@ -96,7 +111,7 @@ template <int TYPE> struct fq_unit;
 template <> struct fq_unit<FQ_Q4_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q4_0, 0>(w, u)); r.dm = ld_u16(fq_at<FQ_Q4_0, 1>(w, u)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -109,7 +124,7 @@ template <> struct fq_unit<FQ_Q4_0> {
 template <> struct fq_unit<FQ_Q4_1> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.dm = ld_u32(w.p1 + 4 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q4_1, 0>(w, u)); r.dm = ld_u32(fq_at<FQ_Q4_1, 1>(w, u)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -125,7 +140,7 @@ FQ_HD fq_u4 q5_hi(uint32_t qh, int base) {
 template <> struct fq_unit<FQ_Q5_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u16(w.p2 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q5_0, 0>(w, u)); r.s0 = ld_u32(fq_at<FQ_Q5_0, 1>(w, u)); r.dm = ld_u16(fq_at<FQ_Q5_0, 2>(w, u)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -138,7 +153,7 @@ template <> struct fq_unit<FQ_Q5_0> {
 template <> struct fq_unit<FQ_Q5_1> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 16 * (size_t) u); r.s0 = ld_u32(w.p1 + 4 * (size_t) u); r.dm = ld_u32(w.p2 + 4 * (size_t) u); return r;
+        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q5_1, 0>(w, u)); r.s0 = ld_u32(fq_at<FQ_Q5_1, 1>(w, u)); r.dm = ld_u32(fq_at<FQ_Q5_1, 2>(w, u)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -150,7 +165,7 @@ template <> struct fq_unit<FQ_Q5_1> {
 template <> struct fq_unit<FQ_Q8_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(w.p0 + 32 * (size_t) u); r.q2 = ld_w4(w.p0 + 32 * (size_t) u + 16); r.dm = ld_u16(w.p1 + 2 * (size_t) u); return r;
+        fq_unit_regs r{}; const uint8_t * q = fq_at<FQ_Q8_0, 0>(w, u); r.q = ld_w4(q); r.q2 = ld_w4(q + 16); r.dm = ld_u16(fq_at<FQ_Q8_0, 1>(w, u)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -295,3 +310,35 @@ template <> struct fq_unit<FQ_Q6_K> {
         return (fq_h2f((uint16_t) r.dm) * a.d[sb]) * (float) isum;
     }
 };
+
+// ---- unit (64 c + lane) of a row for the streaming loops: column c is wave-uniform, so for the interleaved formats the
+// column's base and plane offsets are scalar work and only the lane's own offset is per-lane; units beyond the row's end
+// are clamped to its last unit (the callers mask their contribution)
+template <int TYPE>
+FQ_HD fq_unit_regs fq_unit_load_col(const fq_wrow & w, int c, int lane, int units) {
+    if constexpr (TYPE == FQ_Q4_0 || TYPE == FQ_Q4_1 || TYPE == FQ_Q5_0 || TYPE == FQ_Q5_1) {
+        constexpr int TS = TYPE == FQ_Q4_0 ? 18 : TYPE == FQ_Q4_1 ? 20 : TYPE == FQ_Q5_0 ? 22 : 24;
+        constexpr int PB1 = TYPE == FQ_Q4_0 ? 2 : 4;
+        const int last = (units - 1) >> 6;
+        const int cc = c < last ? c : last;
+        const int rem = units - 64 * cc;
+        const int nbc = rem < 64 ? rem : 64;
+        const int jl = lane < nbc ? lane : nbc - 1;
+        const uint8_t * base = w.p0 + (size_t) cc * (64 * TS);
+        fq_unit_regs r{};
+        r.q = ld_w4(base + 16 * jl);
+        const uint8_t * p1 = base + 16 * nbc + PB1 * jl;
+        if constexpr (TYPE == FQ_Q4_0)      r.dm = ld_u16(p1);
+        else if constexpr (TYPE == FQ_Q4_1) r.dm = ld_u32(p1);
+        else {
+            r.s0 = ld_u32(p1);
+            const uint8_t * p2 = base + (16 + PB1) * nbc + (TYPE == FQ_Q5_0 ? 2 : 4) * jl;
+            if constexpr (TYPE == FQ_Q5_0) r.dm = ld_u16(p2); else r.dm = ld_u32(p2);
+        }
+        return r;
+    } else {
+        const int u = 64 * c + lane;
+        return fq_unit<TYPE>::load(w, u < units ? u : units - 1);
+    }
+}
+

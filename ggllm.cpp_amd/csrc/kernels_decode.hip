@@ -47,9 +47,8 @@ __device__ __forceinline__ void rows_issue(const fq_wrow (&rows)[R], int units, 
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = C0; i < C1; ++i) {
-        const int u = i * 64 + lane; const int uc = u < units ? u : units - 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
+        for (int r = 0; r < R; ++r) regs[i][r] = fq_unit_load_col<TYPE>(rows[r], i, lane, units);
     }
 }
 template <int TYPE, int R, int NPRE>
@@ -69,9 +68,8 @@ __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int unit
         fq_unit_regs regs[UNROLL][R];
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) {
-            const int u = u0 + i * 64 + lane; const int uc = u < units ? u : units - 1;
 #pragma unroll
-            for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
+            for (int r = 0; r < R; ++r) regs[i][r] = fq_unit_load_col<TYPE>(rows[r], (u0 >> 6) + i, lane, units);
         }
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) {

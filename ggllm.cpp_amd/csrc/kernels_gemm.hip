@@ -45,7 +45,7 @@ template <int TYPE> struct gemm_group;
 template <> struct gemm_group<FQ_Q4_0> {
     static constexpr int SUB = 1;            // ggml.c:1509-1527
     static constexpr bool HAS_MIN = false;
-    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u16(r.p1 + 2 * (size_t) g); }
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(fq_at<FQ_Q4_0, 0>(r, g)); w.s0 = ld_u16(fq_at<FQ_Q4_0, 1>(r, g)); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
@@ -56,7 +56,7 @@ template <> struct gemm_group<FQ_Q4_0> {
 template <> struct gemm_group<FQ_Q4_1> {
     static constexpr int SUB = 1;            // ggml.c:1529-1548
     static constexpr bool HAS_MIN = true;
-    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); }
+    __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) { w.a = ld_w4(fq_at<FQ_Q4_1, 0>(r, g)); w.s0 = ld_u32(fq_at<FQ_Q4_1, 1>(r, g)); }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t v[4] = { w.a.x, w.a.y, w.a.z, w.a.w };
 #pragma unroll
@@ -68,7 +68,7 @@ template <> struct gemm_group<FQ_Q5_0> {
     static constexpr int SUB = 1;            // ggml.c:1550-1574
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u16(r.p2 + 2 * (size_t) g);
+        w.a = ld_w4(fq_at<FQ_Q5_0, 0>(r, g)); w.s0 = ld_u32(fq_at<FQ_Q5_0, 1>(r, g)); w.s1 = ld_u16(fq_at<FQ_Q5_0, 2>(r, g));
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t qh = w.s0;
@@ -85,7 +85,7 @@ template <> struct gemm_group<FQ_Q5_1> {
     static constexpr int SUB = 1;            // ggml.c:1576-1601
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_w4(r.p0 + 16 * (size_t) g); w.s0 = ld_u32(r.p1 + 4 * (size_t) g); w.s1 = ld_u32(r.p2 + 4 * (size_t) g);
+        w.a = ld_w4(fq_at<FQ_Q5_1, 0>(r, g)); w.s0 = ld_u32(fq_at<FQ_Q5_1, 1>(r, g)); w.s1 = ld_u32(fq_at<FQ_Q5_1, 2>(r, g));
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         const uint32_t qh = w.s0;
@@ -102,7 +102,7 @@ template <> struct gemm_group<FQ_Q8_0> {
     static constexpr int SUB = 1;            // ggml.c:1603-1619
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        w.a = ld_w4(r.p0 + 32 * (size_t) g); w.b = ld_w4(r.p0 + 32 * (size_t) g + 16); w.s0 = ld_u16(r.p1 + 2 * (size_t) g);
+        const uint8_t * q = fq_at<FQ_Q8_0, 0>(r, g); w.a = ld_w4(q); w.b = ld_w4(q + 16); w.s0 = ld_u16(fq_at<FQ_Q8_0, 1>(r, g));
     }
     __device__ static void finish(const gemm_raw & w, int, v4i & lo, v4i & hi, float & sc, float & mn) {
         lo = v4i{ (int) w.a.x, (int) w.a.y, (int) w.a.z, (int) w.a.w }; hi = v4i{ (int) w.b.x, (int) w.b.y, (int) w.b.z, (int) w.b.w };

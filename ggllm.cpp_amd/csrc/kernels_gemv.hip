@@ -69,10 +69,8 @@ __global__ void __launch_bounds__(256) k_gemv(fq_weight w, fq_act act, float * d
             fq_unit_regs regs[UNROLL][R];
 #pragma unroll
             for (int i = 0; i < UNROLL; ++i) {
-                const int u  = u0 + i * 64 + lane;
-                const int uc = u < units ? u : units - 1;
 #pragma unroll
-                for (int r = 0; r < R; ++r) regs[i][r] = fq_unit<TYPE>::load(rows[r], uc);
+                for (int r = 0; r < R; ++r) regs[i][r] = fq_unit_load_col<TYPE>(rows[r], (u0 >> 6) + i, lane, units);
             }
 #pragma unroll
             for (int i = 0; i < UNROLL; ++i) {

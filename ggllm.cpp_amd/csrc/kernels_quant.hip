@@ -1,6 +1,6 @@
 // kernels_quant.hip -- weight re-tiling, dequantize_row, activation quantizers (gfx950).
 //
-//  * k_retile        ggml array-of-blocks -> planes (upload time; replaces the raw cudaMemcpy of
+//  * k_retile        ggml array-of-blocks -> planes / column-interleaved planes (fq_types.h; upload time; replaces the raw cudaMemcpy of
 //                    ggml_cuda_transform_tensor, reference ggml-cuda.cu:3030-3073)
 //  * k_dequant_rows  dequantize_row_q* (ggml.c:1509-1619, k_quants.c:344-876): bit-exact, used by get_rows
 //                    (embedding lookup, ggml.c:11975) and by the parity tests
@@ -18,8 +18,10 @@ __global__ void k_retile(const uint8_t * __restrict__ src, fq_weight w, int type
     const int64_t total = w.M * w.nblk;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
         const uint8_t * s = src + (size_t) i * d.tsize;
+        const int64_t row = i / w.nblk, blk = i - row * w.nblk;
         for (int p = 0; p < d.nplanes; ++p) {
-            uint8_t * o = w.plane[p] + (size_t) i * d.plane[p].bytes;
+            uint8_t * o = fq_interleaved(type) ? w.plane[0] + (size_t) row * w.row_stride + fq_il_offset(d, p, w.nblk, blk)
+                                               : w.plane[p] + (size_t) i * d.plane[p].bytes;
             for (int b = 0; b < d.plane[p].bytes; ++b) o[b] = s[d.plane[p].src_off + b];
         }
     }
@@ -37,24 +39,28 @@ template <int TYPE>
 __device__ __forceinline__ float dequant_elem(const fq_wrow & r, int64_t e) {
     if constexpr (TYPE == FQ_Q4_0) {                                 // ggml.c:1509-1527
         const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
-        const int q = hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15);
-        return (float)(q - 8) * fq_h2f(ld_u16(r.p1 + 2 * b));
+        const int qb = fq_at<FQ_Q4_0, 0>(r, b)[j];
+        const int q = hi ? (qb >> 4) : (qb & 15);
+        return (float)(q - 8) * fq_h2f(ld_u16(fq_at<FQ_Q4_0, 1>(r, b)));
     } else if constexpr (TYPE == FQ_Q4_1) {                          // ggml.c:1529-1548
         const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
-        const int q = hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15);
-        const uint32_t dm = ld_u32(r.p1 + 4 * b);
+        const int qb = fq_at<FQ_Q4_1, 0>(r, b)[j];
+        const int q = hi ? (qb >> 4) : (qb & 15);
+        const uint32_t dm = ld_u32(fq_at<FQ_Q4_1, 1>(r, b));
         return (float) q * fq_h2f((uint16_t) dm) + fq_h2f((uint16_t)(dm >> 16));
     } else if constexpr (TYPE == FQ_Q5_0) {                          // ggml.c:1550-1574
         const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
-        const int q = (hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15)) | (int)(((ld_u32(r.p1 + 4 * b) >> (e & 31)) & 1u) << 4);
-        return (float)(q - 16) * fq_h2f(ld_u16(r.p2 + 2 * b));
+        const int qb = fq_at<FQ_Q5_0, 0>(r, b)[j];
+        const int q = (hi ? (qb >> 4) : (qb & 15)) | (int)(((ld_u32(fq_at<FQ_Q5_0, 1>(r, b)) >> (e & 31)) & 1u) << 4);
+        return (float)(q - 16) * fq_h2f(ld_u16(fq_at<FQ_Q5_0, 2>(r, b)));
     } else if constexpr (TYPE == FQ_Q5_1) {                          // ggml.c:1576-1601
         const int64_t b = e >> 5; const int j = e & 15, hi = (e >> 4) & 1;
-        const int q = (hi ? (r.p0[16 * b + j] >> 4) : (r.p0[16 * b + j] & 15)) | (int)(((ld_u32(r.p1 + 4 * b) >> (e & 31)) & 1u) << 4);
-        const uint32_t dm = ld_u32(r.p2 + 4 * b);
+        const int qb = fq_at<FQ_Q5_1, 0>(r, b)[j];
+        const int q = (hi ? (qb >> 4) : (qb & 15)) | (int)(((ld_u32(fq_at<FQ_Q5_1, 1>(r, b)) >> (e & 31)) & 1u) << 4);
+        const uint32_t dm = ld_u32(fq_at<FQ_Q5_1, 2>(r, b));
         return (float) q * fq_h2f((uint16_t) dm) + fq_h2f((uint16_t)(dm >> 16));
     } else if constexpr (TYPE == FQ_Q8_0) {                          // ggml.c:1603-1619
-        return (float)(int)(int8_t) r.p0[e] * fq_h2f(ld_u16(r.p1 + 2 * (e >> 5)));
+        return (float)(int)(int8_t) fq_at<FQ_Q8_0, 0>(r, e >> 5)[e & 31] * fq_h2f(ld_u16(fq_at<FQ_Q8_0, 1>(r, e >> 5)));
     } else if constexpr (TYPE == FQ_Q2_K) {                          // k_quants.c:344-375
         const int64_t sb = e >> 8; const int i = e & 255;
         const int is = (i >> 7) * 8 + ((i & 127) >> 5) * 2 + ((i & 31) >> 4);

@@ -42,6 +42,29 @@ __global__ void __launch_bounds__(1024) k_chunk(const u32x4 * __restrict__ p, lo
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the decode GEMV's access shape: per wave and step 1 KiB of quants (16 B per lane) + 128 B of fp16 scales (2 B per lane),
+// either from two planes (quants [n][16 B], scales [n][2 B]) or interleaved per 64 units ([1024 B quants | 128 B scales])
+template <bool INTERLEAVED>
+__global__ void __launch_bounds__(768) k_units(const unsigned char * __restrict__ q, const unsigned char * __restrict__ d, long nunits, unsigned * out) {
+    const long nwaves = (long) gridDim.x * (blockDim.x >> 6);
+    const long wave = (long) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long per_wave = (nunits / 64 / nwaves) * 64;                 // units per wave, contiguous
+    unsigned acc = 0;
+    for (long u0 = wave * per_wave; u0 + 256 <= (wave + 1) * per_wave; u0 += 256) {
+        u32x4 v[4]; unsigned short s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long u = u0 + 64 * k + lane;
+            if (INTERLEAVED) { const unsigned char * b = q + (u >> 6) * 1152; v[k] = __builtin_nontemporal_load((const u32x4 *)(b + (u & 63) * 16)); s[k] = *(const unsigned short *)(b + 1024 + (u & 63) * 2); }
+            else             { v[k] = __builtin_nontemporal_load((const u32x4 *)(q + u * 16)); s[k] = *(const unsigned short *)(d + u * 2); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += (v[k].x ^ v[k].y ^ v[k].z ^ v[k].w) + s[k];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 __global__ void k_empty(unsigned * out) { if (out == (unsigned *) 1) out[0] = 0; }
 
 int main(int argc, char ** argv) {
@@ -68,6 +91,20 @@ int main(int argc, char ** argv) {
     timeit("empty kernel", [&](u32x4 *) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, out); });
 #define LIN(U, G, B) { char n[64]; snprintf(n, 64, "linear U=%d grid=%d x %d", U, G, B); timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_linear<U>), dim3(G), dim3(B), 0, st, b, nvec, out); }); }
 #define CHK(U, G, B) { char n[64]; snprintf(n, 64, "chunk  U=%d grid=%d x %d", U, G, B); timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_chunk<U>), dim3(G), dim3(B), 0, st, b, nvec, out); }); }
+    if (argc > 2 && argv[2][0] == 'u') {   // two planes vs interleaved scales
+        const long nunits = bytes / 18;
+        std::vector<unsigned char *> dp(nbuf);
+        for (auto & b : dp) { CK(hipMalloc(&b, nunits * 2 + 4096)); CK(hipMemset(b, 1, nunits * 2 + 4096)); }
+        int bi = 0;
+        for (int g : {239, 256}) {
+            char n[96];
+            snprintf(n, 96, "two planes   grid=%d x 768", g);
+            timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_units<false>), dim3(g), dim3(768), 0, st, (const unsigned char *) b, dp[bi++ % nbuf], nunits, out); });
+            snprintf(n, 96, "interleaved  grid=%d x 768", g);
+            timeit(n, [&](u32x4 * b) { hipLaunchKernelGGL((k_units<true>), dim3(g), dim3(768), 0, st, (const unsigned char *) b, (const unsigned char *) nullptr, nunits * 16 / 18, out); });
+        }
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'm') {   // Infinity-Cache (MALL) residency: the SAME 58 MB again right after a read of it, with
                                            // 0 / 58 / 117 / 234 MB of other traffic in between
         auto pair = [&](const char * name, int between) {

@@ -19,6 +19,16 @@ extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const u
     const int64_t nblk = K / d.blck;
     fq_weight w{}; w.type = type; w.K = K; w.M = 1; w.nblk = nblk;
     std::vector<std::vector<uint8_t>> planes(FQ_MAX_PLANES);
+    std::vector<uint8_t> il;
+    if (fq_interleaved(type)) {                                  // legacy formats: column-interleaved row (fq_types.h)
+        w.row_stride = fq_il_row_stride(d, nblk);
+        il.resize(w.row_stride + 32);
+        uint8_t * base = (uint8_t *)(((uintptr_t) il.data() + 15) & ~(uintptr_t) 15);
+        for (int p = 0; p < d.nplanes; ++p)
+            for (int64_t b = 0; b < nblk; ++b)
+                memcpy(base + fq_il_offset(d, p, nblk, b), row + (size_t) b * d.tsize + d.plane[p].src_off, d.plane[p].bytes);
+        for (int p = 0; p < d.nplanes; ++p) w.plane[p] = base;
+    } else
     for (int p = 0; p < d.nplanes; ++p) {
         planes[p].resize((size_t) nblk * d.plane[p].bytes + 16);
         for (int64_t b = 0; b < nblk; ++b)
