@@ -126,7 +126,7 @@ static fq_weight upload_weight(falcon_hip_model * m, int type, const void * data
         fq_weight sub = w;
         sub.M = nr;
         for (int p = 0; p < d.nplanes; ++p)
-            sub.plane[p] = fq_interleaved(type) ? w.plane[0] + (size_t) r0 * w.row_stride : w.plane[p] + (size_t) r0 * w.nblk * d.plane[p].bytes;
+            sub.plane[p] = w.plane[0] + (size_t) r0 * w.row_stride;
         fq_launch_retile(stage, sub, c.stream);
         HIP_CHECK(hipStreamSynchronize(c.stream));
     }

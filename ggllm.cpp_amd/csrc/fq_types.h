@@ -5,12 +5,13 @@
 // arrays). Total bytes are unchanged (18 B / 32 weights for Q4_0 ...); what changes is that the 16-byte quant
 // groups become 16-byte aligned so that one lane = one `global_load_dwordx4`, and a wave reads 1 KiB of
 // consecutive HBM per instruction.
-//   k-quants: every plane is [row][block][bytes_per_block] contiguous (side data is per 256-element super-block).
-//   legacy formats (side data per 32-element block): the planes are INTERLEAVED per "column" of 64 blocks (32 for
-//   Q8_0) inside a row: [64 x 16 B quants | 64 x 2 B scales | ...], so that the 128-byte scale read of a wave follows
-//   its 1 KiB quant read in the same DRAM page instead of opening another one in a separate plane (a pure-read
-//   kernel of this access shape is 12 % faster with the scales interleaved, scripts/microbench/mb_stream.hip). Rows
-//   are padded to a multiple of 16 bytes; a last, partial column packs its planes the same way.
+//   The planes are INTERLEAVED per "column" inside a row: a column = the blocks whose plane-0 bytes add up to 1 KiB
+//   (64 blocks of Q4_0 .. Q5_1, 32 of Q8_0, 16 super-blocks of Q2_K / Q3_K, 8 of Q4_K / Q5_K / Q6_K), stored as
+//   [plane 0 of all its blocks | plane 1 of all its blocks | ...], e.g. Q4_0: [64 x 16 B quants | 64 x 2 B scales].
+//   The side data a wave needs then follows its 1 KiB quant read in the same DRAM page instead of opening another page
+//   in a separate plane (a pure-read kernel of this access shape is 12 % faster with the scales interleaved,
+//   scripts/microbench/mb_stream.hip). Rows are padded to a multiple of 16 bytes; a last, partial column packs its
+//   planes the same way.
 //
 //   type   plane0 (quants)   plane1          plane2         plane3      ggml block (bytes @offset)
 //   Q4_0   qs 16             d f16 2                                     d@0 qs@2            (ggml.c:879-883)
@@ -53,7 +54,7 @@ struct fq_type_desc {
     int unit_elems;                   // weights covered by one "unit" = 16-byte quant group of plane0 (32 B for Q8_0)
 };
 
-FQ_HD fq_type_desc fq_desc(int type) {
+constexpr FQ_HD fq_type_desc fq_desc(int type) {
     switch (type) {
         case FQ_Q4_0: return { 32,  18, FQ_Q8_0, 2, {{2, 16}, {0, 2}, {0, 0}, {0, 0}}, 32 };
         case FQ_Q4_1: return { 32,  20, FQ_Q8_1, 2, {{4, 16}, {0, 4}, {0, 0}, {0, 0}}, 32 };
@@ -79,8 +80,8 @@ struct fq_weight {
     int     type;
     int64_t K, M;
     int64_t nblk;                     // ggml blocks per row = K / blck
-    uint8_t * plane[FQ_MAX_PLANES];   // device pointers, plane p is [M][nblk][plane[p].bytes]; interleaved formats: plane[0] = base
-    size_t  row_stride;               // interleaved formats: bytes from one row to the next
+    uint8_t * plane[FQ_MAX_PLANES];   // plane[0] = device pointer of row 0 (the other entries repeat it)
+    size_t  row_stride;               // bytes from one row to the next
     size_t  bytes;                    // total device bytes = M * nblk * tsize  (== ggml_nbytes)
 };
 
@@ -106,8 +107,8 @@ FQ_HD size_t fq_act_col_bytes(int act_type, int64_t K) {
     return (fq_act_aux_off(act_type, K) + fq_act_aux_elems(act_type, K) * fq_act_aux_esize(act_type) + 15) & ~(size_t) 15;
 }
 
-// ---- interleaved layout of the legacy formats
-FQ_HD bool fq_interleaved(int type) { return type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0; }
+// ---- interleaved layout (header comment)
+constexpr FQ_HD int fq_plane_pre(const fq_type_desc & d, int p) { int pre = 0; for (int q = 0; q < p; ++q) pre += d.plane[q].bytes; return pre; }
 FQ_HD size_t fq_il_row_stride(const fq_type_desc & d, int64_t nblk) { return ((size_t) nblk * (size_t) d.tsize + 15) & ~(size_t) 15; }
 // byte offset, inside its row, of plane p's chunk of block b. cb = blocks per column (1024 / plane0 bytes), pre = bytes of
 // the planes before p in a block, pb = bytes of plane p in a block
@@ -118,12 +119,6 @@ FQ_HD size_t fq_il_offset(int cb, int tsize, int pre, int pb, int64_t nblk, int6
     return (size_t) col * (size_t)(cb * tsize) + (size_t) nbc * (size_t) pre + (size_t) j * (size_t) pb;
 }
 FQ_HD size_t fq_il_offset(const fq_type_desc & d, int p, int64_t nblk, int64_t b) {
-    int pre = 0;
-    for (int q = 0; q < p; ++q) pre += d.plane[q].bytes;
-    return fq_il_offset(1024 / d.plane[0].bytes, d.tsize, pre, d.plane[p].bytes, nblk, b);
+    return fq_il_offset(1024 / d.plane[0].bytes, d.tsize, fq_plane_pre(d, p), d.plane[p].bytes, nblk, b);
 }
 
-// AoS -> plane re-tiling: byte `i` of plane `p` of block (row, blk) comes from ggml byte src_off + i of that block.
-FQ_HD size_t fq_plane_offset(const fq_type_desc & d, int p, int64_t nblk, int64_t row, int64_t blk) {
-    return ((size_t) row * (size_t) nblk + (size_t) blk) * (size_t) d.plane[p].bytes;
-}

@@ -36,33 +36,39 @@ FQ_HD float fq_h2f(uint16_t h) {
 #endif
 }
 
-// pointers to one weight row's planes (interleaved formats: p0 = the row, everything is addressed through fq_at)
-struct fq_wrow { const uint8_t * p0, * p1, * p2, * p3; int64_t nblk; };
+// one weight row (fq_types.h: planes interleaved per column)
+struct fq_wrow { const uint8_t * p0; int64_t nblk; };
 
 template <int TYPE>
-FQ_HD fq_wrow fq_row(const fq_weight & w, int64_t r) {
-    const fq_type_desc d = fq_desc(TYPE);
-    fq_wrow o;
-    o.nblk = w.nblk;
-    if (fq_interleaved(TYPE)) { o.p0 = w.plane[0] + (size_t) r * w.row_stride; o.p1 = o.p2 = o.p3 = nullptr; return o; }
-    o.p0 = w.plane[0] + (size_t) r * w.nblk * d.plane[0].bytes;
-    o.p1 = w.plane[1] + (size_t) r * w.nblk * d.plane[1].bytes;
-    o.p2 = d.nplanes > 2 ? w.plane[2] + (size_t) r * w.nblk * d.plane[2].bytes : nullptr;
-    o.p3 = d.nplanes > 3 ? w.plane[3] + (size_t) r * w.nblk * d.plane[3].bytes : nullptr;
-    return o;
-}
+FQ_HD fq_wrow fq_row(const fq_weight & w, int64_t r) { return { w.plane[0] + (size_t) r * w.row_stride, w.nblk }; }
 
-// plane P's chunk of block b of an INTERLEAVED row (fq_types.h)
+// layout constants of a format: unit = 16 bytes of plane 0 (32 for Q8_0)
+template <int TYPE> struct fq_lay {
+    static constexpr int UB  = (TYPE == FQ_Q8_0) ? 32 : 16;
+    static constexpr int PB0 = fq_desc(TYPE).plane[0].bytes;
+    static constexpr int TS  = fq_desc(TYPE).tsize;
+    static constexpr int CB  = 1024 / PB0;                 // blocks per column
+    static constexpr int UPS = PB0 / UB;                   // units per block
+    static constexpr int UPC = CB * UPS;                   // units per column: 64 (Q8_0: 32)
+};
+// one column of a row: nbc blocks (CB, fewer in the row's last column), planes packed back to back
+struct fq_col { const uint8_t * base; int nbc; };
+template <int TYPE>
+FQ_HD fq_col fq_col_at(const fq_wrow & r, int64_t c) {
+    const int64_t rem = r.nblk - c * fq_lay<TYPE>::CB;
+    return { r.p0 + (size_t) c * (size_t)(fq_lay<TYPE>::CB * fq_lay<TYPE>::TS), (int)(rem < fq_lay<TYPE>::CB ? rem : fq_lay<TYPE>::CB) };
+}
+// plane P's chunk of block bj of the column
+template <int TYPE, int P>
+FQ_HD const uint8_t * fq_cp(const fq_col & k, int bj) {
+    constexpr int PRE = fq_plane_pre(fq_desc(TYPE), P), PB = fq_desc(TYPE).plane[P].bytes;
+    return k.base + k.nbc * PRE + bj * PB;
+}
+// plane P's chunk of block b of the row
 template <int TYPE, int P>
 FQ_HD const uint8_t * fq_at(const fq_wrow & r, int64_t b) {
-    constexpr int PB0 = (TYPE == FQ_Q8_0) ? 32 : 16;
-    constexpr int CB  = 1024 / PB0;
-    constexpr int TS  = TYPE == FQ_Q4_0 ? 18 : TYPE == FQ_Q4_1 ? 20 : TYPE == FQ_Q5_0 ? 22 : TYPE == FQ_Q5_1 ? 24 : 34;
-    constexpr int PB1 = (TYPE == FQ_Q4_0 || TYPE == FQ_Q8_0) ? 2 : 4;                 // d | d,m | qh | qh | d
-    constexpr int PB2 = TYPE == FQ_Q5_0 ? 2 : 4;                                      // d | d,m (Q5_0 / Q5_1 only)
-    constexpr int PRE = P == 0 ? 0 : (P == 1 ? PB0 : PB0 + PB1);
-    constexpr int PB  = P == 0 ? PB0 : (P == 1 ? PB1 : PB2);
-    return r.p0 + fq_il_offset(CB, TS, PRE, PB, r.nblk, b);
+    const int64_t c = b / fq_lay<TYPE>::CB;
+    return fq_cp<TYPE, P>(fq_col_at<TYPE>(r, c), (int)(b - c * fq_lay<TYPE>::CB));
 }
 
 // one activation column as seen by the dot (LDS on the device)
@@ -110,8 +116,8 @@ template <int TYPE> struct fq_unit;
 // ---------------------------------------------------------------- Q4_0  (ggml.c:2591-2609)
 template <> struct fq_unit<FQ_Q4_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q4_0, 0>(w, u)); r.dm = ld_u16(fq_at<FQ_Q4_0, 1>(w, u)); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_0, 0>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q4_0, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -123,8 +129,8 @@ template <> struct fq_unit<FQ_Q4_0> {
 // ---------------------------------------------------------------- Q4_1  (ggml.c:2716-2735)
 template <> struct fq_unit<FQ_Q4_1> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q4_1, 0>(w, u)); r.dm = ld_u32(fq_at<FQ_Q4_1, 1>(w, u)); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_1, 0>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q4_1, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -139,8 +145,8 @@ FQ_HD fq_u4 q5_hi(uint32_t qh, int base) {
 // ---------------------------------------------------------------- Q5_0  (ggml.c:2951-2972)
 template <> struct fq_unit<FQ_Q5_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q5_0, 0>(w, u)); r.s0 = ld_u32(fq_at<FQ_Q5_0, 1>(w, u)); r.dm = ld_u16(fq_at<FQ_Q5_0, 2>(w, u)); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_0, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_0, 1>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q5_0, 2>(k, ju)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -152,8 +158,8 @@ template <> struct fq_unit<FQ_Q5_0> {
 // ---------------------------------------------------------------- Q5_1  (ggml.c:3207-3228)
 template <> struct fq_unit<FQ_Q5_1> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_at<FQ_Q5_1, 0>(w, u)); r.s0 = ld_u32(fq_at<FQ_Q5_1, 1>(w, u)); r.dm = ld_u32(fq_at<FQ_Q5_1, 2>(w, u)); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_1, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_1, 1>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q5_1, 2>(k, ju)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -164,8 +170,8 @@ template <> struct fq_unit<FQ_Q5_1> {
 // ---------------------------------------------------------------- Q8_0  (ggml.c:3317-3329)  unit = whole block (2 x 16 B)
 template <> struct fq_unit<FQ_Q8_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const uint8_t * q = fq_at<FQ_Q8_0, 0>(w, u); r.q = ld_w4(q); r.q2 = ld_w4(q + 16); r.dm = ld_u16(fq_at<FQ_Q8_0, 1>(w, u)); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; const uint8_t * q = fq_cp<FQ_Q8_0, 0>(k, ju); r.q = ld_w4(q); r.q2 = ld_w4(q + 16); r.dm = ld_u16(fq_cp<FQ_Q8_0, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int8_t * x = a.qs + 32 * (size_t) u;
@@ -177,11 +183,12 @@ template <> struct fq_unit<FQ_Q8_0> {
 // unit u: super-block sb=u>>2, 128-half hf=(u>>1)&1, 16-byte group g=u&1; covers elements 128hf+32j+16g+l, j=0..3
 template <> struct fq_unit<FQ_Q2_K> {
     static constexpr int ELEMS = 64;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const size_t sb = (size_t)(u >> 2); const int hf = (u >> 1) & 1;
-        r.q = ld_w4(w.p0 + 16 * (size_t) u);
-        r.s0 = ld_u32(w.p1 + 16 * sb + 8 * hf); r.s1 = ld_u32(w.p1 + 16 * sb + 8 * hf + 4);
-        r.dm = ld_u32(w.p2 + 4 * sb); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // ju: unit inside the column (4 per super-block)
+        fq_unit_regs r{}; const int sb = ju >> 2, hf = (ju >> 1) & 1;
+        r.q = ld_w4(fq_cp<FQ_Q2_K, 0>(k, sb) + 16 * (ju & 3));
+        const uint8_t * sc = fq_cp<FQ_Q2_K, 1>(k, sb) + 8 * hf;
+        r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4);
+        r.dm = ld_u32(fq_cp<FQ_Q2_K, 2>(k, sb)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int sb = u >> 2, hf = (u >> 1) & 1, g = u & 1;
@@ -210,12 +217,13 @@ FQ_HD int q3_scale(uint32_t s0, uint32_t s1, uint32_t s2, int is) {
 // ---------------------------------------------------------------- Q3_K  (k_quants.c:1684-1746)
 template <> struct fq_unit<FQ_Q3_K> {
     static constexpr int ELEMS = 64;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const size_t sb = (size_t)(u >> 2); const int g = u & 1;
-        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_w4(w.p1 + 32 * sb + 16 * g);                          // hmask bytes of this 16-byte group
-        r.s0 = ld_u32(w.p2 + 12 * sb); r.s1 = ld_u32(w.p2 + 12 * sb + 4); r.s2 = ld_u32(w.p2 + 12 * sb + 8);
-        r.dm = ld_u16(w.p3 + 2 * sb); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; const int sb = ju >> 2, g = ju & 1;
+        r.q  = ld_w4(fq_cp<FQ_Q3_K, 0>(k, sb) + 16 * (ju & 3));
+        r.q2 = ld_w4(fq_cp<FQ_Q3_K, 1>(k, sb) + 16 * g);                // hmask bytes of this 16-byte group
+        const uint8_t * sc = fq_cp<FQ_Q3_K, 2>(k, sb);
+        r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
+        r.dm = ld_u16(fq_cp<FQ_Q3_K, 3>(k, sb)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int sb = u >> 2, hf = (u >> 1) & 1, g = u & 1;
@@ -244,11 +252,12 @@ FQ_HD void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j, int & sc, 
 // unit u: sb=u>>3, 64-chunk c=(u>>1)&3, group g=u&1; low nibbles -> elements 64c+16g+l (sub-block 2c), high -> +32 (2c+1)
 template <> struct fq_unit<FQ_Q4_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3);
-        r.q = ld_w4(w.p0 + 16 * (size_t) u);
-        r.s0 = ld_u32(w.p1 + 12 * sb); r.s1 = ld_u32(w.p1 + 12 * sb + 4); r.s2 = ld_u32(w.p1 + 12 * sb + 8);
-        r.dm = ld_u32(w.p2 + 4 * sb); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // 8 units per super-block
+        fq_unit_regs r{}; const int sb = ju >> 3;
+        r.q = ld_w4(fq_cp<FQ_Q4_K, 0>(k, sb) + 16 * (ju & 7));
+        const uint8_t * sc = fq_cp<FQ_Q4_K, 1>(k, sb);
+        r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
+        r.dm = ld_u32(fq_cp<FQ_Q4_K, 2>(k, sb)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int sb = u >> 3, c = (u >> 1) & 3, g = u & 1;
@@ -265,12 +274,13 @@ template <> struct fq_unit<FQ_Q4_K> {
 // ---------------------------------------------------------------- Q5_K  (k_quants.c:2340-2400)
 template <> struct fq_unit<FQ_Q5_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3); const int g = u & 1;
-        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_w4(w.p1 + 32 * sb + 16 * g);                          // qh bytes of this group
-        r.s0 = ld_u32(w.p2 + 12 * sb); r.s1 = ld_u32(w.p2 + 12 * sb + 4); r.s2 = ld_u32(w.p2 + 12 * sb + 8);
-        r.dm = ld_u32(w.p3 + 4 * sb); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; const int sb = ju >> 3, g = ju & 1;
+        r.q  = ld_w4(fq_cp<FQ_Q5_K, 0>(k, sb) + 16 * (ju & 7));
+        r.q2 = ld_w4(fq_cp<FQ_Q5_K, 1>(k, sb) + 16 * g);                // qh bytes of this group
+        const uint8_t * sc = fq_cp<FQ_Q5_K, 2>(k, sb);
+        r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
+        r.dm = ld_u32(fq_cp<FQ_Q5_K, 3>(k, sb)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int sb = u >> 3, c = (u >> 1) & 3, g = u & 1;
@@ -290,12 +300,13 @@ template <> struct fq_unit<FQ_Q5_K> {
 // unit u: sb=u>>3, half h=(u>>2)&1, t01=(u>>1)&1, g=u&1; low nibbles -> quarter t01, high nibbles -> quarter t01+2
 template <> struct fq_unit<FQ_Q6_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load(const fq_wrow & w, int u) {
-        fq_unit_regs r{}; const size_t sb = (size_t)(u >> 3); const int h = (u >> 2) & 1, g = u & 1;
-        r.q  = ld_w4(w.p0 + 16 * (size_t) u);
-        r.q2 = ld_w4(w.p1 + 64 * sb + 32 * h + 16 * g);
-        r.s0 = ld_u32(w.p2 + 16 * sb + 8 * h); r.s1 = ld_u32(w.p2 + 16 * sb + 8 * h + 4);   // int8 scales[8h .. 8h+7]
-        r.dm = ld_u16(w.p3 + 2 * sb); return r;
+    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; const int sb = ju >> 3, h = (ju >> 2) & 1, g = ju & 1;
+        r.q  = ld_w4(fq_cp<FQ_Q6_K, 0>(k, sb) + 16 * (ju & 7));
+        r.q2 = ld_w4(fq_cp<FQ_Q6_K, 1>(k, sb) + 32 * h + 16 * g);
+        const uint8_t * sc = fq_cp<FQ_Q6_K, 2>(k, sb) + 8 * h;
+        r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4);                       // int8 scales[8h .. 8h+7]
+        r.dm = ld_u16(fq_cp<FQ_Q6_K, 3>(k, sb)); return r;
     }
     FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
         const int sb = u >> 3, h = (u >> 2) & 1, t = (u >> 1) & 1, g = u & 1;
@@ -311,34 +322,27 @@ template <> struct fq_unit<FQ_Q6_K> {
     }
 };
 
-// ---- unit (64 c + lane) of a row for the streaming loops: column c is wave-uniform, so for the interleaved formats the
-// column's base and plane offsets are scalar work and only the lane's own offset is per-lane; units beyond the row's end
-// are clamped to its last unit (the callers mask their contribution)
+// ---- generic entry points over load_at
+// unit u of a row
+template <int TYPE>
+FQ_HD fq_unit_regs fq_unit_load(const fq_wrow & w, int u) {
+    constexpr int UPC = fq_lay<TYPE>::UPC;
+    const int c = u / UPC;
+    return fq_unit<TYPE>::load_at(fq_col_at<TYPE>(w, c), u - c * UPC);
+}
+// unit (64 c + lane) of a row for the streaming loops: c is wave-uniform, so the column's base and the plane offsets are
+// scalar work and only the lane's own offset is per-lane; units beyond the row's end are clamped to its last unit (the
+// callers mask their contribution)
 template <int TYPE>
 FQ_HD fq_unit_regs fq_unit_load_col(const fq_wrow & w, int c, int lane, int units) {
-    if constexpr (TYPE == FQ_Q4_0 || TYPE == FQ_Q4_1 || TYPE == FQ_Q5_0 || TYPE == FQ_Q5_1) {
-        constexpr int TS = TYPE == FQ_Q4_0 ? 18 : TYPE == FQ_Q4_1 ? 20 : TYPE == FQ_Q5_0 ? 22 : 24;
-        constexpr int PB1 = TYPE == FQ_Q4_0 ? 2 : 4;
+    if constexpr (fq_lay<TYPE>::UPC == 64) {
         const int last = (units - 1) >> 6;
-        const int cc = c < last ? c : last;
-        const int rem = units - 64 * cc;
-        const int nbc = rem < 64 ? rem : 64;
-        const int jl = lane < nbc ? lane : nbc - 1;
-        const uint8_t * base = w.p0 + (size_t) cc * (64 * TS);
-        fq_unit_regs r{};
-        r.q = ld_w4(base + 16 * jl);
-        const uint8_t * p1 = base + 16 * nbc + PB1 * jl;
-        if constexpr (TYPE == FQ_Q4_0)      r.dm = ld_u16(p1);
-        else if constexpr (TYPE == FQ_Q4_1) r.dm = ld_u32(p1);
-        else {
-            r.s0 = ld_u32(p1);
-            const uint8_t * p2 = base + (16 + PB1) * nbc + (TYPE == FQ_Q5_0 ? 2 : 4) * jl;
-            if constexpr (TYPE == FQ_Q5_0) r.dm = ld_u16(p2); else r.dm = ld_u32(p2);
-        }
-        return r;
-    } else {
+        const fq_col k = fq_col_at<TYPE>(w, c < last ? c : last);
+        const int nu = k.nbc * fq_lay<TYPE>::UPS;
+        return fq_unit<TYPE>::load_at(k, lane < nu ? lane : nu - 1);
+    } else {                                                            // Q8_0: 32 units per column
         const int u = 64 * c + lane;
-        return fq_unit<TYPE>::load(w, u < units ? u : units - 1);
+        return fq_unit_load<TYPE>(w, u < units ? u : units - 1);
     }
 }
 

@@ -127,16 +127,11 @@ fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out) {
     fq_weight w{};
     w.type = type; w.K = K; w.M = M; w.nblk = K / d.blck;
     w.bytes = (size_t) M * w.nblk * d.tsize;
-    size_t off[FQ_MAX_PLANES] = {0, 0, 0, 0}, total = 0;
-    if (fq_interleaved(type)) {                                // one slab, rows of row_stride bytes (fq_types.h)
-        w.row_stride = fq_il_row_stride(d, w.nblk);
-        total = (size_t) M * w.row_stride;
-    } else {
-        for (int p = 0; p < d.nplanes; ++p) { off[p] = total; total += ((size_t) M * w.nblk * d.plane[p].bytes + 255) & ~(size_t) 255; }
-    }
+    w.row_stride = fq_il_row_stride(d, w.nblk);               // one slab, rows of row_stride bytes (fq_types.h)
+    const size_t total = (size_t) M * w.row_stride;
     uint8_t * slab = nullptr;
     HIP_CHECK(hipMalloc((void **) &slab, total + 256));        // +256: clamped tail loads never leave the allocation
-    for (int p = 0; p < d.nplanes; ++p) w.plane[p] = fq_interleaved(type) ? slab : slab + off[p];
+    for (int p = 0; p < d.nplanes; ++p) w.plane[p] = slab;
     *slab_out = slab;
     return w;
 }
@@ -159,7 +154,7 @@ extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_
         fq_weight sub = hw->w;
         sub.M = nr;
         for (int p = 0; p < d.nplanes; ++p)
-            sub.plane[p] = fq_interleaved(type) ? hw->w.plane[0] + (size_t) r0 * hw->w.row_stride : hw->w.plane[p] + (size_t) r0 * hw->w.nblk * d.plane[p].bytes;
+            sub.plane[p] = hw->w.plane[0] + (size_t) r0 * hw->w.row_stride;
         fq_launch_retile(stage, sub, c.stream);
         HIP_CHECK(hipStreamSynchronize(c.stream));
     }

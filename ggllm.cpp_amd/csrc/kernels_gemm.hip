@@ -114,11 +114,13 @@ template <int TYPE> struct gemm_group_k45 {
     static constexpr int SUB = 1;
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        const size_t sb = (size_t)(g >> 3); const int j = g & 7, c = j >> 1;
-        const uint8_t * q = r.p0 + 128 * sb + 32 * c;
+        const int64_t sb = g >> 3; const int j = g & 7, c = j >> 1;
+        const uint8_t * q = fq_at<TYPE, 0>(r, sb) + 32 * c;
+        constexpr int PSC = (TYPE == FQ_Q4_K) ? 1 : 2;                  // plane of the 12 packed scale bytes; d/dmin follows
         if constexpr (TYPE == FQ_Q5_K) {
             // only the 16 bytes of each half that carry this sub-block's 5th bits are kept: bit j of every byte
-            const fq_u4 qa = ld_w4(r.p1 + 32 * sb), qb = ld_w4(r.p1 + 32 * sb + 16);
+            const uint8_t * qh = fq_at<TYPE, 1>(r, sb);
+            const fq_u4 qa = ld_w4(qh), qb = ld_w4(qh + 16);
             const fq_u4 a = ld_w4(q), b = ld_w4(q + 16);
             const uint32_t xa[4] = { qa.x, qa.y, qa.z, qa.w }, xb[4] = { qb.x, qb.y, qb.z, qb.w };
             uint32_t ha[4], hb[4];
@@ -130,9 +132,9 @@ template <int TYPE> struct gemm_group_k45 {
         } else {
             w.a = ld_w4(q); w.b = ld_w4(q + 16);
         }
-        const uint8_t * scp = (TYPE == FQ_Q4_K ? r.p1 : r.p2) + 12 * sb;
+        const uint8_t * scp = fq_at<TYPE, PSC>(r, sb);
         w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
-        w.s3 = ld_u32((TYPE == FQ_Q4_K ? r.p2 : r.p3) + 4 * sb);
+        w.s3 = ld_u32(fq_at<TYPE, PSC + 1>(r, sb));
     }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
         const int j = g & 7;
@@ -157,10 +159,11 @@ template <> struct gemm_group<FQ_Q2_K> {            // k_quants.c:344-375: w = d
     static constexpr int SUB = 2;
     static constexpr bool HAS_MIN = true;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1, j = g & 3;
-        w.a = ld_w4(r.p0 + 64 * sb + 32 * hf); w.b = ld_w4(r.p0 + 64 * sb + 32 * hf + 16);
-        w.s0 = ld_u16(r.p1 + 16 * sb + 8 * hf + 2 * j);                // scales[8 hf + 2 j], [.. + 1]
-        w.s1 = ld_u32(r.p2 + 4 * sb);
+        const int64_t sb = g >> 3; const int hf = (g >> 2) & 1, j = g & 3;
+        const uint8_t * q = fq_at<FQ_Q2_K, 0>(r, sb) + 32 * hf;
+        w.a = ld_w4(q); w.b = ld_w4(q + 16);
+        w.s0 = ld_u16(fq_at<FQ_Q2_K, 1>(r, sb) + 8 * hf + 2 * j);      // scales[8 hf + 2 j], [.. + 1]
+        w.s1 = ld_u32(fq_at<FQ_Q2_K, 2>(r, sb));
     }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int sh = 2 * (g & 3);
@@ -178,11 +181,12 @@ template <> struct gemm_group<FQ_Q3_K> {            // k_quants.c:472-521: w = d
     static constexpr int SUB = 2;
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        const size_t sb = (size_t)(g >> 3); const int hf = (g >> 2) & 1;
-        w.a = ld_w4(r.p0 + 64 * sb + 32 * hf); w.b = ld_w4(r.p0 + 64 * sb + 32 * hf + 16);
-        w.c = ld_w4(r.p1 + 32 * sb); w.d = ld_w4(r.p1 + 32 * sb + 16);                 // hmask bytes 0..15 / 16..31
-        w.s0 = ld_u32(r.p2 + 12 * sb); w.s1 = ld_u32(r.p2 + 12 * sb + 4); w.s2 = ld_u32(r.p2 + 12 * sb + 8);
-        w.s3 = ld_u16(r.p3 + 2 * sb);
+        const int64_t sb = g >> 3; const int hf = (g >> 2) & 1;
+        const uint8_t * q = fq_at<FQ_Q3_K, 0>(r, sb) + 32 * hf, * hm = fq_at<FQ_Q3_K, 1>(r, sb), * scp = fq_at<FQ_Q3_K, 2>(r, sb);
+        w.a = ld_w4(q); w.b = ld_w4(q + 16);
+        w.c = ld_w4(hm); w.d = ld_w4(hm + 16);                          // hmask bytes 0..15 / 16..31
+        w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
+        w.s3 = ld_u16(fq_at<FQ_Q3_K, 3>(r, sb));
     }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int hf = (g >> 2) & 1, j = g & 3, sh = 2 * j, hb = 4 * hf + j;
@@ -200,12 +204,12 @@ template <> struct gemm_group<FQ_Q6_K> {            // k_quants.c:845-876: w = d
     static constexpr int SUB = 2;
     static constexpr bool HAS_MIN = false;
     __device__ static void load(const fq_wrow & r, int g, gemm_raw & w) {
-        const size_t sb = (size_t)(g >> 3); const int h = (g >> 2) & 1, t = g & 3;
-        const uint8_t * ql = r.p0 + 128 * sb + 64 * h + 32 * (t & 1);
+        const int64_t sb = g >> 3; const int h = (g >> 2) & 1, t = g & 3;
+        const uint8_t * ql = fq_at<FQ_Q6_K, 0>(r, sb) + 64 * h + 32 * (t & 1), * qh = fq_at<FQ_Q6_K, 1>(r, sb) + 32 * h;
         w.a = ld_w4(ql); w.b = ld_w4(ql + 16);
-        w.c = ld_w4(r.p1 + 64 * sb + 32 * h); w.d = ld_w4(r.p1 + 64 * sb + 32 * h + 16);
-        w.s0 = ld_u16(r.p2 + 16 * sb + 8 * h + 2 * t);                 // int8 scales[8 h + 2 t], [.. + 1]
-        w.s1 = ld_u16(r.p3 + 2 * sb);
+        w.c = ld_w4(qh); w.d = ld_w4(qh + 16);
+        w.s0 = ld_u16(fq_at<FQ_Q6_K, 2>(r, sb) + 8 * h + 2 * t);       // int8 scales[8 h + 2 t], [.. + 1]
+        w.s1 = ld_u16(fq_at<FQ_Q6_K, 3>(r, sb));
     }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int t = g & 3, nsh = (t >> 1) ? 4 : 0, hsh = 2 * t;

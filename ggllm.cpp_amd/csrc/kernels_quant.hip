@@ -1,6 +1,6 @@
 // kernels_quant.hip -- weight re-tiling, dequantize_row, activation quantizers (gfx950).
 //
-//  * k_retile        ggml array-of-blocks -> planes / column-interleaved planes (fq_types.h; upload time; replaces the raw cudaMemcpy of
+//  * k_retile        ggml array-of-blocks -> column-interleaved planes (fq_types.h; upload time; replaces the raw cudaMemcpy of
 //                    ggml_cuda_transform_tensor, reference ggml-cuda.cu:3030-3073)
 //  * k_dequant_rows  dequantize_row_q* (ggml.c:1509-1619, k_quants.c:344-876): bit-exact, used by get_rows
 //                    (embedding lookup, ggml.c:11975) and by the parity tests
@@ -20,8 +20,7 @@ __global__ void k_retile(const uint8_t * __restrict__ src, fq_weight w, int type
         const uint8_t * s = src + (size_t) i * d.tsize;
         const int64_t row = i / w.nblk, blk = i - row * w.nblk;
         for (int p = 0; p < d.nplanes; ++p) {
-            uint8_t * o = fq_interleaved(type) ? w.plane[0] + (size_t) row * w.row_stride + fq_il_offset(d, p, w.nblk, blk)
-                                               : w.plane[p] + (size_t) i * d.plane[p].bytes;
+            uint8_t * o = w.plane[0] + (size_t) row * w.row_stride + fq_il_offset(d, p, w.nblk, blk);
             for (int b = 0; b < d.plane[p].bytes; ++b) o[b] = s[d.plane[p].src_off + b];
         }
     }
@@ -64,39 +63,41 @@ __device__ __forceinline__ float dequant_elem(const fq_wrow & r, int64_t e) {
     } else if constexpr (TYPE == FQ_Q2_K) {                          // k_quants.c:344-375
         const int64_t sb = e >> 8; const int i = e & 255;
         const int is = (i >> 7) * 8 + ((i & 127) >> 5) * 2 + ((i & 31) >> 4);
-        const int sc = r.p1[16 * sb + is];
-        const int q  = (r.p0[64 * sb + (i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
-        const uint32_t dm = ld_u32(r.p2 + 4 * sb);
+        const int sc = fq_at<FQ_Q2_K, 1>(r, sb)[is];
+        const int q  = (fq_at<FQ_Q2_K, 0>(r, sb)[(i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
+        const uint32_t dm = ld_u32(fq_at<FQ_Q2_K, 2>(r, sb));
         const float dl = fq_h2f((uint16_t) dm) * (float)(sc & 15), ml = fq_h2f((uint16_t)(dm >> 16)) * (float)(sc >> 4);
         return dl * (float) q - ml;
     } else if constexpr (TYPE == FQ_Q3_K) {                          // k_quants.c:472-521
         const int64_t sb = e >> 8; const int i = e & 255;
         const int is = (i >> 7) * 8 + ((i & 127) >> 5) * 2 + ((i & 31) >> 4);
-        const int lo = (r.p0[64 * sb + (i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
-        const int hb = (r.p1[32 * sb + (i & 31)] >> (i >> 5)) & 1;
-        const int sc = q3_scale(ld_u32(r.p2 + 12 * sb), ld_u32(r.p2 + 12 * sb + 4), ld_u32(r.p2 + 12 * sb + 8), is);
-        const float dl = fq_h2f(ld_u16(r.p3 + 2 * sb)) * (float)(sc - 32);
+        const int lo = (fq_at<FQ_Q3_K, 0>(r, sb)[(i >> 7) * 32 + (i & 31)] >> (2 * ((i & 127) >> 5))) & 3;
+        const int hb = (fq_at<FQ_Q3_K, 1>(r, sb)[i & 31] >> (i >> 5)) & 1;
+        const uint8_t * scp = fq_at<FQ_Q3_K, 2>(r, sb);
+        const int sc = q3_scale(ld_u32(scp), ld_u32(scp + 4), ld_u32(scp + 8), is);
+        const float dl = fq_h2f(ld_u16(fq_at<FQ_Q3_K, 3>(r, sb))) * (float)(sc - 32);
         return dl * (float)(lo - (hb ? 0 : 4));
     } else if constexpr (TYPE == FQ_Q4_K || TYPE == FQ_Q5_K) {      // k_quants.c:607-631, 734-760
         const int64_t sb = e >> 8; const int i = e & 255;
         const int c = i >> 6, hi = (i >> 5) & 1;
-        const uint8_t * scp = (TYPE == FQ_Q4_K) ? r.p1 + 12 * sb : r.p2 + 12 * sb;
+        constexpr int PSC = (TYPE == FQ_Q4_K) ? 1 : 2;
+        const uint8_t * scp = fq_at<TYPE, PSC>(r, sb);
         int sc, mn; k4_scale_min(ld_u32(scp), ld_u32(scp + 4), ld_u32(scp + 8), 2 * c + hi, sc, mn);
-        const int byte = r.p0[128 * sb + 32 * c + (i & 31)];
+        const int byte = fq_at<TYPE, 0>(r, sb)[32 * c + (i & 31)];
         int q = hi ? (byte >> 4) : (byte & 15);
-        if constexpr (TYPE == FQ_Q5_K) q += ((r.p1[32 * sb + (i & 31)] >> (i >> 5)) & 1) ? 16 : 0;
-        const uint32_t dm = ld_u32((TYPE == FQ_Q4_K ? r.p2 : r.p3) + 4 * sb);
+        if constexpr (TYPE == FQ_Q5_K) q += ((fq_at<TYPE, 1>(r, sb)[i & 31] >> (i >> 5)) & 1) ? 16 : 0;
+        const uint32_t dm = ld_u32(fq_at<TYPE, PSC + 1>(r, sb));
         const float dl = fq_h2f((uint16_t) dm) * (float) sc, ml = fq_h2f((uint16_t)(dm >> 16)) * (float) mn;
         return dl * (float) q - ml;
     } else {                                                         // Q6_K, k_quants.c:845-876
         const int64_t sb = e >> 8; const int i = e & 255;
         const int h = i >> 7, t = (i & 127) >> 5, l = i & 31;
-        const int byte = r.p0[128 * sb + 64 * h + 32 * (t & 1) + l];
+        const int byte = fq_at<FQ_Q6_K, 0>(r, sb)[64 * h + 32 * (t & 1) + l];
         const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
-        const int hi = (r.p1[64 * sb + 32 * h + l] >> (2 * t)) & 3;
+        const int hi = (fq_at<FQ_Q6_K, 1>(r, sb)[32 * h + l] >> (2 * t)) & 3;
         const int q = (int)(int8_t)(lo | (hi << 4)) - 32;
-        const int sc = (int)(int8_t) r.p2[16 * sb + 8 * h + 2 * t + (l >> 4)];
-        return fq_h2f(ld_u16(r.p3 + 2 * sb)) * (float) sc * (float) q;
+        const int sc = (int)(int8_t) fq_at<FQ_Q6_K, 2>(r, sb)[8 * h + 2 * t + (l >> 4)];
+        return fq_h2f(ld_u16(fq_at<FQ_Q6_K, 3>(r, sb))) * (float) sc * (float) q;
     }
 }
 

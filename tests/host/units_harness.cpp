@@ -10,7 +10,7 @@ static float row_dot(const fq_weight & w, const fq_actcol & a, int64_t K) {
     const fq_wrow r = fq_row<TYPE>(w, 0);
     const int units = (int)(K / fq_unit<TYPE>::ELEMS);
     float acc = 0.0f;
-    for (int u = 0; u < units; ++u) acc += fq_unit<TYPE>::dot(fq_unit<TYPE>::load(r, u), a, u);
+    for (int u = 0; u < units; ++u) acc += fq_unit<TYPE>::dot(fq_unit_load<TYPE>(r, u), a, u);
     return acc;
 }
 
@@ -18,23 +18,14 @@ extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const u
     const fq_type_desc d = fq_desc(type);
     const int64_t nblk = K / d.blck;
     fq_weight w{}; w.type = type; w.K = K; w.M = 1; w.nblk = nblk;
-    std::vector<std::vector<uint8_t>> planes(FQ_MAX_PLANES);
     std::vector<uint8_t> il;
-    if (fq_interleaved(type)) {                                  // legacy formats: column-interleaved row (fq_types.h)
-        w.row_stride = fq_il_row_stride(d, nblk);
-        il.resize(w.row_stride + 32);
-        uint8_t * base = (uint8_t *)(((uintptr_t) il.data() + 15) & ~(uintptr_t) 15);
-        for (int p = 0; p < d.nplanes; ++p)
-            for (int64_t b = 0; b < nblk; ++b)
-                memcpy(base + fq_il_offset(d, p, nblk, b), row + (size_t) b * d.tsize + d.plane[p].src_off, d.plane[p].bytes);
-        for (int p = 0; p < d.nplanes; ++p) w.plane[p] = base;
-    } else
-    for (int p = 0; p < d.nplanes; ++p) {
-        planes[p].resize((size_t) nblk * d.plane[p].bytes + 16);
+    w.row_stride = fq_il_row_stride(d, nblk);                   // column-interleaved row (fq_types.h)
+    il.resize(w.row_stride + 32);
+    uint8_t * base = (uint8_t *)(((uintptr_t) il.data() + 15) & ~(uintptr_t) 15);
+    for (int p = 0; p < d.nplanes; ++p)
         for (int64_t b = 0; b < nblk; ++b)
-            memcpy(planes[p].data() + fq_plane_offset(d, p, nblk, 0, b), row + (size_t) b * d.tsize + d.plane[p].src_off, d.plane[p].bytes);
-        w.plane[p] = planes[p].data();
-    }
+            memcpy(base + fq_il_offset(d, p, nblk, b), row + (size_t) b * d.tsize + d.plane[p].src_off, d.plane[p].bytes);
+    for (int p = 0; p < d.nplanes; ++p) w.plane[p] = base;
     // activations: ggml blocks -> SoA
     std::vector<int8_t> qs((size_t) K + 64);
     int8_t * qsa = (int8_t *)(((uintptr_t) qs.data() + 15) & ~(uintptr_t) 15);
