@@ -28,7 +28,7 @@ VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_
 EXPORTS_OPS = """ggml_hip_init ggml_hip_debug_force_gemv ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
 ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
-ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_acts_alloc ggml_hip_acts_free
+ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_quantize_rows ggml_hip_weight_quantize ggml_hip_fp16_to_fp32_row ggml_hip_acts_alloc ggml_hip_acts_free
 ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
@@ -73,6 +73,8 @@ def load():
         "ggml_hip_event_destroy": (None, [vp]), "ggml_hip_gelu_table_dev": (vp, []), "ggml_hip_exp_table_dev": (vp, []),
         "ggml_hip_weight_upload": (vp, [C.c_int, vp, i64, i64]), "ggml_hip_weight_free": (None, [vp]), "ggml_hip_weight_nbytes": (sz, [vp]),
         "ggml_hip_dequantize_rows": (None, [vp, vp, i64, vp]),
+        "ggml_hip_quantize_rows": (C.c_int, [C.c_int, vp, i64, i64, vp, vp]), "ggml_hip_weight_quantize": (vp, [C.c_int, vp, i64, i64]),
+        "ggml_hip_fp16_to_fp32_row": (None, [vp, vp, i64]),
         "ggml_hip_acts_alloc": (vp, [C.c_int, i64, i64]), "ggml_hip_acts_free": (None, [vp]),
         "ggml_hip_quantize_acts": (None, [vp, vp, i64, i64]), "ggml_hip_acts_export": (None, [vp, i64, vp]),
         "ggml_hip_mul_mat_q": (None, [vp, vp, i64, i64, vp, i64]),
@@ -133,7 +135,40 @@ class DevBuf:
             self.ptr = None
 
 
+def quantize_rows(wtype, x, hist=False):
+    """x: [nrows, K] f32 -> ggml blocks (uint8 [nrows, K/blck*tsize]) through ggml_hip_quantize_rows; hist=True also
+    returns the 16-bin histogram the reference's quantizer prints"""
+    L = load()
+    x = np.ascontiguousarray(x, np.float32)
+    nrows, K = x.shape
+    xb = DevBuf(host=x)
+    ob = DevBuf(nrows * (K // BLCK[wtype]) * TSIZE[wtype])
+    hb = DevBuf(host=np.zeros(16, np.int64)) if hist else None
+    rc = L.ggml_hip_quantize_rows(wtype, xb.ptr, K, nrows, ob.ptr, hb.ptr if hb else None)
+    if rc != 0:
+        raise ValueError("ggml_hip_quantize_rows failed")
+    out = ob.to_host(np.uint8, (nrows, (K // BLCK[wtype]) * TSIZE[wtype]))
+    h = hb.to_host(np.int64, (16,)) if hb else None
+    for b in (xb, ob, hb):
+        if b:
+            b.free()
+    return (out, h) if hist else out
+
+
 class Weight:
+    @classmethod
+    def quantize(cls, wtype, x):
+        """x: [M, K] f32, quantized and re-tiled on the device (ggml_hip_weight_quantize)"""
+        x = np.ascontiguousarray(x, np.float32)
+        self = cls.__new__(cls)
+        self.type, self.M, self.K = wtype, x.shape[0], x.shape[1]
+        xb = DevBuf(host=x)
+        self.h = load().ggml_hip_weight_quantize(wtype, xb.ptr, self.K, self.M)
+        xb.free()
+        if not self.h:
+            raise ValueError("ggml_hip_weight_quantize failed")
+        return self
+
     def __init__(self, wtype, blocks, K, M):
         blocks = np.ascontiguousarray(blocks, np.uint8)
         assert blocks.size == M * (K // BLCK[wtype]) * TSIZE[wtype]

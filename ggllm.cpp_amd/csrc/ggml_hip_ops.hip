@@ -164,6 +164,34 @@ extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_
 extern "C" void ggml_hip_weight_free(ggml_hip_weight * w) { if (!w) return; HIP_CHECK(hipFree(w->slab)); delete w; }
 extern "C" size_t ggml_hip_weight_nbytes(const ggml_hip_weight * w) { return w->w.bytes; }
 
+// ---- weight quantizers (kernels_wquant.hip): what ggml_quantize_chunk (ggml.c:19479-19560) writes into a model file
+extern "C" int ggml_hip_quantize_rows(int type, const float * x_dev, int64_t K, int64_t nrows, void * blocks_dev, int64_t * hist_dev) {
+    const fq_type_desc d = fq_desc(type);
+    if (d.blck == 0 || K <= 0 || K % d.blck != 0 || nrows < 0) {
+        fprintf(stderr, "ggml-hip: cannot quantize rows of %lld weights to type %d (row length must be a multiple of %d)\n", (long long) K, type, d.blck);
+        return -1;
+    }
+    if (!fq_launch_wquant(type, x_dev, K * nrows, (uint8_t *) blocks_dev, (unsigned long long *) hist_dev, fq_ctx().stream)) return -1;
+    return 0;
+}
+extern "C" void ggml_hip_fp16_to_fp32_row(const uint16_t * src_dev, float * dst_dev, int64_t n) {
+    fq_launch_f16_to_f32(src_dev, dst_dev, n, fq_ctx().stream);
+}
+extern "C" ggml_hip_weight * ggml_hip_weight_quantize(int type, const float * x_dev, int64_t K, int64_t M) {
+    hip_context & c = fq_ctx();
+    const fq_type_desc d = fq_desc(type);
+    if (d.blck == 0 || K % d.blck != 0) { fprintf(stderr, "ggml-hip: weight type %d with K=%lld unsupported\n", type, (long long) K); return nullptr; }
+    ggml_hip_weight * hw = new ggml_hip_weight();
+    hw->w = fq_weight_alloc(type, K, M, &hw->slab);
+    uint8_t * blocks = nullptr;
+    HIP_CHECK(hipMalloc((void **) &blocks, hw->w.bytes + 16));
+    fq_launch_wquant(type, x_dev, K * M, blocks, nullptr, c.stream);
+    fq_launch_retile(blocks, hw->w, c.stream);
+    HIP_CHECK(hipStreamSynchronize(c.stream));
+    HIP_CHECK(hipFree(blocks));
+    return hw;
+}
+
 extern "C" void ggml_hip_dequantize_rows(const ggml_hip_weight * w, const int32_t * rows_dev, int64_t nrows, float * dst_dev) {
     fq_launch_dequant_rows(w->w, rows_dev, nrows, dst_dev, fq_ctx().stream);
 }

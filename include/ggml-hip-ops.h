@@ -62,6 +62,16 @@ size_t  ggml_hip_weight_nbytes(const ggml_hip_weight * w);         /* == ggml_nb
  * dst_dev[i][0..K) = dequantized weight row rows_dev[i] (rows_dev == NULL: rows 0..nrows-1)                  */
 void    ggml_hip_dequantize_rows(const ggml_hip_weight * w, const int32_t * rows_dev, int64_t nrows, float * dst_dev);
 
+/* ---- weight quantizers: ggml_quantize_chunk (ggml.c:19479-19560) over quantize_row_q*_reference
+ * (ggml.c:927-1129; k_quants.c:275-343, 396-471, 542-606, 652-733, 781-844) ------------------------------- */
+/* nrows rows of K f32 -> nrows * K/blck ggml blocks, byte-identical with the reference's model files.
+ * hist_dev: 16 int64 counters that are ADDED to (the reference's quantize histogram; legacy formats only, the
+ * k-quants never count), or NULL. Returns 0, or -1 (message on stderr) for a bad type / row length.             */
+int     ggml_hip_quantize_rows(int type, const float * x_dev, int64_t K, int64_t nrows, void * blocks_dev, int64_t * hist_dev);
+/* same, straight into a resident weight matrix (quantize + re-tile on the device)                              */
+ggml_hip_weight * ggml_hip_weight_quantize(int type, const float * x_dev, int64_t K, int64_t M);
+void    ggml_hip_fp16_to_fp32_row(const uint16_t * src_dev, float * dst_dev, int64_t n);   /* ggml.c:370-374 */
+
 /* ---- activations: INIT phase of mul_mat_q (ggml.c:11462-11476) ------------------------------------------- */
 /* act_type: 8 = Q8_0 (ggml.c:1106-1129), 9 = Q8_1 (ggml.c:1292-1325), 15 = Q8_K (k_quants.c:899-934)          */
 ggml_hip_acts * ggml_hip_acts_alloc(int act_type, int64_t K, int64_t max_cols);

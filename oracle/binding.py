@@ -224,6 +224,9 @@ class Ref(_Base):
         for f in ("ref_quantize_reference", "ref_quantize_native", "ref_quantize_dot"):
             getattr(L, f).argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ref_dequantize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(L, "ref_quantize_chunk"):
+            L.ref_quantize_chunk.restype = C.c_size_t
+            L.ref_quantize_chunk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ref_vec_dot.restype = C.c_float
         L.ref_vec_dot.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
@@ -249,6 +252,15 @@ class Ref(_Base):
         out = np.zeros(row_bytes(t, x.size), np.uint8)
         (self.lib.ref_quantize_native if native else self.lib.ref_quantize_reference)(t, _ptr(x), _ptr(out), x.size)
         return out
+
+    def quantize_chunk(self, t, x):
+        """ggml_quantize_chunk over the whole array: (blocks, hist[16])"""
+        x = _f32(x).ravel()
+        out = np.zeros(row_bytes(t, x.size), np.uint8)
+        hist = np.zeros(16, np.int64)
+        n = self.lib.ref_quantize_chunk(t, _ptr(x), _ptr(out), 0, x.size, _ptr(hist))
+        assert n == out.size
+        return out, hist
 
     def quantize_dot(self, wt, x):
         x = _f32(x).ravel()

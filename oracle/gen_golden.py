@@ -97,7 +97,40 @@ def gen_ggcc(O):
     np.savez_compressed(os.path.join(OUT, "ggcc_models.npz"), **d)
 
 
+def wquant_inputs():
+    """inputs of the weight-quantizer vectors (tests/golden/wquant.npz): ordinary weights plus the branches the reference's
+    quantizers special-case -- all-zero and constant (sub-)blocks, sparse rows, heavy tails, huge and tiny magnitudes"""
+    rng = np.random.default_rng(20240926)
+    n = 2048
+    x = {}
+    x["gauss"] = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    x["uniform"] = rng.uniform(-1, 1, n).astype(np.float32)
+    v = (rng.standard_normal(n) * 0.05).astype(np.float32); v[rng.random(n) < 0.3] = 0
+    x["sparse"] = v
+    x["heavy"] = (rng.standard_normal(n).astype(np.float32) ** 3).astype(np.float32)
+    v = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    v[:256] = 0; v[512:528] = 0; v[768:800] = 0.5; v[1024:1280] = -0.25; v[1500] = 1e30; v[1600] = 3.0; v[1792:1808] = 1e-30
+    x["edges"] = v
+    x["positive"] = np.abs(rng.standard_normal(n) * 0.1).astype(np.float32)
+    return x
+
+
+def gen_wquant():
+    """ggml_quantize_chunk of the reference build on wquant_inputs(): blocks + histogram per format"""
+    R = ob.Ref()
+    d = {}
+    for name, xv in wquant_inputs().items():
+        d[f"x_{name}"] = xv
+        for t in ob.WEIGHT_TYPES:
+            q, h = R.quantize_chunk(t, xv)
+            d[f"{ob.TYPE_NAME[t]}_{name}_q"], d[f"{ob.TYPE_NAME[t]}_{name}_hist"] = q, h
+    np.savez_compressed(os.path.join(OUT, "wquant.npz"), **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wquant":
+        os.makedirs(OUT, exist_ok=True)
+        return gen_wquant()
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
     os.makedirs(OUT, exist_ok=True)
@@ -197,6 +230,7 @@ def main():
             d[f"{name}_decode_logits_{tag}"] = np.concatenate(dec)
     np.savez_compressed(os.path.join(OUT, "tiny_models.npz"), **d)
     gen_ggcc(O)
+    gen_wquant()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

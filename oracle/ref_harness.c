@@ -51,6 +51,11 @@ uint16_t ref_fp32_to_fp16(float f)    { ggml_fp16_t x = ggml_fp32_to_fp16(f); ui
 void ref_quantize_reference(int type, const float * x, void * out, int k) {
     ggml_internal_get_quantize_fn(type).quantize_row_q_reference(x, out, k);
 }
+/* the model-file quantizer entry (falcon_model_quantize_internal calls it per chunk, libfalcon.cpp:3669-3705): blocks of
+ * src[start .. start+n) into dst, histogram added to hist[16] */
+size_t ref_quantize_chunk(int type, const float * src, void * dst, int start, int n, int64_t * hist) {
+    return ggml_quantize_chunk((enum ggml_type) type, src, dst, start, n, hist);
+}
 /* weight quantizer, build-native flavour (SIMD where the build has it) */
 void ref_quantize_native(int type, const float * x, void * out, int k) {
     ggml_internal_get_quantize_fn(type).quantize_row_q(x, out, k);
