@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_perplexity""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_model_quantize falcon_hip_perplexity""".split()
 
 
 def build(verbose=False):
@@ -95,6 +95,7 @@ def load():
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
+        "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_perplexity": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
@@ -220,6 +221,16 @@ def ggcc_scan(path):
     assert len(rows) == n
     d = dict(n_vocab=hp.n_vocab, n_embd=hp.n_embd, n_head=hp.n_head, n_head_kv=hp.n_head_kv, n_layer=hp.n_layer, n_ff=hp.n_ff, two_norms=bool(hp.two_norms))
     return d, ft.value, rows
+
+
+def quantize_model(path_in, path_out, ftype, quantize_output_tensor=True, allow_requantize=False):
+    """falcon_model_quantize on the device (falcon_hip_model_quantize); returns the 16-bin histogram"""
+    hist = np.zeros(16, np.int64)
+    rc = load().falcon_hip_model_quantize(os.fsencode(path_in), os.fsencode(path_out), int(ftype), int(bool(quantize_output_tensor)),
+                                          int(bool(allow_requantize)), hist.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("falcon_hip_model_quantize(%s, ftype %d) failed" % (path_in, ftype))
+    return hist
 
 
 def quantize_acts(act_type, x):

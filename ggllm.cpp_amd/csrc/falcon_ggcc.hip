@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/falcon-hip.h"
 #include "fq_types.h"
+#include "hip_context.h"
+#include "../../include/ggml-hip-ops.h"
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -23,10 +25,11 @@
 #include <vector>
 
 namespace {
-struct ggcc_tensor { std::string name; int type; int n_dims; int64_t ne[2]; size_t offset, size; };
+struct ggcc_tensor { std::string name; int type; int n_dims; int64_t ne[2]; size_t offset, size; };   // offset of the data
 struct ggcc_file {
     int fd = -1; const uint8_t * base = nullptr; size_t size = 0;
     falcon_hip_hparams hp{}; int ftype = 0, falcon_type = 0, n_merges = 0;
+    size_t vocab_begin = 0, vocab_end = 0;                       // vocabulary + merges, byte range in the file
     std::vector<ggcc_tensor> tensors;
     std::string error;
     ~ggcc_file() { if (base) munmap((void *) base, size); if (fd >= 0) close(fd); }
@@ -68,6 +71,7 @@ bool ggcc_open(const char * path, ggcc_file & f) {
     if (f.hp.n_embd <= 0 || f.hp.n_head <= 0 || f.hp.n_embd != 64 * f.hp.n_head || f.hp.n_head_kv <= 0 || f.hp.n_head % f.hp.n_head_kv) {
         f.error = "implausible hparams (head_dim must be 64)"; return false;
     }
+    f.vocab_begin = pos;
     for (int i = 0; i < f.hp.n_vocab; ++i) {                     // vocabulary: len, bytes, f32 score
         uint32_t len = 0;
         if (!u32(len) || !skip((size_t) len + 4)) { f.error = "truncated vocabulary"; return false; }
@@ -79,6 +83,7 @@ bool ggcc_open(const char * path, ggcc_file & f) {
         uint32_t l1 = 0, l2 = 0;
         if (!u32(l1) || !skip(l1) || !u32(l2) || !skip(l2)) { f.error = "truncated merges"; return false; }
     }
+    f.vocab_end = pos;
     while (pos < f.size) {
         uint32_t n_dims = 0, name_len = 0, type = 0, ne[2] = {1, 1};
         if (!u32(n_dims) || !u32(name_len) || !u32(type)) { f.error = "truncated tensor record"; return false; }
@@ -147,4 +152,114 @@ extern "C" falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int 
     }
     if (hp_out) *hp_out = hp;
     return m;
+}
+
+// ------------------------------------------------------------------------------------------------ model quantization
+// falcon_model_quantize (libfalcon.cpp:3533-3743, 3914-3925) for GGCC v10 input: header and vocabulary are copied with the
+// new ftype, every 2-D tensor whose name ends in "weight" is converted to the ftype's tensor type (lm_head.weight only
+// when quantize_output_tensor), everything else is copied. The conversion itself runs on the device
+// (kernels_wquant.hip), a tensor at a time: the f32 source of the largest Falcon tensor is 2.1 GB. Output files are
+// byte-identical with the reference's (see fq_wquant.h for the one exception its uninitialised array allows).
+namespace {
+int ftype_tensor_type(int ftype) {                                // libfalcon.cpp:3538-3562
+    switch (ftype) {
+        case 0: return FQ_F32;  case 1: return 1 /* F16 */;
+        case 2: return FQ_Q4_0; case 3: return FQ_Q4_1; case 7: return FQ_Q8_0; case 8: return FQ_Q5_0; case 9: return FQ_Q5_1;
+        case 10: return FQ_Q2_K; case 11: case 12: case 13: return FQ_Q3_K; case 14: case 15: return FQ_Q4_K;
+        case 16: case 17: return FQ_Q5_K; case 18: return FQ_Q6_K;
+    }
+    return -1;
+}
+bool ends_with(const std::string & s, const char * tail) { const size_t n = strlen(tail); return s.size() >= n && s.compare(s.size() - n, n, tail) == 0; }
+struct dev_buf {
+    void * p = nullptr;
+    explicit dev_buf(size_t n) { p = ggml_hip_malloc(n ? n : 16); }
+    ~dev_buf() { ggml_hip_free(p); }
+};
+}   // namespace
+
+extern "C" int falcon_hip_model_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor,
+                                         int allow_requantize, int64_t * hist_out) {
+    const int qtype = ftype_tensor_type(ftype);
+    if (qtype < 0) { fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: invalid output file type %d\n", ftype); return 1; }
+    ggcc_file f;
+    if (!ggcc_open(path_in, f)) { fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: %s: %s\n", path_in, f.error.c_str()); return 1; }
+    if (ggml_hip_init(-1) <= 0) { fprintf(stderr, "falcon_hip_model_quantize: no HIP device\n"); return 1; }
+    FILE * out = fopen(path_out, "wb");
+    if (!out) { fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: cannot open %s\n", path_out); return 1; }
+    bool ok = true;
+    auto put = [&](const void * p, size_t n) { if (n && fwrite(p, 1, n, out) != n) ok = false; };
+    auto put_u32 = [&](uint32_t v) { put(&v, 4); };
+    // magic, version, hparams with the new ftype, vocabulary + merges verbatim (llama_file_saver, libfalcon.cpp:975-1025)
+    put(f.base, 8 + 6 * 4);
+    put_u32((uint32_t) ftype);
+    put(f.base + 8 + 7 * 4, 4);
+    put(f.base + f.vocab_begin, f.vocab_end - f.vocab_begin);
+    int64_t hist_all[16] = {0};
+    dev_buf hist_dev(16 * sizeof(int64_t));
+    const bool q_is_k = qtype >= FQ_Q2_K && qtype <= FQ_Q6_K;
+    for (const ggcc_tensor & t : f.tensors) {
+        bool quantize = ends_with(t.name, "weight") && t.n_dims == 2;                 // libfalcon.cpp:3609-3616
+        quantize = quantize && (quantize_output_tensor || t.name != "lm_head.weight");
+        quantize = quantize && qtype != t.type;
+        int new_type = t.type;
+        std::vector<uint8_t> converted;
+        const uint8_t * data = f.base + t.offset;
+        size_t new_size = t.size;
+        if (quantize) {
+            new_type = qtype;
+            if (q_is_k && t.ne[0] % 256 != 0) {                                        // libfalcon.cpp:3634-3643
+                fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: tensor %s: row length %lld is not divisible by 256 - use a legacy format\n",
+                        t.name.c_str(), (long long) t.ne[0]);
+                ok = false; break;
+            }
+            const int64_t n = t.ne[0] * t.ne[1];
+            dev_buf f32((size_t) n * 4);
+            if (t.type == FQ_F32) ggml_hip_memcpy_h2d(f32.p, data, (size_t) n * 4);
+            else if (t.type == 1) {
+                dev_buf h((size_t) n * 2);
+                ggml_hip_memcpy_h2d(h.p, data, (size_t) n * 2);
+                ggml_hip_fp16_to_fp32_row((const uint16_t *) h.p, (float *) f32.p, n);
+                ggml_hip_synchronize();
+            } else {
+                if (!allow_requantize) {
+                    fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: requantizing from type %d is disabled\n", t.type);
+                    ok = false; break;
+                }
+                ggml_hip_weight * w = ggml_hip_weight_upload(t.type, data, t.ne[0], t.ne[1]);
+                ggml_hip_dequantize_rows(w, nullptr, t.ne[1], (float *) f32.p);
+                ggml_hip_synchronize();
+                ggml_hip_weight_free(w);
+            }
+            new_size = tensor_bytes(new_type, t.ne[0], t.ne[1]);
+            if (!new_size) { fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: tensor %s: row length %lld does not fit type %d\n", t.name.c_str(), (long long) t.ne[0], new_type); ok = false; break; }
+            converted.resize(new_size);
+            if (new_type == FQ_F32) ggml_hip_memcpy_d2h(converted.data(), f32.p, new_size);
+            else {
+                dev_buf q(new_size);
+                if (new_type == 1) fq_launch_f32_to_f16((const float *) f32.p, (uint16_t *) q.p, n, (hipStream_t) ggml_hip_stream());
+                else {
+                    ggml_hip_memset(hist_dev.p, 0, 16 * sizeof(int64_t));
+                    if (ggml_hip_quantize_rows(new_type, (const float *) f32.p, t.ne[0], t.ne[1], q.p, (int64_t *) hist_dev.p) != 0) { ok = false; break; }
+                    int64_t h[16];
+                    ggml_hip_memcpy_d2h(h, hist_dev.p, sizeof h);
+                    for (int i = 0; i < 16; ++i) hist_all[i] += h[i];
+                }
+                ggml_hip_memcpy_d2h(converted.data(), q.p, new_size);
+            }
+            data = converted.data();
+        }
+        // tensor record (llama_file_saver::write_tensor, libfalcon.cpp:1026-1051)
+        put_u32((uint32_t) t.n_dims); put_u32((uint32_t) t.name.size()); put_u32((uint32_t) new_type);
+        for (int d = 0; d < t.n_dims; ++d) put_u32((uint32_t) t.ne[d]);
+        put(t.name.data(), t.name.size());
+        static const uint8_t zeros[32] = {0};
+        put(zeros, (size_t)(-(int64_t) ftell(out) & 31));
+        put(data, new_size);
+        if (!ok) break;
+    }
+    if (fclose(out) != 0) ok = false;
+    if (!ok) { fprintf(stderr, "falcon_hip_model_quantize: failed to quantize: write to %s incomplete\n", path_out); remove(path_out); return 1; }
+    if (hist_out) memcpy(hist_out, hist_all, sizeof hist_all);
+    return 0;
 }

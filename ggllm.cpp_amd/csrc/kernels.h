@@ -16,6 +16,7 @@ struct fq_gemv_epi {
 // kernels_quant.hip
 void   fq_launch_retile(const uint8_t * src_dev, const fq_weight & w, hipStream_t st);
 bool   fq_launch_wquant(int type, const float * x, int64_t n_elems, uint8_t * out, unsigned long long * hist, hipStream_t st);
+void   fq_launch_f32_to_f16(const float * src, uint16_t * dst, int64_t n, hipStream_t st);
 void   fq_launch_f16_to_f32(const uint16_t * src, float * dst, int64_t n, hipStream_t st);
 void   fq_launch_dequant_rows(const fq_weight & w, const int32_t * rows_dev, int64_t nrows, float * dst, hipStream_t st);
 void   fq_launch_quantize_act(const float * x, int64_t ldx, const fq_act & a, hipStream_t st);

@@ -7,7 +7,8 @@
 //  * k_wquant_k       one thread = one sub-block (16 or 32 weights) of a 256-weight super-block: fit -> (LDS) -> one
 //                     thread per super-block packs the 4/6/8-bit scales -> every thread re-quantizes its sub-block
 //                     with the dequantized scale -> the super-block's bytes are packed cooperatively
-//  * k_f16_to_f32     ggml_fp16_to_fp32_row (ggml.c:370-374), the f16 model file's weights before quantizing
+//  * k_f16_to_f32 / k_f32_to_f16   ggml_fp16_to_fp32_row / ggml_fp32_to_fp16_row (ggml.c:370-391): an f16 model file's
+//                     weights before quantizing, and the F16 output type of ggml_quantize_chunk
 //
 // The fits are sequential, data-dependent loops (up to 5 refinement passes per sub-block): the kernel is bound by its
 // per-thread instruction stream, not by HBM (4 bytes read + ~0.6 written per weight).
@@ -91,6 +92,10 @@ __global__ void k_f16_to_f32(const uint16_t * __restrict__ src, float * __restri
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) dst[i] = fq_h2f(src[i]);
 }
 
+__global__ void k_f32_to_f16(const float * __restrict__ src, uint16_t * __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) dst[i] = fq_f2h(src[i]);
+}
+
 template <int TYPE>
 static void launch_legacy(const float * x, int64_t nblocks, uint8_t * out, unsigned long long * hist, hipStream_t st) {
     const int64_t wgs = (nblocks + 255) / 256;
@@ -124,4 +129,9 @@ void fq_launch_f16_to_f32(const uint16_t * src, float * dst, int64_t n, hipStrea
     if (n <= 0) return;
     const int64_t wgs = (n + 255) / 256;
     hipLaunchKernelGGL(k_f16_to_f32, dim3((unsigned)(wgs > 8192 ? 8192 : wgs)), dim3(256), 0, st, src, dst, n);
+}
+void fq_launch_f32_to_f16(const float * src, uint16_t * dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return;
+    const int64_t wgs = (n + 255) / 256;
+    hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)(wgs > 8192 ? 8192 : wgs)), dim3(256), 0, st, src, dst, n);
 }

@@ -52,6 +52,15 @@ size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m);   /* quantized
 falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int layer_begin, int layer_end, falcon_hip_hparams * hp_out);
 int  falcon_hip_ggcc_scan(const char * path, falcon_hip_hparams * hp_out, int * ftype_out, char * dir_out, size_t dir_cap);
 
+/* falcon_model_quantize (libfalcon.h:176-179, libfalcon.cpp:3533-3743) for GGCC v10 files: writes path_out with every
+ * 2-D "...weight" tensor converted to the tensor type of ftype (enum llama_ftype value: 0 f32, 1 f16, 2 Q4_0, 3 Q4_1,
+ * 7 Q8_0, 8 Q5_0, 9 Q5_1, 10 Q2_K, 11-13 Q3_K, 14-15 Q4_K, 16-17 Q5_K, 18 Q6_K), lm_head.weight only when
+ * quantize_output_tensor, already-quantized sources only when allow_requantize; the quantizers run on the device and the
+ * file is byte-identical with the reference's. hist_out: NULL or 16 counters (the reference's printed histogram, summed
+ * over tensors). Returns 0, or 1 after a message on stderr (the reference's convention); a failed run leaves no file.   */
+int  falcon_hip_model_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor,
+                               int allow_requantize, int64_t * hist_out);
+
 /* n_ctx: KV capacity; n_batch: largest N of one eval; rope_n_ctx: the n_ctx handed to ggml_rope
  * (n_max_real_ctx or n_ctx, libfalcon.cpp:2229-2230)                                                           */
 falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx);

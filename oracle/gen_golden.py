@@ -97,6 +97,46 @@ def gen_ggcc(O):
     np.savez_compressed(os.path.join(OUT, "ggcc_models.npz"), **d)
 
 
+QUANT_FTYPES = {"gqa_f32": (0, 1, 2, 3, 7, 8, 9, 10, 12, 15, 17, 18), "mqa_f16": (0, 2, 9), "gqa_f32_keep_output": (15,)}
+
+
+def gen_model_quantize():
+    """6. falcon_model_quantize of the real reference (one thread) on synthetic f32 / f16 GGCC files: sha256 + size of
+    every output file; tests/test_gpu_falcon.py quantizes the same inputs on the device and compares the files."""
+    import ctypes as C
+    import tempfile
+    import ggcc_writer
+    so = os.path.join(ROOT, "oracle", "_ref", "libfalcon_ref.so")
+    if not os.path.exists(so):
+        print("oracle/_ref/libfalcon_ref.so not built: model_quantize.npz not regenerated")
+        return
+    L = C.CDLL(so)
+    L.reff_quantize.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    d = {}
+    for name, ftypes in QUANT_FTYPES.items():
+        hp = synth.HP_TINY_GQA if name.startswith("gqa") else synth.HP_TINY_MQA
+        w = synth.make_model_float(hp, seed=2468, f16=name.endswith("f16"))
+        keep = name.endswith("keep_output")
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "in.ggcc")
+            ggcc_writer.write_ggcc(src, w)
+            d[f"{name}_src_sha256"] = np.frombuffer(hashlib.sha256(open(src, "rb").read()).digest(), np.uint8)
+            for ft in ftypes:
+                dst = os.path.join(td, "out_%d.ggcc" % ft)
+                rc = L.reff_quantize(src.encode(), dst.encode(), ft, 0 if keep else 1, 0)
+                assert rc == 0, (name, ft)
+                d[f"{name}_ft{ft}_sha256"] = np.frombuffer(hashlib.sha256(open(dst, "rb").read()).digest(), np.uint8)
+                d[f"{name}_ft{ft}_bytes"] = np.int64(os.path.getsize(dst))
+            if name == "gqa_f32":                               # requantize: the Q8_0 file again to Q4_0 and Q6_K
+                q8 = os.path.join(td, "out_7.ggcc")
+                assert L.reff_quantize(q8.encode(), os.path.join(td, "rq.ggcc").encode(), 2, 1, 0) == 1   # refused by default
+                for ft in (2, 18):
+                    dst = os.path.join(td, "rq_%d.ggcc" % ft)
+                    assert L.reff_quantize(q8.encode(), dst.encode(), ft, 1, 1) == 0
+                    d[f"{name}_requant_ft{ft}_sha256"] = np.frombuffer(hashlib.sha256(open(dst, "rb").read()).digest(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "model_quantize.npz"), **d)
+
+
 def wquant_inputs():
     """inputs of the weight-quantizer vectors (tests/golden/wquant.npz): ordinary weights plus the branches the reference's
     quantizers special-case -- all-zero and constant (sub-)blocks, sparse rows, heavy tails, huge and tiny magnitudes"""
@@ -128,9 +168,9 @@ def gen_wquant():
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "wquant":
+    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize"):
         os.makedirs(OUT, exist_ok=True)
-        return gen_wquant()
+        return gen_wquant() if sys.argv[1] == "wquant" else gen_model_quantize()
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
     os.makedirs(OUT, exist_ok=True)
@@ -231,6 +271,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "tiny_models.npz"), **d)
     gen_ggcc(O)
     gen_wquant()
+    gen_model_quantize()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -12,12 +12,26 @@
 
 extern "C" {
 
-void * reff_load(const char * path, int n_ctx, int n_batch) {
+// falcon_init_backend once: ggml_init fills the fp16 tables this SIMD-less build converts through (the reference's tools
+// call it first thing, examples/falcon_quantize/quantize.cpp; without it the k-quant quantizers read d = 0)
+static void init_once() {
     static bool once = false;
     if (!once) { falcon_init_backend(); once = true; }
+}
+
+void * reff_load(const char * path, int n_ctx, int n_batch) {
+    init_once();
     falcon_context_params p = falcon_context_default_params();
     p.n_ctx = n_ctx; p.n_batch = n_batch; p.n_gpu_layers = 0; p.logits_all = true; p.f16_kv = false; p.use_mmap = true; p.seed = 1;
     return (void *) falcon_init_from_file(path, p);
+}
+
+// falcon_model_quantize (the falcon_quantize tool's work, libfalcon.cpp:3914-3925) with one thread (deterministic)
+int reff_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor, int allow_requantize) {
+    init_once();
+    llama_model_quantize_params p = llama_model_quantize_default_params();
+    p.nthread = 1; p.ftype = (enum llama_ftype) ftype; p.quantize_output_tensor = quantize_output_tensor != 0; p.allow_requantize = allow_requantize != 0;
+    return falcon_model_quantize(path_in, path_out, &p);
 }
 
 // logits_out: n * n_vocab floats (logits_all). Returns 0 on success.

@@ -10,7 +10,7 @@ WHAT=${1:-all}
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/gpu.txt
 if [[ $WHAT == all || $WHAT == tests ]]; then
-  for f in test_gpu_quant test_gpu_mul_mat test_gpu_block_ops test_gpu_falcon test_gpu_shim test_gpu_wquant; do
+  for f in test_gpu_quant test_gpu_mul_mat test_gpu_block_ops test_gpu_falcon test_gpu_shim test_gpu_wquant test_gpu_model_quantize; do
     timeout 600 python -m pytest tests/$f.py -m gpu -q -x --no-header -p no:cacheprovider -s > $OUT/$f.log 2>&1
     echo "$f exit $?" | tee -a $OUT/summary.txt
     tail -3 $OUT/$f.log

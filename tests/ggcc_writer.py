@@ -12,7 +12,7 @@ import numpy as np
 from oracle import binding as ob
 
 GGCC_MAGIC, GGCC_VERSION = 0x67676363, 10
-FTYPE_OF = {ob.Q4_0: 2, ob.Q4_1: 3, ob.Q8_0: 7, ob.Q5_0: 8, ob.Q5_1: 9, ob.Q2_K: 10, ob.Q3_K: 12, ob.Q4_K: 15, ob.Q5_K: 17, ob.Q6_K: 18}
+FTYPE_OF = {0: 0, 1: 1, ob.Q4_0: 2, ob.Q4_1: 3, ob.Q8_0: 7, ob.Q5_0: 8, ob.Q5_1: 9, ob.Q2_K: 10, ob.Q3_K: 12, ob.Q4_K: 15, ob.Q5_K: 17, ob.Q6_K: 18}
 F32 = 0
 NAMES_7B = {"ln_w": "input_layernorm.weight", "ln_b": "input_layernorm.bias"}
 NAMES_40B = {"ln_w": "ln_mlp.weight", "ln_b": "ln_mlp.bias", "ln2_w": "ln_attn.weight", "ln2_b": "ln_attn.bias"}

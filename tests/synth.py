@@ -51,3 +51,34 @@ def make_model(oracle, hp, wtype, seed=1234, emb_type=None):
     return m
 
 
+
+
+def make_model_float(hp, seed=1234, f16=False):
+    """the same model shape with unquantized weights (f32, or f16 for the matrices): the input of falcon_quantize"""
+    E, H, HKV, L, FF, V = hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_layer"], hp["n_ff"], hp["n_vocab"]
+    D = E // H
+    idx = [0]
+
+    def rng():
+        idx[0] += 1
+        return np.random.default_rng(seed + idx[0])
+
+    def mat(rows, k):
+        w = (rng().standard_normal((rows, k)) * 0.02).astype(np.float32)
+        return w.astype(np.float16) if f16 else w
+
+    def ln():
+        r = rng()
+        return ((1.0 + 0.02 * r.standard_normal(E)).astype(np.float32), (0.02 * r.standard_normal(E)).astype(np.float32))
+
+    m = dict(hparams=dict(hp), wtype=1 if f16 else 0, layers=[])
+    m["tok_emb"] = mat(V, E)
+    for _ in range(L):
+        lw = dict(qkv=mat((H + 2 * HKV) * D, E), wo=mat(E, E), up=mat(FF, E), down=mat(E, FF))
+        lw["ln_w"], lw["ln_b"] = ln()
+        if hp.get("two_norms"):
+            lw["ln2_w"], lw["ln2_b"] = ln()
+        m["layers"].append(lw)
+    m["out_norm_w"], m["out_norm_b"] = ln()
+    m["lm_head"] = mat(V, E)
+    return m
