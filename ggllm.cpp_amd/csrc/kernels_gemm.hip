@@ -257,8 +257,11 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     const bool has_w = tid < GQ_TM * GQ_GROUPS;
     const int w_row = (tid >> 2) & (GQ_TM - 1), w_gg = tid & 3;
     const fq_wrow wrow = fq_row<TYPE>(w, m0 + w_row < M ? m0 + w_row : M - 1);
-    const bool has_sc = tid < TN;
-    const int sc_tok = tid & (TN - 1);
+    // (the weight tasks sit in waves 0-1, the token-scale tasks in waves 2..: a stage's critical path is the longest
+    // per-wave instruction stream up to the barrier, so the two staging roles must not land in the same wave)
+    static_assert(NT >= 128 + TN || NT >= 256, "staging roles need separate waves");
+    const bool has_sc = tid >= 128 && tid < 128 + TN;
+    const int sc_tok = (tid - 128) & (TN - 1);
     const uint8_t * sc_col = act.base + (size_t)(n0 + sc_tok < N ? n0 + sc_tok : N - 1) * img;
 
     struct stage_regs { gemm_raw w; v4i x[VT]; float4 d4; float2 sa, sb; uint2 ba, bb; };
@@ -327,14 +330,14 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             for (int gg = 0; gg < 4; ++gg) {
                 // a tail stage (fewer than 4 groups left) re-read the LAST four groups: shift them back into place
                 const int src = full ? gg : gg + (g0 - (ngroups >= 4 ? ngroups - 4 : 0));
-                const bool ok = n0 + tid < N && g0 + gg < ngroups && src < 4;
+                const bool ok = n0 + sc_tok < N && g0 + gg < ngroups && src < 4;
                 float dv = 0.0f, sv = 0.0f, sv1 = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (q == src) { dv = dx[q]; sv = sx[q]; sv1 = sx1[q]; }
-                ((float *)(B + LB::DX))[gg * TN + tid] = ok ? dv : 0.0f;
+                ((float *)(B + LB::DX))[gg * TN + sc_tok] = ok ? dv : 0.0f;
                 if constexpr (HAS_MIN) {
-                    ((float *)(B + LB::SX))[(gg * SUB) * TN + tid] = ok ? sv : 0.0f;
-                    if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + tid] = ok ? sv1 : 0.0f;
+                    ((float *)(B + LB::SX))[(gg * SUB) * TN + sc_tok] = ok ? sv : 0.0f;
+                    if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + sc_tok] = ok ? sv1 : 0.0f;
                 }
             }
         }
