@@ -235,7 +235,12 @@ template <bool HAS_MIN, int TN, int SUB> struct gemm_lds {           // TN = tok
                          BYTES = MW + (HAS_MIN ? GQ_GROUPS * SUB * GQ_TM * 4 : 0);
 };
 
-// S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves
+// S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves.
+// The S waves of a tile split K: wave sw takes the groups g = sw (mod S) of every stage, in order, into its own partial
+// sum; the partial sums are added at the end as ((P0 + P1) + P2) + P3. S = 1 is the reference's scalar order (one
+// left-to-right sum over the blocks of a row); S > 1 trades that for S times the parallelism on shapes with few tiles
+// (a 128-token prompt on a 4544-row matrix has 568 tiles for 1024 SIMDs) -- a fixed, documented association, the same
+// kind the reference's own 8-lane AVX2 loop applies (oracle: orc_set_sum_order).
 template <int TYPE, int S, int TT>
 __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -243,30 +248,34 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
     constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB;
     typedef gemm_lds<HAS_MIN, TN, SUB> LB;
-    constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16 / S;     // threads, token vectors per thread and stage, results per lane
+    constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16;         // threads, token vectors per thread and stage, results per lane
     static_assert(NT >= GQ_TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tt = wid % TT, sw = wid / TT;                               // token tile, share of the tile's 16 result registers
+    const int tt = wid % TT, sw = wid / TT;                               // token tile, K share (groups sw, sw + S, ... of a stage)
     const int64_t m0 = (int64_t) blockIdx.x * GQ_TM, n0 = (int64_t) blockIdx.y * TN;
     const int64_t K = w.K, M = w.M;
     const int ngroups = (int)(K >> 5);
     const size_t img = fq_act_col_bytes(ACT, K);
 
-    // ---- what this thread stages per K stage: weights = (row, group) tasks of threads < 128; tokens = 16-byte vectors
-    // of all threads; token scales = the 4 groups' d (and s / bsums) of token tid, threads < 128
-    const bool has_w = tid < GQ_TM * GQ_GROUPS;
+    // ---- what a thread stages per K stage: weights = (row, group) tasks of threads < 128 (waves 0-1); tokens = 16-byte
+    // vectors of all threads; token scales = the 4 groups' d (and s / bsums) of token tid - 128, the following wave(s)
     const int w_row = (tid >> 2) & (GQ_TM - 1), w_gg = tid & 3;
     const fq_wrow wrow = fq_row<TYPE>(w, m0 + w_row < M ? m0 + w_row : M - 1);
     // (the weight tasks sit in waves 0-1, the token-scale tasks in waves 2..: a stage's critical path is the longest
     // per-wave instruction stream up to the barrier, so the two staging roles must not land in the same wave)
     static_assert(NT >= 128 + TN || NT >= 256, "staging roles need separate waves");
-    const bool has_sc = tid >= 128 && tid < 128 + TN;
     const int sc_tok = (tid - 128) & (TN - 1);
+    // The pipeline below exists once per staging ROLE of a wave (1 = weights: waves 0-1; 2 = token scales: the next
+    // ceil(TN / 64) waves; 0 = none), selected by a wave-uniform branch: inside one copy every load is unconditional, so the
+    // compiler can count them (s_waitcnt vmcnt(N) that leaves the NEXT stages' loads in flight). With the roles as
+    // per-thread predicates in one copy it must assume the fewest loads and waits for the loads it has just issued.
+    constexpr int SC_WAVES = (TN + 63) / 64;
     const uint8_t * sc_col = act.base + (size_t)(n0 + sc_tok < N ? n0 + sc_tok : N - 1) * img;
 
     struct stage_regs { gemm_raw w; v4i x[VT]; float4 d4; float2 sa, sb; uint2 ba, bb; };
-    auto issue = [&](int g0, stage_regs & R) {
-        if (has_w) { const int g = g0 + w_gg; gemm_group<TYPE>::load(wrow, g < ngroups ? g : ngroups - 1, R.w); }
+    auto issue = [&](int g0, stage_regs & R, auto role) {
+        constexpr int ROLE = decltype(role)::value;
+        if constexpr (ROLE == 1) { const int g = g0 + w_gg; gemm_group<TYPE>::load(wrow, g < ngroups ? g : ngroups - 1, R.w); }
 #pragma unroll
         for (int i = 0; i < VT; ++i) {
             const int t = tid + i * NT, tok = t >> 3, part = t & 7;
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             const int64_t kb = (int64_t) g0 * 32 + 16 * part;
             R.x[i] = *(const v4i *)(act.base + (size_t) n * img + (size_t)(kb < K ? kb : 0));
         }
-        if (has_sc) {
+        if constexpr (ROLE == 2) {                                         // (lanes beyond TN of the role's last wave re-read a valid token)
             const int gc = g0 + 3 < ngroups ? g0 : (ngroups >= 4 ? ngroups - 4 : 0);     // (K % 128 != 0: the tail stage re-reads valid groups)
             if constexpr (ACT == FQ_Q8_K) {
                 R.d4.x = ((const float *)(sc_col + fq_act_d_off(ACT, K)))[g0 >> 3];
@@ -289,8 +298,9 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             }
         }
     };
-    auto commit = [&](int g0, const stage_regs & R, uint8_t * B) {        // registers -> LDS buffer B (zeros beyond K / N / M)
-        if (has_w) {
+    auto commit = [&](int g0, const stage_regs & R, uint8_t * B, auto role) {   // registers -> LDS buffer B (zeros beyond K / N / M)
+        constexpr int ROLE = decltype(role)::value;
+        if constexpr (ROLE == 1) {
             const int g = g0 + w_gg;
             v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; float sc[2] = {0.0f, 0.0f}, mn[2] = {0.0f, 0.0f};
             if (g < ngroups && m0 + w_row < M) {
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             const bool ok = n0 + tok < N && (int64_t) g0 * 32 + 16 * part < K;
             *(v4i *)(B + LB::XQ + tok * GQ_STRIDE + 16 * part) = ok ? R.x[i] : v4i{0, 0, 0, 0};
         }
-        if (has_sc) {
+        if constexpr (ROLE == 2) {                                         // (aliased lanes write the same values again)
             float dx[4], sx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sx1[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // sx1: second sub-group (SUB == 2)
             const bool full = g0 + 3 < ngroups;
             if constexpr (ACT == FQ_Q8_K) {
@@ -347,9 +357,8 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
     const int half = lane >> 5, l31 = lane & 31;
-    // the S waves of a tile feed the MFMA the tile's tokens ROTATED by (32 / S) sw rows, so that each finds its own share of
-    // the results in the first 16 / S result registers (a run-time register index would cost a select chain per value)
-    const int rot = (32 / S) * sw, arow = (l31 + rot) & 31;
+    constexpr int rot = 0;
+    const int arow = l31;
 
     const int dbgm = g_gemm_dbg;
     // ---- software pipeline, prefetch distance TWO stages (a stage's math, ~0.7 us, is shorter than a load round trip):
@@ -357,7 +366,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     // into the other
     auto compute = [&](const uint8_t * B) {
 #pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
-        for (int gg = 0; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); ++gg) {
+        for (int gg = sw; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); gg += S) {
             const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
             const v4i b = *(const v4i *)(B + LB::WQ + l31 * GQ_STRIDE + 32 * gg + 16 * half);
             // the lane's result i  <->  token 32 tt + rot + (i & 3) + 8 (i >> 2) + 4 half: runs of 4 consecutive tokens
@@ -404,27 +413,46 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     const int nstages = (ngroups + GQ_GROUPS - 1) / GQ_GROUPS;
     const int last_g0 = (nstages - 1) * GQ_GROUPS;
     auto g0_of = [&](int st) { return st < nstages ? st * GQ_GROUPS : last_g0; };      // beyond the end: re-read the last stage (unused)
-    stage_regs R0, R1;
-    issue(0, R0);
-    issue(g0_of(1), R1);
-    commit(0, R0, smem);
-    __syncthreads();
-    // (measured: the kernel is instruction-issue bound -- ~28 issue slots per group and wave in the MFMA loop, ~50 per stage
-    // for issue + commit, 4 waves per SIMD; making the idle threads' loads unconditional so that the waits become countable
-    // vmcnt(N) instead of vmcnt(0) costs more in extra load instructions than the deeper prefetch gains)
-    for (int st = 0; st < nstages; st += 2) {
-        // even stage st out of buffer 0; R1 holds st + 1; st + 2 goes into R0
-        issue(g0_of(st + 2), R0);
-        compute(smem);
-        commit(g0_of(st + 1), R1, smem + LB::BYTES);
+    auto pipeline = [&](auto role) {
+        stage_regs R0, R1;
+        issue(0, R0, role);
+        issue(g0_of(1), R1, role);
+        commit(0, R0, smem, role);
         __syncthreads();
-        // odd stage st + 1 out of buffer 1; R0 holds st + 2; st + 3 goes into R1
-        issue(g0_of(st + 3), R1);
-        if (st + 1 < nstages) compute(smem + LB::BYTES);
-        commit(g0_of(st + 2), R0, smem);
-        __syncthreads();
+        for (int st = 0; st < nstages; st += 2) {
+            // even stage st out of buffer 0; R1 holds st + 1; st + 2 goes into R0
+            issue(g0_of(st + 2), R0, role);
+            compute(smem);
+            commit(g0_of(st + 1), R1, smem + LB::BYTES, role);
+            __syncthreads();
+            // odd stage st + 1 out of buffer 1; R0 holds st + 2; st + 3 goes into R1
+            issue(g0_of(st + 3), R1, role);
+            if (st + 1 < nstages) compute(smem + LB::BYTES);
+            commit(g0_of(st + 2), R0, smem, role);
+            __syncthreads();
+        }
+    };
+    if (wid < 2)                 pipeline(std::integral_constant<int, 1>{});
+    else if (wid < 2 + SC_WAVES) pipeline(std::integral_constant<int, 2>{});
+    else                         pipeline(std::integral_constant<int, 0>{});
+    // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free now)
+    if constexpr (S > 1) {
+        float * xch = (float *) smem;                                      // [tt][i][lane]
+        for (int r = 1; r < S; ++r) {
+            __syncthreads();
+            if (sw == r) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) xch[(tt * NR + i) * 64 + lane] = acc[i];
+            }
+            __syncthreads();
+            if (sw == 0) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) acc[i] = acc[i] + xch[(tt * NR + i) * 64 + lane];
+            }
+        }
+        if (sw != 0) return;
     }
-    // ---- epilogue: token n = n0 + 32*tt + rot + (i&3) + 8*(i>>2) + 4*half, row m = m0 + (lane&31)
+    // ---- epilogue: token n = n0 + 32*tt + (i&3) + 8*(i>>2) + 4*half, row m = m0 + (lane&31)
     const int64_t m = m0 + l31;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -437,6 +465,10 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         }
     }
 }
+
+// 1: every shape through S = 1, i.e. the reference's left-to-right sum over a row's blocks (ggml_hip_gemm_sequential)
+static int g_gemm_sequential = 0;
+void fq_gemm_set_sequential(int on) { g_gemm_sequential = on != 0; }
 
 bool fq_gemm_supported(int type) {
     return type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0 ||
@@ -454,13 +486,14 @@ static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, fl
 
 // dst[n*ldd + m], n < N; act holds N quantized columns
 void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int n_cu, hipStream_t st) {
-    // The unit of parallelism is a 32-token x 32-row tile (568 of them for a 4544-row matrix and 128 tokens); the scaling
-    // epilogue is instruction-issue bound. Measured on MI355X, Falcon-7B shapes, 128 tokens, Q4_0 (scripts/gpu_gemm_prof.sh):
-    //   <S = 1, 4 tiles per workgroup>   up 18176 x 4544: 92 us     wo 4544 x 4544: 60 us    down 4544 x 18176: 216 us
-    //   <S = 4, 4 tiles per workgroup>   up: 101-123 us             wo: 45 us                down: 161 us
-    //   <S = 4, 1 tile per workgroup>    (all CUs busy, but 4 x the weight staging)  wo: 52 us   down: 181 us
+    // The unit of parallelism is a 32-token x 32-row tile (568 of them for a 4544-row matrix and 128 tokens), split S ways
+    // over K. Measured on MI355X, Falcon-7B shapes, Q4_0 (scripts/gpu_gemm_prof.sh), us for qkv / wo / up / down:
+    //   128 tokens   <S 1, 4 tiles>  44 / 44 /  92 / 163    <S 2, 4 tiles>  34 / 34 /  82 / 119    <S 4, 4 tiles>  31 / 31 /  95 / 106
+    //   512 tokens   <S 1, 4 tiles>  94 / 93 / 265 / 340    <S 2, 4 tiles>  83 / 83 / 242 / 296    <S 4, 4 tiles>  94 / 94 / 290 / 331
+    //   2048 tokens  <S 1, 4 tiles> 287 / 266 / 1043 / 1038 <S 2, 4 tiles> 259 / 238 / 969 / 929   <S 4, 4 tiles> 316 / 289 / 1157 / 1061
+    // -> four partial sums per row below 4 x #CU tiles, two above; one (the reference's order) only on request
     const int64_t tiles = ((w.M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
-    int cfg = tiles >= 8 * (int64_t) n_cu ? 0 : 2;
+    int cfg = g_gemm_sequential ? 0 : (tiles < 4 * (int64_t) n_cu ? 2 : 3);
     if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>
 #define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \

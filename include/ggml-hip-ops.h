@@ -25,6 +25,12 @@ int     ggml_hip_device_count(void);
 /* tuning aid: wall_clock64 phase stamps (8 per workgroup) of the last k_gemv_ln [0,4096) and k_gemv_out [4096,8192) */
 void    ggml_hip_debug_stamps(int enable, long long * out_host);
 void    ggml_hip_debug_force_gemv(int on);        /* tests: N > 4 through column-chunked mat-vec instead of the MFMA GEMM */
+/* Prefill GEMM (N > 4): by default each row's sum over its 32-element blocks is split into S interleaved partial sums,
+ * P_s = blocks s, s + S, ... added left to right, result ((P0 + P1) + P2) + P3: S = 4 for matrices with fewer than 4 x #CU
+ * 32x32 tiles, S = 2 above (S times the K-parallelism; 1.1-1.5 x faster). on = 1: S = 1 always, the reference's single
+ * left-to-right sum (ggml_vec_dot_q*_q8_*, scalar branch) -- legacy-format results are then bit-identical with the
+ * reference's scalar build.                                                                                              */
+void    ggml_hip_gemm_sequential(int on);
 int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
 /* soft_max's fp16 EXP table entries are recomputed in the attention kernels instead of gathered when -- checked at init, for
  * every non-NaN fp16 input -- the recomputation equals the host-built table. Returns the number of mismatching inputs (0 = in

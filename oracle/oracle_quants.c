@@ -375,8 +375,16 @@ void orc_dequantize_row(int type, const void * in, float * y, int64_t k) {
  * partial sums + xor butterfly in the order 1,2,4,..,32 (what the kernels' 64-lane wave reduction does). Used only to MEASURE how far a legitimate re-association moves
  * the logits of a whole model (tests/test_oracle_spread.py); the oracle proper always runs with 0. */
 static int g_sum_order = 0;       /* effective order for the current mat-mul */
-static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend: wave for N <= 4 columns, scalar (MFMA GEMM, block order) above */
-void orc_set_sum_order(int mode) { g_sum_mode = mode; g_sum_order = (mode == 1); }
+static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (below), 3 = four interleaved partial sums */
+/* order 2 = what the backend's prefill GEMM does (ggllm.cpp_amd/csrc/kernels_gemm.hip): g_split interleaved partial sums,
+ * P_s = blocks s, s + g_split, ... left to right, result ((P0 + P1) + P2) + P3; 4 of them on matrices with fewer than
+ * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
+ * columns, order 2 for GEMMs. mode 3 / 4: order 2 with 4 / 2 partial sums for every mat-mul. */
+static int g_split = 4;
+void orc_set_sum_order(int mode) {
+    g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4) ? 2 : 0);
+    g_split = (mode == 4) ? 2 : 4;
+}
 
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     const uint8_t * w = (const uint8_t *) wv;
@@ -392,6 +400,15 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
         /* xor butterfly, pairing order 1, 2, 4, ..., 32 (every lane ends with the total; lane 0 is returned) */
         for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
         return lane[0];
+    }
+    if (orc_blck_size(wtype) == 32 && g_sum_order == 2 && n > 32) {
+        const int at = orc_vec_dot_type(wtype);
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int64_t i = 0; i < n / 32; ++i) {
+            const float one = orc_vec_dot(wtype, 32, w + i * orc_type_size(wtype), a + i * orc_type_size(at));
+            part[i & (g_split - 1)] = part[i & (g_split - 1)] + one;
+        }
+        return ((part[0] + part[1]) + part[2]) + part[3];
     }
     if (orc_blck_size(wtype) == 32) {
         const int at = orc_vec_dot_type(wtype);
@@ -503,7 +520,7 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
                    float * dst, int n_threads, int flavour) {
     const int at = orc_vec_dot_type(wtype);
     const size_t act_row = orc_row_bytes(at, K);
-    if (g_sum_mode == 2) g_sum_order = (N <= 4);
+    if (g_sum_mode == 2) { g_sum_order = (N <= 4) ? 1 : 2; g_split = (((M + 31) / 32) * ((N + 31) / 32) < 4 * 256) ? 4 : 2; }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
     /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */
     for (int64_t n = 0; n < N; ++n) orc_quantize_act(at, x + n * K, act + (size_t) n * act_row, K, flavour);

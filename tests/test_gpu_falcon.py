@@ -29,7 +29,8 @@ CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQ
 # and then, and one flip moves the logits by ~1e-3..1e-2 (measured: the reference's own AVX2 and scalar builds differ
 # by 2.8e-2 on gqa_q5_1 -- tests/golden/tiny_models.npz holds both). So two checks:
 #   (1) against the oracle run with the backend's association of that sum (orc_set_sum_order(2): 64 strided partial
-#       sums + xor butterfly for N <= 4 columns = the mat-vec kernels, block order for N > 4 = the MFMA GEMM): TIGHT --
+#       sums + xor butterfly for N <= 4 columns = the mat-vec kernels; for N > 4 = the MFMA GEMM: block order, or four
+#       interleaved partial sums on matrices with few tiles): TIGHT --
 #       this pins every kernel of the stack;
 #   (2) against the logits captured from the reference itself: within 1e-3, or within 2x the reference's own
 #       build-to-build spread when that is larger.
@@ -209,7 +210,7 @@ def test_falcon40b_shaped_layer_vs_oracle(oracle):
 def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     """falcon_hip_model_load_ggcc on a GGCC v10 file (the reference's model format; the file is byte-identical to the one
     the real libfalcon.cpp loaded when tests/golden/ggcc_models.npz was captured): same logits as the in-memory upload of
-    the same weights, bit for bit; for the legacy formats the prefill logits (MFMA GEMM, scalar block order) are the
+    the same weights, bit for bit; for the legacy formats the prefill logits (MFMA GEMM in sequential block order) are the
     REFERENCE's own logits bit for bit; a pipeline stage loads only its own blocks"""
     import ggcc_writer
     gg = golden["ggcc_models"]
@@ -227,7 +228,13 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     assert np.array_equal(da, db)
     ref_pre, ref_dec = gg[f"{name}_prefill_logits"], gg[f"{name}_decode_logits"]
     if t in ob.LEGACY:
-        assert np.array_equal(la, ref_pre)
+        g.load().ggml_hip_gemm_sequential(1)                         # prefill GEMM in the reference's block order
+        try:
+            ls = a.eval(toks[:9], 0)
+        finally:
+            g.load().ggml_hip_gemm_sequential(0)
+        assert np.array_equal(ls, ref_pre)
+        assert relrms(la, ref_pre) <= max(1e-3, 2 * 2.8e-2)          # default: partial sums per row (ggml_hip_gemm_sequential)
         assert relrms(da, ref_dec) <= max(1e-3, 2 * 2.8e-2)          # decode: wave-order association, see DESIGN.md section 2
     else:
         assert relrms(la, ref_pre) <= 5e-2 and relrms(da, ref_dec) <= 5e-2
@@ -243,14 +250,22 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
 def test_perplexity_loop(oracle, golden, name, hp, t):
     """falcon_hip_perplexity = the reference's perplexity loop (falcon_perplexity.cpp:28-124): chunks of n_ctx 32 in batches
     of 8, NLL of the second half of every chunk. The fixture was produced by driving the same loop over the REAL reference's
-    falcon_eval (oracle/gen_golden.py); the prefill logits are bit-identical to the reference's, so the NLL is too (same libm)"""
+    falcon_eval (oracle/gen_golden.py); with the GEMM in sequential block order the prefill logits are bit-identical to the
+    reference's, so the NLL is too (same libm); the default order (partial sums) moves it within the reference's own
+    build-to-build spread"""
     gg = golden["ggcc_models"]
     w = synth.make_model(oracle, hp, t, seed=4321)
     m = g.FalconModel(w, n_ctx=64, n_batch=16)
     nll, count = m.perplexity(gg[f"{name}_ppl_tokens"], n_ctx=32, n_batch=8)
+    g.load().ggml_hip_gemm_sequential(1)
+    try:
+        nll_seq, count_seq = m.perplexity(gg[f"{name}_ppl_tokens"], n_ctx=32, n_batch=8)
+    finally:
+        g.load().ggml_hip_gemm_sequential(0)
     m.free()
-    assert count == int(gg[f"{name}_ppl_count"]) == 45
-    assert abs(nll - float(gg[f"{name}_ppl_nll"])) <= 1e-9 * abs(nll)
+    assert count == count_seq == int(gg[f"{name}_ppl_count"]) == 45
+    assert abs(nll_seq - float(gg[f"{name}_ppl_nll"])) <= 1e-9 * abs(nll_seq)
+    assert abs(nll - float(gg[f"{name}_ppl_nll"])) <= 2e-3 * abs(nll)
 
 
 @pytest.mark.parametrize("graph", [1, 0])

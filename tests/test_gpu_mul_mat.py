@@ -90,8 +90,9 @@ GEMM_TYPES = [ob.Q4_0, ob.Q4_1, ob.Q5_0, ob.Q5_1, ob.Q8_0, ob.Q4_K, ob.Q5_K]
 @pytest.mark.parametrize("K,M,N", [(512, 37, 9), (4544, 200, 33), (8192, 129, 128), (1024, 300, 257), (18176, 70, 40)])
 def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
     """N > 4 columns: int8 MFMA GEMM (legacy formats + Q4_K/Q5_K) or column-chunked mat-vec (Q2_K/Q3_K/Q6_K).
-    Legacy formats through the GEMM add the per-block terms in block order with the reference's scalar expression:
-    BIT-EXACT against the oracle (= the reference's scalar vec_dot)."""
+    Legacy formats through the GEMM use the reference's scalar per-block expression; with ggml_hip_gemm_sequential(1) the
+    blocks are added left to right: BIT-EXACT against the oracle (= the reference's scalar vec_dot). The default order on
+    every shape (4 or 2 interleaved partial sums) is bit-exact against the oracle run with that association."""
     if K % ob.BLCK[t]:
         pytest.skip("k-quants need K % 256 == 0")
     rng = np.random.default_rng(K + M + N + t)
@@ -100,9 +101,20 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
     dw = g.Weight(t, w, K, M)
     got = dw.mul_mat(x)
     exp = oracle.mul_mat(t, w, K, M, x, 8)
+    g.load().ggml_hip_gemm_sequential(1)
+    try:
+        seq = dw.mul_mat(x)
+    finally:
+        g.load().ggml_hip_gemm_sequential(0)
+    oracle.lib.orc_set_sum_order(2)          # the backend's choice for this shape: 4 or 2 interleaved partial sums
+    try:
+        exp_split = oracle.mul_mat(t, w, K, M, x, 8)
+    finally:
+        oracle.lib.orc_set_sum_order(0)
     if t in ob.LEGACY:
-        assert np.array_equal(got, exp)
-    assert relrms(got, exp) <= TOL
+        assert np.array_equal(seq, exp)      # sequential order == the reference's scalar loop, bit for bit
+        assert np.array_equal(got, exp_split)
+    assert relrms(got, exp) <= TOL and relrms(seq, exp) <= TOL
     # and the same columns through the mat-vec kernel agree within the association tolerance
     g.load().ggml_hip_debug_force_gemv(1)
     try:
