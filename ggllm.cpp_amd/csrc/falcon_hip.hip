@@ -302,7 +302,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     auto acts = [&](const fq_act & a, int64_t n) { fq_act v = a; v.ncols = n; return v; };
     // the fused kernels are instantiated per weight format: a model that mixes formats inside a block (e.g. the reference's
     // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
-    const bool fused = c->fused_decode && stage_uniform(m);
+    const bool fused = c->fused_decode && stage_uniform(m) && !fq_attn_f64();       // (ggml_hip_reference_order: the op list)
     if (N == 1 && fused) {
         // ---- fused single-token path (kernels_decode.hip), bit-identical to the op list below. Per block, by mode:
         //   3 launches  k_gemv_ln | k_attn_decode | k_gemv_out

@@ -5,8 +5,14 @@
 //   scores  K.Q (ggml.c:11049-11088) * 1/sqrt(64) (libfalcon.cpp:2313-2317); keys j >= n_kv are masked (ggml.c:12341)
 //   softmax max, exp through the fp16 table, f64 sum, scale by (float)(1/sum)  (ggml.c:12389-12456)
 //   V.P     out[d] = sum_j V[j][d] * p[j]
-// f32 products are accumulated in f64 like the reference's portable ggml_vec_dot_f32 (ggml.c:2296-2300); the f64 sums
-// are associated differently (8 lanes x 8 dims / waves / 16 row classes), which changes the f32 result with probability ~1e-9.
+// Two arithmetic variants of the two dot products (template parameter F64):
+//   F64 = false (default, every fused kernel): f32 fused multiply-add chains, as the reference's SIMD builds accumulate
+//           (ggml_vec_dot_f32 with GGML_F32_VEC_FMA, ggml.c:2270-2294): per lane 8 dims, then a butterfly over the 8 lanes;
+//           per value-row class (j mod 16) one chain, the 16 classes added in order. One instruction per multiply-add.
+//   F64 = true  (ggml_hip_reference_order): f32 products accumulated in f64 like the reference's portable
+//           ggml_vec_dot_f32 (ggml.c:2296-2300); the f64 sums are associated as above, which changes the f32 result with
+//           probability ~1e-9. Three instructions per multiply-add (v_mul_f32, v_cvt_f64_f32, v_add_f64): 4-6 x slower.
+// The oracle models both (orc_set_sum_order).
 // (One thread per key row would reproduce the reference's order exactly and needs a third of the instructions, but its
 // 64 scattered 16-byte requests per load instruction cost more than they save: measured +3 us per decode attention.)
 //
@@ -75,6 +81,27 @@ __device__ __forceinline__ void attn_prefetch(const float * __restrict__ kc, con
 }
 
 // scores of the 128 rows [j0, j0 + 128) held in k8
+// one lane's share of a 64-dim dot (dims 4 s8.. and 32 + 4 s8..), then the sum over the row's 8 lanes
+template <bool F64>
+__device__ __forceinline__ float attn_dot8(const f32x4 ka, const f32x4 kb, const f32x4 qa, const f32x4 qb) {
+    if constexpr (F64) {
+        double s = (double)(ka.x * qa.x); s += (double)(ka.y * qa.y); s += (double)(ka.z * qa.z); s += (double)(ka.w * qa.w);
+        s += (double)(kb.x * qb.x); s += (double)(kb.y * qb.y); s += (double)(kb.z * qb.z); s += (double)(kb.w * qb.w);
+        return (float) reduce8(s, op_add());
+    } else {
+        float s = ka.x * qa.x; s = __builtin_fmaf(ka.y, qa.y, s); s = __builtin_fmaf(ka.z, qa.z, s); s = __builtin_fmaf(ka.w, qa.w, s);
+        s = __builtin_fmaf(kb.x, qb.x, s); s = __builtin_fmaf(kb.y, qb.y, s); s = __builtin_fmaf(kb.z, qb.z, s); s = __builtin_fmaf(kb.w, qb.w, s);
+        return reduce8(s, op_add());
+    }
+}
+template <bool F64> struct attn_acc { typedef float t; };
+template <> struct attn_acc<true> { typedef double t; };
+template <bool F64>
+__device__ __forceinline__ void attn_mac(typename attn_acc<F64>::t & a, float v, float p) {
+    if constexpr (F64) a += (double)(v * p); else a = __builtin_fmaf(v, p, a);
+}
+
+template <bool F64 = false>
 __device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_cached, int n_kv, const float * new_k, const f32x4 qa, const f32x4 qb,
                                                 int tid, float * p, float & lmax) {
     const int s8 = tid & 7, rowg = tid >> 3;
@@ -83,27 +110,26 @@ __device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_
         const int j = j0 + 32 * b + rowg;
         f32x4 ka = k8[2 * b], kb = k8[2 * b + 1];
         if (new_k && j == n_cached) { ka = *(const f32x4 *)(new_k + 4 * s8); kb = *(const f32x4 *)(new_k + 32 + 4 * s8); }
-        double s = (double)(ka.x * qa.x); s += (double)(ka.y * qa.y); s += (double)(ka.z * qa.z); s += (double)(ka.w * qa.w);
-        s += (double)(kb.x * qb.x); s += (double)(kb.y * qb.y); s += (double)(kb.z * qb.z); s += (double)(kb.w * qb.w);
-        s = reduce8(s, op_add());
-        const float sc = (float) s * 0.125f;
-        if (j < n_kv) { if (s8 == 0) p[j] = sc; lmax = fmaxf(lmax, sc); }
+        const float sc = attn_dot8<F64>(ka, kb, qa, qb) * 0.125f;
+        if (j < n_kv && s8 == 0) p[j] = sc;
+        lmax = j < n_kv ? fmaxf(lmax, sc) : lmax;
     }
 }
-__device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cached, int tid, const float * p, double & a0, double & a1, double & a2, double & a3) {
+template <bool F64 = false>
+__device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cached, int tid, const float * p, typename attn_acc<F64>::t & a0,
+                                             typename attn_acc<F64>::t & a1, typename attn_acc<F64>::t & a2, typename attn_acc<F64>::t & a3) {
     const int rowi = tid >> 4;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int j = j0 + 16 * b + rowi;
-        if (j < n_cached) {
-            const float pj = p[j];
-            const f32x4 v4 = v8[b];
-            a0 += (double)(v4.x * pj); a1 += (double)(v4.y * pj); a2 += (double)(v4.z * pj); a3 += (double)(v4.w * pj);
-        }
+        const float pj = j < n_cached ? p[j] : 0.0f;              // (a row beyond the end is a clamped, finite re-read: v * 0 adds nothing)
+        const f32x4 v4 = v8[b];
+        attn_mac<F64>(a0, v4.x, pj); attn_mac<F64>(a1, v4.y, pj); attn_mac<F64>(a2, v4.z, pj); attn_mac<F64>(a3, v4.w, pj);
     }
 }
 
 // q: 64 floats (rotated) in LDS or global; returns out[d] for d = tid (valid for tid < 64)
+template <bool F64 = false>
 __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, const float * __restrict__ kc, const float * __restrict__ vc,
                                                  int HKV, int hk, int n_cached, const float * new_k, const float * new_v,
                                                  const uint16_t * __restrict__ exp_tab, const attn_lds & L, const int tid, attn_pre & P,
@@ -118,10 +144,10 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
         const int s8 = tid & 7;
         const f32x4 qa = *(const f32x4 *)(q + 4 * s8), qb = *(const f32x4 *)(q + 32 + 4 * s8);
         for (int j0 = 0; j0 < n_kv; j0 += 256) {
-            attn_score_step(P.k, j0, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+            attn_score_step<F64>(P.k, j0, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
             if (j0 + 256 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 256, tid, P.k);
             if (j0 + 128 < n_kv) {
-                attn_score_step(P.k + 8, j0 + 128, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+                attn_score_step<F64>(P.k + 8, j0 + 128, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
                 if (j0 + 384 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 384, tid, P.k + 8);
             }
         }
@@ -149,37 +175,153 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
     __syncthreads();
     FQ_ATTN_STAMP(dbg, 4);
     // ---- V.P
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    typedef typename attn_acc<F64>::t acc_t;
+    acc_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    acc_t * const pvred = (acc_t *) L.red;                         // 16 row classes x 64 dims
     for (int j0 = 0; j0 < n_cached; j0 += 256) {
-        attn_pv_step(P.v, j0, n_cached, tid, L.p, a0, a1, a2, a3);
+        attn_pv_step<F64>(P.v, j0, n_cached, tid, L.p, a0, a1, a2, a3);
         if (j0 + 256 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 256, tid, P.v);
         if (j0 + 128 < n_cached) {
-            attn_pv_step(v1, j0 + 128, n_cached, tid, L.p, a0, a1, a2, a3);
+            attn_pv_step<F64>(v1, j0 + 128, n_cached, tid, L.p, a0, a1, a2, a3);
             if (j0 + 384 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 384, tid, v1);
         }
     }
     if (new_v && rowi == (n_cached & 15)) {
         const float4 v = *(const float4 *)(new_v + 4 * sub);
         const float pj = L.p[n_cached];
-        a0 += (double)(v.x * pj); a1 += (double)(v.y * pj); a2 += (double)(v.z * pj); a3 += (double)(v.w * pj);
+        attn_mac<F64>(a0, v.x, pj); attn_mac<F64>(a1, v.y, pj); attn_mac<F64>(a2, v.z, pj); attn_mac<F64>(a3, v.w, pj);
     }
     FQ_ATTN_STAMP(dbg, 5);
-    L.red[rowi * 64 + 4 * sub + 0] = a0; L.red[rowi * 64 + 4 * sub + 1] = a1;
-    L.red[rowi * 64 + 4 * sub + 2] = a2; L.red[rowi * 64 + 4 * sub + 3] = a3;
+    pvred[rowi * 64 + 4 * sub + 0] = a0; pvred[rowi * 64 + 4 * sub + 1] = a1;
+    pvred[rowi * 64 + 4 * sub + 2] = a2; pvred[rowi * 64 + 4 * sub + 3] = a3;
     __syncthreads();
     float out = 0.0f;
     if (tid < 64) {
-        double o = L.red[tid];
+        acc_t o = pvred[tid];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) o += L.red[r * 64 + tid];
+        for (int r = 1; r < 16; ++r) o += pvred[r * 64 + tid];
         out = (float) o;
     }
     return out;
 }
+template <bool F64 = false>
 __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, const float * __restrict__ kc, const float * __restrict__ vc,
                                                  int HKV, int hk, int n_cached, const float * new_k, const float * new_v,
                                                  const uint16_t * __restrict__ exp_tab, const attn_lds & L) {
     attn_pre P;
     attn_prefetch(kc, vc, HKV, hk, n_cached, (int) threadIdx.x, P);
-    return attn_head_block(q, kc, vc, HKV, hk, n_cached, new_k, new_v, exp_tab, L, (int) threadIdx.x, P);
+    return attn_head_block<F64>(q, kc, vc, HKV, hk, n_cached, new_k, new_v, exp_tab, L, (int) threadIdx.x, P);
+}
+
+// ---- prefill: R consecutive tokens of one head by one 256-thread workgroup --------------------------------------------
+// Every number is produced exactly as attn_head_block produces it for one token (same lane -> dimension map, same f64
+// partial sums, same reduction trees: the results are bit-identical), but a tile of 128 key rows / value rows is loaded
+// into registers ONCE and used for all R tokens: with one workgroup per (head, token) a 2048-token prompt re-reads the
+// head's keys and values 2048 times from L2 (72 GB per block of Falcon-7B), with R = 8 an eighth of that.
+//   p: R rows of p_stride floats in LDS (scores, then probabilities); token t0 + r sees keys [0, n_past + t0 + r + 1)
+template <int R, bool F64>
+__device__ __forceinline__ void attn_rows_block(const float * __restrict__ qkv, int heads, int h, int t0, int nrows, int n_past,
+                                                const float * __restrict__ kc, const float * __restrict__ vc, int HKV, int hk,
+                                                const uint16_t * __restrict__ exp_tab, float * redf, double * red, float * p, int p_stride,
+                                                float * __restrict__ att, int H) {
+    constexpr int NT = 256;
+    const int tid = (int) threadIdx.x, s8 = tid & 7, rowg = tid >> 3, sub = tid & 15, rowi = tid >> 4;
+    const int n_kv_max = n_past + t0 + nrows;                       // keys the block's last token sees
+    // ---- scores
+    f32x4 qa[R], qb[R];
+    float lmax[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float * q = qkv + ((int64_t)(t0 + (r < nrows ? r : nrows - 1)) * heads + h) * 64;
+        qa[r] = *(const f32x4 *)(q + 4 * s8); qb[r] = *(const f32x4 *)(q + 32 + 4 * s8);
+        lmax[r] = -INFINITY;
+    }
+    {
+        f32x4 k8[8], kn[8];
+        attn_load_k(kc, HKV, hk, n_kv_max, 0, tid, k8);
+        for (int j0 = 0; j0 < n_kv_max; j0 += 128) {
+            if (j0 + 128 < n_kv_max) attn_load_k(kc, HKV, hk, n_kv_max, j0 + 128, tid, kn);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = j0 + 32 * b + rowg;
+                const f32x4 ka = k8[2 * b], kb = k8[2 * b + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float sc = attn_dot8<F64>(ka, kb, qa[r], qb[r]) * 0.125f;
+                    const bool vis = r < nrows && j < n_past + t0 + r + 1;      // (selects, not branches: a branch per
+                    if (vis && s8 == 0) p[r * p_stride + j] = sc;               //  accumulator update costs a copy of every live accumulator)
+                    lmax[r] = vis ? fmaxf(lmax[r], sc) : lmax[r];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) k8[i] = kn[i];
+        }
+    }
+    // ---- soft_max, one token after the other with all 256 threads (three barriers each, as in attn_head_block)
+    for (int r = 0; r < nrows; ++r) {
+        const int n_kv = n_past + t0 + r + 1;
+        float * pr = p + r * p_stride;
+        float lm = lmax[0];
+#pragma unroll
+        for (int q = 1; q < R; ++q) if (q == r) lm = lmax[q];
+        lm = wave_max(lm);
+        if ((tid & 63) == 0) redf[tid >> 6] = lm;
+        __syncthreads();
+        const float mx = waves_combine(redf, NT >> 6, op_max());
+        double lsum = 0.0;
+        for (int j = tid; j < n_kv; j += NT) {
+            const float e = soft_max_exp(exp_tab, pr[j] - mx);
+            pr[j] = e;
+            lsum += (double) e;
+        }
+        lsum = wave_sum(lsum);
+        if ((tid & 63) == 0) red[tid >> 6] = lsum;
+        __syncthreads();
+        const double sum = waves_combine(red, NT >> 6, op_add());
+        const float inv = (float)(1.0 / sum);
+        for (int j = tid; j < n_kv; j += NT) pr[j] *= inv;
+        __syncthreads();
+    }
+    // ---- V.P
+    typedef typename attn_acc<F64>::t acc_t;
+    acc_t * const pvred = (acc_t *) red;
+    acc_t a[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { a[r][0] = 0; a[r][1] = 0; a[r][2] = 0; a[r][3] = 0; }
+    {
+        f32x4 v8[8], vn[8];
+        attn_load_v(vc, HKV, hk, n_kv_max, 0, tid, v8);
+        for (int j0 = 0; j0 < n_kv_max; j0 += 128) {
+            if (j0 + 128 < n_kv_max) attn_load_v(vc, HKV, hk, n_kv_max, j0 + 128, tid, vn);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int j = j0 + 16 * b + rowi;
+                const f32x4 v4 = v8[b];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    // an invisible key contributes v * 0 (v is a clamped, finite re-read): the accumulator keeps its value
+                    const bool vis = r < nrows && j < n_past + t0 + r + 1;
+                    const float pj = vis ? p[r * p_stride + j] : 0.0f;
+                    attn_mac<F64>(a[r][0], v4.x, pj); attn_mac<F64>(a[r][1], v4.y, pj); attn_mac<F64>(a[r][2], v4.z, pj); attn_mac<F64>(a[r][3], v4.w, pj);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v8[i] = vn[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r < nrows) {                                            // (uniform)
+            pvred[rowi * 64 + 4 * sub + 0] = a[r][0]; pvred[rowi * 64 + 4 * sub + 1] = a[r][1];
+            pvred[rowi * 64 + 4 * sub + 2] = a[r][2]; pvred[rowi * 64 + 4 * sub + 3] = a[r][3];
+            __syncthreads();
+            if (tid < 64) {
+                acc_t o = pvred[tid];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) o += pvred[q * 64 + tid];
+                att[(int64_t)(t0 + r) * H * 64 + (int64_t) h * 64 + tid] = (float) o;
+            }
+            __syncthreads();
+        }
+    }
 }

@@ -238,6 +238,7 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
 static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
 extern "C" void ggml_hip_debug_force_gemv(int on) { g_force_gemv = on != 0; }
 extern "C" void ggml_hip_gemm_sequential(int on) { fq_gemm_set_sequential(on); }
+extern "C" void ggml_hip_reference_order(int on) { fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
 
 // ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream
 static bool g_prof_on = false;

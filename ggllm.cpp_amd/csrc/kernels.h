@@ -32,6 +32,8 @@ void   fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float 
 bool   fq_gemm_supported(int type);
 void   fq_gemm_debug_mode(int m);
 void   fq_gemm_set_sequential(int on);
+void   fq_attn_set_f64(int on);
+int    fq_attn_f64();
 void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd,
                       const fq_gemv_epi & ep, int n_cu, hipStream_t st);
 

@@ -85,6 +85,7 @@ void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_
 // ------------------------------------------------------------------------------------------------ attention
 // One 256-thread workgroup per (head, token); n_kv = n_past + t + 1 keys are visible, all read from the KV cache
 // (k_rope_kv has already appended this launch's keys). The arithmetic lives in fq_attn_dev.h.
+template <bool F64>
 __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                    const float * __restrict__ kc, const float * __restrict__ vc,
                                                    const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
@@ -95,17 +96,66 @@ __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qk
     const int heads = H + 2 * HKV;
     const int hk = h / (H / HKV);
     const attn_lds L = attn_lds_carve(smem);
-    const float o = attn_head_block(qkv + ((int64_t) t * heads + h) * D, kc, vc, HKV, hk, n_kv, nullptr, nullptr, exp_tab, L);
+    const float o = attn_head_block<F64>(qkv + ((int64_t) t * heads + h) * D, kc, vc, HKV, hk, n_kv, nullptr, nullptr, exp_tab, L);
     if (threadIdx.x < 64) att[(int64_t) t * H * D + (int64_t) h * D + threadIdx.x] = o;
+}
+
+// R consecutive tokens of a head per workgroup (prefill): key / value tiles are loaded once per R tokens (fq_attn_dev.h)
+template <int R, bool F64>
+__global__ void __launch_bounds__(256) k_attention_rows(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                        const float * __restrict__ kc, const float * __restrict__ vc,
+                                                        const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int p_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int h = blockIdx.x, t0 = blockIdx.y * R;
+    const int nrows = N - t0 < R ? N - t0 : R;
+    float * redf = (float *) smem;
+    double * red = (double *)(smem + 64);
+    float * p = (float *)(smem + 64 + 16 * 64 * 8);
+    attn_rows_block<R, F64>(qkv, H + 2 * HKV, h, t0, nrows, *n_past_ptr, kc, vc, HKV, h / (H / HKV), exp_tab, redf, red, p, p_stride, att, H);
+}
+template <int R, bool F64>
+static void launch_attention_rows_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, int p_stride, size_t lds, const float * k_cache,
+                                    const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_rows<R, F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
+    hipLaunchKernelGGL((k_attention_rows<R, F64>), dim3((unsigned) H, (unsigned)((N + R - 1) / R)), dim3(256), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, p_stride);
+}
+// 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
+static int g_attn_f64 = 0;
+void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
+int  fq_attn_f64() { return g_attn_f64; }
+template <int R>
+static void launch_attention_rows(const float * qkv, int N, int H, int HKV, const int * n_past_dev, int p_stride, size_t lds, const float * k_cache,
+                                  const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+    if (g_attn_f64) launch_attention_rows_t<R, true>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, st);
+    else            launch_attention_rows_t<R, false>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, st);
 }
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                          const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
     if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
-    const size_t lds = 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15);    // sized for the largest n_past + N the launch may see
-    if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
-    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
-    hipLaunchKernelGGL(k_attention, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
+    const int p_stride = (max_n_kv + 3) & ~3;
+    const size_t fixed = 16 * 4 + 16 * 64 * 8, row = (size_t) p_stride * 4, budget = 150 * 1024;
+    if (fixed + row > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
+    // tokens per workgroup: 4 where their score rows fit LDS (measured, Falcon-7B: 2048-token prompt 2.08 ms per block with 4,
+    // 2.21 with 2, 2.40 with 8 -- more tokens per workgroup re-use a key tile more often but leave fewer waves per CU --
+    // and 3.66 ms for the f64 variant; 128 tokens: 27 / 28 / 44 us)
+    static const int force = getenv("FQ_ATTN_ROWS") ? atoi(getenv("FQ_ATTN_ROWS")) : -1;      // tuning override: 0 = one token per workgroup
+    if (force == 8 && N >= 4 && fixed + 8 * row <= budget) launch_attention_rows<8>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 8 * row, k_cache, v_cache, exp_table, att, st);
+    else if (force != 0 && force != 2 && N >= 4 && fixed + 4 * row <= budget) launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 4 * row, k_cache, v_cache, exp_table, att, st);
+    else if (force != 0 && N >= 2 && fixed + 2 * row <= budget) launch_attention_rows<2>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 2 * row, k_cache, v_cache, exp_table, att, st);
+    else {
+        const size_t lds = fixed + row;
+        if (lds > 64 * 1024) {
+            static size_t g = 0;
+            if (lds > g) {
+                HIP_CHECK(hipFuncSetAttribute((const void *) k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                HIP_CHECK(hipFuncSetAttribute((const void *) k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                g = lds;
+            }
+        }
+        if (g_attn_f64) hipLaunchKernelGGL(k_attention<true>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
+        else            hipLaunchKernelGGL(k_attention<false>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ self-test

@@ -130,6 +130,31 @@ static float dot_f32(const float * a, const float * b, int64_t n, int64_t stride
     return (float) s;
 }
 
+/* The HIP backend's default attention arithmetic (ggllm.cpp_amd/csrc/fq_attn_dev.h, F64 = false): f32 fused multiply-add
+ * chains like the reference's SIMD builds. K.Q: lane s (0..7) owns dims 4s..4s+3 and 32+4s..32+4s+3 in that order, the
+ * eight partial sums are added as ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)). V.P: one chain per class j mod 16 over
+ * increasing j, the 16 classes added in order. Selected by orc_set_sum_order(2) ("as the backend"). */
+int orc_attn_backend_order(void);
+static float dot_qk_backend(const float * k, const float * q) {
+    float part[8];
+    for (int s = 0; s < 8; ++s) {
+        const float * a = k + 4 * s, * b = q + 4 * s;
+        float v = a[0] * b[0];
+        v = fmaf(a[1], b[1], v); v = fmaf(a[2], b[2], v); v = fmaf(a[3], b[3], v);
+        v = fmaf(a[32], b[32], v); v = fmaf(a[33], b[33], v); v = fmaf(a[34], b[34], v); v = fmaf(a[35], b[35], v);
+        part[s] = v;
+    }
+    return ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+}
+static float dot_pv_backend(const float * v, const float * p, int64_t n, int64_t stride_v) {
+    float part[16];
+    for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+    for (int64_t j = 0; j < n; ++j) part[j & 15] = fmaf(v[j * stride_v], p[j], part[j & 15]);
+    float o = part[0];
+    for (int r = 1; r < 16; ++r) o = o + part[r];
+    return o;
+}
+
 void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_past, int n_threads,
                      int flavour, float * logits_out, float * hidden_out) {
     orc_tables_init();
@@ -179,19 +204,22 @@ void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_p
         memcpy(kc + (size_t) n_past * HKV * D, krot, sizeof(float) * N * HKV * D);      /* libfalcon.cpp:2238-2244 */
 
         const float kq_scale = 1.0f / sqrtf((float) D);
+        const int backend_attn = orc_attn_backend_order() && D == 64;
         for (int t = 0; t < N; ++t) {
             for (int h = 0; h < H; ++h) {
                 const int hk = h / group;
                 const float * q = qrot + ((size_t) t * H + h) * D;
                 for (int64_t s = 0; s < n_kv; ++s) {
-                    float v = dot_f32(kc + ((size_t) s * HKV + hk) * D, q, D, 1) * kq_scale;  /* K.Q then scale */
+                    float v = (backend_attn ? dot_qk_backend(kc + ((size_t) s * HKV + hk) * D, q)
+                                            : dot_f32(kc + ((size_t) s * HKV + hk) * D, q, D, 1)) * kq_scale;  /* K.Q then scale */
                     if (s > n_past + t) v = -INFINITY;                                    /* ggml.c:12341-12347 */
                     p[s] = v;
                 }
                 orc_softmax_rows(p, n_kv, 1);
                 float * o = att + (size_t) t * E + (size_t) h * D;                        /* merged [n_embd, N] */
                 for (int64_t d = 0; d < D; ++d) {
-                    o[d] = dot_f32(vc + (size_t) hk * D + d, p, n_kv, HKV * D);    /* V^T row . P row */
+                    o[d] = backend_attn ? dot_pv_backend(vc + (size_t) hk * D + d, p, n_kv, HKV * D)
+                                        : dot_f32(vc + (size_t) hk * D + d, p, n_kv, HKV * D);    /* V^T row . P row */
                 }
             }
         }

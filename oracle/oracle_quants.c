@@ -381,6 +381,7 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
  * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
  * columns, order 2 for GEMMs. mode 3 / 4: order 2 with 4 / 2 partial sums for every mat-mul. */
 static int g_split = 4;
+int orc_attn_backend_order(void) { return g_sum_mode == 2; }
 void orc_set_sum_order(int mode) {
     g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4) ? 2 : 0);
     g_split = (mode == 4) ? 2 : 4;

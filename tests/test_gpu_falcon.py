@@ -210,7 +210,7 @@ def test_falcon40b_shaped_layer_vs_oracle(oracle):
 def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     """falcon_hip_model_load_ggcc on a GGCC v10 file (the reference's model format; the file is byte-identical to the one
     the real libfalcon.cpp loaded when tests/golden/ggcc_models.npz was captured): same logits as the in-memory upload of
-    the same weights, bit for bit; for the legacy formats the prefill logits (MFMA GEMM in sequential block order) are the
+    the same weights, bit for bit; for the legacy formats the prefill logits in reference order (ggml_hip_reference_order) are the
     REFERENCE's own logits bit for bit; a pipeline stage loads only its own blocks"""
     import ggcc_writer
     gg = golden["ggcc_models"]
@@ -228,11 +228,11 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     assert np.array_equal(da, db)
     ref_pre, ref_dec = gg[f"{name}_prefill_logits"], gg[f"{name}_decode_logits"]
     if t in ob.LEGACY:
-        g.load().ggml_hip_gemm_sequential(1)                         # prefill GEMM in the reference's block order
+        g.load().ggml_hip_reference_order(1)                         # GEMM in block order, attention dots in f64
         try:
             ls = a.eval(toks[:9], 0)
         finally:
-            g.load().ggml_hip_gemm_sequential(0)
+            g.load().ggml_hip_reference_order(0)
         assert np.array_equal(ls, ref_pre)
         assert relrms(la, ref_pre) <= max(1e-3, 2 * 2.8e-2)          # default: partial sums per row (ggml_hip_gemm_sequential)
         assert relrms(da, ref_dec) <= max(1e-3, 2 * 2.8e-2)          # decode: wave-order association, see DESIGN.md section 2
@@ -250,18 +250,18 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
 def test_perplexity_loop(oracle, golden, name, hp, t):
     """falcon_hip_perplexity = the reference's perplexity loop (falcon_perplexity.cpp:28-124): chunks of n_ctx 32 in batches
     of 8, NLL of the second half of every chunk. The fixture was produced by driving the same loop over the REAL reference's
-    falcon_eval (oracle/gen_golden.py); with the GEMM in sequential block order the prefill logits are bit-identical to the
+    falcon_eval (oracle/gen_golden.py); in reference order (ggml_hip_reference_order) the prefill logits are bit-identical to the
     reference's, so the NLL is too (same libm); the default order (partial sums) moves it within the reference's own
     build-to-build spread"""
     gg = golden["ggcc_models"]
     w = synth.make_model(oracle, hp, t, seed=4321)
     m = g.FalconModel(w, n_ctx=64, n_batch=16)
     nll, count = m.perplexity(gg[f"{name}_ppl_tokens"], n_ctx=32, n_batch=8)
-    g.load().ggml_hip_gemm_sequential(1)
+    g.load().ggml_hip_reference_order(1)
     try:
         nll_seq, count_seq = m.perplexity(gg[f"{name}_ppl_tokens"], n_ctx=32, n_batch=8)
     finally:
-        g.load().ggml_hip_gemm_sequential(0)
+        g.load().ggml_hip_reference_order(0)
     m.free()
     assert count == count_seq == int(gg[f"{name}_ppl_count"]) == 45
     assert abs(nll_seq - float(gg[f"{name}_ppl_nll"])) <= 1e-9 * abs(nll_seq)
