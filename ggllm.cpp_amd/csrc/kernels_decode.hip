@@ -202,6 +202,7 @@ __device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const in
         }
     }
     FQ_STAMP(a.dbg, 5);
+    if (a.dbg && lane == 0) atomicMax((unsigned long long *)(a.dbg + (size_t) blockIdx.x * 8 + 6), (unsigned long long) wall_clock64());   // slowest wave
     __syncthreads();
     for (int grp = wid; grp < (RW * nw) / 32; grp += nw) {     // a wave finishes rows [32*grp, 32*grp+32) (lanes 32..63 mirror 0..31)
         const int j = lane & 31;

@@ -1,4 +1,5 @@
-"""phase timeline of the fused decode kernels (tuning aid): python scripts/gpu_stamps.py [layers]"""
+"""phase timeline of the fused decode kernels (tuning aid): python scripts/gpu_stamps.py [layers]
+(k_gemv_ln: stamp 5 = the workgroup's first wave has streamed its rows, slot 6 = its LAST wave has)"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
