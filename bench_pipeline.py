@@ -31,15 +31,46 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-def partition(n_layer, world):
-    """contiguous, balanced block ranges: [(begin, end)] per rank (40B: 60 -> 15/15/15/15 or 8,8,8,8,7,7,7,7)"""
-    base, extra = divmod(n_layer, world)
+def partition(n_layer, world, head_units=0.0):
+    """contiguous block ranges [(begin, end)] per rank, balanced by the bytes a stage streams per token: a block is one
+    unit, the last stage also owns ln_f + lm_head = head_units blocks' worth of weights (Falcon-7B Q4_0: 166 MB / 122 MB =
+    1.4; 40B: 0.8). Minimises the slowest stage -- the pipeline's throughput is its reciprocal. head_units = 0: the plain
+    split (40B: 60 -> 15/15/15/15 or 8,8,8,8,7,7,7,7)."""
+    if world == 1:
+        return [(0, n_layer)]
+    if head_units <= 0:
+        base, extra = divmod(n_layer, world)
+        out, b = [], 0
+        for r in range(world):
+            e = b + base + (1 if r < extra else 0)
+            out.append((b, e))
+            b = e
+        return out
+    best = None
+    for last in range(1, n_layer - (world - 1) + 1):            # blocks of the last stage; the others split the rest evenly
+        rest = n_layer - last
+        if rest < world - 1:
+            continue
+        front = -(-rest // (world - 1))                          # ceil
+        cost = max(front, last + head_units)
+        if best is None or cost < best[0] - 1e-9 or (abs(cost - best[0]) <= 1e-9 and last > best[1]):
+            best = (cost, last)
+    last = best[1]
+    base, extra = divmod(n_layer - last, world - 1)
+    counts = [base + (1 if r < extra else 0) for r in range(world - 1)] + [last]
     out, b = [], 0
-    for r in range(world):
-        e = b + base + (1 if r < extra else 0)
-        out.append((b, e))
-        b = e
+    for c in counts:
+        out.append((b, b + c))
+        b += c
     return out
+
+
+def head_units(hp, wtype_bits_per_weight=None):
+    """lm_head's weight bytes in units of one block's weight bytes (same format for both: the ratio is format-free)"""
+    E, FF, V = hp["n_embd"], hp["n_ff"], hp["n_vocab"]
+    qkv = (hp["n_head"] + 2 * hp["n_head_kv"]) * 64
+    per_block = E * qkv + E * E + 2 * E * FF
+    return (V * E) / per_block
 
 
 class PipelineRunner:
@@ -177,7 +208,8 @@ def main(a, rank, world, local):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    lb, le = partition(hp["n_layer"], world)[rank]
+    parts = partition(hp["n_layer"], world, head_units(hp))
+    lb, le = parts[rank]
     S = max(2 * world, 2) if world > 1 else getattr(a, "streams", 1)
     n_ctx = min(a.n_ctx, 512)
 
@@ -228,7 +260,7 @@ def main(a, rank, world, local):
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
             "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPUs "
-                                   f"({[e - b for b, e in partition(hp['n_layer'], world)]} blocks per stage), {S} greedy decode streams in flight, "
+                                   f"({[e - b for b, e in parts]} blocks per stage, balanced by bytes incl. lm_head), {S} greedy decode streams in flight, "
                                    f"a step = one round (one token per stream); hidden-state hand-off by RCCL send/recv",
                        "streams": S, "weight_bytes_per_token": wbytes, "n_past_timed": [n_past - a.steps, n_past]},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),

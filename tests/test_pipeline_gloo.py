@@ -94,8 +94,21 @@ def test_partition():
     assert [e - b for b, e in bp.partition(60, 8)] == [8, 8, 8, 8, 7, 7, 7, 7]
     assert bp.partition(32, 1) == [(0, 32)]
     for L, w in ((32, 8), (80, 8), (5, 3)):
-        parts = bp.partition(L, w)
-        assert parts[0][0] == 0 and parts[-1][1] == L and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        for hu in (0.0, 0.8, 1.4):
+            parts = bp.partition(L, w, hu)
+            assert len(parts) == w and all(e > b for b, e in parts)
+            assert parts[0][0] == 0 and parts[-1][1] == L and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    # balanced by the bytes a stage streams: the last stage also owns lm_head (1.4 blocks' worth for Falcon-7B)
+    from ggllm_cpp_amd import synth
+    hu7, hu40 = bp.head_units(synth.HP_7B), bp.head_units(synth.HP_40B)
+    assert 1.3 < hu7 < 1.5 and 0.7 < hu40 < 0.9
+    def slowest(parts, hu):
+        return max([e - b for b, e in parts[:-1]] + [parts[-1][1] - parts[-1][0] + hu])
+    for w in (2, 4, 8):
+        assert slowest(bp.partition(32, w, hu7), hu7) <= slowest(bp.partition(32, w), hu7)
+    assert [e - b for b, e in bp.partition(32, 8, hu7)] == [5, 4, 4, 4, 4, 4, 4, 3]
+    assert [e - b for b, e in bp.partition(32, 2, hu7)] == [17, 15]
+    assert [e - b for b, e in bp.partition(60, 8, hu40)] == [8, 8, 8, 8, 7, 7, 7, 7]
 
 
 @pytest.mark.parametrize("world,n_layer,n_streams", [(2, 5, 4), (3, 7, 6), (2, 4, 2), (3, 3, 3)])
