@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# the host driver of these boxes only supports dmabuf IPC: without this, RCCL / cross-process device memory sharing fails
+# with hipIpcGetMemHandle: invalid argument (must be set before the HIP runtime initialises)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
