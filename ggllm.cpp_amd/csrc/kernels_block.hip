@@ -136,13 +136,17 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     const int p_stride = (max_n_kv + 3) & ~3;
     const size_t fixed = 16 * 4 + 16 * 64 * 8, row = (size_t) p_stride * 4, budget = 150 * 1024;
     if (fixed + row > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
-    // tokens per workgroup: 4 where their score rows fit LDS (measured, Falcon-7B: 2048-token prompt 2.08 ms per block with 4,
-    // 2.21 with 2, 2.40 with 8 -- more tokens per workgroup re-use a key tile more often but leave fewer waves per CU --
-    // and 3.66 ms for the f64 variant; 128 tokens: 27 / 28 / 44 us)
+    // tokens per workgroup: more tokens re-use a key tile more often, but their score rows (n_kv floats each) sit in LDS and
+    // leave fewer workgroups per CU. Measured on Falcon-7B, ms per block for 4 / 2 / 1 tokens: 2048-token prompt 2.08 / 2.21 /
+    // (f64: 3.7); 4096 tokens 8.65 / 8.36; 8192 tokens 52.9 / 36.1 / 41.9 -> 4 while that keeps >= 3 workgroups per CU
+    // (n_kv <= ~3000), else 2
     static const int force = getenv("FQ_ATTN_ROWS") ? atoi(getenv("FQ_ATTN_ROWS")) : -1;      // tuning override: 0 = one token per workgroup
-    if (force == 8 && N >= 4 && fixed + 8 * row <= budget) launch_attention_rows<8>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 8 * row, k_cache, v_cache, exp_table, att, st);
-    else if (force != 0 && force != 2 && N >= 4 && fixed + 4 * row <= budget) launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 4 * row, k_cache, v_cache, exp_table, att, st);
-    else if (force != 0 && N >= 2 && fixed + 2 * row <= budget) launch_attention_rows<2>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 2 * row, k_cache, v_cache, exp_table, att, st);
+    const bool fit4 = fixed + 4 * row <= budget, fit2 = fixed + 2 * row <= budget;
+    int R = (N >= 4 && fixed + 4 * row <= 56 * 1024) ? 4 : ((N >= 2 && fit2) ? 2 : 1);
+    if (force == 0) R = 1; else if (force == 8 && N >= 4 && fixed + 8 * row <= budget) R = 8; else if (force == 4 && N >= 4 && fit4) R = 4; else if (force == 2 && N >= 2 && fit2) R = 2;
+    if (R == 8)      launch_attention_rows<8>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 8 * row, k_cache, v_cache, exp_table, att, st);
+    else if (R == 4) launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 4 * row, k_cache, v_cache, exp_table, att, st);
+    else if (R == 2) launch_attention_rows<2>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 2 * row, k_cache, v_cache, exp_table, att, st);
     else {
         const size_t lds = fixed + row;
         if (lds > 64 * 1024) {
