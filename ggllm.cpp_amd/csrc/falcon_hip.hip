@@ -413,12 +413,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const layer_weights & L = m->layers[li];
         if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
-        fq_launch_layer_norm(c->x, E, N, L.ln_w, L.ln_b, c->ln, st);
-        fq_launch_quantize_act(c->ln, E, acts(c->act_e, N), st);
+        fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, acts(c->act_e, N), st);      // (the f32 row is not needed)
         const fq_act * attn_in = &c->act_e;
         if (hp.two_norms) {
-            fq_launch_layer_norm(c->x, E, N, L.ln2_w, L.ln2_b, c->ln2, st);
-            fq_launch_quantize_act(c->ln2, E, acts(c->act_e2, N), st);
+            fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, acts(c->act_e2, N), st);
             attn_in = &c->act_e2;
         }
         fq_mul_mat_q_acts(L.qkv, acts(*attn_in, N), N, c->qkv, QKV, store, st);
@@ -439,8 +437,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         c->hidden_tokens = N;
     }
     if (m->last_stage()) {
-        fq_launch_layer_norm(c->x, E, N, m->out_norm_w, m->out_norm_b, c->ln, st);
-        fq_launch_quantize_act(c->ln, E, acts(c->act_e, N), st);
+        fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, acts(c->act_e, N), st);
         fq_mul_mat_q_acts(m->lm_head, acts(c->act_e, N), N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
     }
 }

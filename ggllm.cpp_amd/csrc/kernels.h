@@ -39,6 +39,7 @@ void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float 
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
+void   fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st);
 void   fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st);
 void   fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st);
 // qkv: [N][(H+2HKV)*D] fused rows; rotates Q (in place) and K, appends K/V at positions n_past.. of the layer's cache

@@ -26,6 +26,30 @@ __global__ void __launch_bounds__(256) k_layer_norm(const float * __restrict__ x
     for (int64_t i = threadIdx.x; i < (n >> 2); i += blockDim.x) ((float4 *) yr)[i] = ((const float4 *) row)[i];
 }
 
+// layer norm + the mat-mul's activation quantizer in one launch (prefill): the normalised row goes from LDS straight into
+// the Q8 image; y (optional) also receives the f32 row. Same device functions as k_layer_norm + k_quantize_q8*.
+template <int ACT>
+__global__ void __launch_bounds__(256) k_layer_norm_quant(const float * __restrict__ x, int64_t n, const float * __restrict__ w,
+                                                          const float * __restrict__ b, float * __restrict__ y, fq_act a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float  * row = (float *) smem;
+    double * red = (double *)(smem + ((n * 4 + 15) & ~(int64_t) 15));
+    layer_norm_row_block(x + (int64_t) blockIdx.x * n, n, w, b, row, red);
+    if (y) {
+        float * yr = y + (int64_t) blockIdx.x * n;
+        for (int64_t i = threadIdx.x; i < (n >> 2); i += blockDim.x) ((float4 *) yr)[i] = ((const float4 *) row)[i];
+    }
+    __syncthreads();
+    uint8_t * col = a.base + (size_t) blockIdx.x * fq_act_col_bytes(ACT, n);
+    quantize_row_block<ACT>(row, n, act_image_at(col, ACT, n));
+}
+void fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st) {
+    const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
+    if (a.type == FQ_Q8_0)      hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_0>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
+    else if (a.type == FQ_Q8_1) hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_1>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
+    else                        hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_K>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
+}
+
 void fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st) {
     const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
     hipLaunchKernelGGL(k_layer_norm, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y);
