@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_model_quantize falcon_hip_perplexity""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity""".split()
 
 
 def build(verbose=False):
@@ -96,6 +96,7 @@ def load():
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
+        "falcon_hip_plan_stages": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
         "falcon_hip_perplexity": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
@@ -221,6 +222,16 @@ def ggcc_scan(path):
     assert len(rows) == n
     d = dict(n_vocab=hp.n_vocab, n_embd=hp.n_embd, n_head=hp.n_head, n_head_kv=hp.n_head_kv, n_layer=hp.n_layer, n_ff=hp.n_ff, two_norms=bool(hp.two_norms))
     return d, ft.value, rows
+
+
+def plan_stages(path, n_stages, n_ctx=2048, n_batch=1, n_streams=1, vram_per_gpu=0):
+    """host-only: ([(layer_begin, layer_end)], [device bytes per stage], fits) for a layer pipeline over a GGCC file"""
+    lb, le = (C.c_int * n_stages)(), (C.c_int * n_stages)()
+    sb = (C.c_size_t * n_stages)()
+    rc = load().falcon_hip_plan_stages(os.fsencode(path), n_stages, n_ctx, n_batch, n_streams, vram_per_gpu, lb, le, sb)
+    if rc < 0:
+        raise RuntimeError("falcon_hip_plan_stages(%s, %d) failed" % (path, n_stages))
+    return [(lb[i], le[i]) for i in range(n_stages)], [int(sb[i]) for i in range(n_stages)], rc == 0
 
 
 def quantize_model(path_in, path_out, ftype, quantize_output_tensor=True, allow_requantize=False):

@@ -154,6 +154,63 @@ extern "C" falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int 
     return m;
 }
 
+// ------------------------------------------------------------------------------------------------ stage planner
+// The job of the reference's VRAM planner (falcon_model_load_internal, libfalcon.cpp:1660-1900: how many blocks fit the
+// device) for a fully resident layer pipeline: split the blocks of a GGCC file over n_stages contiguous ranges so that the
+// slowest stage streams as few weight bytes per token as possible (the first stage also owns the embedding, which it only
+// gathers from; the last one ln_f + lm_head, which it streams), and report what each stage needs in device memory:
+// weights, n_streams KV caches of n_ctx positions, activations of n_batch tokens. Host-only (no device needed).
+// Returns 0, 1 if a stage exceeds vram_per_gpu (> 0), -1 on error.
+extern "C" int falcon_hip_plan_stages(const char * path, int n_stages, int n_ctx, int n_batch, int n_streams, size_t vram_per_gpu,
+                                      int * layer_begin, int * layer_end, size_t * stage_bytes) {
+    ggcc_file f;
+    if (!ggcc_open(path, f)) { fprintf(stderr, "falcon-hip: %s: %s\n", path, f.error.c_str()); return -1; }
+    const int L = f.hp.n_layer;
+    if (n_stages < 1 || n_stages > L || n_ctx < 1 || n_batch < 1 || n_streams < 1) { fprintf(stderr, "falcon-hip: plan: %d stages for %d blocks\n", n_stages, L); return -1; }
+    std::vector<size_t> blk((size_t) L, 0);
+    size_t emb = 0, head = 0;
+    for (const ggcc_tensor & t : f.tensors) {
+        int il = -1;
+        if (sscanf(t.name.c_str(), "transformer.h.%d.", &il) == 1 && il >= 0 && il < L) blk[(size_t) il] += t.size;
+        else if (t.name == "transformer.word_embeddings.weight") emb = t.size;
+        else head += t.size;                                               // ln_f, lm_head
+    }
+    // contiguous partition minimising the largest streamed-bytes load: cost[s][i] = best max over the first s stages covering
+    // blocks [0, i); the last stage's load includes the head
+    std::vector<size_t> pre((size_t) L + 1, 0);
+    for (int i = 0; i < L; ++i) pre[(size_t) i + 1] = pre[(size_t) i] + blk[(size_t) i];
+    const size_t INF = ~(size_t) 0;
+    std::vector<std::vector<size_t>> best((size_t) n_stages + 1, std::vector<size_t>((size_t) L + 1, INF));
+    std::vector<std::vector<int>> cut((size_t) n_stages + 1, std::vector<int>((size_t) L + 1, 0));
+    best[0][0] = 0;
+    for (int s = 1; s <= n_stages; ++s)
+        for (int i = s; i <= L - (n_stages - s); ++i)
+            for (int j = s - 1; j < i; ++j) {
+                if (best[(size_t) s - 1][(size_t) j] == INF) continue;
+                size_t load = pre[(size_t) i] - pre[(size_t) j];
+                if (s == n_stages) { if (i != L) continue; load += head; }
+                const size_t c = load > best[(size_t) s - 1][(size_t) j] ? load : best[(size_t) s - 1][(size_t) j];
+                if (c < best[(size_t) s][(size_t) i]) { best[(size_t) s][(size_t) i] = c; cut[(size_t) s][(size_t) i] = j; }
+            }
+    int end = L;
+    for (int s = n_stages; s >= 1; --s) { const int b = cut[(size_t) s][(size_t) end]; layer_begin[s - 1] = b; layer_end[s - 1] = end; end = b; }
+    const size_t E = (size_t) f.hp.n_embd, QKV = (size_t)(f.hp.n_head + 2 * f.hp.n_head_kv) * 64, FF = (size_t) f.hp.n_ff, V = (size_t) f.hp.n_vocab;
+    int over = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        const size_t nb = (size_t)(layer_end[s] - layer_begin[s]);
+        size_t bytes = pre[(size_t) layer_end[s]] - pre[(size_t) layer_begin[s]];
+        if (s == 0) bytes += emb;
+        if (s == n_stages - 1) bytes += head;
+        const size_t kv = 2 * nb * (size_t) n_ctx * (size_t) f.hp.n_head_kv * 64 * 4;                  // f32 K and V per context
+        size_t act = (size_t) n_batch * (5 * E + QKV + FF) * 4 + (size_t) n_batch * (3 * E + FF) * 5 / 4;   // f32 rows + Q8 images
+        if (s == n_stages - 1) act += (size_t) n_batch * V * 4;
+        bytes += (size_t) n_streams * (kv + act);
+        if (stage_bytes) stage_bytes[s] = bytes;
+        if (vram_per_gpu && bytes > vram_per_gpu) over = 1;
+    }
+    return over;
+}
+
 // ------------------------------------------------------------------------------------------------ model quantization
 // falcon_model_quantize (libfalcon.cpp:3533-3743, 3914-3925) for GGCC v10 input: header and vocabulary are copied with the
 // new ftype, every 2-D tensor whose name ends in "weight" is converted to the ftype's tensor type (lm_head.weight only

@@ -52,6 +52,14 @@ size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m);   /* quantized
 falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int layer_begin, int layer_end, falcon_hip_hparams * hp_out);
 int  falcon_hip_ggcc_scan(const char * path, falcon_hip_hparams * hp_out, int * ftype_out, char * dir_out, size_t dir_cap);
 
+/* Stage plan of a layer pipeline for a GGCC file (host-only): n_stages contiguous block ranges that minimise the weight
+ * bytes the slowest stage streams per token (the last stage also streams ln_f + lm_head) -- what the reference's VRAM
+ * planner decides per device (libfalcon.cpp:1660-1900) -- and the device bytes each stage needs (weights + embedding on
+ * the first stage + n_streams x (KV cache of n_ctx positions + activations of n_batch tokens)). layer_begin / layer_end /
+ * stage_bytes: n_stages entries. Returns 0, 1 if a stage needs more than vram_per_gpu (0 = no limit), -1 on error.       */
+int  falcon_hip_plan_stages(const char * path, int n_stages, int n_ctx, int n_batch, int n_streams, size_t vram_per_gpu,
+                            int * layer_begin, int * layer_end, size_t * stage_bytes);
+
 /* falcon_model_quantize (libfalcon.h:176-179, libfalcon.cpp:3533-3743) for GGCC v10 files: writes path_out with every
  * 2-D "...weight" tensor converted to the tensor type of ftype (enum llama_ftype value: 0 f32, 1 f16, 2 Q4_0, 3 Q4_1,
  * 7 Q8_0, 8 Q5_0, 9 Q5_1, 10 Q2_K, 11-13 Q3_K, 14-15 Q4_K, 16-17 Q5_K, 18 Q6_K), lm_head.weight only when

@@ -89,3 +89,35 @@ def test_scan_refuses_damaged_files(files, tmp_path):
         bad.write_bytes(mutated)
         with pytest.raises(RuntimeError):
             g.ggcc_scan(str(bad))
+
+
+def test_stage_planner(oracle, tmp_path):
+    """falcon_hip_plan_stages (host-only): contiguous block ranges that minimise the bytes the slowest stage streams (the
+    last one also streams lm_head), device bytes per stage, the capacity check"""
+    hp = dict(synth.HP_TINY_MQA); hp["n_layer"] = 7
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=9)
+    p = str(tmp_path / "seven.ggcc")
+    ggcc_writer.write_ggcc(p, w)
+    _, _, rows = g.ggcc_scan(p)
+    blk = [sum(r[5] for r in rows if r[0].startswith("transformer.h.%d." % i)) for i in range(7)]
+    emb = next(r[5] for r in rows if r[0] == "transformer.word_embeddings.weight")
+    head = sum(r[5] for r in rows if r[0] in ("lm_head.weight", "transformer.ln_f.weight", "transformer.ln_f.bias"))
+    for P in (1, 2, 3, 7):
+        parts, bytes_, fits = g.plan_stages(p, P, n_ctx=64, n_batch=4, n_streams=2)
+        assert fits and len(parts) == P and parts[0][0] == 0 and parts[-1][1] == 7
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:])) and all(e > b for b, e in parts)
+        load = [sum(blk[b:e]) + (head if i == P - 1 else 0) for i, (b, e) in enumerate(parts)]
+        # optimal: no other contiguous partition has a smaller slowest stage (brute force over the cut positions)
+        import itertools
+        best = min(max(sum(blk[a:b]) + (head if k == P - 1 else 0) for k, (a, b) in enumerate(zip((0,) + cuts, cuts + (7,))))
+                   for cuts in itertools.combinations(range(1, 7), P - 1))
+        assert max(load) == best
+        kv = lambda nb: 2 * nb * 64 * hp["n_head_kv"] * 64 * 4
+        for i, (b, e) in enumerate(parts):
+            assert bytes_[i] >= sum(blk[b:e]) + (emb if i == 0 else 0) + (head if i == P - 1 else 0) + 2 * kv(e - b)
+    # lm_head weighs 0.67 blocks here: with 2 stages the last one gets fewer blocks
+    parts, bytes_, _ = g.plan_stages(p, 2, n_ctx=64)
+    assert parts[1][1] - parts[1][0] <= parts[0][1] - parts[0][0]
+    assert g.plan_stages(p, 2, n_ctx=64, vram_per_gpu=max(bytes_) - 1)[2] is False
+    with pytest.raises(RuntimeError):
+        g.plan_stages(p, 8)                                   # more stages than blocks
