@@ -114,7 +114,10 @@ def _attention_ref(oracle, q, kc, vc, n_past, H, HKV):
     return out
 
 
-@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 1, 0), (71, 1, 1, 300), (8, 2, 5, 37), (16, 8, 3, 1000)])
+# (the last three: the prefill kernel's other shapes -- 2 tokens per workgroup beyond ~3000 keys, one token per workgroup
+#  when two score rows no longer fit LDS, and a ragged last token block)
+@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 1, 0), (71, 1, 1, 300), (8, 2, 5, 37), (16, 8, 3, 1000), (2, 1, 6, 3500),
+                                            (2, 1, 2, 20000), (3, 1, 7, 0)])
 def test_attention(oracle, H, HKV, N, n_past):
     L = g.load()
     D = 64
