@@ -128,20 +128,25 @@ __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qk
 template <int R, bool F64>
 __global__ void __launch_bounds__(256) k_attention_rows(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                         const float * __restrict__ kc, const float * __restrict__ vc,
-                                                        const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int p_stride) {
+                                                        const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int p_stride,
+                                                        float * __restrict__ p_scratch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int h = blockIdx.x, t0 = blockIdx.y * R;
     const int nrows = N - t0 < R ? N - t0 : R;
     float * redf = (float *) smem;
     double * red = (double *)(smem + 64);
-    float * p = (float *)(smem + 64 + 16 * 64 * 8);
+    // the R score rows: LDS, or (long contexts) this workgroup's own slice of a global scratch buffer -- written and read
+    // back by the same workgroup within microseconds (L2 / Infinity Cache), and the LDS they would take no longer limits
+    // the number of workgroups per CU
+    float * p = p_scratch ? p_scratch + ((size_t) blockIdx.y * gridDim.x + blockIdx.x) * (size_t) R * (size_t) p_stride
+                          : (float *)(smem + 64 + 16 * 64 * 8);
     attn_rows_block<R, F64>(qkv, H + 2 * HKV, h, t0, nrows, *n_past_ptr, kc, vc, HKV, h / (H / HKV), exp_tab, redf, red, p, p_stride, att, H);
 }
 template <int R, bool F64>
 static void launch_attention_rows_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, int p_stride, size_t lds, const float * k_cache,
-                                    const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+                                    const float * v_cache, const uint16_t * exp_table, float * att, float * p_scratch, hipStream_t st) {
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_rows<R, F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
-    hipLaunchKernelGGL((k_attention_rows<R, F64>), dim3((unsigned) H, (unsigned)((N + R - 1) / R)), dim3(256), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, p_stride);
+    hipLaunchKernelGGL((k_attention_rows<R, F64>), dim3((unsigned) H, (unsigned)((N + R - 1) / R)), dim3(256), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, p_stride, p_scratch);
 }
 // 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
 static int g_attn_f64 = 0;
@@ -149,9 +154,24 @@ void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
 int  fq_attn_f64() { return g_attn_f64; }
 template <int R>
 static void launch_attention_rows(const float * qkv, int N, int H, int HKV, const int * n_past_dev, int p_stride, size_t lds, const float * k_cache,
-                                  const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
-    if (g_attn_f64) launch_attention_rows_t<R, true>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, st);
-    else            launch_attention_rows_t<R, false>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, st);
+                                  const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, float * p_scratch = nullptr) {
+    if (g_attn_f64) launch_attention_rows_t<R, true>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, p_scratch, st);
+    else            launch_attention_rows_t<R, false>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, p_scratch, st);
+}
+// score rows of long-context launches (one slice per workgroup), grown on demand up to 4 GiB
+static float * g_att_scratch = nullptr;
+static size_t  g_att_scratch_bytes = 0;
+static float * att_scratch(size_t bytes, hipStream_t st) {
+    static const size_t cap = (size_t)(getenv("FQ_ATTN_SCRATCH_GB") ? atoi(getenv("FQ_ATTN_SCRATCH_GB")) : 4) << 30;
+    if (bytes > cap) return nullptr;
+    if (bytes > g_att_scratch_bytes) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (g_att_scratch) HIP_CHECK(hipFree(g_att_scratch));
+        g_att_scratch = nullptr; g_att_scratch_bytes = 0;
+        if (hipMalloc((void **) &g_att_scratch, bytes) != hipSuccess) { (void) hipGetLastError(); g_att_scratch = nullptr; return nullptr; }
+        g_att_scratch_bytes = bytes;
+    }
+    return g_att_scratch;
 }
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
@@ -168,6 +188,15 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     const bool fit4 = fixed + 4 * row <= budget, fit2 = fixed + 2 * row <= budget;
     int R = (N >= 4 && fixed + 4 * row <= 56 * 1024) ? 4 : ((N >= 2 && fit2) ? 2 : 1);
     if (force == 0) R = 1; else if (force == 8 && N >= 4 && fixed + 8 * row <= budget) R = 8; else if (force == 4 && N >= 4 && fit4) R = 4; else if (force == 2 && N >= 2 && fit2) R = 2;
+    // beyond ~3000 keys: 4 tokens per workgroup with the score rows in the global scratch instead of 2 with them in LDS
+    // (8192-token prompt: 32 ms per block against 36-40; 8 tokens per workgroup: 38). The scratch is N x H x n_kv floats --
+    // 1.2 GB for a 512-token batch at 8192 keys -- and is not used beyond FQ_ATTN_SCRATCH_GB (default 4) GiB
+    static const int use_scratch = getenv("FQ_ATTN_SCRATCH") ? atoi(getenv("FQ_ATTN_SCRATCH")) : 1;
+    if (use_scratch && force < 0 && R == 2 && N >= 4) {
+        const size_t need = (size_t)((N + 3) / 4) * (size_t) H * 4 * row;
+        float * scr = att_scratch(need, st);
+        if (scr) { launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed, k_cache, v_cache, exp_table, att, st, scr); return; }
+    }
     if (R == 8)      launch_attention_rows<8>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 8 * row, k_cache, v_cache, exp_table, att, st);
     else if (R == 4) launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 4 * row, k_cache, v_cache, exp_table, att, st);
     else if (R == 2) launch_attention_rows<2>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 2 * row, k_cache, v_cache, exp_table, att, st);
