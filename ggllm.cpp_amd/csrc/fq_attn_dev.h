@@ -112,7 +112,7 @@ __device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_
         if (new_k && j == n_cached) { ka = *(const f32x4 *)(new_k + 4 * s8); kb = *(const f32x4 *)(new_k + 32 + 4 * s8); }
         const float sc = attn_dot8<F64>(ka, kb, qa, qb) * 0.125f;
         if (j < n_kv && s8 == 0) p[j] = sc;
-        lmax = j < n_kv ? fmaxf(lmax, sc) : lmax;
+        lmax = fq_max_f32(lmax, j < n_kv ? sc : -INFINITY);
     }
 }
 template <bool F64 = false>
@@ -122,7 +122,8 @@ __device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cac
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int j = j0 + 16 * b + rowi;
-        const float pj = j < n_cached ? p[j] : 0.0f;              // (a row beyond the end is a clamped, finite re-read: v * 0 adds nothing)
+        const float pv = p[j < n_cached ? j : 0];
+        const float pj = j < n_cached ? pv : 0.0f;                // (a row beyond the end is a clamped, finite re-read: v * 0 adds nothing)
         const f32x4 v4 = v8[b];
         attn_mac<F64>(a0, v4.x, pj); attn_mac<F64>(a1, v4.y, pj); attn_mac<F64>(a2, v4.z, pj); attn_mac<F64>(a3, v4.w, pj);
     }
@@ -250,7 +251,7 @@ __device__ __forceinline__ void attn_rows_block(const float * __restrict__ qkv, 
                     const float sc = attn_dot8<F64>(ka, kb, qa[r], qb[r]) * 0.125f;
                     const bool vis = r < nrows && j < n_past + t0 + r + 1;      // (selects, not branches: a branch per
                     if (vis && s8 == 0) p[r * p_stride + j] = sc;               //  accumulator update costs a copy of every live accumulator)
-                    lmax[r] = vis ? fmaxf(lmax[r], sc) : lmax[r];
+                    lmax[r] = fq_max_f32(lmax[r], vis ? sc : -INFINITY);
                 }
             }
 #pragma unroll

@@ -25,7 +25,9 @@
 // lane of a quad holds the quad's value, so mirror pairings combine exactly the operands xor 4 / xor 8 would. Steps
 // 16 and 32 combine the four row results through v_readlane: (r0 + r1) + (r2 + r3).
 // FQ_SHFL_REDUCE selects plain __shfl_xor for every step (same association; used by the self-test as the reference).
-template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+// (old = 0 with bound_ctrl: every source lane of these patterns exists, so the value is the same, and the compiler may fold
+//  the move into the consuming instruction, e.g. v_add_f32_dpp)
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ __forceinline__ float  dpp_mov(float v)  { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
 template <int CTRL> __device__ __forceinline__ int    dpp_mov(int v)    { return dpp_i32<CTRL>(v); }
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
@@ -41,7 +43,9 @@ __device__ __forceinline__ double lane_get(double v, int l) {
     return __builtin_bit_cast(double, (long long)(((unsigned long long) hi << 32) | lo));
 }
 struct op_add { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
-struct op_max { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+// maxNum of two floats in ONE instruction (fmaxf() adds a canonicalising v_max_f32 x, x per operand)
+__device__ __forceinline__ float fq_max_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+struct op_max { __device__ __forceinline__ float operator()(float a, float b) const { return fq_max_f32(a, b); } };
 
 template <typename T, typename OP>
 __device__ __forceinline__ T wave_reduce_shfl(T v, OP op) {
