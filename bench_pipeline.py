@@ -88,7 +88,8 @@ class PipelineRunner:
                                                                              token buffer of that item's stream)
     then computes. Send and receive are posted together (ncclGroup / async gloo ops), so the ring cannot deadlock, and
     in steady state all P stages compute concurrently on P different streams. S >= P keeps stage 0 from waiting for
-    a token that is still in flight.
+    a token that is still in flight. With S >= 2P streams (what bench.py runs) the schedule is stretched to one extra slot
+    per hop so that every transfer overlaps a compute slot instead of preceding it (_run_overlapped).
     """
 
     def __init__(self, rank, world, n_streams, engine, comm):
@@ -105,6 +106,8 @@ class PipelineRunner:
                 self.engine.step(w % S, n_past0 + w // S)
                 self.engine.feed_back_token(w % S)
             return
+        if S >= 2 * P and hasattr(self.comm, "post"):
+            return self._run_overlapped(W, n_past0)
         for t in range(W + P):
             sends, recvs = [], []
             w_prev = t - 1 - r                              # item computed in the previous slot
@@ -120,6 +123,36 @@ class PipelineRunner:
                 self.comm.exchange(sends, recvs)
             if 0 <= w < W:
                 self.engine.step(w % S, n_past0 + w // S)
+
+    def _run_overlapped(self, W, n_past0):
+        """S >= 2P streams: a hop gets a whole slot. Rank r computes item t - 2r in slot t; the exchange posted at the start
+        of slot t carries the result of slot t-1 to the next rank and brings in the input of slot t+1, and is only waited
+        for at the start of slot t+1 -- the transfer overlaps the compute of slot t. (The last rank's token of item x
+        travels in the exchange of slot x + 2P - 1 and is needed by rank 0 for item x + S in slot x + S >= x + 2P.)"""
+        P, S, r = self.world, self.S, self.rank
+        pending = None
+        for t in range(W + 2 * P):
+            sends, recvs = [], []
+            w_prev = t - 1 - 2 * r
+            if 0 <= w_prev < W:
+                sends.append(("token", w_prev % S, 0) if self.last else ("hidden", w_prev % S, r + 1))
+            if self.first:
+                x = t - 2 * P + 1                           # the item whose token the last rank sends in this exchange
+                if 0 <= x < W:
+                    recvs.append(("token", x % S, P - 1))
+            else:
+                w_next = t + 1 - 2 * r
+                if 0 <= w_next < W:
+                    recvs.append(("hidden", w_next % S, r - 1))
+            posted = self.comm.post(sends, recvs) if (sends or recvs) else None
+            if pending is not None:
+                self.comm.finish(pending)
+            pending = posted
+            w = t - 2 * r
+            if 0 <= w < W:
+                self.engine.step(w % S, n_past0 + w // S)
+        if pending is not None:
+            self.comm.finish(pending)
 
 
 # ------------------------------------------------------------------------------------------------ GPU backend
@@ -153,14 +186,20 @@ class TorchComm:
     def __init__(self, dist, engine):
         self.dist, self.e = dist, engine
 
-    def exchange(self, sends, recvs):
+    def post(self, sends, recvs):
         ops = []
         for kind, s, peer in sends:
             ops.append(self.dist.P2POp(self.dist.isend, self.e.tok_out[s] if kind == "token" else self.e.hidden_out[s], peer))
         for kind, s, peer in recvs:
             ops.append(self.dist.P2POp(self.dist.irecv, self.e.tok_in[s] if kind == "token" else self.e.hidden_in[s], peer))
-        for w in self.dist.batch_isend_irecv(ops):
+        return self.dist.batch_isend_irecv(ops)
+
+    def finish(self, works):
+        for w in works:                  # nccl: the current stream waits (not the host); gloo: the host waits
             w.wait()
+
+    def exchange(self, sends, recvs):
+        self.finish(self.post(sends, recvs))
 
 
 class HostStagedComm:
@@ -171,7 +210,7 @@ class HostStagedComm:
     def __init__(self, dist, engine, torch):
         self.dist, self.e, self.torch = dist, engine, torch
 
-    def exchange(self, sends, recvs):
+    def post(self, sends, recvs):
         works, pend = [], []
         for kind, s, peer in sends:
             t = (self.e.tok_out[s] if kind == "token" else self.e.hidden_out[s]).cpu()
@@ -181,10 +220,17 @@ class HostStagedComm:
             buf = self.torch.empty(dst.shape, dtype=dst.dtype)
             works.append(self.dist.irecv(buf, peer))
             pend.append((dst, buf))
+        return works, pend
+
+    def finish(self, posted):
+        works, pend = posted
         for w in works:
             w.wait()
         for dst, buf in pend:
             dst.copy_(buf)
+
+    def exchange(self, sends, recvs):
+        self.finish(self.post(sends, recvs))
 
 
 def main(a, rank, world, local):
