@@ -136,6 +136,11 @@ template <int TYPE> struct gemm_group_k45 {
         w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
         w.s3 = ld_u32(fq_at<TYPE, PSC + 1>(r, sb));
     }
+    __device__ static void split(const gemm_raw & w, int g, int (&isc)[2], int (&imn)[2], float & d, float & dmin) {
+        int s6, m6; k4_scale_min(w.s0, w.s1, w.s2, g & 7, s6, m6);
+        isc[0] = s6; imn[0] = m6; isc[1] = 0; imn[1] = 0;
+        d = fq_h2f((uint16_t) w.s3); dmin = fq_h2f((uint16_t)(w.s3 >> 16));
+    }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float & sc, float & mn) {
         const int j = g & 7;
         if constexpr (TYPE == FQ_Q5_K) {
@@ -151,6 +156,12 @@ template <int TYPE> struct gemm_group_k45 {
     }
 };
 template <> struct gemm_group<FQ_Q4_K> : gemm_group_k45<FQ_Q4_K> {};
+// ---- k-quants in the INTEGER domain (gemm_kint): a super-block's 8 groups share one fp16 d (and dmin) per weight row and
+// one f32 d per token, the sub-block scales / mins are small integers, so  sum_j d sc_j I_j = d (sum_j sc_j I_j)  with
+// the sum exact in int32 -- what the reference's own k-quant dots do (k_quants.c:1267-1306 ...). The f32 work drops from
+// 5-6 instructions per (row, token, group) to 1-2 integer multiply-adds plus one f32 flush per super-block.
+//   split(w, g, isc, imn, d, dmin): the group's integer scale(s) / min(s) and the row's super-block floats
+template <int TYPE> struct gemm_kint { static constexpr bool value = false; };
 template <> struct gemm_group<FQ_Q5_K> : gemm_group_k45<FQ_Q5_K> {};
 
 // ---- formats with 16-element sub-blocks. Group g of a row = elements [32 g, 32 g + 32) = sub-blocks 2g, 2g+1 of the row.
@@ -164,6 +175,11 @@ template <> struct gemm_group<FQ_Q2_K> {            // k_quants.c:344-375: w = d
         w.a = ld_w4(q); w.b = ld_w4(q + 16);
         w.s0 = ld_u16(fq_at<FQ_Q2_K, 1>(r, sb) + 8 * hf + 2 * j);      // scales[8 hf + 2 j], [.. + 1]
         w.s1 = ld_u32(fq_at<FQ_Q2_K, 2>(r, sb));
+    }
+    __device__ static void split(const gemm_raw & w, int, int (&isc)[2], int (&imn)[2], float & d, float & dmin) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const uint32_t b = (w.s0 >> (8 * s)) & 0xFFu; isc[s] = (int)(b & 0xFu); imn[s] = (int)(b >> 4); }
+        d = fq_h2f((uint16_t) w.s1); dmin = fq_h2f((uint16_t)(w.s1 >> 16));
     }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int sh = 2 * (g & 3);
@@ -188,6 +204,12 @@ template <> struct gemm_group<FQ_Q3_K> {            // k_quants.c:472-521: w = d
         w.s0 = ld_u32(scp); w.s1 = ld_u32(scp + 4); w.s2 = ld_u32(scp + 8);
         w.s3 = ld_u16(fq_at<FQ_Q3_K, 3>(r, sb));
     }
+    __device__ static void split(const gemm_raw & w, int g, int (&isc)[2], int (&imn)[2], float & d, float & dmin) {
+        const int hf = (g >> 2) & 1, j = g & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { isc[s] = q3_scale(w.s0, w.s1, w.s2, 8 * hf + 2 * j + s) - 32; imn[s] = 0; }
+        d = fq_h2f((uint16_t) w.s3); dmin = 0.0f;
+    }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int hf = (g >> 2) & 1, j = g & 3, sh = 2 * j, hb = 4 * hf + j;
         auto val = [&](uint32_t q, uint32_t h) {                        // per byte: 2 bits | (high bit << 2), minus 4
@@ -211,6 +233,11 @@ template <> struct gemm_group<FQ_Q6_K> {            // k_quants.c:845-876: w = d
         w.s0 = ld_u16(fq_at<FQ_Q6_K, 2>(r, sb) + 8 * h + 2 * t);       // int8 scales[8 h + 2 t], [.. + 1]
         w.s1 = ld_u16(fq_at<FQ_Q6_K, 3>(r, sb));
     }
+    __device__ static void split(const gemm_raw & w, int, int (&isc)[2], int (&imn)[2], float & d, float & dmin) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { isc[s] = (int)(int8_t)(w.s0 >> (8 * s)); imn[s] = 0; }
+        d = fq_h2f((uint16_t) w.s1); dmin = 0.0f;
+    }
     __device__ static void finish(const gemm_raw & w, int g, v4i & lo, v4i & hi, float (&sc)[2], float (&mn)[2]) {
         const int t = g & 3, nsh = (t >> 1) ? 4 : 0, hsh = 2 * t;
         auto val = [&](uint32_t l, uint32_t h) {
@@ -224,6 +251,12 @@ template <> struct gemm_group<FQ_Q6_K> {            // k_quants.c:845-876: w = d
     }
 };
 
+template <> struct gemm_kint<FQ_Q2_K> { static constexpr bool value = true; };
+template <> struct gemm_kint<FQ_Q3_K> { static constexpr bool value = true; };
+template <> struct gemm_kint<FQ_Q4_K> { static constexpr bool value = true; };
+template <> struct gemm_kint<FQ_Q5_K> { static constexpr bool value = true; };
+template <> struct gemm_kint<FQ_Q6_K> { static constexpr bool value = true; };
+
 // tuning aid (ggml_hip_debug_gemm_mode): bit 0 = no global loads after the first stage, bit 1 = no MFMA / scaling (timing only)
 __device__ int g_gemm_dbg = 0;
 void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
@@ -232,7 +265,8 @@ void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_d
 template <bool HAS_MIN, int TN, int SUB> struct gemm_lds {           // TN = tokens per workgroup, SUB = scale sub-groups per group
     static constexpr int XQ = 0, WQ = TN * GQ_STRIDE, DX = WQ + GQ_TM * GQ_STRIDE, SX = DX + GQ_GROUPS * TN * 4,
                          DW = SX + (HAS_MIN ? GQ_GROUPS * SUB * TN * 4 : 0), MW = DW + GQ_GROUPS * SUB * GQ_TM * 4,
-                         BYTES = MW + (HAS_MIN ? GQ_GROUPS * SUB * GQ_TM * 4 : 0);
+                         DS = MW + (HAS_MIN ? GQ_GROUPS * SUB * GQ_TM * 4 : 0),      // k-quants: d [32 rows], dmin [32 rows]
+                         BYTES = DS + 2 * GQ_TM * 4;
 };
 
 // S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves.
@@ -245,7 +279,7 @@ template <int TYPE, int S, int TT>
 __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = fq_act_of(TYPE);
-    constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
+    constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN, KINT = gemm_kint<TYPE>::value;
     constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB;
     typedef gemm_lds<HAS_MIN, TN, SUB> LB;
     constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16;         // threads, token vectors per thread and stage, results per lane
@@ -273,7 +307,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     const uint8_t * sc_col = act.base + (size_t)(n0 + sc_tok < N ? n0 + sc_tok : N - 1) * img;
 
     struct stage_regs { gemm_raw w; v4i x[VT]; float4 d4; float2 sa, sb; uint2 ba, bb; };
-    auto issue = [&](int g0, stage_regs & R, auto role) {
+    auto issue = [&](int g0, stage_regs & R, auto role) __attribute__((always_inline)) {
         constexpr int ROLE = decltype(role)::value;
         if constexpr (ROLE == 1) { const int g = g0 + w_gg; gemm_group<TYPE>::load(wrow, g < ngroups ? g : ngroups - 1, R.w); }
 #pragma unroll
@@ -298,7 +332,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             }
         }
     };
-    auto commit = [&](int g0, const stage_regs & R, uint8_t * B, auto role) {   // registers -> LDS buffer B (zeros beyond K / N / M)
+    auto commit = [&](int g0, const stage_regs & R, uint8_t * B, auto role) __attribute__((always_inline)) {   // registers -> LDS buffer B (zeros beyond K / N / M)
         constexpr int ROLE = decltype(role)::value;
         if constexpr (ROLE == 1) {
             const int g = g0 + w_gg;
@@ -309,10 +343,24 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             }
             *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg)      = lo;
             *(v4i *)(B + LB::WQ + w_row * GQ_STRIDE + 32 * w_gg + 16) = hi;
+            if constexpr (KINT) {
+                int isc[2] = {0, 0}, imn[2] = {0, 0}; float dd = 0.0f, dm = 0.0f;
+                if (g < ngroups && m0 + w_row < M) gemm_group<TYPE>::split(R.w, g, isc, imn, dd, dm);
 #pragma unroll
-            for (int ss = 0; ss < SUB; ++ss) {
-                ((float *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = sc[ss];
-                if constexpr (HAS_MIN) ((float *)(B + LB::MW))[(w_gg * SUB + ss) * GQ_TM + w_row] = mn[ss];
+                for (int ss = 0; ss < SUB; ++ss) {
+                    ((int *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = isc[ss];
+                }
+                if constexpr (HAS_MIN) {        // the stage's 4 SUB mins of a row: k slots 0..7 of an int8 MFMA operand (below)
+                    if constexpr (SUB == 2) ((uint16_t *)(B + LB::MW))[w_row * 4 + w_gg] = (uint16_t)(imn[0] | (imn[1] << 8));
+                    else { (B + LB::MW)[w_row * 8 + w_gg] = (uint8_t) imn[0]; (B + LB::MW)[w_row * 8 + 4 + w_gg] = 0; }
+                }
+                if (w_gg == 0) { ((float *)(B + LB::DS))[w_row] = dd; ((float *)(B + LB::DS))[GQ_TM + w_row] = dm; }
+            } else {
+#pragma unroll
+                for (int ss = 0; ss < SUB; ++ss) {
+                    ((float *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = sc[ss];
+                    if constexpr (HAS_MIN) ((float *)(B + LB::MW))[(w_gg * SUB + ss) * GQ_TM + w_row] = mn[ss];
+                }
             }
         }
 #pragma unroll
@@ -329,7 +377,8 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dx[i] = R.d4.x;
-                    if constexpr (SUB == 1) sx[i] = R.d4.x * (float)((int)(int16_t) bw[i] + (int)(int16_t)(bw[i] >> 16));
+                    if constexpr (KINT) continue;
+                    else if constexpr (SUB == 1) sx[i] = R.d4.x * (float)((int)(int16_t) bw[i] + (int)(int16_t)(bw[i] >> 16));
                     else { sx[i] = R.d4.x * (float)(int)(int16_t) bw[i]; sx1[i] = R.d4.x * (float)(int)(int16_t)(bw[i] >> 16); }
                 }
             } else {
@@ -345,17 +394,42 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (q == src) { dv = dx[q]; sv = sx[q]; sv1 = sx1[q]; }
                 ((float *)(B + LB::DX))[gg * TN + sc_tok] = ok ? dv : 0.0f;
-                if constexpr (HAS_MIN) {
+                if constexpr (HAS_MIN && !KINT) {
                     ((float *)(B + LB::SX))[(gg * SUB) * TN + sc_tok] = ok ? sv : 0.0f;
                     if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + sc_tok] = ok ? sv1 : 0.0f;
                 }
+            }
+            if constexpr (KINT && HAS_MIN) {
+                // the stage's 4 SUB block sums of a token as int8 MFMA operand bytes: bsum = 64 hi + lo, hi in [-64, 63]
+                // (|bsum| <= 32 * 127), lo in [0, 63]; k slot = gg SUB + ss, hi bytes in the low 8 bytes, lo in the high 8
+                const uint32_t bw[4] = { R.ba.x, R.ba.y, R.bb.x, R.bb.y };
+                uint32_t H[2] = {0, 0}, Lo[2] = {0, 0};
+                if (n0 + sc_tok < N) {
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int b0 = (int)(int16_t) bw[gg], b1 = (int)(int16_t)(bw[gg] >> 16);
+                        if constexpr (SUB == 1) {
+                            const int v = b0 + b1;
+                            H[0] |= (uint32_t)((v >> 6) & 0xFF) << (8 * gg); Lo[0] |= (uint32_t)(v & 63) << (8 * gg);
+                        } else {
+                            const int sl = 2 * gg;
+                            H[sl >> 2]  |= ((uint32_t)((b0 >> 6) & 0xFF) | ((uint32_t)((b1 >> 6) & 0xFF) << 8)) << (8 * (sl & 3));
+                            Lo[sl >> 2] |= ((uint32_t)(b0 & 63) | ((uint32_t)(b1 & 63) << 8)) << (8 * (sl & 3));
+                        }
+                    }
+                }
+                *(v4i *)(B + LB::SX + sc_tok * 16) = v4i{ (int) H[0], (int) H[1], (int) Lo[0], (int) Lo[1] };
             }
         }
     };
 
     float acc[NR];
+    int iacc[KINT ? NR : 1];                                             // k-quants: integer sums of the current super-block
+    v16i chi = {0}, clo = {0};                                           // ... and of its mins term (wave sw == S - 1)
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < (KINT ? NR : 1); ++r) iacc[r] = 0;
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int rot = 0;
     const int arow = l31;
@@ -364,11 +438,23 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     // ---- software pipeline, prefetch distance TWO stages (a stage's math, ~0.7 us, is shorter than a load round trip):
     // while stage s is computed out of LDS buffer s & 1, stage s+1 sits in one register set and stage s+2 is in flight
     // into the other
-    auto compute = [&](const uint8_t * B) {
+    auto compute = [&](const uint8_t * B, const bool sb_end) __attribute__((always_inline)) {
 #pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
         for (int gg = sw; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); gg += S) {
             const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
             const v4i b = *(const v4i *)(B + LB::WQ + l31 * GQ_STRIDE + 32 * gg + 16 * half);
+            if constexpr (KINT) {
+#pragma unroll
+                for (int ss = 0; ss < SUB; ++ss) {
+                    const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
+                    const int isc = ((const int *)(B + LB::DW))[(gg * SUB + ss) * GQ_TM + l31];
+                    v16i c = {0};
+                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) iacc[i] = __mul24(c[i], isc) + iacc[i];       // |c| < 2^17, |isc| <= 128
+                }
+                continue;
+            }
             // the lane's result i  <->  token 32 tt + rot + (i & 3) + 8 (i >> 2) + 4 half: runs of 4 consecutive tokens
             float dxv[NR];
 #pragma unroll
@@ -409,11 +495,45 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                 }
             }
         }
+        if constexpr (KINT && HAS_MIN) {
+            // the mins term  sum_j m_j bsum_j  of the stage's 4 SUB sub-blocks for the whole 32 x 32 tile: a [tokens x j] by
+            // [j x rows] int8 product, so two MFMAs (hi / lo bytes of the block sums) instead of 4 SUB x 16 multiply-adds;
+            // one wave per tile does it (the last K share: never one of the staging waves)
+            if (sw == S - 1 && !(dbgm & 2)) {
+                v4i am = {0, 0, 0, 0}; int2 bn = {0, 0};
+                if (half == 0) { am = *(const v4i *)(B + LB::SX + (32 * tt + arow) * 16); bn = *(const int2 *)(B + LB::MW + l31 * 8); }
+                const v4i bmn = { bn.x, bn.y, 0, 0 };
+                chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[0], am[1], 0, 0 }, bmn, chi, 0, 0, 0);
+                clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[2], am[3], 0, 0 }, bmn, clo, 0, 0, 0);
+            }
+        }
+        if constexpr (KINT) {
+            // end of a super-block (every second stage): one f32 step per result, the reference's own k-quant expression
+            // sumf += (d * y.d) * sum_j sc_j I_j  -  (dmin * y.d) * sum_j m_j bsum_j   (k_quants.c:1565-1583 ...)
+            if (sb_end) {
+                const float dd = ((const float *)(B + LB::DS))[l31], dm = HAS_MIN ? ((const float *)(B + LB::DS))[GQ_TM + l31] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < NR / 4; ++q) {
+                    const int tok = 32 * tt + rot + 8 * q + 4 * half;
+                    const float4 t = *(const float4 *)(B + LB::DX + tok * 4);      // y.d of the super-block (all four groups alike)
+                    const float dxq[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q + e;
+                        acc[i] = acc[i] + (dd * dxq[e]) * (float) iacc[i];
+                        iacc[i] = 0;
+                        if constexpr (HAS_MIN) {
+                            if (sw == S - 1) { acc[i] = acc[i] - (dm * dxq[e]) * (float)((chi[i] << 6) + clo[i]); chi[i] = 0; clo[i] = 0; }
+                        }
+                    }
+                }
+            }
+        }
     };
     const int nstages = (ngroups + GQ_GROUPS - 1) / GQ_GROUPS;
     const int last_g0 = (nstages - 1) * GQ_GROUPS;
     auto g0_of = [&](int st) { return st < nstages ? st * GQ_GROUPS : last_g0; };      // beyond the end: re-read the last stage (unused)
-    auto pipeline = [&](auto role) {
+    auto pipeline = [&](auto role) __attribute__((always_inline)) {
         stage_regs R0, R1;
         issue(0, R0, role);
         issue(g0_of(1), R1, role);
@@ -422,12 +542,12 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         for (int st = 0; st < nstages; st += 2) {
             // even stage st out of buffer 0; R1 holds st + 1; st + 2 goes into R0
             issue(g0_of(st + 2), R0, role);
-            compute(smem);
+            compute(smem, false);
             commit(g0_of(st + 1), R1, smem + LB::BYTES, role);
             __syncthreads();
             // odd stage st + 1 out of buffer 1; R0 holds st + 2; st + 3 goes into R1
             issue(g0_of(st + 3), R1, role);
-            if (st + 1 < nstages) compute(smem + LB::BYTES);
+            if (st + 1 < nstages) compute(smem + LB::BYTES, true);
             commit(g0_of(st + 2), R0, smem, role);
             __syncthreads();
         }
