@@ -262,11 +262,11 @@ __device__ int g_gemm_dbg = 0;
 void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
 
 // LDS buffer of one K stage
-template <bool HAS_MIN, int TN, int SUB> struct gemm_lds {           // TN = tokens per workgroup, SUB = scale sub-groups per group
-    static constexpr int XQ = 0, WQ = TN * GQ_STRIDE, DX = WQ + GQ_TM * GQ_STRIDE, SX = DX + GQ_GROUPS * TN * 4,
-                         DW = SX + (HAS_MIN ? GQ_GROUPS * SUB * TN * 4 : 0), MW = DW + GQ_GROUPS * SUB * GQ_TM * 4,
-                         DS = MW + (HAS_MIN ? GQ_GROUPS * SUB * GQ_TM * 4 : 0),      // k-quants: d [32 rows], dmin [32 rows]
-                         BYTES = DS + 2 * GQ_TM * 4;
+template <bool HAS_MIN, int TN, int SUB, int TM> struct gemm_lds {   // TN = tokens, TM = weight rows per workgroup, SUB = scale sub-groups per group
+    static constexpr int XQ = 0, WQ = TN * GQ_STRIDE, DX = WQ + TM * GQ_STRIDE, SX = DX + GQ_GROUPS * TN * 4,
+                         DW = SX + (HAS_MIN ? GQ_GROUPS * SUB * TN * 4 : 0), MW = DW + GQ_GROUPS * SUB * TM * 4,
+                         DS = MW + (HAS_MIN ? GQ_GROUPS * SUB * TM * 4 : 0),         // k-quants: d [TM rows], dmin [TM rows]
+                         BYTES = DS + 2 * TM * 4;
 };
 
 // S = waves per 32 x 32 tile (1, 2, 4), TT = 32-token tiles per workgroup (4 or 1): workgroup = TT S waves.
@@ -275,30 +275,34 @@ template <bool HAS_MIN, int TN, int SUB> struct gemm_lds {           // TN = tok
 // left-to-right sum over the blocks of a row); S > 1 trades that for S times the parallelism on shapes with few tiles
 // (a 128-token prompt on a 4544-row matrix has 568 tiles for 1024 SIMDs) -- a fixed, documented association, the same
 // kind the reference's own 8-lane AVX2 loop applies (oracle: orc_set_sum_order).
-template <int TYPE, int S, int TT>
+// RB = 32-row blocks per workgroup (1 or 2): with 2, a wave runs its token tile against both row blocks of every group it
+// owns -- the token bytes a workgroup pulls through the CU's memory pipeline (16 KB per stage, against 2.3 KB of Q4_0
+// weights per row block) are then used twice. A CU keeps ~48 KB of requests in flight whatever the kernel does, so at large
+// N the 32-row form is bound by exactly that: the kernel with its math compiled out runs at 76 % of the full kernel's time.
+template <int TYPE, int S, int TT, int RB>
 __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = fq_act_of(TYPE);
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN, KINT = gemm_kint<TYPE>::value;
-    constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB;
-    typedef gemm_lds<HAS_MIN, TN, SUB> LB;
+    constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB, TM = GQ_TM * RB;
+    typedef gemm_lds<HAS_MIN, TN, SUB, TM> LB;
     constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16;         // threads, token vectors per thread and stage, results per lane
-    static_assert(NT >= GQ_TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
+    static_assert(NT >= TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tt = wid % TT, sw = wid / TT;                               // token tile, K share (groups sw, sw + S, ... of a stage)
-    const int64_t m0 = (int64_t) blockIdx.x * GQ_TM, n0 = (int64_t) blockIdx.y * TN;
+    const int64_t m0 = (int64_t) blockIdx.x * TM, n0 = (int64_t) blockIdx.y * TN;
     const int64_t K = w.K, M = w.M;
     const int ngroups = (int)(K >> 5);
     const size_t img = fq_act_col_bytes(ACT, K);
 
     // ---- what a thread stages per K stage: weights = (row, group) tasks of threads < 128 (waves 0-1); tokens = 16-byte
     // vectors of all threads; token scales = the 4 groups' d (and s / bsums) of token tid - 128, the following wave(s)
-    const int w_row = (tid >> 2) & (GQ_TM - 1), w_gg = tid & 3;
+    const int w_row = (tid >> 2) & (TM - 1), w_gg = tid & 3;
     const fq_wrow wrow = fq_row<TYPE>(w, m0 + w_row < M ? m0 + w_row : M - 1);
     // (the weight tasks sit in waves 0-1, the token-scale tasks in waves 2..: a stage's critical path is the longest
     // per-wave instruction stream up to the barrier, so the two staging roles must not land in the same wave)
-    static_assert(NT >= 128 + TN || NT >= 256, "staging roles need separate waves");
-    const int sc_tok = (tid - 128) & (TN - 1);
+    static_assert(NT >= 128 * RB + TN || (RB == 1 && NT >= 256), "staging roles need separate waves");
+    const int sc_tok = (tid - 128 * RB) & (TN - 1);
     // The pipeline below exists once per staging ROLE of a wave (1 = weights: waves 0-1; 2 = token scales: the next
     // ceil(TN / 64) waves; 0 = none), selected by a wave-uniform branch: inside one copy every load is unconditional, so the
     // compiler can count them (s_waitcnt vmcnt(N) that leaves the NEXT stages' loads in flight). With the roles as
@@ -348,18 +352,18 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                 if (g < ngroups && m0 + w_row < M) gemm_group<TYPE>::split(R.w, g, isc, imn, dd, dm);
 #pragma unroll
                 for (int ss = 0; ss < SUB; ++ss) {
-                    ((int *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = isc[ss];
+                    ((int *)(B + LB::DW))[(w_gg * SUB + ss) * TM + w_row] = isc[ss];
                 }
                 if constexpr (HAS_MIN) {        // the stage's 4 SUB mins of a row: k slots 0..7 of an int8 MFMA operand (below)
                     if constexpr (SUB == 2) ((uint16_t *)(B + LB::MW))[w_row * 4 + w_gg] = (uint16_t)(imn[0] | (imn[1] << 8));
                     else { (B + LB::MW)[w_row * 8 + w_gg] = (uint8_t) imn[0]; (B + LB::MW)[w_row * 8 + 4 + w_gg] = 0; }
                 }
-                if (w_gg == 0) { ((float *)(B + LB::DS))[w_row] = dd; ((float *)(B + LB::DS))[GQ_TM + w_row] = dm; }
+                if (w_gg == 0) { ((float *)(B + LB::DS))[w_row] = dd; ((float *)(B + LB::DS))[TM + w_row] = dm; }
             } else {
 #pragma unroll
                 for (int ss = 0; ss < SUB; ++ss) {
-                    ((float *)(B + LB::DW))[(w_gg * SUB + ss) * GQ_TM + w_row] = sc[ss];
-                    if constexpr (HAS_MIN) ((float *)(B + LB::MW))[(w_gg * SUB + ss) * GQ_TM + w_row] = mn[ss];
+                    ((float *)(B + LB::DW))[(w_gg * SUB + ss) * TM + w_row] = sc[ss];
+                    if constexpr (HAS_MIN) ((float *)(B + LB::MW))[(w_gg * SUB + ss) * TM + w_row] = mn[ss];
                 }
             }
         }
@@ -423,13 +427,16 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         }
     };
 
-    float acc[NR];
-    int iacc[KINT ? NR : 1];                                             // k-quants: integer sums of the current super-block
-    v16i chi = {0}, clo = {0};                                           // ... and of its mins term (wave sw == S - 1)
+    float acc[RB][NR];
+    int iacc[RB][KINT ? NR : 1];                                         // k-quants: integer sums of the current super-block
+    v16i chi[RB], clo[RB];                                               // ... and of its mins term (wave sw == S - 1)
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
+    for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
-    for (int r = 0; r < (KINT ? NR : 1); ++r) iacc[r] = 0;
+        for (int r = 0; r < NR; ++r) { acc[rb][r] = 0.0f; chi[rb][r] = 0; clo[rb][r] = 0; }
+#pragma unroll
+        for (int r = 0; r < (KINT ? NR : 1); ++r) iacc[rb][r] = 0;
+    }
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int rot = 0;
     const int arow = l31;
@@ -442,16 +449,20 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
         for (int gg = sw; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); gg += S) {
             const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
-            const v4i b = *(const v4i *)(B + LB::WQ + l31 * GQ_STRIDE + 32 * gg + 16 * half);
             if constexpr (KINT) {
 #pragma unroll
-                for (int ss = 0; ss < SUB; ++ss) {
-                    const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
-                    const int isc = ((const int *)(B + LB::DW))[(gg * SUB + ss) * GQ_TM + l31];
-                    v16i c = {0};
-                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = 32 * rb + l31;
+                    const v4i b = *(const v4i *)(B + LB::WQ + row * GQ_STRIDE + 32 * gg + 16 * half);
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) iacc[i] = __mul24(c[i], isc) + iacc[i];       // |c| < 2^17, |isc| <= 128
+                    for (int ss = 0; ss < SUB; ++ss) {
+                        const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
+                        const int isc = ((const int *)(B + LB::DW))[(gg * SUB + ss) * TM + row];
+                        v16i c = {0};
+                        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) iacc[rb][i] = __mul24(c[i], isc) + iacc[rb][i];       // |c| < 2^17, |isc| <= 128
+                    }
                 }
                 continue;
             }
@@ -465,11 +476,6 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             }
 #pragma unroll
             for (int ss = 0; ss < SUB; ++ss) {
-                // 16-element sub-blocks: lanes of half h hold the group's weight bytes [16 h, 16 h + 16); zeroing the other
-                // half's operand leaves exactly sub-block ss in the MFMA's sum
-                const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
-                const float dw = ((const float *)(B + LB::DW))[(gg * SUB + ss) * GQ_TM + l31];
-                const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[(gg * SUB + ss) * GQ_TM + l31] : 0.0f;
                 float sxv[NR];
                 if constexpr (HAS_MIN) {
 #pragma unroll
@@ -479,51 +485,70 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         sxv[4 * q] = u.x; sxv[4 * q + 1] = u.y; sxv[4 * q + 2] = u.z; sxv[4 * q + 3] = u.w;
                     }
                 }
-                v16i c = {0};
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
-                // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
-                // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    const float ci = (float) c[i];
-                    float t;
-                    if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
-                    else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
-                    else if constexpr (!HAS_MIN)                            t = (dw * dxv[i]) * ci;                    // Q3_K, Q6_K
-                    else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
-                    acc[i] = acc[i] + t;
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = 32 * rb + l31;
+                    const v4i b = *(const v4i *)(B + LB::WQ + row * GQ_STRIDE + 32 * gg + 16 * half);
+                    // 16-element sub-blocks: lanes of half h hold the group's weight bytes [16 h, 16 h + 16); zeroing the other
+                    // half's operand leaves exactly sub-block ss in the MFMA's sum
+                    const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
+                    const float dw = ((const float *)(B + LB::DW))[(gg * SUB + ss) * TM + row];
+                    const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[(gg * SUB + ss) * TM + row] : 0.0f;
+                    v16i c = {0};
+                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+                    // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
+                    // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        const float ci = (float) c[i];
+                        float t;
+                        if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
+                        else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
+                        else if constexpr (!HAS_MIN)                            t = (dw * dxv[i]) * ci;                    // Q3_K, Q6_K
+                        else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
+                        acc[rb][i] = acc[rb][i] + t;
+                    }
                 }
             }
         }
         if constexpr (KINT && HAS_MIN) {
-            // the mins term  sum_j m_j bsum_j  of the stage's 4 SUB sub-blocks for the whole 32 x 32 tile: a [tokens x j] by
+            // the mins term  sum_j m_j bsum_j  of the stage's 4 SUB sub-blocks for a whole 32 x 32 tile: a [tokens x j] by
             // [j x rows] int8 product, so two MFMAs (hi / lo bytes of the block sums) instead of 4 SUB x 16 multiply-adds;
-            // one wave per tile does it (the last K share: never one of the staging waves)
+            // one wave per tile does it (the last K share: never one of the 32-row form's staging waves)
             if (sw == S - 1 && !(dbgm & 2)) {
-                v4i am = {0, 0, 0, 0}; int2 bn = {0, 0};
-                if (half == 0) { am = *(const v4i *)(B + LB::SX + (32 * tt + arow) * 16); bn = *(const int2 *)(B + LB::MW + l31 * 8); }
-                const v4i bmn = { bn.x, bn.y, 0, 0 };
-                chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[0], am[1], 0, 0 }, bmn, chi, 0, 0, 0);
-                clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[2], am[3], 0, 0 }, bmn, clo, 0, 0, 0);
+                v4i am = {0, 0, 0, 0};
+                if (half == 0) am = *(const v4i *)(B + LB::SX + (32 * tt + arow) * 16);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    int2 bn = {0, 0};
+                    if (half == 0) bn = *(const int2 *)(B + LB::MW + (32 * rb + l31) * 8);
+                    const v4i bmn = { bn.x, bn.y, 0, 0 };
+                    chi[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[0], am[1], 0, 0 }, bmn, chi[rb], 0, 0, 0);
+                    clo[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[2], am[3], 0, 0 }, bmn, clo[rb], 0, 0, 0);
+                }
             }
         }
         if constexpr (KINT) {
             // end of a super-block (every second stage): one f32 step per result, the reference's own k-quant expression
             // sumf += (d * y.d) * sum_j sc_j I_j  -  (dmin * y.d) * sum_j m_j bsum_j   (k_quants.c:1565-1583 ...)
             if (sb_end) {
-                const float dd = ((const float *)(B + LB::DS))[l31], dm = HAS_MIN ? ((const float *)(B + LB::DS))[GQ_TM + l31] : 0.0f;
 #pragma unroll
-                for (int q = 0; q < NR / 4; ++q) {
-                    const int tok = 32 * tt + rot + 8 * q + 4 * half;
-                    const float4 t = *(const float4 *)(B + LB::DX + tok * 4);      // y.d of the super-block (all four groups alike)
-                    const float dxq[4] = { t.x, t.y, t.z, t.w };
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int row = 32 * rb + l31;
+                    const float dd = ((const float *)(B + LB::DS))[row], dm = HAS_MIN ? ((const float *)(B + LB::DS))[TM + row] : 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q + e;
-                        acc[i] = acc[i] + (dd * dxq[e]) * (float) iacc[i];
-                        iacc[i] = 0;
-                        if constexpr (HAS_MIN) {
-                            if (sw == S - 1) { acc[i] = acc[i] - (dm * dxq[e]) * (float)((chi[i] << 6) + clo[i]); chi[i] = 0; clo[i] = 0; }
+                    for (int q = 0; q < NR / 4; ++q) {
+                        const int tok = 32 * tt + rot + 8 * q + 4 * half;
+                        const float4 t = *(const float4 *)(B + LB::DX + tok * 4);      // y.d of the super-block (all four groups alike)
+                        const float dxq[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * q + e;
+                            acc[rb][i] = acc[rb][i] + (dd * dxq[e]) * (float) iacc[rb][i];
+                            iacc[rb][i] = 0;
+                            if constexpr (HAS_MIN) {
+                                if (sw == S - 1) { acc[rb][i] = acc[rb][i] - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]); chi[rb][i] = 0; clo[rb][i] = 0; }
+                            }
                         }
                     }
                 }
@@ -552,36 +577,44 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             __syncthreads();
         }
     };
-    if (wid < 2)                 pipeline(std::integral_constant<int, 1>{});
-    else if (wid < 2 + SC_WAVES) pipeline(std::integral_constant<int, 2>{});
+    if (wid < 2 * RB)                 pipeline(std::integral_constant<int, 1>{});
+    else if (wid < 2 * RB + SC_WAVES) pipeline(std::integral_constant<int, 2>{});
     else                         pipeline(std::integral_constant<int, 0>{});
     // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free now)
     if constexpr (S > 1) {
-        float * xch = (float *) smem;                                      // [tt][i][lane]
+        float * xch = (float *) smem;                                      // [tt][rb][i][lane]
+        static_assert(TT * RB * NR * 64 * 4 <= 2 * LB::BYTES, "partial sums do not fit the stage buffers");
         for (int r = 1; r < S; ++r) {
             __syncthreads();
             if (sw == r) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) xch[(tt * NR + i) * 64 + lane] = acc[i];
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) xch[((tt * RB + rb) * NR + i) * 64 + lane] = acc[rb][i];
             }
             __syncthreads();
             if (sw == 0) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) acc[i] = acc[i] + xch[(tt * NR + i) * 64 + lane];
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) acc[rb][i] = acc[rb][i] + xch[((tt * RB + rb) * NR + i) * 64 + lane];
             }
         }
         if (sw != 0) return;
     }
-    // ---- epilogue: token n = n0 + 32*tt + (i&3) + 8*(i>>2) + 4*half, row m = m0 + (lane&31)
-    const int64_t m = m0 + l31;
+    // ---- epilogue: token n = n0 + 32*tt + (i&3) + 8*(i>>2) + 4*half, row m = m0 + 32*rb + (lane&31)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int64_t n = n0 + 32 * tt + rot + (i & 3) + 8 * (i >> 2) + 4 * half;
-        if (n < N && m < M) {
-            float v = acc[i];
-            if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
-            else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
-            dst[n * ldd + m] = v;
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t m = m0 + 32 * rb + l31;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int64_t n = n0 + 32 * tt + rot + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (n < N && m < M) {
+                float v = acc[rb][i];
+                if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+                else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+                dst[n * ldd + m] = v;
+            }
         }
     }
 }
@@ -595,13 +628,17 @@ bool fq_gemm_supported(int type) {
            type == FQ_Q2_K || type == FQ_Q3_K || type == FQ_Q4_K || type == FQ_Q5_K || type == FQ_Q6_K;
 }
 
-template <int TYPE, int S, int TT>
+template <int TYPE, int S, int TT, int RB = 1>
 static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
-    constexpr int TN = 32 * TT;
-    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB>::BYTES;
-    const dim3 grid((unsigned)((w.M + GQ_TM - 1) / GQ_TM), (unsigned)((N + TN - 1) / TN));
-    hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
+    constexpr int TN = 32 * TT, TM = GQ_TM * RB;
+    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB, TM>::BYTES;
+    if (lds > 64 * 1024) {
+        static bool set = false;
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_q<TYPE, S, TT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; }
+    }
+    const dim3 grid((unsigned)((w.M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN));
+    hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT, RB>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
 }
 
 // dst[n*ldd + m], n < N; act holds N quantized columns
@@ -614,10 +651,15 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // -> four partial sums per row below 4 x #CU tiles, two above; one (the reference's order) only on request
     const int64_t tiles = ((w.M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
     int cfg = g_gemm_sequential ? 0 : (tiles < 4 * (int64_t) n_cu ? 2 : 3);
-    if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>
+    // 64-row workgroups (RB = 2) where there are tiles enough to fill the chip with them: two partial sums as <2,4> above,
+    // or four (<4,4,2>: 16 waves) for the formats whose 64-row kernel stays within 128 VGPRs
+    static const int64_t rb_min = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : 32;      // x #CU tiles; 0 = never
+    if (cfg == 3 && rb_min > 0 && tiles >= rb_min * (int64_t) n_cu) cfg = 6;
+    if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>, 6 = <2,4,2>, 7 = <4,4,2>
 #define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
-                           else if (cfg == 4) launch_gemm_t<T, 4, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 2, 2>(w, act, N, dst, ldd, ep, st); break;
+                           else if (cfg == 4) launch_gemm_t<T, 4, 2>(w, act, N, dst, ldd, ep, st); else if (cfg == 5) launch_gemm_t<T, 2, 2>(w, act, N, dst, ldd, ep, st); \
+                           else if (cfg == 6) launch_gemm_t<T, 2, 4, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 4, 4, 2>(w, act, N, dst, ldd, ep, st); break;
     switch (w.type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
