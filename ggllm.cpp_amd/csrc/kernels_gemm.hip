@@ -544,11 +544,12 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int i = 4 * q + e;
-                            acc[rb][i] = acc[rb][i] + (dd * dxq[e]) * (float) iacc[rb][i];
+                            float t = (dd * dxq[e]) * (float) iacc[rb][i];
                             iacc[rb][i] = 0;
-                            if constexpr (HAS_MIN) {
-                                if (sw == S - 1) { acc[rb][i] = acc[rb][i] - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]); chi[rb][i] = 0; clo[rb][i] = 0; }
+                            if constexpr (HAS_MIN) {       // (the oracle's / reference's expression: sumf += d isum - dmin msum)
+                                if (sw == S - 1) { t = t - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]); chi[rb][i] = 0; clo[rb][i] = 0; }
                             }
+                            acc[rb][i] = acc[rb][i] + t;
                         }
                     }
                 }

@@ -446,11 +446,19 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     }
     /* k-quants against Q8_K. Integer parts are exact; the float epilogue is d*isum (- dmin*msum) per super-block.
      * The reference's scalar code keeps 8 float lanes (k_quants.c:1699-1743) and its AVX2 code 8 SIMD lanes; only
-     * the association of the float sums differs. */
+     * the association of the float sums differs.
+     * order 2 (the backend's prefill GEMM): the super-block's eight 32-element groups are dealt to g_split partial sums
+     * (group g -> g mod g_split), each adds (d dy) * (its groups' integer sum) per super-block, the last one with the mins
+     * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3. */
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int split = (g_sum_order == 2 && n > 32) ? g_split : 0;
     for (int64_t i = 0; i < n / 256; ++i, w += orc_type_size(wtype), a += 292) {
         const float  dy = rd_f32(a);
         const int8_t * q8 = (const int8_t *)(a + 4);
-        int isum = 0, msum = 0;
+        int isg[8] = {0, 0, 0, 0, 0, 0, 0, 0};                /* integer sums of the 32-element groups */
+        int msum = 0, has_min = 0;
+        float dd = 0.0f, dmn = 0.0f;
+#define isum isg[e / 32]
         switch (wtype) {
             case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
                 for (int sb = 0; sb < 16; ++sb) msum += rd_i16(a + 260 + 2 * sb) * (w[sb] >> 4);
@@ -459,7 +467,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     const int q  = (w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
                     isum += (w[sb] & 15) * q * q8[e];
                 }
-                sumf += (dy * rd_f16(w + 80)) * (float) isum - (dy * rd_f16(w + 82)) * (float) msum; } break;
+                dd = dy * rd_f16(w + 80); dmn = dy * rd_f16(w + 82); has_min = 1; } break;
             case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
                 int sc[16]; q3_scales(w + 96, sc);
                 for (int e = 0; e < 256; ++e) {
@@ -468,7 +476,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     const int hb = (w[e % 32] >> (e / 32)) & 1;
                     isum += (sc[sb] - 32) * (lo - (hb ? 0 : 4)) * q8[e];
                 }
-                sumf += (rd_f16(w + 108) * dy) * (float) isum; } break;
+                dd = rd_f16(w + 108) * dy; } break;
             case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
                 const int qs_off = (wtype == ORC_Q4_K) ? 16 : 48;
                 for (int g = 0; g < 16; ++g) { int sc, mn; k4_scale_min(w + 4, g / 2, &sc, &mn); msum += rd_i16(a + 260 + 2 * g) * mn; }
@@ -480,7 +488,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
                     isum += sc * q * q8[e];
                 }
-                sumf += (rd_f16(w) * dy) * (float) isum - (rd_f16(w + 2) * dy) * (float) msum; } break;
+                dd = rd_f16(w) * dy; dmn = rd_f16(w + 2) * dy; has_min = 1; } break;
             case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
                 const int8_t * sc = (const int8_t *)(w + 192);
                 for (int e = 0; e < 256; ++e) {
@@ -490,11 +498,24 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
                     isum += sc[8 * h + 2 * t + l / 16] * ((int)(int8_t)(lo | (hi << 4)) - 32) * q8[e];
                 }
-                sumf += (rd_f16(w + 208) * dy) * (float) isum; } break;
+                dd = rd_f16(w + 208) * dy; } break;
             default: abort();
         }
+#undef isum
+        if (split) {
+            for (int sp = 0; sp < split; ++sp) {
+                int is = 0;
+                for (int g = sp; g < 8; g += split) is += isg[g];
+                const float A = dd * (float) is;
+                part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
+            }
+        } else {
+            int is = 0;
+            for (int g = 0; g < 8; ++g) is += isg[g];
+            sumf += has_min ? dd * (float) is - dmn * (float) msum : dd * (float) is;
+        }
     }
-    return sumf;
+    return split ? ((part[0] + part[1]) + part[2]) + part[3] : sumf;
 }
 
 /* ------------------------------------------------------------------ quantized mat-mul (ggml.c:11318-11529) */

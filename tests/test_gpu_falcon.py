@@ -34,7 +34,15 @@ CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQ
 #       this pins every kernel of the stack;
 #   (2) against the logits captured from the reference itself: within 1e-3, or within 2x the reference's own
 #       build-to-build spread when that is larger.
+# k-quants: the prefill GEMM's sums are pinned bit-exactly by the oracle too (integer sums per super-block, the backend's
+# split association: orc_set_sum_order(2)), so (1) holds for the prefill; the mat-vec kernels' 64-lane association of the
+# super-blocks is not restated in the oracle, the decode steps are checked by (2) only. For the k-quant prefill (2) is held
+# to FLIP: both the reference's builds and this GEMM compute exact integer sums per super-block, but the reference then
+# adds eight f32 lane sums (k_quants.c:1575-1583) where the GEMM multiplies the whole integer sum once -- a 1e-7 difference
+# that flips an activation rounding in this stack (measured 1.1e-2 on gqa_q4_K, the scale of the reference's own
+# AVX2-vs-scalar spread on gqa_q5_1).
 TIGHT = 1e-4
+FLIP = 3e-2
 
 
 @pytest.mark.parametrize("name,hp,t", CASES)
@@ -46,22 +54,22 @@ def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t):
     lg, hid = m.eval(toks[:8], 0, logits_all=True, want_hidden=True)
     dec = np.concatenate([m.eval(toks[i:i + 1], i, logits_all=True) for i in range(8, 12)])
     m.free()
-    if t in ob.LEGACY:
-        oracle.lib.orc_set_sum_order(2)
-        try:
-            mo = oracle.model(w, 64)
-            lo, ho = mo.eval(toks[:8], 0, 2, want_hidden=True)
-            do = np.concatenate([mo.eval(toks[i:i + 1], i, 2) for i in range(8, 12)])
-        finally:
-            oracle.lib.orc_set_sum_order(0)
-        e = (relrms(hid, ho), relrms(lg, lo), relrms(dec, do))
-        print(name, "vs wave-association oracle: hidden %.2e prefill %.2e decode %.2e" % e)
-        assert max(e) <= TIGHT
+    oracle.lib.orc_set_sum_order(2)
+    try:
+        mo = oracle.model(w, 64)
+        lo, ho = mo.eval(toks[:8], 0, 2, want_hidden=True)
+        do = np.concatenate([mo.eval(toks[i:i + 1], i, 2) for i in range(8, 12)])
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    e = (relrms(hid, ho), relrms(lg, lo), relrms(dec, do))
+    print(name, "vs backend-association oracle: hidden %.2e prefill %.2e decode %.2e" % e)
+    assert max(e if t in ob.LEGACY else e[:2]) <= TIGHT
     ref_l, ref_d = gt[f"{name}_prefill_logits_scalar"], gt[f"{name}_decode_logits_scalar"]
     spread = max(relrms(gt[f"{name}_prefill_logits_avx"], ref_l), relrms(gt[f"{name}_decode_logits_avx"], ref_d))
     e_l, e_d = relrms(lg, ref_l), relrms(dec, ref_d)
     print(name, "vs reference logits: prefill %.2e decode %.2e (reference AVX2-vs-scalar spread %.2e)" % (e_l, e_d, spread))
-    assert max(e_l, e_d) <= max(LOGIT_TOL, 2 * spread)
+    tol = max(LOGIT_TOL, 2 * spread)
+    assert e_d <= tol and e_l <= (tol if t in ob.LEGACY else max(tol, FLIP))
     assert np.array_equal(lg.argmax(1), ref_l.argmax(1))
 
 
@@ -71,8 +79,7 @@ def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
     w = synth.make_model(oracle, hp, t, seed=77)
     toks = synth.tokens(10, hp["n_vocab"], seed=5)
     m = g.FalconModel(w, n_ctx=32, n_batch=6)
-    if t in ob.LEGACY:
-        oracle.lib.orc_set_sum_order(2)
+    oracle.lib.orc_set_sum_order(2)
     try:
         mo = oracle.model(w, 32)
         lo, ho = mo.eval(toks[:6], 0, 4, want_hidden=True)
@@ -84,10 +91,10 @@ def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
     m.free()
     e = (relrms(hid[1], ho[1]), relrms(lg, lo), relrms(np.concatenate(d), np.concatenate(do)))
     print(ob.TYPE_NAME[t], "first block %.2e prefill logits %.2e decode logits %.2e" % e)
-    assert e[0] <= TIGHT                                  # one block deep: no room for a flip to be amplified
-    # k-quants: the per-unit f32 epilogue is a different (legitimate) association than the oracle's per-super-block one,
-    # so deeper layers see the chaotic spread discussed above
-    assert max(e) <= (TIGHT if t in ob.LEGACY else 5e-2)
+    assert max(e[:2]) <= TIGHT                            # the prefill (GEMM) is pinned by the oracle's backend association
+    # k-quants, decode steps: the mat-vec kernels' per-unit f32 epilogue is a different (legitimate) association than the
+    # oracle's per-super-block one, so the deeper layers see the chaotic spread discussed above
+    assert e[2] <= (TIGHT if t in ob.LEGACY else 5e-2)
 
 
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),

@@ -92,7 +92,9 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
     """N > 4 columns: int8 MFMA GEMM (legacy formats + Q4_K/Q5_K) or column-chunked mat-vec (Q2_K/Q3_K/Q6_K).
     Legacy formats through the GEMM use the reference's scalar per-block expression; with ggml_hip_gemm_sequential(1) the
     blocks are added left to right: BIT-EXACT against the oracle (= the reference's scalar vec_dot). The default order on
-    every shape (4 or 2 interleaved partial sums) is bit-exact against the oracle run with that association."""
+    every shape (4 or 2 interleaved partial sums) is bit-exact against the oracle run with that association. The k-quants
+    accumulate scale * (group dot) in int32 per super-block (exact) and take one f32 step per super-block, like the
+    reference's own k-quant dots: bit-exact against the oracle in both orders as well."""
     if K % ob.BLCK[t]:
         pytest.skip("k-quants need K % 256 == 0")
     rng = np.random.default_rng(K + M + N + t)
@@ -111,9 +113,10 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
         exp_split = oracle.mul_mat(t, w, K, M, x, 8)
     finally:
         oracle.lib.orc_set_sum_order(0)
-    if t in ob.LEGACY:
-        assert np.array_equal(seq, exp)      # sequential order == the reference's scalar loop, bit for bit
-        assert np.array_equal(got, exp_split)
+    # sequential order == the reference's scalar loop over the blocks (legacy formats), == the oracle's per-super-block
+    # expression d * isum - dmin * msum added left to right (k-quants: integer sums exact, as in k_quants.c), bit for bit
+    assert np.array_equal(seq, exp)
+    assert np.array_equal(got, exp_split)
     assert relrms(got, exp) <= TOL and relrms(seq, exp) <= TOL
     # and the same columns through the mat-vec kernel agree within the association tolerance
     g.load().ggml_hip_debug_force_gemv(1)
@@ -123,6 +126,32 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
         g.load().ggml_hip_debug_force_gemv(0)
     dw.free()
     assert relrms(got, via_gemv) <= TOL
+
+
+@pytest.mark.parametrize("cfg,order", [(6, 4), (7, 3)])
+@pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
+def test_prefill_gemm_64_row_workgroups(oracle, t, cfg, order, monkeypatch):
+    """The 64-row workgroup forms (<2,4,2> = two partial sums per row, <4,4,2> = four; picked by the launcher from 32 x #CU
+    tiles upwards, forced here through FQ_GEMM_CFG): the same sums in the same association as the 32-row forms, so the
+    oracle run with that association pins them -- bit-exactly for the legacy formats."""
+    if cfg == 7 and t in ob.KQUANTS:
+        pytest.skip("<4,4,2> is not used for k-quants (register budget)")
+    monkeypatch.setenv("FQ_GEMM_CFG", str(cfg))
+    for K, M, N in [(512, 37, 9), (4544, 200, 33), (8192, 129, 130), (1024, 300, 257)]:
+        if K % ob.BLCK[t]:
+            continue
+        rng = np.random.default_rng(K + M + N + t)
+        w = synth.quantized_matrix(oracle, t, M, K, rng)
+        x = rng.standard_normal((N, K)).astype(np.float32)
+        dw = g.Weight(t, w, K, M)
+        got = dw.mul_mat(x)
+        dw.free()
+        oracle.lib.orc_set_sum_order(order)
+        try:
+            exp = oracle.mul_mat(t, w, K, M, x, 8)
+        finally:
+            oracle.lib.orc_set_sum_order(0)
+        assert np.array_equal(got, exp), (K, M, N)
 
 
 def test_epilogues(oracle):
