@@ -446,74 +446,100 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     }
     /* k-quants against Q8_K. Integer parts are exact; the float epilogue is d*isum (- dmin*msum) per super-block.
      * The reference's scalar code keeps 8 float lanes (k_quants.c:1699-1743) and its AVX2 code 8 SIMD lanes; only
-     * the association of the float sums differs.
+     * the association of the float sums differs. Per super-block: sc16[b] / mn16[b] = integer scale / min of the 16-element
+     * block b (a 32-element sub-block's pair repeated), i16[b] = its unscaled integer dot, bs16[b] = Q8_K's block sum.
+     * order 0: sumf += d dy * sum_b sc16 i16 - dmin dy * sum_b mn16 bs16, left to right over the super-blocks.
      * order 2 (the backend's prefill GEMM): the super-block's eight 32-element groups are dealt to g_split partial sums
      * (group g -> g mod g_split), each adds (d dy) * (its groups' integer sum) per super-block, the last one with the mins
-     * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3. */
+     * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3.
+     * order 1 (the backend's mat-vec kernels, fq_units.h): the row is cut into UNITS of 2 or 4 blocks (below), unit u goes
+     * to lane u mod 64 as one f32 term (d dy) isum_u - (dmin dy) msum_u, lanes add their units in ascending order and are
+     * combined by the xor butterfly 1, 2, 4, .., 32. */
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lane[64] = {0};
     const int split = (g_sum_order == 2 && n > 32) ? g_split : 0;
+    const int wave  = (g_sum_order == 1 && n > 32);
+    int64_t unit = 0;
     for (int64_t i = 0; i < n / 256; ++i, w += orc_type_size(wtype), a += 292) {
         const float  dy = rd_f32(a);
         const int8_t * q8 = (const int8_t *)(a + 4);
-        int isg[8] = {0, 0, 0, 0, 0, 0, 0, 0};                /* integer sums of the 32-element groups */
-        int msum = 0, has_min = 0;
+        int sc16[16], mn16[16] = {0}, i16[16] = {0}, bs16[16];
+        int has_min = 0;
         float dd = 0.0f, dmn = 0.0f;
-#define isum isg[e / 32]
+        for (int b = 0; b < 16; ++b) bs16[b] = rd_i16(a + 260 + 2 * b);
         switch (wtype) {
             case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
-                for (int sb = 0; sb < 16; ++sb) msum += rd_i16(a + 260 + 2 * sb) * (w[sb] >> 4);
-                for (int e = 0; e < 256; ++e) {
-                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
-                    const int q  = (w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
-                    isum += (w[sb] & 15) * q * q8[e];
-                }
+                for (int b = 0; b < 16; ++b) { sc16[b] = w[b] & 15; mn16[b] = w[b] >> 4; }
+                for (int e = 0; e < 256; ++e)
+                    i16[e / 16] += ((w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3) * q8[e];
                 dd = dy * rd_f16(w + 80); dmn = dy * rd_f16(w + 82); has_min = 1; } break;
             case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
                 int sc[16]; q3_scales(w + 96, sc);
+                for (int b = 0; b < 16; ++b) sc16[b] = sc[b] - 32;
                 for (int e = 0; e < 256; ++e) {
-                    const int sb = (e / 128) * 8 + ((e % 128) / 32) * 2 + ((e % 32) / 16);
                     const int lo = (w[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
                     const int hb = (w[e % 32] >> (e / 32)) & 1;
-                    isum += (sc[sb] - 32) * (lo - (hb ? 0 : 4)) * q8[e];
+                    i16[e / 16] += (lo - (hb ? 0 : 4)) * q8[e];
                 }
                 dd = rd_f16(w + 108) * dy; } break;
             case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
                 const int qs_off = (wtype == ORC_Q4_K) ? 16 : 48;
-                for (int g = 0; g < 16; ++g) { int sc, mn; k4_scale_min(w + 4, g / 2, &sc, &mn); msum += rd_i16(a + 260 + 2 * g) * mn; }
+                for (int b = 0; b < 16; ++b) k4_scale_min(w + 4, b / 2, &sc16[b], &mn16[b]);
                 for (int e = 0; e < 256; ++e) {
                     const int c = e / 64, hi = (e % 64) / 32;
-                    int sc, mn; k4_scale_min(w + 4, 2 * c + hi, &sc, &mn);
                     const int byte = w[qs_off + 32 * c + e % 32];
                     int q = hi ? (byte >> 4) : (byte & 15);
                     if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
-                    isum += sc * q * q8[e];
+                    i16[e / 16] += q * q8[e];
                 }
                 dd = rd_f16(w) * dy; dmn = rd_f16(w + 2) * dy; has_min = 1; } break;
             case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
                 const int8_t * sc = (const int8_t *)(w + 192);
+                for (int b = 0; b < 16; ++b) sc16[b] = sc[b];
                 for (int e = 0; e < 256; ++e) {
                     const int h = e / 128, t = (e % 128) / 32, l = e % 32;
                     const int byte = w[64 * h + 32 * (t & 1) + l];
                     const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
                     const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
-                    isum += sc[8 * h + 2 * t + l / 16] * ((int)(int8_t)(lo | (hi << 4)) - 32) * q8[e];
+                    i16[e / 16] += ((int)(int8_t)(lo | (hi << 4)) - 32) * q8[e];
                 }
                 dd = rd_f16(w + 208) * dy; } break;
             default: abort();
         }
-#undef isum
+        if (wave) {
+            /* units (fq_units.h): Q2_K / Q3_K: 4 per super-block, unit (hf, g) = blocks 8 hf + 2 j + g, j = 0..3;
+             * Q4_K / Q5_K: 8, unit (c, g) = blocks 4 c + g and 4 c + g + 2; Q6_K: 8, unit (h, t, g) = blocks 8 h + 2 t + g, + 4 */
+            const int four = (wtype == ORC_Q2_K || wtype == ORC_Q3_K);
+            for (int uu = 0; uu < (four ? 4 : 8); ++uu, ++unit) {
+                int blk[4], nb;
+                if (four) { nb = 4; for (int j = 0; j < 4; ++j) blk[j] = 8 * (uu >> 1) + 2 * j + (uu & 1); }
+                else if (wtype == ORC_Q6_K) { nb = 2; blk[0] = 8 * (uu >> 2) + 2 * ((uu >> 1) & 1) + (uu & 1); blk[1] = blk[0] + 4; }
+                else { nb = 2; blk[0] = 4 * (uu >> 1) + (uu & 1); blk[1] = blk[0] + 2; }
+                int is = 0, ms = 0;
+                for (int j = 0; j < nb; ++j) { is += sc16[blk[j]] * i16[blk[j]]; ms += mn16[blk[j]] * bs16[blk[j]]; }
+                const float v = has_min ? dd * (float) is - dmn * (float) ms : dd * (float) is;
+                lane[unit & 63] += v;
+            }
+            continue;
+        }
+        int msum = 0;
+        for (int b = 0; b < 16; ++b) msum += mn16[b] * bs16[b];
         if (split) {
             for (int sp = 0; sp < split; ++sp) {
                 int is = 0;
-                for (int g = sp; g < 8; g += split) is += isg[g];
+                for (int g = sp; g < 8; g += split) is += sc16[2 * g] * i16[2 * g] + sc16[2 * g + 1] * i16[2 * g + 1];
                 const float A = dd * (float) is;
                 part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
             }
         } else {
             int is = 0;
-            for (int g = 0; g < 8; ++g) is += isg[g];
+            for (int b = 0; b < 16; ++b) is += sc16[b] * i16[b];
             sumf += has_min ? dd * (float) is - dmn * (float) msum : dd * (float) is;
         }
+    }
+    if (wave) {
+        for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
+        return lane[0];
     }
     return split ? ((part[0] + part[1]) + part[2]) + part[3] : sumf;
 }

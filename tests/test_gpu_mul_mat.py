@@ -36,6 +36,14 @@ def test_mul_mat_vs_oracle(oracle, t, K, M, N):
     exp = oracle.mul_mat(t, w, K, M, x, 4)
     dw.free()
     assert relrms(got, exp) <= TOL, relrms(got, exp)
+    # and bit for bit against the oracle run with the backend's association of the same terms (N <= 4: the mat-vec kernels,
+    # one f32 term per unit of fq_units.h, 64 lanes, ascending units per lane, xor butterfly; N = 5: the GEMM's split order)
+    oracle.lib.orc_set_sum_order(2)
+    try:
+        exp_wave = oracle.mul_mat(t, w, K, M, x, 4)
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    assert np.array_equal(got, exp_wave)
 
 
 @pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
