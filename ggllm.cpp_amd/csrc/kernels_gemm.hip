@@ -257,7 +257,8 @@ template <> struct gemm_kint<FQ_Q4_K> { static constexpr bool value = true; };
 template <> struct gemm_kint<FQ_Q5_K> { static constexpr bool value = true; };
 template <> struct gemm_kint<FQ_Q6_K> { static constexpr bool value = true; };
 
-// tuning aid (ggml_hip_debug_gemm_mode): bit 0 = no global loads after the first stage, bit 1 = no MFMA / scaling (timing only)
+// tuning aid (ggml_hip_debug_gemm_mode): bit 1 = no MFMA / scaling (timing only: what the staging alone costs). Bit 0 (no
+// global loads) went with the role-specialised pipeline, whose loads are unconditional on purpose.
 __device__ int g_gemm_dbg = 0;
 void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
 
