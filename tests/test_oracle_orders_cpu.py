@@ -1,0 +1,60 @@
+"""CPU: the oracle's restated summation orders (orc_set_sum_order: 1 = the mat-vec kernels' unit-per-lane order, 2 = as the
+backend picks per mat-mul, 3 / 4 = the GEMM's four / two interleaved partial sums) are re-associations of the SAME terms
+as the reference order 0: every order agrees with order 0 within the f32 association tolerance, for all ten formats, and
+where every term is an integer below 2^24 they agree exactly."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+import synth
+
+TOL = 2e-5
+
+
+def relrms(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
+
+
+@pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
+@pytest.mark.parametrize("K,M,N", [(512, 9, 1), (1024, 7, 3), (4608, 5, 6), (8192, 3, 40)])
+def test_orders_are_reassociations(oracle, t, K, M, N):
+    if K % ob.BLCK[t]:
+        pytest.skip("k-quants need K % 256 == 0")
+    rng = np.random.default_rng(K + M + N + t)
+    w = synth.quantized_matrix(oracle, t, M, K, rng)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    ref = oracle.mul_mat(t, w, K, M, x, 2)
+    for order in (1, 2, 3, 4):
+        oracle.lib.orc_set_sum_order(order)
+        try:
+            got = oracle.mul_mat(t, w, K, M, x, 2)
+        finally:
+            oracle.lib.orc_set_sum_order(0)
+        assert relrms(got, ref) <= TOL, (order, relrms(got, ref))
+        assert not np.array_equal(got, np.zeros_like(got))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q8_0])
+def test_orders_exact_on_integer_terms(oracle, t):
+    """scale-1 blocks: every partial sum is an integer < 2^24, so every order gives the same bits"""
+    K, M = 1024, 5
+    rng = np.random.default_rng(t)
+    x = rng.integers(-127, 128, size=(2, K)).astype(np.float32)
+    x[:, ::32] = 127.0
+    if t == ob.Q8_0:
+        blk = np.zeros((M, K // 32, 34), np.uint8)
+        blk[:, :, 0:2] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+        blk[:, :, 2:] = rng.integers(-20, 21, size=(M, K // 32, 32)).astype(np.int8).view(np.uint8)
+    else:
+        blk = np.zeros((M, K // 32, 18), np.uint8)
+        blk[:, :, 0:2] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+        blk[:, :, 2:] = rng.integers(0, 256, size=(M, K // 32, 16), dtype=np.uint8)
+    w = blk.reshape(M, -1)
+    ref = oracle.mul_mat(t, w, K, M, x, 1)
+    for order in (1, 2, 3, 4):
+        oracle.lib.orc_set_sum_order(order)
+        try:
+            got = oracle.mul_mat(t, w, K, M, x, 1)
+        finally:
+            oracle.lib.orc_set_sum_order(0)
+        assert np.array_equal(got, ref), order
