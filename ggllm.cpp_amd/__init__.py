@@ -34,7 +34,9 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity""".split()
+falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
+falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
+falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos""".split()
 
 
 def build(verbose=False):
@@ -93,6 +95,11 @@ def load():
         "falcon_hip_stage_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
+        "falcon_hip_vocab_load_ggcc": (vp, [C.c_char_p]), "falcon_hip_vocab_error": (C.c_char_p, [vp]), "falcon_hip_vocab_free": (None, [vp]),
+        "falcon_hip_vocab_size": (C.c_int, [vp]), "falcon_hip_vocab_merges": (C.c_int, [vp]),
+        "falcon_hip_tokenize": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int]),
+        "falcon_hip_token_to_bytes": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p)]),
+        "falcon_hip_token_bos": (C.c_int32, []), "falcon_hip_token_eos": (C.c_int32, []),
         "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
@@ -363,3 +370,43 @@ class FalconModel:
         L = load()
         L.falcon_hip_context_free(self.ctx)
         L.falcon_hip_model_free(self.m)
+
+
+class Vocab:
+    """the tokenizer of a GGCC v10 file (falcon_tokenize / falcon_token_to_str of the reference); host only"""
+
+    def __init__(self, path):
+        L = load()
+        self.h = L.falcon_hip_vocab_load_ggcc(os.fsencode(path))
+        err = L.falcon_hip_vocab_error(self.h)
+        if err:
+            L.falcon_hip_vocab_free(self.h)
+            self.h = None
+            raise ValueError("%s: %s" % (path, err.decode()))
+        self.n_vocab, self.n_merges = L.falcon_hip_vocab_size(self.h), L.falcon_hip_vocab_merges(self.h)
+
+    def tokenize(self, text, add_bos=False, n_max=None):
+        """token ids (np.int32); with n_max: the C return value when the buffer is too small (minus the count)"""
+        L = load()
+        raw = text if isinstance(text, bytes) else text.encode("utf-8")
+        cap = n_max if n_max is not None else 4 * len(raw) + 8
+        buf = np.zeros(max(cap, 1), np.int32)
+        n = L.falcon_hip_tokenize(self.h, raw, buf.ctypes.data, cap, 1 if add_bos else 0)
+        if n < 0:
+            return n
+        return buf[:n].copy()
+
+    def token_bytes(self, tid):
+        p = C.c_char_p()
+        n = load().falcon_hip_token_to_bytes(self.h, int(tid), C.byref(p))
+        if n < 0:
+            raise IndexError(tid)
+        return C.string_at(p, n)
+
+    def detokenize(self, ids):
+        return b"".join(self.token_bytes(i) for i in ids)
+
+    def free(self):
+        if self.h:
+            load().falcon_hip_vocab_free(self.h)
+            self.h = None

@@ -107,6 +107,22 @@ void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
 
+/* ---- tokenizer (host only): falcon_tokenize / falcon_token_to_str (libfalcon.h:236-247, libfalcon.cpp:2594-3035, 4623-4641)
+   on the vocabulary and BPE merges stored in a GGCC v10 file. Same ids as the reference for any text. */
+typedef struct falcon_hip_vocab falcon_hip_vocab;
+falcon_hip_vocab * falcon_hip_vocab_load_ggcc(const char * path);          /* never NULL; check falcon_hip_vocab_error */
+const char * falcon_hip_vocab_error(const falcon_hip_vocab * v);           /* NULL = loaded */
+void  falcon_hip_vocab_free(falcon_hip_vocab * v);
+int   falcon_hip_vocab_size(const falcon_hip_vocab * v);
+int   falcon_hip_vocab_merges(const falcon_hip_vocab * v);
+/* ids of `text` (bos = 11 first when add_bos and the text is not empty); returns their number, or minus that number when
+   n_max is too small (nothing written), as falcon_tokenize does */
+int   falcon_hip_tokenize(const falcon_hip_vocab * v, const char * text, int32_t * tokens, int n_max, int add_bos);
+/* the token's bytes (not NUL-terminated: byte tokens may be 0); returns their number or -1 */
+int   falcon_hip_token_to_bytes(const falcon_hip_vocab * v, int32_t id, const char ** bytes);
+int32_t falcon_hip_token_bos(void);
+int32_t falcon_hip_token_eos(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,10 +167,69 @@ def gen_wquant():
     np.savez_compressed(os.path.join(OUT, "wquant.npz"), **d)
 
 
+def fuzz_texts(n=160, seed=99):
+    """seeded random strings over an alphabet that hits every branch of the pre-tokenizer"""
+    rng = np.random.default_rng(seed)
+    atoms = list("abcdefgstmdrvlexyzABC") + list("0123456789") + [" ", " ", " ", "  ", "\n", "\t", "'", "'", ".", ",", "!", "?", "-", "_", "(", ")", "\"",
+             "é", "ß", "ж", "語", "한", "😀", "½", "²", "٣", "\u00a0", "\u2003", ">>TITLE<<", "<|endoftext|>", ">>", "<|", "the", " the", " and", "ing", "tion"]
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(1, 24))
+        out.append("".join(atoms[int(i)] for i in rng.integers(0, len(atoms), size=k)))
+    return out
+
+
+def gen_tokenizer():
+    """7. falcon_tokenize of the real reference on the BPE vocabulary of tests/bpe_fixture.py (stored in a synthetic GGCC file
+    as the reference's loader expects it): token ids for the fixture's texts and for seeded random strings, with and
+    without bos; and the reference's class of every code point (what the pre-tokenizer's letter / digit / whitespace tests
+    see). tests/test_tokenizer_cpu.py runs falcon_hip_tokenize on the same file."""
+    import ctypes as C
+    import tempfile
+    import ggcc_writer
+    import bpe_fixture
+    so = os.path.join(ROOT, "oracle", "_ref", "libfalcon_ref.so")
+    if not os.path.exists(so):
+        print("oracle/_ref/libfalcon_ref.so not built: tokenizer.npz not regenerated")
+        return
+    L = C.CDLL(so)
+    L.reff_load.restype = C.c_void_p; L.reff_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.reff_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    L.reff_free.argtypes = [C.c_void_p]
+    vocab, merges = bpe_fixture.build()
+    hp = dict(synth.HP_TINY_MQA); hp["n_vocab"] = len(vocab)
+    w = synth.make_model_float(hp, seed=97)
+    d = {"n_vocab": np.int64(len(vocab)), "n_merges": np.int64(len(merges))}
+    texts = list(bpe_fixture.TEXTS) + fuzz_texts()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "tok.ggcc")
+        ggcc_writer.write_ggcc(path, w, vocab, merges)
+        d["file_head_sha256"] = np.frombuffer(hashlib.sha256(open(path, "rb").read()[:1 << 16]).digest(), np.uint8)
+        ctx = L.reff_load(path.encode(), 64, 8)
+        assert ctx
+        buf = (C.c_int * 4096)()
+        for i, t in enumerate(texts):
+            raw = t.encode("utf-8")
+            d[f"s{i}"] = np.frombuffer(raw, np.uint8)
+            for bos in (0, 1):
+                n = L.reff_tokenize(ctx, raw, buf, 4096, bos)
+                assert n >= 0, (t, n)
+                d[f"t{i}_{bos}"] = np.array(buf[:n], np.int32)
+        n_small = L.reff_tokenize(ctx, b"The quick brown fox", buf, 2, 0)          # too small: minus the count
+        d["too_small_rc"] = np.int64(n_small)
+        L.reff_free(ctx)
+    d["n_texts"] = np.int64(len(texts))
+    L.reff_code_type.argtypes = [C.c_int]
+    cls = np.fromiter((L.reff_code_type(c) for c in range(0x110000)), np.uint8, count=0x110000)
+    d["code_class"] = cls
+    np.savez_compressed(os.path.join(OUT, "tokenizer.npz"), **d)
+    print("tokenizer.npz:", len(texts), "texts,", len(vocab), "tokens,", len(merges), "merges")
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize", "tokenizer"):
         os.makedirs(OUT, exist_ok=True)
-        return gen_wquant() if sys.argv[1] == "wquant" else gen_model_quantize()
+        return {"wquant": gen_wquant, "model_quantize": gen_model_quantize, "tokenizer": gen_tokenizer}[sys.argv[1]]()
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
     os.makedirs(OUT, exist_ok=True)

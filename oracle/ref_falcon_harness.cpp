@@ -4,6 +4,7 @@
 // Used by oracle/gen_golden.py in the build container to capture logits of synthetic GGCC files written by
 // tests/ggcc_writer.py (which pins the writer, our loader and our graph restatement against the reference itself).
 #include "libfalcon.h"
+#include "cmpnct_unicode.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -56,6 +57,14 @@ double reff_token_nll(const float * logits, int n_vocab, int target) {
     const float prob = probs[target];
     return (double) -std::log(prob);
 }
+
+// falcon_tokenize (libfalcon.cpp:4623-4641) on the loaded model's vocabulary
+int reff_tokenize(void * ctx, const char * text, int * tokens, int n_max, int add_bos) {
+    return falcon_tokenize((falcon_context *) ctx, text, (falcon_token *) tokens, n_max, add_bos != 0);
+}
+
+// the pre-tokenizer's class of a code point (cmpnct_unicode.cpp:98-115): 0 digit, 1 letter, 2 whitespace, 3.. others
+int reff_code_type(int c) { return (int) CNCTUnicode::get_code_type(c); }
 
 int reff_n_vocab(void * ctx) { return falcon_n_vocab((falcon_context *) ctx); }
 void reff_free(void * ctx) { llama_free((falcon_context *) ctx); }

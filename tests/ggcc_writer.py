@@ -38,17 +38,22 @@ def tensor_list(weights):
     return out
 
 
-def write_ggcc(path, weights):
+def write_ggcc(path, weights, vocab=None, merges=None):
+    """vocab: list of token byte strings (len == n_vocab), merges: list of (bytes, bytes) pairs in the printable BPE alphabet;
+    default: unique dummy tokens and no merges (the tokenizer is not on the eval path)"""
     hp, wt = weights["hparams"], weights["wtype"]
     assert hp["n_ff"] == 4 * hp["n_embd"], "the format does not store n_ff: the loader assumes 4 * n_embd (libfalcon.cpp:1598)"
     with open(path, "wb") as f:
         f.write(struct.pack("<II", GGCC_MAGIC, GGCC_VERSION))
         f.write(struct.pack("<8I", hp["n_vocab"], hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_layer"],
-                            40 if hp.get("two_norms") else 7, FTYPE_OF[wt], 0))
-        for i in range(hp["n_vocab"]):                       # unique dummy tokens; the tokenizer is not on the path
-            w = ("<%d>" % i).encode()
+                            40 if hp.get("two_norms") else 7, FTYPE_OF[wt], len(merges) if merges else 0))
+        assert vocab is None or len(vocab) == hp["n_vocab"]
+        for i in range(hp["n_vocab"]):
+            w = vocab[i] if vocab is not None else ("<%d>" % i).encode()
             f.write(struct.pack("<I", len(w))); f.write(w); f.write(struct.pack("<f", 0.0))
-        f.write(struct.pack("<I", 0))                        # BPE merges
+        f.write(struct.pack("<I", len(merges) if merges else 0))        # BPE merges
+        for a, b in (merges or []):
+            f.write(struct.pack("<I", len(a))); f.write(a); f.write(struct.pack("<I", len(b))); f.write(b)
         for name, t, ne, data in tensor_list(weights):
             nb = name.encode()
             f.write(struct.pack("<III", len(ne), len(nb), t))
