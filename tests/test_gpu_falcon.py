@@ -1,4 +1,6 @@
 """GPU parity: the device-resident Falcon stack against the oracle and against logits captured from the reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -301,3 +303,39 @@ def test_pipeline_stage_steps_match_whole_model(oracle, monkeypatch, hp, t, cut,
     for b in (tok, hid, nxt):
         b.free()
     assert got == [int(x) for x in want]
+
+
+def test_text_in_text_out_example(oracle, tmp_path):
+    """examples/falcon_generate.py end to end on a GGCC file that carries a real byte-level BPE vocabulary: tokenizer ->
+    prefill -> greedy decode on the device -> detokenizer; the generated ids are the oracle's greedy continuation"""
+    import importlib.util
+    import bpe_fixture
+    import ggcc_writer
+    vocab, merges = bpe_fixture.build(n_merges=308)                  # 12 + 256 + 308 = 576 tokens
+    hp = dict(synth.HP_TINY_MQA)
+    hp["n_vocab"] = len(vocab)
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=321)
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    ggcc_writer.write_ggcc(path, w, vocab, merges)
+    spec = importlib.util.spec_from_file_location("falcon_generate", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "falcon_generate.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    prompt = "The quick brown fox didn't jump"
+    ids, out, text = ex.generate(path, prompt, 6, n_ctx=64)
+    assert 4 < ids.size < len(prompt)                                # merges applied
+    oracle.lib.orc_set_sum_order(2)
+    try:
+        mo = oracle.model(w, 64)
+        lg = mo.eval(ids, 0, 2)
+        exp = [int(lg[-1].argmax())]
+        for i in range(5):
+            exp.append(int(mo.eval(np.array(exp[-1:], np.int32), ids.size + i, 2)[-1].argmax()))
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    eos = 11
+    if eos in exp:
+        exp = exp[:exp.index(eos)]
+    assert out.tolist() == exp
+    v = g.Vocab(path)
+    assert v.detokenize(out) == text and v.detokenize(ids) == prompt.encode()
+    v.free()
