@@ -339,3 +339,30 @@ def test_text_in_text_out_example(oracle, tmp_path):
     v = g.Vocab(path)
     assert v.detokenize(out) == text and v.detokenize(ids) == prompt.encode()
     v.free()
+
+
+def test_text_perplexity_example(oracle, tmp_path):
+    """examples/falcon_perplexity.py: tokenizer (bos first, as the reference's tool) + the perplexity loop on a GGCC file"""
+    import importlib.util
+    import math
+    import bpe_fixture
+    import ggcc_writer
+    vocab, merges = bpe_fixture.build(n_merges=308)
+    hp = dict(synth.HP_TINY_MQA)
+    hp["n_vocab"] = len(vocab)
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=322)
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    ggcc_writer.write_ggcc(path, w, vocab, merges)
+    spec = importlib.util.spec_from_file_location("falcon_perplexity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "falcon_perplexity.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    text = (bpe_fixture.CORPUS * 2).encode("utf-8")
+    ppl, n, total = ex.perplexity(path, text, n_ctx=32, n_batch=8)
+    v = g.Vocab(path)
+    ids = v.tokenize(text, add_bos=True)
+    v.free()
+    assert ids[0] == 11 and total == ids.size and n == (ids.size // 32) * (32 - 1 - 16)
+    m = g.FalconModel.from_ggcc(path, n_ctx=32, n_batch=8)
+    nll, n2 = m.perplexity(ids, 32, 8)
+    m.free()
+    assert n2 == n and ppl == math.exp(nll / n) and 1.0 < ppl < 10.0 * len(vocab)
