@@ -31,16 +31,17 @@ namespace {
 
 enum cp_class { CP_LETTER, CP_DIGIT, CP_SPACE, CP_OTHER };
 
-template <size_t N> bool in_ranges(int c, const fq_cp_range (&r)[N]) {
-    size_t lo = 0, hi = N;                                   // first range with hi >= c
-    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (r[mid].hi < c) lo = mid + 1; else hi = mid; }
-    return lo < N && r[lo].lo <= c;
+template <size_t N> bool in_runs(int c, const int (&first)[N], const int (&extra)[N]) {
+    const int * it = std::upper_bound(first, first + N, c);  // the last run that starts at or before c
+    if (it == first) return false;
+    const size_t i = (size_t)(it - first) - 1;
+    return c - first[i] <= extra[i];
 }
 cp_class classify(int c) {                                   // cmpnct_unicode.cpp:98-115 (letters are tested first)
     if (c < 0) return CP_OTHER;
-    if (in_ranges(c, fq_cp_letters)) return CP_LETTER;
-    if (in_ranges(c, fq_cp_digits)) return CP_DIGIT;
-    if (in_ranges(c, fq_cp_spaces)) return CP_SPACE;
+    if (in_runs(c, fq_cp_letters_first, fq_cp_letters_extra)) return CP_LETTER;
+    if (in_runs(c, fq_cp_digits_first, fq_cp_digits_extra)) return CP_DIGIT;
+    if (in_runs(c, fq_cp_spaces_first, fq_cp_spaces_extra)) return CP_SPACE;
     return CP_OTHER;
 }
 // lead byte -> sequence length, as the reference counts it (cmpnct_unicode.cpp:135-147): continuation bytes and 0xF8..0xFF
