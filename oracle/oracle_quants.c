@@ -444,11 +444,12 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
         }
         return sumf;
     }
-    /* k-quants against Q8_K. Integer parts are exact; the float epilogue is d*isum (- dmin*msum) per super-block.
-     * The reference's scalar code keeps 8 float lanes (k_quants.c:1699-1743) and its AVX2 code 8 SIMD lanes; only
-     * the association of the float sums differs. Per super-block: sc16[b] / mn16[b] = integer scale / min of the 16-element
+    /* k-quants against Q8_K. Integer parts are exact; only the association of the float sums differs between the
+     * orders below (and between the reference's scalar and AVX2 branches). Per super-block: sc16[b] / mn16[b] = integer scale / min of the 16-element
      * block b (a 32-element sub-block's pair repeated), i16[b] = its unscaled integer dot, bs16[b] = Q8_K's block sum.
-     * order 0: sumf += d dy * sum_b sc16 i16 - dmin dy * sum_b mn16 bs16, left to right over the super-blocks.
+     * order 0 = the reference's scalar branches, bit for bit: Q2_K sumf += d dy * sum_b sc16 i16 - dmin dy * sum_b mn16 bs16
+     * left to right over the super-blocks (k_quants.c:1303); Q3_K .. Q6_K eight float lanes, element e -> lane e mod 8,
+     * sums[l] += (d dy) * aux32[l] per super-block, mins subtracted from sumf per super-block, lanes added 0..7 at the end.
      * order 2 (the backend's prefill GEMM): the super-block's eight 32-element groups are dealt to g_split partial sums
      * (group g -> g mod g_split), each adds (d dy) * (its groups' integer sum) per super-block, the last one with the mins
      * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3.
@@ -457,6 +458,8 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
      * combined by the xor butterfly 1, 2, 4, .., 32. */
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float lane[64] = {0};
+    float lanes8[8] = {0};
+    int   eight = 0;
     const int split = (g_sum_order == 2 && n > 32) ? g_split : 0;
     const int wave  = (g_sum_order == 1 && n > 32);
     int64_t unit = 0;
@@ -464,6 +467,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
         const float  dy = rd_f32(a);
         const int8_t * q8 = (const int8_t *)(a + 4);
         int sc16[16], mn16[16] = {0}, i16[16] = {0}, bs16[16];
+        int qv[256];                         /* the super-block's integer weights (the reference's aux8[]) */
         int has_min = 0;
         float dd = 0.0f, dmn = 0.0f;
         for (int b = 0; b < 16; ++b) bs16[b] = rd_i16(a + 260 + 2 * b);
@@ -471,7 +475,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
             case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
                 for (int b = 0; b < 16; ++b) { sc16[b] = w[b] & 15; mn16[b] = w[b] >> 4; }
                 for (int e = 0; e < 256; ++e)
-                    i16[e / 16] += ((w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3) * q8[e];
+                    qv[e] = (w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
                 dd = dy * rd_f16(w + 80); dmn = dy * rd_f16(w + 82); has_min = 1; } break;
             case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
                 int sc[16]; q3_scales(w + 96, sc);
@@ -479,7 +483,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                 for (int e = 0; e < 256; ++e) {
                     const int lo = (w[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
                     const int hb = (w[e % 32] >> (e / 32)) & 1;
-                    i16[e / 16] += (lo - (hb ? 0 : 4)) * q8[e];
+                    qv[e] = lo - (hb ? 0 : 4);
                 }
                 dd = rd_f16(w + 108) * dy; } break;
             case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
@@ -490,7 +494,7 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     const int byte = w[qs_off + 32 * c + e % 32];
                     int q = hi ? (byte >> 4) : (byte & 15);
                     if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
-                    i16[e / 16] += q * q8[e];
+                    qv[e] = q;
                 }
                 dd = rd_f16(w) * dy; dmn = rd_f16(w + 2) * dy; has_min = 1; } break;
             case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
@@ -501,11 +505,12 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                     const int byte = w[64 * h + 32 * (t & 1) + l];
                     const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
                     const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
-                    i16[e / 16] += ((int)(int8_t)(lo | (hi << 4)) - 32) * q8[e];
+                    qv[e] = (int)(int8_t)(lo | (hi << 4)) - 32;
                 }
                 dd = rd_f16(w + 208) * dy; } break;
             default: abort();
         }
+        for (int e = 0; e < 256; ++e) i16[e / 16] += qv[e] * q8[e];
         if (wave) {
             /* units (fq_units.h): Q2_K / Q3_K: 4 per super-block, unit (hf, g) = blocks 8 hf + 2 j + g, j = 0..3;
              * Q4_K / Q5_K: 8, unit (c, g) = blocks 4 c + g and 4 c + g + 2; Q6_K: 8, unit (h, t, g) = blocks 8 h + 2 t + g, + 4 */
@@ -531,12 +536,22 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
                 const float A = dd * (float) is;
                 part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
             }
-        } else {
+        } else if (wtype == ORC_Q2_K) {                                       /* k_quants.c:1303 */
             int is = 0;
             for (int b = 0; b < 16; ++b) is += sc16[b] * i16[b];
-            sumf += has_min ? dd * (float) is - dmn * (float) msum : dd * (float) is;
+            sumf += dd * (float) is - dmn * (float) msum;
+        } else {
+            /* the reference's scalar branches of Q3_K .. Q6_K (k_quants.c:1733-1743, 2044-2053, 2389-2398, 2780-2787):
+             * element e of the super-block feeds integer lane e mod 8, aux32[l] += scale * q8 * a; per super-block
+             * sums[l] += d * aux32[l] for the eight float lanes and (Q4_K / Q5_K) sumf -= dmin * sumi */
+            int aux32[8] = {0};
+            for (int e = 0; e < 256; ++e) aux32[e & 7] += sc16[e / 16] * (qv[e] * q8[e]);
+            for (int l = 0; l < 8; ++l) lanes8[l] += dd * (float) aux32[l];
+            if (has_min) sumf -= dmn * (float) msum;
+            eight = 1;
         }
     }
+    if (eight) for (int l = 0; l < 8; ++l) sumf += lanes8[l];
     if (wave) {
         for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
         return lane[0];
