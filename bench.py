@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the model to this many blocks (marks the line invalid)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-tokens", type=int, default=6)
+    ap.add_argument("--cpu-tokens", type=int, default=12, help="timed CPU decode steps after the CPU prompt (cpu_baseline leg)")
+    ap.add_argument("--prefill-long", type=int, default=2048, help="also time one prompt of this many tokens (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
     ap.add_argument("--streams", type=int, default=2, help="decode streams in flight for --force-pipeline at one GPU")
     return ap.parse_args()
@@ -59,29 +61,85 @@ def kv_bytes_per_token(hp, n_past):
     return hp["n_layer"] * 2 * (n_past + 1) * hp["n_head_kv"] * 64 * 4 + hp["n_layer"] * 2 * hp["n_head_kv"] * 64 * 4
 
 
-def cpu_baseline(weights, hp, n_tokens, first_logits_gpu, tokens):
-    """decode steps on the host: the real reference if its .so is here, else the oracle port"""
-    from oracle import binding as ob
-    cores = os.cpu_count() or 1
+def host_cores():
+    """(physical cores of ONE socket, sockets) of this host"""
+    phys = set()
     try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or cores
-    except Exception:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                cid = int(line.split(":")[1])
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
         pass
-    threads = max(1, min(cores, 32))
+    if not phys:
+        return max(1, (os.cpu_count() or 2) // 2), 1
+    sockets = len({p for p, _ in phys})
+    return max(1, len(phys) // sockets), sockets
+
+
+def cpu_baseline(weights, hp, wbytes, prompt, n_tokens, tokens):
+    """The same workload on the host cores: the prompt as one batch, then n_tokens timed decode steps -- with the
+    threads of one socket's physical cores, and again with the reference's default -t 4 (examples/falcon_common.cpp:115-118).
+    Runs the REAL reference (oracle/_ref/libggml_ref.so, its AVX2 build: what a user of the reference executes) when the .so
+    travelled, else the oracle port (scalar)."""
+    from oracle import binding as ob
+    cores, sockets = host_cores()
     ob.build_oracle()
     if ob.Ref.available():
-        runner, kind = ob.Ref().model(weights, 64), "reference"
+        runner, kind = ob.Ref().model(weights, prompt + n_tokens + 8), "reference"
     else:
-        runner, kind = ob.Oracle().model(weights, 64), "port"
-    lg0 = runner.eval(tokens[:1], 0, threads)              # warm-up + parity sample
-    err = float(np.abs(lg0[0] - first_logits_gpu).max() / np.sqrt((lg0[0].astype(np.float64) ** 2).mean()))
+        runner, kind = ob.Oracle().model(weights, prompt + n_tokens + 8), "port"
     t0 = time.time()
-    for i in range(1, 1 + n_tokens):
-        runner.eval(tokens[i:i + 1], i, threads)
-    dt = time.time() - t0
-    return dict(value=n_tokens / dt, unit="tokens/s", cores=threads, kind=kind,
-                sample=f"{n_tokens} decode steps (N=1, n_past 1..{n_tokens}) of the same synthetic model, {threads} threads"), err
+    lg = runner.eval(tokens[:prompt], 0, cores)
+    t_prompt = time.time() - t0
+    cur = int(lg[-1].argmax())
+    seq = []
+    for i in range(3):                                                   # 3 warm-up steps
+        cur = int(runner.eval(np.array([cur], np.int32), prompt + i, cores)[0].argmax()); seq.append(cur)
+    res = {}
+    for threads in (cores, 4):
+        t0 = time.time()
+        c = seq[-1]
+        for i in range(n_tokens):
+            c = int(runner.eval(np.array([c], np.int32), prompt + 3 + i, threads)[0].argmax())
+        res[threads] = n_tokens / (time.time() - t0)
+    return dict(value=res[cores], unit="tokens/s", cores=cores, kind=kind,
+                effective_GBs=wbytes * res[cores] / 1e9,
+                t4_value=res[4], t4_effective_GBs=wbytes * res[4] / 1e9,
+                prefill_tok_s=prompt / t_prompt, sockets=sockets,
+                sample=f"{prompt}-token prompt as one batch, 3 warm-up + {n_tokens} timed greedy decode steps of the same synthetic model; "
+                       f"{cores} threads (the physical cores of one of {sockets} sockets) and the reference's default -t 4")
+
+
+def parity_sample(model, weights, toks, L):
+    """logits of two decode steps (n_past 0 and 1) against the reference's SCALAR build on the host: bit-identical in
+    reference order (ggml_hip_reference_order), and the distance of the default (fast) order from it = the model's
+    re-association spread"""
+    from oracle import binding as ob
+    ob.build_oracle()
+    if ob.Ref.available(scalar=True):
+        runner, kind = ob.Ref(scalar=True).model(weights, 8), "reference (scalar build)"
+    else:
+        runner, kind = ob.Oracle().model(weights, 8), "port (order 0 == the reference's scalar build, tests/test_oracle_vs_golden.py)"
+    th = min(32, os.cpu_count() or 4)
+    ref = [runner.eval(toks[i:i + 1], i, th)[0] for i in range(2)]
+
+    def rel(a, b):
+        return float(np.abs(a.astype(np.float64) - b).max() / np.sqrt((b.astype(np.float64) ** 2).mean()))
+    fast = [model.eval(toks[i:i + 1], i, logits_all=False)[0].copy() for i in range(2)]
+    L.ggml_hip_reference_order(1)
+    try:
+        exact = [model.eval(toks[i:i + 1], i, logits_all=False)[0].copy() for i in range(2)]
+    finally:
+        L.ggml_hip_reference_order(0)
+    return dict(max_rel_logit_err_vs_cpu=max(rel(exact[i], ref[i]) for i in range(2)),
+                assoc_spread_default_order_vs_cpu=max(rel(fast[i], ref[i]) for i in range(2)), cpu=kind)
 
 
 def main():
@@ -110,16 +168,25 @@ def main():
     weights = synth.make_model_fast(hp, wtype, seed=1234)
     t_gen = time.time() - t0
     t0 = time.time()
-    model = g.FalconModel(weights, n_ctx=a.n_ctx, n_batch=max(a.prompt, 1))
+    model = g.FalconModel(weights, n_ctx=max(a.n_ctx, a.prefill_long), n_batch=max(a.prompt, a.prefill_long, 1))
     t_up = time.time() - t0
     wbytes = model.weight_bytes()
 
-    toks = synth.tokens(a.prompt + 8, hp["n_vocab"], seed=42)
-    # ---- parity sample for the cpu leg: logits of the first token at n_past 0
-    first_logits = model.eval(toks[:1], 0, logits_all=False)[0].copy()
+    toks = synth.tokens(max(a.prompt, a.prefill_long) + 8, hp["n_vocab"], seed=42)
+    # ---- parity sample: reference order against the reference's scalar build on the host (expected 0.0)
+    parity = None if a.no_cpu else parity_sample(model, weights, toks, L)
+
+    # ---- one long prompt (BASELINE config 3's size), timed with hipEvents
+    e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
+    long_ms = None
+    if a.prefill_long:
+        model.eval(toks[:a.prefill_long], 0, logits_all=False)
+        L.ggml_hip_event_record(e0)
+        model.eval(toks[:a.prefill_long], 0, logits_all=False)
+        L.ggml_hip_event_record(e1)
+        long_ms = L.ggml_hip_event_elapsed_ms(e0, e1)
 
     # ---- prefill of the prompt (timed with hipEvents, reported beside the decode number)
-    e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
     model.eval(toks[:a.prompt], 0, logits_all=False)                   # warm (allocations, code load)
     L.ggml_hip_event_record(e0)
     lg = model.eval(toks[:a.prompt], 0, logits_all=False)
@@ -132,12 +199,16 @@ def main():
     # ---- warm-up decode steps (also captures the graph)
     out_w = model.decode_greedy(first, n_past, max(a.warmup, 1), use_graph=use_graph)
     n_past += max(a.warmup, 1)
-    # ---- timed region: exactly K decode steps
-    L.ggml_hip_synchronize()
-    t0 = time.perf_counter()
-    out = model.decode_greedy(int(out_w[-1]), n_past, a.steps, use_graph=use_graph)
-    L.ggml_hip_synchronize()
-    dt = time.perf_counter() - t0
+    # ---- timed region: exactly K decode steps between device synchronisations; run `repeats` times over the SAME positions
+    # (the KV entries are rewritten with the same values) and report the median run, all runs listed beside it
+    runs = []
+    for _ in range(max(1, a.repeats)):
+        L.ggml_hip_synchronize()
+        t0 = time.perf_counter()
+        out = model.decode_greedy(int(out_w[-1]), n_past, a.steps, use_graph=use_graph)
+        L.ggml_hip_synchronize()
+        runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[len(runs) // 2]
     tok_s = a.steps / dt
     n_mid = n_past + a.steps // 2
     b_tok = wbytes + kv_bytes_per_token(hp, n_mid)
@@ -170,23 +241,37 @@ def main():
     step_gbs = b_tok * tok_s / 1e9
     roof.update(step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok)
 
+    # ---- prefill: flops / time against the matrix pipe (2 N sum(ne00 ne01) + attention 4 64 n_head n_layer N(N+1)/2)
+    def prefill_roof(N, ms):
+        E, H, HKV, FF, V, NL = hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_ff"], hp["n_vocab"], hp["n_layer"]
+        per_tok = NL * (E * (H + 2 * HKV) * 64 + E * E + 2 * E * FF) + E * V
+        fl = 2.0 * N * per_tok + 4.0 * 64 * H * NL * N * (N + 1) / 2
+        tf = fl / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", tokens=N, achieved=tf, peak=2500.0, unit="TFLOP/s", frac=tf / 2500.0, frac_of_int8_peak=tf / 3944.0, tok_s=N / (ms * 1e-3), ms=ms,
+                    note="peak = dense fp16/bf16 MFMA (SURVEY 8d); the GEMM runs on the int8 MFMA (>= 3944 TOPS dense) with exact per-32-group f32 scaling, "
+                         "which bounds it by VALU issue; MFMA-busy counters: profiles/*pmc_mfma.json")
+    prefill = {"prompt": prefill_roof(a.prompt, prefill_ms)}
+    if long_ms:
+        prefill["long"] = prefill_roof(a.prefill_long, long_ms)
+
     cpu = None
-    err = None
     if not a.no_cpu:
-        cpu, err = cpu_baseline(weights, hp, a.cpu_tokens, first_logits, toks)
+        cpu = cpu_baseline(weights, hp, wbytes, a.prompt, a.cpu_tokens, toks)
 
     valid = (a.layers == 0)
     line = {
         "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
                   else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
         "value": tok_s, "unit": "tokens/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "repeat_ms_per_step": [r / a.steps * 1e3 for r in runs], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
         "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} full offload, {a.prompt}-token prompt + greedy decode, n_ctx {a.n_ctx}"
                                + ("" if valid else f" [TRUNCATED to {a.layers} blocks: not the benchmark config]"),
                    "n_past_timed": [n_past, n_past + a.steps], "hipgraph": use_graph, "weight_bytes_per_token": wbytes},
         "prefill_tok_s": a.prompt / (prefill_ms * 1e-3), "prefill_ms": prefill_ms,
-        "roofline": roof, "cpu_baseline": cpu, "max_rel_logit_err_vs_cpu": err,
+        "prefill_roofline": prefill,
+        "roofline": roof, "cpu_baseline": cpu,
+        "max_rel_logit_err_vs_cpu": parity["max_rel_logit_err_vs_cpu"] if parity else None, "parity": parity,
         "setup_s": {"synthesize": t_gen, "upload": t_up},
     }
     print(json.dumps(line))

@@ -42,7 +42,10 @@ struct falcon_hip_context {
     int n_ctx = 0, n_batch = 0, rope_n_ctx = 0;
     float * x = nullptr, * ln = nullptr, * ln2 = nullptr, * qkv = nullptr, * att = nullptr, * wo_out = nullptr, * up = nullptr;
     float * logits_dev = nullptr;
-    fq_act act_e{}, act_e2{}, act_att{}, act_ff{};
+    // quantized-activation images. Each buffer holds the LARGEST image of its length (Q8_1: 1.25 bytes per element) and is
+    // typed per use from the weight that consumes it (ggml.c:1627-1718 vec_dot_type), so that a file which mixes weight
+    // formats between tensors or blocks never writes an image into a buffer sized for another family.
+    uint8_t * buf_e = nullptr, * buf_e2 = nullptr, * buf_att = nullptr, * buf_ff = nullptr;
     float * k_cache = nullptr, * v_cache = nullptr;
     float * rope_cs = nullptr;
     int * n_past_dev = nullptr;
@@ -79,7 +82,22 @@ struct falcon_hip_context {
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
     int  graph_base = -1;                      // n_past the captured graph was built for
+    int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
+    unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
 };
+
+// k_attn_out hands the attention output from workgroup to workgroup with a BOUNDED spin; a time-out sets sync_words[1] and
+// the launch carries on with whatever the granules hold. Wherever the host waits for the stream anyway the word comes
+// along, and a set word fails the call (callers of the purely stream-ordered falcon_hip_stage_step poll
+// falcon_hip_context_sync_error themselves).
+static void fetch_sync_error(falcon_hip_context * c, hipStream_t st) {
+    HIP_CHECK(hipMemcpyAsync(&c->sync_err_host, c->sync_words + 1, 4, hipMemcpyDeviceToHost, st));
+}
+static int report_sync_error(const falcon_hip_context * c, const char * where) {
+    if (!c->sync_err_host) return 0;
+    fprintf(stderr, "falcon-hip: %s: an in-launch hand-off timed out (sync word %u) -- the results of this call are invalid\n", where, c->sync_err_host);
+    return 3;
+}
 
 static void * dev_alloc(std::vector<void *> & keep, size_t bytes) {
     void * p = nullptr;
@@ -180,11 +198,15 @@ extern "C" int falcon_hip_model_set_tensor(falcon_hip_model * m, const char * na
 
 extern "C" size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m) { return m->weight_bytes; }
 
-static fq_act ctx_act(falcon_hip_context * c, int act_type, int64_t K, int64_t cols) {
-    void * slab = nullptr;
-    fq_act a = fq_act_alloc(act_type, K, cols, &slab);
-    c->allocs.push_back(slab);
-    return a;
+static size_t act_col_bytes_max(int64_t K) {
+    size_t b = fq_act_col_bytes(FQ_Q8_1, K), b0 = fq_act_col_bytes(FQ_Q8_0, K), bk = fq_act_col_bytes(FQ_Q8_K, K);
+    if (b0 > b) b = b0;
+    if (bk > b) b = bk;
+    return b;
+}
+// the image view of `buf` for the activations that weight `w` consumes
+static fq_act act_for(uint8_t * buf, const fq_weight & w, int64_t cols) {
+    fq_act a{}; a.type = fq_desc(w.type).act_type; a.K = w.K; a.ncols = cols; a.base = buf; return a;
 }
 
 extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx) {
@@ -210,12 +232,10 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->wo_out = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
     c->up     = (float *) dev_alloc(c->allocs, (size_t) B * FF * 4);
     if (m->last_stage()) c->logits_dev = (float *) dev_alloc(c->allocs, (size_t) B * hp.n_vocab * 4);
-    const int wt = nl ? m->layers[0].qkv.type : m->lm_head.type;
-    const int at = fq_desc(wt).act_type;
-    c->act_e   = ctx_act(c, at, E, B);
-    c->act_e2  = ctx_act(c, at, E, B);
-    c->act_att = ctx_act(c, at, E, B);
-    c->act_ff  = ctx_act(c, nl ? fq_desc(m->layers[0].down.type).act_type : at, FF, B);
+    c->buf_e   = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(E) * (size_t) B + 256);
+    c->buf_e2  = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(E) * (size_t) B + 256);
+    c->buf_att = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(E) * (size_t) B + 256);
+    c->buf_ff  = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(FF) * (size_t) B + 256);
     const size_t kvb = (size_t) nl * n_ctx * hp.n_head_kv * D * 4;
     c->k_cache = (float *) dev_alloc(c->allocs, kvb);
     c->v_cache = (float *) dev_alloc(c->allocs, kvb);
@@ -286,6 +306,18 @@ static bool stage_uniform(const falcon_hip_model * m) {
     for (const layer_weights & L : m->layers) if (L.qkv.type != L.up.type || L.down.type != L.wo.type) return false;
     return true;
 }
+// THE predicate for "an N = 1 step of this context runs the fused decode kernels" -- launch_stage, the greedy sampler and
+// the pipeline step all ask here, so the sampler reads the per-workgroup argmax candidates exactly when the fused lm_head
+// wrote them. The fused kernels are instantiated per weight format (a model that mixes formats inside a block takes the
+// op list) and implement the default summation order only (ggml_hip_reference_order -> op list).
+static bool stage_fused(const falcon_hip_context * c) {
+    return c->fused_decode && stage_uniform(c->m) && !fq_reference_order() && !fq_attn_f64();
+}
+// everything a captured graph bakes in besides its pointers: a change invalidates decode_graph / step_graph
+static int graph_signature(const falcon_hip_context * c) {
+    return (stage_fused(c) ? 1 : 0) | (fq_reference_order() ? 2 : 0) | (fq_attn_f64() ? 4 : 0) | (c->merged_attn_out ? 8 : 0) |
+           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0);
+}
 
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
@@ -299,11 +331,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
 
     if (m->first_stage()) fq_launch_dequant_rows(m->tok_emb, c->tokens_dev, N, c->x, st);    // ggml_get_rows, libfalcon.cpp:2120
 
-    auto acts = [&](const fq_act & a, int64_t n) { fq_act v = a; v.ncols = n; return v; };
     // the fused kernels are instantiated per weight format: a model that mixes formats inside a block (e.g. the reference's
     // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
-    const bool fused = c->fused_decode && stage_uniform(m) && !fq_attn_f64();       // (ggml_hip_reference_order: the op list)
-    if (N == 1 && fused) {
+    if (N == 1 && stage_fused(c)) {
         // ---- fused single-token path (kernels_decode.hip), bit-identical to the op list below. Per block, by mode:
         //   3 launches  k_gemv_ln | k_attn_decode | k_gemv_out
         //   2 launches  k_gemv_ln | k_attn_out                        (attention inside the output mat-vec launch)
@@ -319,7 +349,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             ga.epoch_word = c->merged_attn_out ? c->sync_words : nullptr;
             if (c->merged_attn_out) { ga.n_past_ptr = c->n_past_dev; ga.rope_cs = c->rope_cs; ga.rope_cur = (float *)(c->sync_words + 16); }
             ga.seg[0] = { L.qkv, hp.two_norms ? L.ln2_w : L.ln_w, hp.two_norms ? L.ln2_b : L.ln_b, FQ_LNEPI_STORE, c->qkv, nullptr, 0, 0 };
-            ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->act_ff.base, ff_act, 0 };
+            ga.seg[1] = { L.up, L.ln_w, L.ln_b, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, c->buf_ff, ff_act, 0 };
             return ga;
         };
         auto head_args = [&]() {
@@ -345,21 +375,21 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
                 HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
                 fq_launch_gemv_ln(gu, hc.n_cu, c->side);
-                if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), c->side);
+                if (!quant_epi) fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), c->side);
                 HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
                 fq_launch_gemv_ln(gq, hc.n_cu, st);
             } else if (!ln_done) {
                 if (prof) fq_prof_open(st);
                 fq_launch_gemv_ln(ga, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
-                if (!quant_epi) fq_launch_quantize_act(c->up, FF, acts(c->act_ff, 1), st);
+                if (!quant_epi) fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st);
             }
             ln_done = false;
             float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
             float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
             const int att_act = fq_desc(L.wo.type).act_type;
             const bool att_q = (att_act == FQ_Q8_0 || att_act == FQ_Q8_1);      // the head's 64 outputs = two 32-blocks
-            fq_gemv_out_args go{ L.down, L.wo, c->act_ff.base, c->att, att_q ? c->act_att.base : nullptr, c->x, c->x,
+            fq_gemv_out_args go{ L.down, L.wo, c->buf_ff, c->att, att_q ? c->buf_att : nullptr, c->x, c->x,
                                  hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
             bool merged = false;
@@ -392,7 +422,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             }
             if (!merged) {
                 fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,
-                                      att_q ? nullptr : c->att, att_q ? c->act_att.base : nullptr, att_act, st);
+                                      att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, st);
                 if (prof) fq_prof_open(st);
                 fq_launch_gemv_out(go, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
@@ -413,32 +443,38 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const layer_weights & L = m->layers[li];
         if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
-        fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, acts(c->act_e, N), st);      // (the f32 row is not needed)
-        const fq_act * attn_in = &c->act_e;
+        const fq_act a_up = act_for(c->buf_e, L.up, N);
+        fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);      // (the f32 row is not needed)
+        fq_act a_qkv = a_up;
         if (hp.two_norms) {
-            fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, acts(c->act_e2, N), st);
-            attn_in = &c->act_e2;
+            a_qkv = act_for(c->buf_e2, L.qkv, N);
+            fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, a_qkv, st);
+        } else if (fq_desc(L.qkv.type).act_type != a_up.type) {                          // same norm, the other activation family
+            a_qkv = act_for(c->buf_e2, L.qkv, N);
+            fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_qkv, st);
         }
-        fq_mul_mat_q_acts(L.qkv, acts(*attn_in, N), N, c->qkv, QKV, store, st);
+        fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
         float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
         float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
         fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st);
         fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st);
-        fq_launch_quantize_act(c->att, E, acts(c->act_att, N), st);
-        fq_mul_mat_q_acts(L.wo, acts(c->act_att, N), N, c->wo_out, E, store, st);
+        const fq_act a_att = act_for(c->buf_att, L.wo, N), a_ff = act_for(c->buf_ff, L.down, N);
+        fq_launch_quantize_act(c->att, E, a_att, st);
+        fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
         const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
-        fq_mul_mat_q_acts(L.up, acts(c->act_e, N), N, c->up, FF, gelu, st);
-        fq_launch_quantize_act(c->up, FF, acts(c->act_ff, N), st);
+        fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
+        fq_launch_quantize_act(c->up, FF, a_ff, st);
         const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place
-        fq_mul_mat_q_acts(L.down, acts(c->act_ff, N), N, c->x, E, resid, st);
+        fq_mul_mat_q_acts(L.down, a_ff, N, c->x, E, resid, st);
     }
     if (c->keep_hidden) {
         HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
         c->hidden_tokens = N;
     }
     if (m->last_stage()) {
-        fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, acts(c->act_e, N), st);
-        fq_mul_mat_q_acts(m->lm_head, acts(c->act_e, N), N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
+        const fq_act a_head = act_for(c->buf_e, m->lm_head, N);
+        fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, a_head, st);
+        fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
     }
 }
 
@@ -449,6 +485,12 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     if (N < 1 || N > c->n_batch || n_past < 0 || n_past + N > c->n_ctx) {
         fprintf(stderr, "falcon-hip: eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, c->n_batch, c->n_ctx);
         exit(1);
+    }
+    if (m->first_stage()) {
+        for (int i = 0; i < N; ++i) if (tokens[i] < 0 || tokens[i] >= m->hp.n_vocab) {
+            fprintf(stderr, "falcon-hip: token id %d at position %d is outside [0, %d)\n", tokens[i], i, m->hp.n_vocab);
+            return 2;
+        }
     }
     hipStream_t st = hc.stream;
     HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
@@ -465,7 +507,9 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
             c->logits_host.resize((size_t) V);
             HIP_CHECK(hipMemcpyAsync(c->logits_host.data(), c->logits_dev + (size_t)(N - 1) * V, (size_t) V * 4, hipMemcpyDeviceToHost, st));
         }
+        fetch_sync_error(c, st);
         HIP_CHECK(hipStreamSynchronize(st));
+        return report_sync_error(c, "eval");
     } else if (hidden_out_dev) {
         HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     }
@@ -491,6 +535,10 @@ extern "C" int falcon_hip_perplexity(falcon_hip_context * c, const int32_t * tok
     }
     const int64_t n_chunk = n_tokens / n_ctx;
     const int V = c->m->hp.n_vocab;
+    for (int64_t i = 0; i < n_chunk * n_ctx; ++i) if (tokens[i] < 0 || tokens[i] >= V) {
+        fprintf(stderr, "falcon-hip: perplexity: token id %d at position %lld is outside [0, %d)\n", tokens[i], (long long) i, V);
+        return -1;
+    }
     double nll = 0.0; int count = 0;
     std::vector<float> logits((size_t) n_ctx * V), probs((size_t) V);
     for (int64_t i = 0; i < n_chunk; ++i) {
@@ -577,7 +625,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
         if (m->last_stage()) {
             if (next_token_dev) {
                 // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
-                if (c->fused_decode && stage_uniform(m))
+                if (stage_fused(c))
                     hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
                 else
                     hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
@@ -591,7 +639,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     if (c->stage_graph && !fq_prof_active() && !fq_ctx().dbg_stamps) {
         // one hipGraph replay per step instead of ~70 launches from the host: a stage of a deep pipeline holds few blocks,
         // and the host side of a step would otherwise cost as much as its device side
-        const bool same = c->step_graph && c->sg_in[0] == token_dev && c->sg_in[1] == hidden_in_dev && c->sg_out[0] == hidden_out_dev && c->sg_out[1] == next_token_dev;
+        const bool same = c->step_graph && c->step_sig == graph_signature(c) && c->sg_in[0] == token_dev && c->sg_in[1] == hidden_in_dev && c->sg_out[0] == hidden_out_dev && c->sg_out[1] == next_token_dev;
         if (!same) {
             if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
             hipGraph_t g;
@@ -601,7 +649,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
             HIP_CHECK(hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
             c->sg_in[0] = token_dev; c->sg_in[1] = hidden_in_dev; c->sg_out[0] = hidden_out_dev; c->sg_out[1] = next_token_dev;
-            c->step_next_n_past = -1;
+            c->step_next_n_past = -1; c->step_sig = graph_signature(c);
         }
         if (n_past != c->step_next_n_past) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
         HIP_CHECK(hipGraphLaunch(c->step_graph, st));
@@ -628,14 +676,14 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
     c->keep_hidden = false;
     auto one_step = [&](hipStream_t s, int max_kv) {
         launch_stage(c, 1, max_kv, s);
-        if (c->fused_decode && stage_uniform(m))
+        if (stage_fused(c))
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, s, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
         else
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
     };
     if (c->use_graph) {
         // the graph bakes n_past0 into k_argmax_advance's arguments: re-capture when the base position changes
-        if (!c->decode_graph || c->graph_base != n_past) {
+        if (!c->decode_graph || c->graph_base != n_past || c->decode_sig != graph_signature(c)) {
             if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
             hipGraph_t g;
             HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -643,14 +691,15 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
             HIP_CHECK(hipStreamEndCapture(st, &g));
             HIP_CHECK(hipGraphInstantiate(&c->decode_graph, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
-            c->graph_base = n_past;
+            c->graph_base = n_past; c->decode_sig = graph_signature(c);
         }
         for (int s = 0; s < n_steps; ++s) HIP_CHECK(hipGraphLaunch(c->decode_graph, st));
     } else {
         for (int s = 0; s < n_steps; ++s) one_step(st, n_past + n_steps);
     }
     HIP_CHECK(hipMemcpyAsync(out_tokens, c->out_tokens_dev, (size_t) n_steps * 4, hipMemcpyDeviceToHost, st));
+    fetch_sync_error(c, st);
     HIP_CHECK(hipStreamSynchronize(st));
     c->keep_hidden = was_keep;
-    return 0;
+    return report_sync_error(c, "greedy decode");
 }

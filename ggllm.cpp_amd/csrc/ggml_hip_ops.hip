@@ -67,6 +67,9 @@ extern "C" int ggml_hip_init(int device) {
         HIP_CHECK(hipMalloc((void **) &g_ctx.scalar_i32, 256));
         g_ctx.ready = true;
     });
+    // one process drives one GPU: a later call naming another device cannot re-bind the library
+    if (device >= 0 && device < g_ctx.n_devices && device != g_ctx.device)
+        fprintf(stderr, "ggml-hip: already initialised on device %d; the request for device %d is ignored (one process per GPU)\n", g_ctx.device, device);
     return g_ctx.n_devices;
 }
 
@@ -238,7 +241,12 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
 static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
 extern "C" void ggml_hip_debug_force_gemv(int on) { g_force_gemv = on != 0; }
 extern "C" void ggml_hip_gemm_sequential(int on) { fq_gemm_set_sequential(on); }
-extern "C" void ggml_hip_reference_order(int on) { fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
+// reference order: every mat-mul through the per-thread scalar restatement (kernels_ref.hip: the reference's own block /
+// lane order for all ten formats and any N), attention with f64 accumulation (the portable ggml_vec_dot_f32)
+static bool g_reference_order = false;
+bool fq_reference_order() { return g_reference_order; }
+extern "C" void ggml_hip_reference_order(int on) { g_reference_order = on != 0; fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
+extern "C" int  ggml_hip_get_reference_order(void) { return g_reference_order ? 1 : 0; }
 
 // ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream
 static bool g_prof_on = false;
@@ -301,6 +309,7 @@ void fq_prof_close(hipStream_t, double bytes) {
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {
     hip_context & c = fq_ctx();
     if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }
+    if (g_reference_order) { fq_launch_mul_mat_ref(w, a, N, dst, ldd, ep0, st); return; }
     if (N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv) {      // prefill: int8 MFMA GEMM
         fq_launch_gemm(w, a, N, dst, ldd, ep0, c.n_cu, st);
         return;

@@ -27,6 +27,7 @@ fq_act    fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_o
 void      fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd,
                             const fq_gemv_epi & ep, hipStream_t st);
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
+bool      fq_reference_order();
 bool      fq_prof_active();
 void      fq_prof_open(hipStream_t st);
 void      fq_prof_close(hipStream_t st, double bytes);

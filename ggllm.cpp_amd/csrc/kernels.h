@@ -28,6 +28,9 @@ size_t fq_gemv_lds_bytes(int act_type, int64_t K, int ncols);
 void   fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float * dst, int64_t ldd,
                       const fq_gemv_epi & ep, int max_blocks, hipStream_t st);
 
+// kernels_ref.hip -- any N, the reference's scalar summation order (ggml_hip_reference_order)
+void   fq_launch_mul_mat_ref(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st);
+
 // kernels_gemm.hip -- int8 MFMA mat-mul for N > 4 columns
 bool   fq_gemm_supported(int type);
 void   fq_gemm_debug_mode(int m);

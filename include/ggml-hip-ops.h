@@ -31,11 +31,14 @@ void    ggml_hip_debug_force_gemv(int on);        /* tests: N > 4 through column
  * left-to-right sum (ggml_vec_dot_q*_q8_*, scalar branch) -- legacy-format results are then bit-identical with the
  * reference's scalar build.                                                                                              */
 void    ggml_hip_gemm_sequential(int on);
-/* on = 1: the arithmetic ORDER of the reference's portable (SIMD-less) build wherever a batch (N > 4) is evaluated: the
- * GEMM's single left-to-right sum (above) and f64 accumulation of the attention's two dot products (ggml.c:2296-2300; the
- * default is f32 fused multiply-add chains like the reference's SIMD builds, 4-6 x faster), with N = 1 steps through the
- * op-by-op launch list. Prefill logits of legacy-format models are then bit-identical with that reference build's.        */
+/* on = 1: the arithmetic ORDER of the reference's portable (SIMD-less) build everywhere: every quantized mat-mul, any N,
+ * through a per-thread restatement of the scalar branches of ggml_vec_dot_q*_q8_* (csrc/fq_ref_dot.h: left-to-right block
+ * sums for the legacy formats, the eight float lanes of k_quants.c:1684-1746 ... for Q3_K .. Q6_K), f64 accumulation of the
+ * attention's two dot products (ggml.c:2296-2300; the default is f32 fused multiply-add chains like the reference's SIMD
+ * builds), N = 1 steps through the op-by-op launch list. Prefill AND decode logits of all ten formats are then
+ * bit-identical with that reference build's (tests/test_gpu_falcon.py). A parity instrument: 10-100 x slower.             */
 void    ggml_hip_reference_order(int on);
+int     ggml_hip_get_reference_order(void);
 int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
 /* soft_max's fp16 EXP table entries are recomputed in the attention kernels instead of gathered when -- checked at init, for
  * every non-NaN fp16 input -- the recomputation equals the host-built table. Returns the number of mismatching inputs (0 = in

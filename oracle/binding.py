@@ -127,6 +127,8 @@ class Oracle(_Base):
         L.orc_exp_table.restype = C.POINTER(C.c_uint16)
         L.orc_falcon_eval.argtypes = [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_set_sum_order.argtypes = [C.c_int]
+        L.orc_falcon_block_sampled.argtypes = [C.POINTER(Model), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_falcon_head_rows.argtypes = [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_tables_init()
 
     def fp16_to_fp32(self, h):
@@ -319,6 +321,29 @@ class Ref(_Base):
 class _ModelRunner:
     def __init__(self, fn, m, keep, weights, has_flavour):
         self.fn, self.m, self.keep, self.w, self.has_flavour = fn, m, keep, weights, has_flavour
+
+    def block_sampled(self, lib, il, X, sample, pos0=0, k_prev=None, v_prev=None, n_threads=8, flavour=ROUND_REFERENCE, want_kv=False):
+        """block `il` for the sampled tokens of a batch whose block inputs X[N, n_embd] are known (orc_falcon_block_sampled)"""
+        hp = self.w["hparams"]
+        X = _f32(X)
+        N = X.shape[0]
+        sample = np.ascontiguousarray(sample, np.int32)
+        out = np.zeros((sample.size, hp["n_embd"]), np.float32)
+        KV = hp["n_head_kv"] * 64
+        ko = np.zeros((N, KV), np.float32) if want_kv else None
+        vo = np.zeros((N, KV), np.float32) if want_kv else None
+        kp = _f32(k_prev) if pos0 else None
+        vp = _f32(v_prev) if pos0 else None
+        lib.orc_falcon_block_sampled(C.byref(self.m), il, _ptr(X), N, pos0, _ptr(kp) if pos0 else None, _ptr(vp) if pos0 else None,
+                                     _ptr(sample), sample.size, n_threads, flavour, _ptr(out), _ptr(ko) if want_kv else None, _ptr(vo) if want_kv else None)
+        return (out, ko, vo) if want_kv else out
+
+    def head_rows(self, lib, X, n_threads=8, flavour=ROUND_REFERENCE):
+        hp = self.w["hparams"]
+        X = _f32(X)
+        lg = np.zeros((X.shape[0], hp["n_vocab"]), np.float32)
+        lib.orc_falcon_head_rows(C.byref(self.m), _ptr(X), X.shape[0], n_threads, flavour, _ptr(lg))
+        return lg
 
     def eval(self, tokens, n_past, n_threads=4, flavour=ROUND_REFERENCE, want_hidden=False):
         hp = self.w["hparams"]

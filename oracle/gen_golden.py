@@ -226,10 +226,37 @@ def gen_tokenizer():
     print("tokenizer.npz:", len(texts), "texts,", len(vocab), "tokens,", len(merges), "merges")
 
 
+TINY_ALL = [("gqa_q4_1", ob.Q4_1), ("gqa_q5_0", ob.Q5_0), ("gqa_q2_K", ob.Q2_K), ("gqa_q3_K", ob.Q3_K), ("gqa_q5_K", ob.Q5_K), ("gqa_q6_K", ob.Q6_K)]
+
+
+def gen_tiny_all():
+    """4b. the six formats tiny_models.npz does not hold, same recipe (whole tiny GQA stack through the reference's graph
+    executor, AVX2 and scalar builds): tests/golden/tiny_models_all.npz. With it every one of the ten weight formats has
+    model-level logits of the REAL reference to be bit-identical with."""
+    ob.build_oracle()
+    O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
+    d = {}
+    hp = synth.HP_TINY_GQA
+    for name, t in TINY_ALL:
+        w = synth.make_model(O, hp, t, seed=1234)
+        d[f"{name}_digest"] = np.frombuffer(bytes.fromhex(weights_digest(w)), np.uint8)
+        toks = synth.tokens(12, hp["n_vocab"], seed=42)
+        d[f"{name}_tokens"] = toks
+        for tag, lib in (("avx", R), ("scalar", RS)):
+            m = lib.model(w, 64)
+            lg, hid = m.eval(toks[:8], 0, 2, want_hidden=True)
+            d[f"{name}_prefill_logits_{tag}"] = lg
+            if tag == "scalar":
+                d[f"{name}_prefill_hidden_{tag}"] = hid
+            d[f"{name}_decode_logits_{tag}"] = np.concatenate([m.eval(toks[i:i + 1], i, 2) for i in range(8, 12)])
+    np.savez_compressed(os.path.join(OUT, "tiny_models_all.npz"), **d)
+    print("tiny_models_all.npz", os.path.getsize(os.path.join(OUT, "tiny_models_all.npz")))
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize", "tokenizer"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize", "tokenizer", "tiny_all"):
         os.makedirs(OUT, exist_ok=True)
-        return {"wquant": gen_wquant, "model_quantize": gen_model_quantize, "tokenizer": gen_tokenizer}[sys.argv[1]]()
+        return {"wquant": gen_wquant, "model_quantize": gen_model_quantize, "tokenizer": gen_tokenizer, "tiny_all": gen_tiny_all}[sys.argv[1]]()
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
     os.makedirs(OUT, exist_ok=True)
@@ -328,6 +355,7 @@ def main():
             dec = [m.eval(toks[i:i + 1], i, 2) for i in range(8, 12)]
             d[f"{name}_decode_logits_{tag}"] = np.concatenate(dec)
     np.savez_compressed(os.path.join(OUT, "tiny_models.npz"), **d)
+    gen_tiny_all()
     gen_ggcc(O)
     gen_wquant()
     gen_model_quantize()

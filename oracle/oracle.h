@@ -84,6 +84,13 @@ typedef struct {
 void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_past, int n_threads,
                      int flavour, float * logits_out, float * hidden_out);
 
+/* block `il` for the tokens sample[0..ns) of a batch of N block-input rows X at positions pos0.. (K / V of the positions
+ * before pos0 in k_prev / v_prev, [pos0][n_head_kv][64]); k_out / v_out (optional) receive the batch's N K / V rows */
+void orc_falcon_block_sampled(const orc_model * m, int il, const float * X, int N, int pos0, const float * k_prev, const float * v_prev,
+                              const int32_t * sample, int ns, int n_threads, int flavour, float * out, float * k_out, float * v_out);
+/* ln_f + lm_head of ns residual rows */
+void orc_falcon_head_rows(const orc_model * m, const float * X, int ns, int n_threads, int flavour, float * logits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,3 +239,107 @@ void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_p
 
     free(inp); free(ln); free(ln2); free(qkv); free(qrot); free(krot); free(att); free(wo); free(up); free(down); free(p);
 }
+
+/* ------------------------------------------------------------------ one block, SAMPLED tokens (full-size parity tests)
+ * The block `il` of libfalcon.cpp:2160-2400 for the tokens sample[0..ns) of a batch whose N block-input rows X (positions
+ * pos0 .. pos0 + N - 1, the context before them empty unless the K / V of earlier positions are passed in kv_prev) are known:
+ * K / V of ALL N tokens (the mat-mul restricted to the K and V rows of Wqkv), everything else for the sampled tokens only.
+ * Exactly the arithmetic of orc_falcon_eval for those tokens -- the masked keys of the full evaluation contribute
+ * soft_max weight 0 and are left out. out: ns rows of n_embd floats (the block's output = next block's input).
+ * A 2048-token prompt through a Falcon-40B-sized block is ~1.4e12 multiply-adds; this is ~2e10. */
+typedef struct { const orc_model * m; int il, N, pos0, ns; const int32_t * sample; const float * q, * kc, * vc; float * att; int ith, nth; } att_job;
+static void * att_worker(void * arg) {
+    const att_job * j = (const att_job *) arg;
+    const orc_hparams * hp = &j->m->hp;
+    const int64_t E = hp->n_embd, H = hp->n_head, HKV = hp->n_head_kv, D = E / H;
+    const int group = (int)(H / HKV);
+    const float kq_scale = 1.0f / sqrtf((float) D);
+    const int backend_attn = orc_attn_backend_order() && D == 64;
+    float * p = (float *) malloc(sizeof(float) * (size_t)(j->pos0 + j->N));
+    for (int64_t w = j->ith; w < (int64_t) j->ns * H; w += j->nth) {
+        const int si = (int)(w / H), h = (int)(w % H), hk = h / group;
+        const int64_t n_kv = (int64_t) j->pos0 + j->sample[si] + 1;
+        const float * q = j->q + ((size_t) si * H + h) * D;
+        for (int64_t s = 0; s < n_kv; ++s)
+            p[s] = (backend_attn ? dot_qk_backend(j->kc + ((size_t) s * HKV + hk) * D, q)
+                                 : dot_f32(j->kc + ((size_t) s * HKV + hk) * D, q, D, 1)) * kq_scale;
+        orc_softmax_rows(p, n_kv, 1);
+        float * o = j->att + (size_t) si * E + (size_t) h * D;
+        for (int64_t d = 0; d < D; ++d)
+            o[d] = backend_attn ? dot_pv_backend(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D)
+                                : dot_f32(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D);
+    }
+    free(p);
+    return NULL;
+}
+
+void orc_falcon_block_sampled(const orc_model * m, int il, const float * X, int N, int pos0, const float * k_prev, const float * v_prev,
+                              const int32_t * sample, int ns, int n_threads, int flavour, float * out, float * k_out, float * v_out) {
+    orc_tables_init();
+    const orc_hparams * hp = &m->hp;
+    const orc_layer * ly = &m->layers[il];
+    const int64_t E = hp->n_embd, H = hp->n_head, HKV = hp->n_head_kv, D = E / H, FF = hp->n_ff;
+    const size_t wrow = orc_row_bytes(hp->wtype, E);
+    const int64_t KV = HKV * D;
+
+    float * ln_all = (float *) malloc(sizeof(float) * (size_t) N * E);                 /* the norm that feeds Wqkv, all tokens */
+    orc_layer_norm(X, E, N, hp->two_norms ? ly->ln2_w : ly->ln_w, hp->two_norms ? ly->ln2_b : ly->ln_b, ln_all);
+    /* K and V rows of the fused matrix: rows [H*D, (H + 2 HKV)*D) (libfalcon.cpp:2205-2227) */
+    float * kvrows = (float *) malloc(sizeof(float) * (size_t) N * 2 * KV);
+    orc_mul_mat_q(hp->wtype, (const uint8_t *) ly->qkv + (size_t)(H * D) * wrow, E, 2 * KV, ln_all, N, kvrows, n_threads, flavour);
+    float * kc = (float *) malloc(sizeof(float) * (size_t)(pos0 + N) * KV);
+    float * vc = (float *) malloc(sizeof(float) * (size_t)(pos0 + N) * KV);
+    if (pos0 > 0) { memcpy(kc, k_prev, sizeof(float) * (size_t) pos0 * KV); memcpy(vc, v_prev, sizeof(float) * (size_t) pos0 * KV); }
+    for (int t = 0; t < N; ++t) {
+        memcpy(kc + (size_t)(pos0 + t) * KV, kvrows + (size_t) t * 2 * KV,      sizeof(float) * KV);
+        memcpy(vc + (size_t)(pos0 + t) * KV, kvrows + (size_t) t * 2 * KV + KV, sizeof(float) * KV);
+    }
+    orc_rope_neox(kc + (size_t) pos0 * KV, (int) D, (int) HKV, N, pos0, hp->rope_n_ctx);
+    if (k_out) memcpy(k_out, kc + (size_t) pos0 * KV, sizeof(float) * (size_t) N * KV);
+    if (v_out) memcpy(v_out, vc + (size_t) pos0 * KV, sizeof(float) * (size_t) N * KV);
+
+    /* sampled tokens */
+    float * xs   = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    float * lnq  = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    float * lnm  = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    float * q    = (float *) malloc(sizeof(float) * (size_t) ns * H * D);
+    float * att  = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    float * wo   = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    float * up   = (float *) malloc(sizeof(float) * (size_t) ns * FF);
+    float * down = (float *) malloc(sizeof(float) * (size_t) ns * E);
+    for (int i = 0; i < ns; ++i) {
+        memcpy(xs  + (size_t) i * E, X + (size_t) sample[i] * E,      sizeof(float) * E);
+        memcpy(lnq + (size_t) i * E, ln_all + (size_t) sample[i] * E, sizeof(float) * E);
+    }
+    orc_layer_norm(xs, E, ns, ly->ln_w, ly->ln_b, lnm);                                  /* the norm that feeds the MLP */
+    orc_mul_mat_q(hp->wtype, ly->qkv, E, H * D, lnq, ns, q, n_threads, flavour);         /* Q rows */
+    for (int i = 0; i < ns; ++i) orc_rope_neox(q + (size_t) i * H * D, (int) D, (int) H, 1, pos0 + sample[i], hp->rope_n_ctx);
+
+    if (n_threads < 1) n_threads = 1;
+    att_job   * jobs = (att_job *) malloc(sizeof(att_job) * (size_t) n_threads);
+    pthread_t * th   = (pthread_t *) malloc(sizeof(pthread_t) * (size_t) n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t] = (att_job){ m, il, N, pos0, ns, sample, q, kc, vc, att, t, n_threads };
+        if (t > 0) pthread_create(&th[t], NULL, att_worker, &jobs[t]);
+    }
+    att_worker(&jobs[0]);
+    for (int t = 1; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+
+    orc_mul_mat_q(hp->wtype, ly->wo, E, E, att, ns, wo, n_threads, flavour);
+    orc_mul_mat_q(hp->wtype, ly->up, E, FF, lnm, ns, up, n_threads, flavour);
+    for (int64_t i = 0; i < (int64_t) ns * FF; ++i) up[i] = orc_gelu(up[i]);
+    orc_mul_mat_q(hp->wtype, ly->down, FF, E, up, ns, down, n_threads, flavour);
+    for (int64_t i = 0; i < (int64_t) ns * E; ++i) out[i] = (down[i] + wo[i]) + xs[i];
+
+    free(ln_all); free(kvrows); free(kc); free(vc); free(xs); free(lnq); free(lnm); free(q); free(att); free(wo); free(up); free(down);
+}
+
+/* ln_f + lm_head for given residual rows (libfalcon.cpp:2421-2440) */
+void orc_falcon_head_rows(const orc_model * m, const float * X, int ns, int n_threads, int flavour, float * logits) {
+    const orc_hparams * hp = &m->hp;
+    float * ln = (float *) malloc(sizeof(float) * (size_t) ns * hp->n_embd);
+    orc_layer_norm(X, hp->n_embd, ns, m->out_norm_w, m->out_norm_b, ln);
+    orc_mul_mat_q(hp->wtype, m->lm_head, hp->n_embd, hp->n_vocab, ln, ns, logits, n_threads, flavour);
+    free(ln);
+}

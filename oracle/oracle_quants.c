@@ -381,10 +381,144 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
  * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
  * columns, order 2 for GEMMs. mode 3 / 4: order 2 with 4 / 2 partial sums for every mat-mul. */
 static int g_split = 4;
-int orc_attn_backend_order(void) { return g_sum_mode == 2; }
+int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 = "as the backend" for the attention too */
 void orc_set_sum_order(int mode) {
     g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4) ? 2 : 0);
     g_split = (mode == 4) ? 2 : 4;
+}
+
+/* ------------------------------------------------------------------ k-quant dots against Q8_K
+ * A super-block decoded to integers: qv[e] = the integer weight of element e (the reference's aux8[]), sc16[b] / mn16[b] =
+ * integer scale / min of the 16-element block b (a 32-element sub-block's pair repeated), d / dmin = its fp16 factors.
+ * Integer parts are exact; only the association of the float sums differs between the orders below (and between the
+ * reference's scalar and AVX2 branches). With i16[b] = the unscaled integer dot of block b and bs16[b] = Q8_K's block sum:
+ * order 0 = the reference's scalar branches, bit for bit: Q2_K sumf += d dy * sum_b sc16 i16 - dmin dy * sum_b mn16 bs16
+ * left to right over the super-blocks (k_quants.c:1303); Q3_K .. Q6_K eight float lanes, element e -> lane e mod 8,
+ * sums[l] += (d dy) * aux32[l] per super-block, mins subtracted from sumf per super-block, lanes added 0..7 at the end
+ * (k_quants.c:1733-1743, 2044-2053, 2389-2398, 2780-2787).
+ * order 2 (the backend's prefill GEMM): the super-block's eight 32-element groups are dealt to g_split partial sums
+ * (group g -> g mod g_split), each adds (d dy) * (its groups' integer sum) per super-block, the last one with the mins
+ * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3.
+ * order 1 (the backend's mat-vec kernels, fq_units.h): the row is cut into UNITS of 2 or 4 blocks (below), unit u goes
+ * to lane u mod 64 as one f32 term (d dy) isum_u - (dmin dy) msum_u, lanes add their units in ascending order and are
+ * combined by the xor butterfly 1, 2, 4, .., 32. */
+typedef struct { int8_t qv[256]; int16_t sc16[16], mn16[16]; float d, dmin; int has_min; } kq_sb;
+
+static void kq_decode_sb(int wtype, const uint8_t * w, kq_sb * o) {
+    memset(o->mn16, 0, sizeof(o->mn16));
+    o->has_min = 0; o->dmin = 0.0f;
+    switch (wtype) {
+        case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
+            for (int b = 0; b < 16; ++b) { o->sc16[b] = w[b] & 15; o->mn16[b] = w[b] >> 4; }
+            for (int e = 0; e < 256; ++e)
+                o->qv[e] = (int8_t)((w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3);
+            o->d = rd_f16(w + 80); o->dmin = rd_f16(w + 82); o->has_min = 1; } break;
+        case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
+            int sc[16]; q3_scales(w + 96, sc);
+            for (int b = 0; b < 16; ++b) o->sc16[b] = (int16_t)(sc[b] - 32);
+            for (int e = 0; e < 256; ++e) {
+                const int lo = (w[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+                const int hb = (w[e % 32] >> (e / 32)) & 1;
+                o->qv[e] = (int8_t)(lo - (hb ? 0 : 4));
+            }
+            o->d = rd_f16(w + 108); } break;
+        case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
+            const int qs_off = (wtype == ORC_Q4_K) ? 16 : 48;
+            for (int b = 0; b < 16; ++b) { int sc, mn; k4_scale_min(w + 4, b / 2, &sc, &mn); o->sc16[b] = (int16_t) sc; o->mn16[b] = (int16_t) mn; }
+            for (int e = 0; e < 256; ++e) {
+                const int c = e / 64, hi = (e % 64) / 32;
+                const int byte = w[qs_off + 32 * c + e % 32];
+                int q = hi ? (byte >> 4) : (byte & 15);
+                if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
+                o->qv[e] = (int8_t) q;
+            }
+            o->d = rd_f16(w); o->dmin = rd_f16(w + 2); o->has_min = 1; } break;
+        case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
+            const int8_t * sc = (const int8_t *)(w + 192);
+            for (int b = 0; b < 16; ++b) o->sc16[b] = sc[b];
+            for (int e = 0; e < 256; ++e) {
+                const int h = e / 128, t = (e % 128) / 32, l = e % 32;
+                const int byte = w[64 * h + 32 * (t & 1) + l];
+                const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
+                const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
+                o->qv[e] = (int8_t)((int)(int8_t)(lo | (hi << 4)) - 32);
+            }
+            o->d = rd_f16(w + 208); } break;
+        default: abort();
+    }
+}
+
+/* a = the column's Q8_K blocks (292 bytes each) */
+static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t * a) {
+    float sumf = 0.0f;
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float lane[64] = {0};
+    float lanes8[8] = {0};
+    int   eight = 0;
+    const int split = (g_sum_order == 2 && nsb > 0) ? g_split : 0;
+    const int wave  = (g_sum_order == 1 && nsb > 0);
+    int64_t unit = 0;
+    for (int64_t i = 0; i < nsb; ++i, a += 292) {
+        const kq_sb * sb = &row[i];
+        const float  dy = rd_f32(a);
+        const int8_t * q8 = (const int8_t *)(a + 4);
+        const int16_t * sc16 = sb->sc16, * mn16 = sb->mn16;
+        const int has_min = sb->has_min;
+        int i16[16], bs16[16];
+        /* Q2_K: dall = y.d * d, dmin = y.d * dmin (k_quants.c:1282-1283); the others d * y.d -- the same product */
+        const float dd = (wtype == ORC_Q2_K) ? dy * sb->d : sb->d * dy;
+        const float dmn = (wtype == ORC_Q2_K) ? dy * sb->dmin : sb->dmin * dy;
+        for (int b = 0; b < 16; ++b) bs16[b] = rd_i16(a + 260 + 2 * b);
+        for (int b = 0; b < 16; ++b) {
+            int t = 0;
+            for (int j = 0; j < 16; ++j) t += sb->qv[16 * b + j] * q8[16 * b + j];
+            i16[b] = t;
+        }
+        if (wave) {
+            /* units (fq_units.h): Q2_K / Q3_K: 4 per super-block, unit (hf, g) = blocks 8 hf + 2 j + g, j = 0..3;
+             * Q4_K / Q5_K: 8, unit (c, g) = blocks 4 c + g and 4 c + g + 2; Q6_K: 8, unit (h, t, g) = blocks 8 h + 2 t + g, + 4 */
+            const int four = (wtype == ORC_Q2_K || wtype == ORC_Q3_K);
+            for (int uu = 0; uu < (four ? 4 : 8); ++uu, ++unit) {
+                int blk[4], nb;
+                if (four) { nb = 4; for (int j = 0; j < 4; ++j) blk[j] = 8 * (uu >> 1) + 2 * j + (uu & 1); }
+                else if (wtype == ORC_Q6_K) { nb = 2; blk[0] = 8 * (uu >> 2) + 2 * ((uu >> 1) & 1) + (uu & 1); blk[1] = blk[0] + 4; }
+                else { nb = 2; blk[0] = 4 * (uu >> 1) + (uu & 1); blk[1] = blk[0] + 2; }
+                int is = 0, ms = 0;
+                for (int j = 0; j < nb; ++j) { is += sc16[blk[j]] * i16[blk[j]]; ms += mn16[blk[j]] * bs16[blk[j]]; }
+                const float v = has_min ? dd * (float) is - dmn * (float) ms : dd * (float) is;
+                lane[unit & 63] += v;
+            }
+            continue;
+        }
+        int msum = 0;
+        for (int b = 0; b < 16; ++b) msum += mn16[b] * bs16[b];
+        if (split) {
+            for (int sp = 0; sp < split; ++sp) {
+                int is = 0;
+                for (int g = sp; g < 8; g += split) is += sc16[2 * g] * i16[2 * g] + sc16[2 * g + 1] * i16[2 * g + 1];
+                const float A = dd * (float) is;
+                part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
+            }
+        } else if (wtype == ORC_Q2_K) {                                       /* k_quants.c:1303 */
+            int is = 0;
+            for (int b = 0; b < 16; ++b) is += sc16[b] * i16[b];
+            sumf += dd * (float) is - dmn * (float) msum;
+        } else {
+            int aux32[8] = {0};
+            for (int b = 0; b < 16; ++b)
+                for (int h = 0; h < 2; ++h)
+                    for (int l = 0; l < 8; ++l) aux32[l] += sc16[b] * (sb->qv[16 * b + 8 * h + l] * q8[16 * b + 8 * h + l]);
+            for (int l = 0; l < 8; ++l) lanes8[l] += dd * (float) aux32[l];
+            if (has_min) sumf -= dmn * (float) msum;
+            eight = 1;
+        }
+    }
+    if (eight) for (int l = 0; l < 8; ++l) sumf += lanes8[l];
+    if (wave) {
+        for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
+        return lane[0];
+    }
+    return split ? ((part[0] + part[1]) + part[2]) + part[3] : sumf;
 }
 
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
@@ -444,119 +578,15 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
         }
         return sumf;
     }
-    /* k-quants against Q8_K. Integer parts are exact; only the association of the float sums differs between the
-     * orders below (and between the reference's scalar and AVX2 branches). Per super-block: sc16[b] / mn16[b] = integer scale / min of the 16-element
-     * block b (a 32-element sub-block's pair repeated), i16[b] = its unscaled integer dot, bs16[b] = Q8_K's block sum.
-     * order 0 = the reference's scalar branches, bit for bit: Q2_K sumf += d dy * sum_b sc16 i16 - dmin dy * sum_b mn16 bs16
-     * left to right over the super-blocks (k_quants.c:1303); Q3_K .. Q6_K eight float lanes, element e -> lane e mod 8,
-     * sums[l] += (d dy) * aux32[l] per super-block, mins subtracted from sumf per super-block, lanes added 0..7 at the end.
-     * order 2 (the backend's prefill GEMM): the super-block's eight 32-element groups are dealt to g_split partial sums
-     * (group g -> g mod g_split), each adds (d dy) * (its groups' integer sum) per super-block, the last one with the mins
-     * term, (d dy) isum_s - (dmin dy) msum; result ((P0 + P1) + P2) + P3.
-     * order 1 (the backend's mat-vec kernels, fq_units.h): the row is cut into UNITS of 2 or 4 blocks (below), unit u goes
-     * to lane u mod 64 as one f32 term (d dy) isum_u - (dmin dy) msum_u, lanes add their units in ascending order and are
-     * combined by the xor butterfly 1, 2, 4, .., 32. */
-    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float lane[64] = {0};
-    float lanes8[8] = {0};
-    int   eight = 0;
-    const int split = (g_sum_order == 2 && n > 32) ? g_split : 0;
-    const int wave  = (g_sum_order == 1 && n > 32);
-    int64_t unit = 0;
-    for (int64_t i = 0; i < n / 256; ++i, w += orc_type_size(wtype), a += 292) {
-        const float  dy = rd_f32(a);
-        const int8_t * q8 = (const int8_t *)(a + 4);
-        int sc16[16], mn16[16] = {0}, i16[16] = {0}, bs16[16];
-        int qv[256];                         /* the super-block's integer weights (the reference's aux8[]) */
-        int has_min = 0;
-        float dd = 0.0f, dmn = 0.0f;
-        for (int b = 0; b < 16; ++b) bs16[b] = rd_i16(a + 260 + 2 * b);
-        switch (wtype) {
-            case ORC_Q2_K: {                                                         /* k_quants.c:1267-1306 */
-                for (int b = 0; b < 16; ++b) { sc16[b] = w[b] & 15; mn16[b] = w[b] >> 4; }
-                for (int e = 0; e < 256; ++e)
-                    qv[e] = (w[16 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
-                dd = dy * rd_f16(w + 80); dmn = dy * rd_f16(w + 82); has_min = 1; } break;
-            case ORC_Q3_K: {                                                         /* k_quants.c:1684-1746 */
-                int sc[16]; q3_scales(w + 96, sc);
-                for (int b = 0; b < 16; ++b) sc16[b] = sc[b] - 32;
-                for (int e = 0; e < 256; ++e) {
-                    const int lo = (w[32 + (e / 128) * 32 + e % 32] >> (2 * ((e % 128) / 32))) & 3;
-                    const int hb = (w[e % 32] >> (e / 32)) & 1;
-                    qv[e] = lo - (hb ? 0 : 4);
-                }
-                dd = rd_f16(w + 108) * dy; } break;
-            case ORC_Q4_K: case ORC_Q5_K: {                                          /* k_quants.c:1999-2055, 2340-2400 */
-                const int qs_off = (wtype == ORC_Q4_K) ? 16 : 48;
-                for (int b = 0; b < 16; ++b) k4_scale_min(w + 4, b / 2, &sc16[b], &mn16[b]);
-                for (int e = 0; e < 256; ++e) {
-                    const int c = e / 64, hi = (e % 64) / 32;
-                    const int byte = w[qs_off + 32 * c + e % 32];
-                    int q = hi ? (byte >> 4) : (byte & 15);
-                    if (wtype == ORC_Q5_K) q += (((w[16 + e % 32] >> (e / 32)) & 1) ? 16 : 0);
-                    qv[e] = q;
-                }
-                dd = rd_f16(w) * dy; dmn = rd_f16(w + 2) * dy; has_min = 1; } break;
-            case ORC_Q6_K: {                                                         /* k_quants.c:2748-2789 */
-                const int8_t * sc = (const int8_t *)(w + 192);
-                for (int b = 0; b < 16; ++b) sc16[b] = sc[b];
-                for (int e = 0; e < 256; ++e) {
-                    const int h = e / 128, t = (e % 128) / 32, l = e % 32;
-                    const int byte = w[64 * h + 32 * (t & 1) + l];
-                    const int lo = (t < 2) ? (byte & 15) : (byte >> 4);
-                    const int hi = (w[128 + 32 * h + l] >> (2 * t)) & 3;
-                    qv[e] = (int)(int8_t)(lo | (hi << 4)) - 32;
-                }
-                dd = rd_f16(w + 208) * dy; } break;
-            default: abort();
-        }
-        for (int e = 0; e < 256; ++e) i16[e / 16] += qv[e] * q8[e];
-        if (wave) {
-            /* units (fq_units.h): Q2_K / Q3_K: 4 per super-block, unit (hf, g) = blocks 8 hf + 2 j + g, j = 0..3;
-             * Q4_K / Q5_K: 8, unit (c, g) = blocks 4 c + g and 4 c + g + 2; Q6_K: 8, unit (h, t, g) = blocks 8 h + 2 t + g, + 4 */
-            const int four = (wtype == ORC_Q2_K || wtype == ORC_Q3_K);
-            for (int uu = 0; uu < (four ? 4 : 8); ++uu, ++unit) {
-                int blk[4], nb;
-                if (four) { nb = 4; for (int j = 0; j < 4; ++j) blk[j] = 8 * (uu >> 1) + 2 * j + (uu & 1); }
-                else if (wtype == ORC_Q6_K) { nb = 2; blk[0] = 8 * (uu >> 2) + 2 * ((uu >> 1) & 1) + (uu & 1); blk[1] = blk[0] + 4; }
-                else { nb = 2; blk[0] = 4 * (uu >> 1) + (uu & 1); blk[1] = blk[0] + 2; }
-                int is = 0, ms = 0;
-                for (int j = 0; j < nb; ++j) { is += sc16[blk[j]] * i16[blk[j]]; ms += mn16[blk[j]] * bs16[blk[j]]; }
-                const float v = has_min ? dd * (float) is - dmn * (float) ms : dd * (float) is;
-                lane[unit & 63] += v;
-            }
-            continue;
-        }
-        int msum = 0;
-        for (int b = 0; b < 16; ++b) msum += mn16[b] * bs16[b];
-        if (split) {
-            for (int sp = 0; sp < split; ++sp) {
-                int is = 0;
-                for (int g = sp; g < 8; g += split) is += sc16[2 * g] * i16[2 * g] + sc16[2 * g + 1] * i16[2 * g + 1];
-                const float A = dd * (float) is;
-                part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
-            }
-        } else if (wtype == ORC_Q2_K) {                                       /* k_quants.c:1303 */
-            int is = 0;
-            for (int b = 0; b < 16; ++b) is += sc16[b] * i16[b];
-            sumf += dd * (float) is - dmn * (float) msum;
-        } else {
-            /* the reference's scalar branches of Q3_K .. Q6_K (k_quants.c:1733-1743, 2044-2053, 2389-2398, 2780-2787):
-             * element e of the super-block feeds integer lane e mod 8, aux32[l] += scale * q8 * a; per super-block
-             * sums[l] += d * aux32[l] for the eight float lanes and (Q4_K / Q5_K) sumf -= dmin * sumi */
-            int aux32[8] = {0};
-            for (int e = 0; e < 256; ++e) aux32[e & 7] += sc16[e / 16] * (qv[e] * q8[e]);
-            for (int l = 0; l < 8; ++l) lanes8[l] += dd * (float) aux32[l];
-            if (has_min) sumf -= dmn * (float) msum;
-            eight = 1;
-        }
+    /* k-quants against Q8_K: decode the row's super-blocks once (kq_decode_sb), then kq_dot_row */
+    {
+        const int64_t nsb = n / 256;
+        kq_sb * row = (kq_sb *) malloc(sizeof(kq_sb) * (size_t)(nsb ? nsb : 1));
+        for (int64_t i = 0; i < nsb; ++i) kq_decode_sb(wtype, w + (size_t) i * orc_type_size(wtype), &row[i]);
+        sumf = kq_dot_row(wtype, nsb, row, a);
+        free(row);
+        return sumf;
     }
-    if (eight) for (int l = 0; l < 8; ++l) sumf += lanes8[l];
-    if (wave) {
-        for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
-        return lane[0];
-    }
-    return split ? ((part[0] + part[1]) + part[2]) + part[3] : sumf;
 }
 
 /* ------------------------------------------------------------------ quantized mat-mul (ggml.c:11318-11529) */
@@ -570,6 +600,16 @@ static void * mm_worker(void * arg) {
     const size_t wrow = orc_row_bytes(j->wtype, j->K);
     const int64_t dr = (j->M + j->nth - 1) / j->nth;               /* rows of W split evenly over threads */
     const int64_t r0 = dr * j->ith, r1 = (r0 + dr < j->M) ? r0 + dr : j->M;
+    if (orc_blck_size(j->wtype) == 256) {                          /* k-quants: decode a weight row once for all N columns */
+        const int64_t nsb = j->K / 256;
+        kq_sb * row = (kq_sb *) malloc(sizeof(kq_sb) * (size_t)(nsb ? nsb : 1));
+        for (int64_t r = r0; r < r1; ++r) {
+            for (int64_t i = 0; i < nsb; ++i) kq_decode_sb(j->wtype, j->w + (size_t) r * wrow + (size_t) i * orc_type_size(j->wtype), &row[i]);
+            for (int64_t n = 0; n < j->N; ++n) j->dst[n * j->M + r] = kq_dot_row(j->wtype, nsb, row, j->act + (size_t) n * j->act_row);
+        }
+        free(row);
+        return NULL;
+    }
     for (int64_t n = 0; n < j->N; ++n) {
         const uint8_t * col = j->act + (size_t) n * j->act_row;
         for (int64_t r = r0; r < r1; ++r) {

@@ -23,35 +23,46 @@ def relrms(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / (np.sqrt((b.astype(np.float64) ** 2).mean()) + 1e-30))
 
 
-CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
-         ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)]
+CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0, "tiny_models"), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1, "tiny_models"),
+         ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K, "tiny_models"), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0, "tiny_models"),
+         ("gqa_q4_1", synth.HP_TINY_GQA, ob.Q4_1, "tiny_models_all"), ("gqa_q5_0", synth.HP_TINY_GQA, ob.Q5_0, "tiny_models_all"),
+         ("gqa_q2_K", synth.HP_TINY_GQA, ob.Q2_K, "tiny_models_all"), ("gqa_q3_K", synth.HP_TINY_GQA, ob.Q3_K, "tiny_models_all"),
+         ("gqa_q5_K", synth.HP_TINY_GQA, ob.Q5_K, "tiny_models_all"), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K, "tiny_models_all")]
 
-# Whole-model parity. The decoder stack is chaotic at the 1e-7 level: re-associating the f32 sum over blocks inside
-# the reference algorithm (which every vectorised build of the reference does) flips an 8-bit activation rounding now
-# and then, and one flip moves the logits by ~1e-3..1e-2 (measured: the reference's own AVX2 and scalar builds differ
-# by 2.8e-2 on gqa_q5_1 -- tests/golden/tiny_models.npz holds both). So two checks:
-#   (1) against the oracle run with the backend's association of that sum (orc_set_sum_order(2): 64 strided partial
-#       sums + xor butterfly for N <= 4 columns = the mat-vec kernels; for N > 4 = the MFMA GEMM: block order, or four
-#       interleaved partial sums on matrices with few tiles): TIGHT --
-#       this pins every kernel of the stack;
-#   (2) against the logits captured from the reference itself: within 1e-3, or within 2x the reference's own
-#       build-to-build spread when that is larger.
-# k-quants: (1) holds as well -- the oracle restates the prefill GEMM's integer sums per super-block in the backend's split
-# association and the mat-vec kernels' unit-per-lane association (orc_set_sum_order(2)). For the k-quant prefill (2) is
-# held to FLIP: both the reference's builds and this GEMM compute exact integer sums per super-block, but the reference then
-# adds eight f32 lane sums (k_quants.c:1575-1583) where the GEMM multiplies the whole integer sum once -- a 1e-7 difference
-# that flips an activation rounding in this stack (measured 1.1e-2 on gqa_q4_K, the scale of the reference's own
-# AVX2-vs-scalar spread on gqa_q5_1).
-TIGHT = 1e-4
-FLIP = 3e-2
+# Whole-model parity, all ten weight formats, against logits captured from the REAL reference (tests/golden/tiny_models.npz,
+# tiny_models_all.npz: the reference's graph executor, scalar and AVX2 builds).
+#   (1) REFERENCE ORDER (ggml_hip_reference_order(1)): hidden states, prefill logits and decode logits are BIT-IDENTICAL with
+#       the reference's scalar build -- every mat-mul walks its rows in the reference's own block / lane order
+#       (csrc/fq_ref_dot.h), the attention accumulates in f64 like the portable ggml_vec_dot_f32. This is the north-star's
+#       "logits within 1e-3 of the CPU reference", met with 0.
+#   (2) DEFAULT ORDER (what the benchmarks run): bit-identical with the oracle run with the backend's association of the
+#       same terms (orc_set_sum_order(2): unit-per-lane partial sums + xor butterfly for the mat-vec kernels, interleaved
+#       K-split partial sums for the MFMA GEMM, f32 fused multiply-add chains in the attention) -- this pins every fast kernel.
+#   (3) The distance between (1) and (2) is a property of the MODEL, not of a kernel: the decoder stack is chaotic at the
+#       1e-7 level -- re-associating an f32 block sum (which every vectorised build of the reference does as well) now and
+#       then flips one 8-bit activation rounding, and one flip moves logits by 1e-3..1e-2. The reference's own AVX2 and
+#       scalar builds differ by up to 2.8e-2 on these fixtures (both are in the golden files). For the legacy formats the
+#       default order is asserted within max(1e-3, 2 x that spread) of the reference; it is printed for all.
 
 
-@pytest.mark.parametrize("name,hp,t", CASES)
-def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t):
-    gt = golden["tiny_models"]
+@pytest.mark.parametrize("name,hp,t,gfile", CASES)
+def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t, gfile):
+    gt = golden[gfile]
     w = synth.make_model(oracle, hp, t, seed=1234)
     toks = gt[f"{name}_tokens"]
+    ref_h, ref_l, ref_d = gt[f"{name}_prefill_hidden_scalar"], gt[f"{name}_prefill_logits_scalar"], gt[f"{name}_decode_logits_scalar"]
     m = g.FalconModel(w, n_ctx=64, n_batch=8)
+    # (1) reference order == the real reference, bit for bit
+    g.load().ggml_hip_reference_order(1)
+    try:
+        lr, hr = m.eval(toks[:8], 0, logits_all=True, want_hidden=True)
+        dr = np.concatenate([m.eval(toks[i:i + 1], i, logits_all=True) for i in range(8, 12)])
+    finally:
+        g.load().ggml_hip_reference_order(0)
+    assert np.array_equal(hr, ref_h), "prefill hidden states differ from the reference's"
+    assert np.array_equal(lr, ref_l), "prefill logits differ from the reference's"
+    assert np.array_equal(dr, ref_d), "decode logits differ from the reference's"
+    # (2) default order == the oracle with the backend's association
     lg, hid = m.eval(toks[:8], 0, logits_all=True, want_hidden=True)
     dec = np.concatenate([m.eval(toks[i:i + 1], i, logits_all=True) for i in range(8, 12)])
     m.free()
@@ -62,37 +73,13 @@ def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t):
         do = np.concatenate([mo.eval(toks[i:i + 1], i, 2) for i in range(8, 12)])
     finally:
         oracle.lib.orc_set_sum_order(0)
-    e = (relrms(hid, ho), relrms(lg, lo), relrms(dec, do))
-    print(name, "vs backend-association oracle: hidden %.2e prefill %.2e decode %.2e" % e)
-    assert max(e) <= TIGHT
-    ref_l, ref_d = gt[f"{name}_prefill_logits_scalar"], gt[f"{name}_decode_logits_scalar"]
+    assert np.array_equal(hid, ho) and np.array_equal(lg, lo) and np.array_equal(dec, do)
+    # (3) the association spread, next to the reference's own
     spread = max(relrms(gt[f"{name}_prefill_logits_avx"], ref_l), relrms(gt[f"{name}_decode_logits_avx"], ref_d))
     e_l, e_d = relrms(lg, ref_l), relrms(dec, ref_d)
-    print(name, "vs reference logits: prefill %.2e decode %.2e (reference AVX2-vs-scalar spread %.2e)" % (e_l, e_d, spread))
-    tol = max(LOGIT_TOL, 2 * spread)
-    assert e_d <= tol and e_l <= (tol if t in ob.LEGACY else max(tol, FLIP))
-    assert np.array_equal(lg.argmax(1), ref_l.argmax(1))
-
-
-@pytest.mark.parametrize("t", [ob.Q4_1, ob.Q5_0, ob.Q2_K, ob.Q3_K, ob.Q5_K, ob.Q6_K])
-def test_tiny_falcon_other_formats_vs_oracle(oracle, t):
-    hp = synth.HP_TINY_GQA
-    w = synth.make_model(oracle, hp, t, seed=77)
-    toks = synth.tokens(10, hp["n_vocab"], seed=5)
-    m = g.FalconModel(w, n_ctx=32, n_batch=6)
-    oracle.lib.orc_set_sum_order(2)
-    try:
-        mo = oracle.model(w, 32)
-        lo, ho = mo.eval(toks[:6], 0, 4, want_hidden=True)
-        do = [mo.eval(toks[i:i + 1], i, 4) for i in range(6, 10)]
-    finally:
-        oracle.lib.orc_set_sum_order(0)
-    lg, hid = m.eval(toks[:6], 0, want_hidden=True)
-    d = [m.eval(toks[i:i + 1], i) for i in range(6, 10)]
-    m.free()
-    e = (relrms(hid[1], ho[1]), relrms(lg, lo), relrms(np.concatenate(d), np.concatenate(do)))
-    print(ob.TYPE_NAME[t], "first block %.2e prefill logits %.2e decode logits %.2e" % e)
-    assert max(e) <= TIGHT                                # every kernel of the stack is pinned by the oracle's backend association
+    print(name, "default order vs reference logits: prefill %.2e decode %.2e (reference AVX2-vs-scalar spread %.2e)" % (e_l, e_d, spread))
+    if t in ob.LEGACY:
+        assert max(e_l, e_d) <= max(LOGIT_TOL, 2 * spread)
 
 
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
@@ -175,48 +162,63 @@ def test_prefill_equals_incremental_and_graph(oracle):
     m.free()
 
 
+def _both_orders(oracle, w, toks, n_pre, n_ctx):
+    """GPU vs oracle for a prefill of n_pre tokens + one decode step: default order against the oracle's backend
+    association, reference order against the oracle's order 0 (= the reference's scalar build, test_oracle_vs_golden.py).
+    Returns the default-vs-reference-order distance of the prefill logits."""
+    m = g.FalconModel(w, n_ctx=n_ctx, n_batch=n_pre)
+    out = {}
+    for order in (0, 2):
+        g.load().ggml_hip_reference_order(1 if order == 0 else 0)
+        oracle.lib.orc_set_sum_order(order)
+        try:
+            mo = oracle.model(w, n_ctx)
+            lo, ho = mo.eval(toks[:n_pre], 0, 8, want_hidden=True)
+            do = mo.eval(toks[n_pre:n_pre + 1], n_pre, 8)
+            lg, hid = m.eval(toks[:n_pre], 0, want_hidden=True)
+            d = m.eval(toks[n_pre:n_pre + 1], n_pre)
+        finally:
+            oracle.lib.orc_set_sum_order(0)
+            g.load().ggml_hip_reference_order(0)
+        assert np.array_equal(hid, ho), "hidden states, order %d" % order
+        assert np.array_equal(lg, lo), "prefill logits, order %d" % order
+        assert np.array_equal(d, do), "decode logits, order %d" % order
+        out[order] = lg
+    m.free()
+    return relrms(out[2], out[0])
+
+
 def test_falcon7b_shaped_layer_vs_oracle(oracle):
-    """one block with the real 7B dimensions (n_embd 4544, 71 heads MQA, n_ff 18176), small vocab"""
+    """one block with the real 7B dimensions (n_embd 4544, 71 heads MQA, n_ff 18176), small vocab: bit-exact in both orders"""
     hp = dict(n_vocab=1024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=1, n_ff=18176, two_norms=False)
     w = synth.make_model(oracle, hp, ob.Q4_0, seed=9)
-    toks = synth.tokens(4, 1024, seed=2)
-    m = g.FalconModel(w, n_ctx=16, n_batch=3)
-    oracle.lib.orc_set_sum_order(2)
-    try:
-        mo = oracle.model(w, 16)
-        lo, ho = mo.eval(toks[:3], 0, 8, want_hidden=True)
-        do = mo.eval(toks[3:4], 3, 8)
-    finally:
-        oracle.lib.orc_set_sum_order(0)
-    lg, hid = m.eval(toks[:3], 0, want_hidden=True)
-    d = m.eval(toks[3:4], 3)
-    m.free()
-    print("7B-shaped block: hidden %.2e logits %.2e decode %.2e" % (relrms(hid, ho), relrms(lg, lo), relrms(d, do)))
-    assert relrms(hid, ho) <= TIGHT and relrms(lg, lo) <= LOGIT_TOL and relrms(d, do) <= LOGIT_TOL
+    print("7B-shaped block: association spread %.2e" % _both_orders(oracle, w, synth.tokens(4, 1024, seed=2), 3, 16))
 
 
 def test_falcon40b_shaped_layer_vs_oracle(oracle):
-    """one block with the 40B geometry (n_embd 8192, 128 heads, 8 kv heads, two norms), Q4_K weights"""
+    """one block with the 40B geometry (n_embd 8192, 128 heads, 8 kv heads, two norms), Q4_K weights: bit-exact in both orders"""
     hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
     w = synth.make_model(oracle, hp, ob.Q4_K, seed=10)
-    toks = synth.tokens(3, 512, seed=4)
-    m = g.FalconModel(w, n_ctx=16, n_batch=2)
-    mo = oracle.model(w, 16)
-    lg = m.eval(toks[:2], 0)
-    lo = mo.eval(toks[:2], 0, 8)
-    d, do = m.eval(toks[2:3], 2), mo.eval(toks[2:3], 2, 8)
-    m.free()
-    print("40B-shaped block: logits %.2e decode %.2e" % (relrms(lg, lo), relrms(d, do)))
-    assert relrms(lg, lo) <= 5e-2 and relrms(d, do) <= 5e-2       # one k-quant block + lm_head, see the note above
+    print("40B-shaped block: association spread %.2e" % _both_orders(oracle, w, synth.tokens(3, 512, seed=4), 2, 16))
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q4_K])
+def test_falcon180b_shaped_layer_vs_oracle(oracle, t):
+    """one block with the 180B geometry (libfalcon.cpp:1578-1582: n_embd 14848, 232 heads, 8 kv heads, n_ff 59392 -- the
+    K = 59392 down projection; at this width k_gemv_ln's LayerNorm leaves its register path): bit-exact in both orders"""
+    hp = dict(n_vocab=512, n_embd=14848, n_head=232, n_head_kv=8, n_layer=1, n_ff=59392, two_norms=True)
+    w = synth.make_model_fast(hp, t, seed=12)
+    print("180B-shaped block %s: association spread %.2e" % (ob.TYPE_NAME[t], _both_orders(oracle, w, synth.tokens(7, 512, seed=4), 6, 16)))
 
 
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
-                                       ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)])
+                                       ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K), ("mqa_q8_0", synth.HP_TINY_MQA, ob.Q8_0)])
 def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     """falcon_hip_model_load_ggcc on a GGCC v10 file (the reference's model format; the file is byte-identical to the one
     the real libfalcon.cpp loaded when tests/golden/ggcc_models.npz was captured): same logits as the in-memory upload of
-    the same weights, bit for bit; for the legacy formats the prefill logits in reference order (ggml_hip_reference_order) are the
-    REFERENCE's own logits bit for bit; a pipeline stage loads only its own blocks"""
+    the same weights, bit for bit; in reference order (ggml_hip_reference_order) prefill AND decode logits are the logits of the
+    REFERENCE's own libfalcon.cpp (its loader, graph builder and falcon_eval on the same file), bit for bit, k-quants included;
+    a pipeline stage loads only its own blocks"""
     import ggcc_writer
     gg = golden["ggcc_models"]
     w = synth.make_model(oracle, hp, t, seed=4321)
@@ -232,17 +234,17 @@ def test_ggcc_file_loader(oracle, golden, tmp_path, name, hp, t):
     db = np.concatenate([b.eval(toks[i:i + 1], i) for i in range(9, 12)])
     assert np.array_equal(da, db)
     ref_pre, ref_dec = gg[f"{name}_prefill_logits"], gg[f"{name}_decode_logits"]
-    if t in ob.LEGACY:
-        g.load().ggml_hip_reference_order(1)                         # GEMM in block order, attention dots in f64
-        try:
-            ls = a.eval(toks[:9], 0)
-        finally:
-            g.load().ggml_hip_reference_order(0)
-        assert np.array_equal(ls, ref_pre)
-        assert relrms(la, ref_pre) <= max(1e-3, 2 * 2.8e-2)          # default: partial sums per row (ggml_hip_gemm_sequential)
-        assert relrms(da, ref_dec) <= max(1e-3, 2 * 2.8e-2)          # decode: wave-order association, see DESIGN.md section 2
-    else:
-        assert relrms(la, ref_pre) <= 5e-2 and relrms(da, ref_dec) <= 5e-2
+    g.load().ggml_hip_reference_order(1)                             # the reference's block / lane order, attention dots in f64
+    try:
+        ls = a.eval(toks[:9], 0)
+        ds = np.concatenate([a.eval(toks[i:i + 1], i) for i in range(9, 12)])
+    finally:
+        g.load().ggml_hip_reference_order(0)
+    assert np.array_equal(ls, ref_pre)
+    assert np.array_equal(ds, ref_dec)
+    print(name, "default order vs libfalcon.cpp logits: prefill %.2e decode %.2e" % (relrms(la, ref_pre), relrms(da, ref_dec)))
+    if t in ob.LEGACY:                                               # default order: DESIGN.md section 2, the reference's own spread
+        assert relrms(la, ref_pre) <= max(1e-3, 2 * 2.8e-2) and relrms(da, ref_dec) <= max(1e-3, 2 * 2.8e-2)
     assert a.weight_bytes() == b.weight_bytes()
     a.free(); b.free()
     # second pipeline stage: block 1 only (+ ln_f, lm_head)

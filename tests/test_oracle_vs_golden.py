@@ -134,3 +134,22 @@ def test_tiny_falcon_end_to_end(oracle, golden, name, hp, t):
     assert np.array_equal(hid, g[f"{name}_prefill_hidden_scalar"])
     assert np.array_equal(lg, g[f"{name}_prefill_logits_scalar"])
     assert np.array_equal(dec, g[f"{name}_decode_logits_scalar"])
+
+
+CASES_ALL = [("gqa_q4_1", ob.Q4_1), ("gqa_q5_0", ob.Q5_0), ("gqa_q2_K", ob.Q2_K), ("gqa_q3_K", ob.Q3_K), ("gqa_q5_K", ob.Q5_K), ("gqa_q6_K", ob.Q6_K)]
+
+
+@pytest.mark.parametrize("name,t", CASES_ALL)
+def test_tiny_falcon_remaining_formats_end_to_end(oracle, golden, name, t):
+    """the other six weight formats (tests/golden/tiny_models_all.npz, same recipe): bit-identical with the reference's
+    scalar build -- so all ten formats are pinned at model level against logits of the real reference"""
+    g = golden["tiny_models_all"]
+    w = synth.make_model(oracle, synth.HP_TINY_GQA, t, seed=1234)
+    assert np.array_equal(_digest(w), g[f"{name}_digest"]), "synthetic weights drifted from the fixture's"
+    toks = g[f"{name}_tokens"]
+    m = oracle.model(w, 64)
+    lg, hid = m.eval(toks[:8], 0, 2, ob.ROUND_REFERENCE, want_hidden=True)
+    dec = np.concatenate([m.eval(toks[i:i + 1], i, 2, ob.ROUND_REFERENCE) for i in range(8, 12)])
+    assert np.array_equal(hid, g[f"{name}_prefill_hidden_scalar"])
+    assert np.array_equal(lg, g[f"{name}_prefill_logits_scalar"])
+    assert np.array_equal(dec, g[f"{name}_decode_logits_scalar"])
