@@ -379,12 +379,13 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
 /* order 2 = what the backend's prefill GEMM does (ggllm.cpp_amd/csrc/kernels_gemm.hip): g_split interleaved partial sums,
  * P_s = blocks s, s + g_split, ... left to right, result ((P0 + P1) + P2) + P3; 4 of them on matrices with fewer than
  * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
- * columns, order 2 for GEMMs. mode 3 / 4: order 2 with 4 / 2 partial sums for every mat-mul. */
+ * columns, order 2 for GEMMs. mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
+ * legacy formats' reference order; for the k-quants one d * isum - dmin * msum term per super-block, left to right). */
 static int g_split = 4;
 int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 = "as the backend" for the attention too */
 void orc_set_sum_order(int mode) {
-    g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4) ? 2 : 0);
-    g_split = (mode == 4) ? 2 : 4;
+    g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4 || mode == 5) ? 2 : 0);
+    g_split = (mode == 4) ? 2 : ((mode == 5) ? 1 : 4);
 }
 
 /* ------------------------------------------------------------------ k-quant dots against Q8_K

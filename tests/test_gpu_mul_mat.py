@@ -97,12 +97,12 @@ GEMM_TYPES = [ob.Q4_0, ob.Q4_1, ob.Q5_0, ob.Q5_1, ob.Q8_0, ob.Q4_K, ob.Q5_K]
 @pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
 @pytest.mark.parametrize("K,M,N", [(512, 37, 9), (4544, 200, 33), (8192, 129, 128), (1024, 300, 257), (18176, 70, 40)])
 def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
-    """N > 4 columns: int8 MFMA GEMM (legacy formats + Q4_K/Q5_K) or column-chunked mat-vec (Q2_K/Q3_K/Q6_K).
-    Legacy formats through the GEMM use the reference's scalar per-block expression; with ggml_hip_gemm_sequential(1) the
-    blocks are added left to right: BIT-EXACT against the oracle (= the reference's scalar vec_dot). The default order on
-    every shape (4 or 2 interleaved partial sums) is bit-exact against the oracle run with that association. The k-quants
-    accumulate scale * (group dot) in int32 per super-block (exact) and take one f32 step per super-block, like the
-    reference's own k-quant dots: bit-exact against the oracle in both orders as well."""
+    """N > 4 columns through the int8 MFMA GEMM, three orders, each bit-exact against the oracle's restatement of it:
+      * default (4 or 2 interleaved K-split partial sums, picked per shape)      == orc_set_sum_order(2)
+      * ggml_hip_gemm_sequential(1) (one partial sum: the legacy formats' blocks left to right = the reference's scalar
+        vec_dot; k-quants one d * isum - dmin * msum term per super-block)        == orc_set_sum_order(5)
+      * ggml_hip_reference_order(1) (kernels_ref.hip, the reference's scalar branches for all ten formats: Q3_K .. Q6_K keep
+        eight float lanes)                                                        == order 0 == the reference's scalar build"""
     if K % ob.BLCK[t]:
         pytest.skip("k-quants need K % 256 == 0")
     rng = np.random.default_rng(K + M + N + t)
@@ -116,14 +116,22 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
         seq = dw.mul_mat(x)
     finally:
         g.load().ggml_hip_gemm_sequential(0)
+    g.load().ggml_hip_reference_order(1)
+    try:
+        ref = dw.mul_mat(x)
+    finally:
+        g.load().ggml_hip_reference_order(0)
     oracle.lib.orc_set_sum_order(2)          # the backend's choice for this shape: 4 or 2 interleaved partial sums
     try:
         exp_split = oracle.mul_mat(t, w, K, M, x, 8)
+        oracle.lib.orc_set_sum_order(5)
+        exp_seq = oracle.mul_mat(t, w, K, M, x, 8)
     finally:
         oracle.lib.orc_set_sum_order(0)
-    # sequential order == the reference's scalar loop over the blocks (legacy formats), == the oracle's per-super-block
-    # expression d * isum - dmin * msum added left to right (k-quants: integer sums exact, as in k_quants.c), bit for bit
-    assert np.array_equal(seq, exp)
+    assert np.array_equal(ref, exp)
+    assert np.array_equal(seq, exp_seq)
+    if t in ob.LEGACY or t == ob.Q2_K:
+        assert np.array_equal(seq, exp)      # there the single left-to-right sum IS the reference's order
     assert np.array_equal(got, exp_split)
     assert relrms(got, exp) <= TOL and relrms(seq, exp) <= TOL
     # and the same columns through the mat-vec kernel agree within the association tolerance
