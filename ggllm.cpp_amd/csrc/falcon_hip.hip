@@ -84,6 +84,11 @@ struct falcon_hip_context {
     int  graph_base = -1;                      // n_past the captured graph was built for
     int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
     unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
+    // the persistent decode engine (kernels_engine.hip): one launch per token. Prepared lazily on the first N = 1 step.
+    bool engine = false;                       // FALCON_HIP_ENGINE=1 / set_fused(4)
+    int  eng_state = 0;                        // 0 not prepared, 1 ready, -1 not supported for this model
+    fq_engine_args eng{};
+    int  eng_nslot = 0; size_t eng_lds = 0;
 };
 
 // k_attn_out hands the attention output from workgroup to workgroup with a BOUNDED spin; a time-out sets sync_words[1] and
@@ -264,6 +269,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
+    if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
 }
 
@@ -294,13 +300,16 @@ extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1
     HIP_CHECK(hipMemcpy(w, c->sync_words, sizeof w, hipMemcpyDeviceToHost));
     return (int) w[1];
 }
-extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one
+extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one, 4 the persistent engine (one per token)
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
     if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
-    c->two_phase = mode >= 3;
+    c->two_phase = mode == 3;
+    c->engine = mode == 4;
 }
+// 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)
+extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c);
 
 static bool stage_uniform(const falcon_hip_model * m) {
     for (const layer_weights & L : m->layers) if (L.qkv.type != L.up.type || L.down.type != L.wo.type) return false;
@@ -316,8 +325,73 @@ static bool stage_fused(const falcon_hip_context * c) {
 // everything a captured graph bakes in besides its pointers: a change invalidates decode_graph / step_graph
 static int graph_signature(const falcon_hip_context * c) {
     return (stage_fused(c) ? 1 : 0) | (fq_reference_order() ? 2 : 0) | (fq_attn_f64() ? 4 : 0) | (c->merged_attn_out ? 8 : 0) |
-           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0);
+           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0) | (c->engine ? 64 : 0);
 }
+
+// ---- the persistent engine: per-context tables (block pointers, work split, hand-off buffers), built on first use
+static bool engine_prepare(falcon_hip_context * c) {
+    if (c->eng_state) return c->eng_state > 0;
+    c->eng_state = -1;
+    falcon_hip_model * m = c->m;
+    const falcon_hip_hparams & hp = m->hp;
+    hip_context & hc = fq_ctx();
+    if (m->layers.empty()) return false;
+    const int type = m->layers[0].qkv.type;
+    for (const layer_weights & L : m->layers) if (L.qkv.type != type || L.up.type != type || L.down.type != type || L.wo.type != type) return false;
+    if (m->last_stage() && m->lm_head.type != type) return false;
+    if (type != FQ_Q4_0 && type != FQ_Q4_1 && type != FQ_Q5_0 && type != FQ_Q5_1 && type != FQ_Q8_0) return false;
+    const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, HKV = hp.n_head_kv, QKVR = (H + 2 * HKV) * 64, V = hp.n_vocab;
+    if (E > 4 * 3 * 64 * 11) return false;                                  // the LayerNorm row must fit the consumers' registers
+    int hpw = 2;
+    if (const char * e = getenv("FALCON_HIP_ENGINE_HPW")) hpw = atoi(e) >= 3 ? 3 : (atoi(e) <= 1 ? 1 : 2);
+    const int n_attn = (H + hpw - 1) / hpw, n_stream = hc.n_cu - n_attn;
+    if (n_stream < 8) return false;
+    std::vector<fq_engine_sched> sched;
+    int mg = 0, mr = 0;
+    if (!fq_engine_plan(type, E, FF, QKVR, V, m->last_stage(), n_stream, sched, &mg, &mr)) return false;
+    const size_t attn_group = (768 + 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) c->n_ctx * 4 + 15) & ~(size_t) 15) + 15) & ~(size_t) 15;
+    int nslot = 0; size_t lds = 0;
+    for (int ns : { 8, 6, 4 }) {
+        const size_t need = fq_engine_lds_bytes(type, ns, E, FF, (int) m->layers.size());
+        if (need <= 160 * 1024) { nslot = ns; lds = need; break; }
+    }
+    if (!nslot) return false;
+    if (attn_group * hpw > lds) lds = attn_group * hpw;
+    if (lds > 160 * 1024) return false;
+    // device tables
+    std::vector<fq_engine_layer> lay(m->layers.size());
+    for (size_t i = 0; i < m->layers.size(); ++i) {
+        const layer_weights & L = m->layers[i];
+        lay[i] = { L.qkv.plane[0], L.up.plane[0], L.down.plane[0], L.wo.plane[0], L.ln_w, L.ln_b, L.ln2_w, L.ln2_b,
+                   c->k_cache + i * (size_t) c->n_ctx * HKV * 64, c->v_cache + i * (size_t) c->n_ctx * HKV * 64 };
+    }
+    fq_engine_layer * lay_dev = (fq_engine_layer *) dev_alloc(c->allocs, lay.size() * sizeof(fq_engine_layer));
+    HIP_CHECK(hipMemcpy(lay_dev, lay.data(), lay.size() * sizeof(fq_engine_layer), hipMemcpyHostToDevice));
+    fq_engine_sched * sched_dev = (fq_engine_sched *) dev_alloc(c->allocs, sched.size() * sizeof(fq_engine_sched));
+    HIP_CHECK(hipMemcpy(sched_dev, sched.data(), sched.size() * sizeof(fq_engine_sched), hipMemcpyHostToDevice));
+    auto gran = [&](size_t n) {
+        unsigned long long * p = (unsigned long long *) dev_alloc(c->allocs, n * 8 + 64);
+        HIP_CHECK(hipMemset(p, 0, n * 8 + 64));
+        return p;
+    };
+    fq_engine_args & a = c->eng;
+    a = fq_engine_args{};
+    a.type = type; a.n_layers = (int) m->layers.size(); a.layers = lay_dev; a.sched = sched_dev;
+    a.E = E; a.FF = FF; a.H = H; a.HKV = HKV; a.V = V; a.two_norms = hp.two_norms ? 1 : 0;
+    a.rsE = (unsigned) m->layers[0].qkv.row_stride; a.rsF = (unsigned) m->layers[0].down.row_stride;
+    a.n_attn = n_attn; a.hpw = hpw; a.n_stream = n_stream; a.attn_lds_group = (int) attn_group;
+    if (m->last_stage()) { a.lm_head = m->lm_head.plane[0]; a.lnf_w = m->out_norm_w; a.lnf_b = m->out_norm_b; a.logits = c->logits_dev; a.argmax_val = c->argmax_val; a.argmax_idx = c->argmax_idx; }
+    a.x = c->x;
+    a.xg = gran((size_t) E); a.qkvg = gran((size_t) QKVR); a.ffg = gran((size_t)(FF / 4 + FF / 16)); a.attg = gran((size_t)(E / 4 + E / 16));
+    unsigned one = 1u;
+    HIP_CHECK(hipMemcpy(c->sync_words + 2, &one, 4, hipMemcpyHostToDevice));
+    a.epoch_word = c->sync_words + 2; a.err = c->sync_words + 1;
+    a.n_past = c->n_past_dev; a.max_n_kv = c->n_ctx; a.rope_cs = c->rope_cs; a.exp_tab = hc.exp_table_attn; a.gelu_tab = hc.gelu_table;
+    c->eng_nslot = nslot; c->eng_lds = lds;
+    c->eng_state = 1;
+    return true;
+}
+extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c) { return c->engine && stage_fused(c) && engine_prepare(c) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
@@ -333,6 +407,23 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
 
     // the fused kernels are instantiated per weight format: a model that mixes formats inside a block (e.g. the reference's
     // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
+    if (N == 1 && stage_fused(c) && c->engine && !c->dual_stream && engine_prepare(c)) {
+        // ---- the persistent engine: every block of the stage (+ ln_f, lm_head) in ONE launch (kernels_engine.hip)
+        fq_engine_args a = c->eng;
+        a.hidden = nullptr;
+        HIP_CHECK(hipMemcpyAsync(c->ln, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));     // the engine reads the row from a buffer it never writes
+        a.x_in = c->ln;
+        if (c->keep_hidden) {
+            HIP_CHECK(hipMemcpyAsync(c->hidden_dev, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
+            a.hidden = c->hidden_dev;
+            c->hidden_tokens = 1;
+        }
+        const bool prof = fq_prof_active();
+        if (prof) fq_prof_open(st);
+        if (!fq_launch_decode_engine(a, c->eng_nslot, c->eng_lds, st)) { fprintf(stderr, "falcon-hip: the decode engine refused a configuration it had accepted\n"); exit(1); }
+        if (prof) fq_prof_close(st, (double) m->weight_bytes);
+        return;
+    }
     if (N == 1 && stage_fused(c)) {
         // ---- fused single-token path (kernels_decode.hip), bit-identical to the op list below. Per block, by mode:
         //   3 launches  k_gemv_ln | k_attn_decode | k_gemv_out

@@ -163,8 +163,8 @@ __device__ __forceinline__ void layer_norm_finish(const ln_row_regs<NLN> & r, co
 // Three stages, the CALLER puts a workgroup barrier between them (every wave must reach it). red: 32 doubles of LDS.
 template <int NLN>
 __device__ __forceinline__ void ln_regs_issue(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b,
-                                              int64_t n, int nt, ln_row_regs<NLN> & xr, ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br) {
-    const int tid = threadIdx.x;
+                                              int64_t n, int nt, ln_row_regs<NLN> & xr, ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br, int tid_ = -1) {
+    const int tid = tid_ < 0 ? (int) threadIdx.x : tid_;      // tid_: index among the nt threads that run the LayerNorm
     const int64_t nv = n >> 2;
 #pragma unroll
     for (int k = 0; k < NLN; ++k) { const int64_t i = (int64_t) k * nt + tid; xr.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
@@ -179,8 +179,8 @@ __device__ __forceinline__ void ln_regs_issue(const float * __restrict__ x, cons
 // (bounded; *err is set if it gives up). w and b are plain loads and can be requested before this.
 template <int NLN>
 __device__ __forceinline__ void ln_regs_issue_wb(const float * __restrict__ w, const float * __restrict__ b, int64_t n, int nt,
-                                                 ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br) {
-    const int tid = threadIdx.x;
+                                                 ln_row_regs<NLN> & wr, ln_row_regs<NLN> & br, int tid_ = -1) {
+    const int tid = tid_ < 0 ? (int) threadIdx.x : tid_;
     const int64_t nv = n >> 2;
 #pragma unroll
     for (int k = 0; k < NLN; ++k) {
@@ -211,8 +211,8 @@ __device__ __forceinline__ void ln_regs_sweep_x(const unsigned long long * gran,
 }
 
 template <int NLN>
-__device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64_t n, int nt, double * red, int tid_ = -1) {
+    const int tid = tid_ < 0 ? (int) threadIdx.x : tid_;
     const int64_t nv = n >> 2;
     double s = 0.0;
 #pragma unroll
@@ -224,8 +224,8 @@ __device__ __forceinline__ void ln_regs_stage1(const ln_row_regs<NLN> & r, int64
     if ((tid & 63) == 0) red[tid >> 6] = s;
 }
 template <int NLN>
-__device__ __forceinline__ void ln_regs_stage2(ln_row_regs<NLN> & r, int64_t n, int nt, double * red) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void ln_regs_stage2(ln_row_regs<NLN> & r, int64_t n, int nt, double * red, int tid_ = -1) {
+    const int tid = tid_ < 0 ? (int) threadIdx.x : tid_;
     const int64_t nv = n >> 2;
     const double s = waves_combine(red, nt >> 6, op_add());
     const float mean = (float)(s / (double) n);
@@ -243,8 +243,8 @@ __device__ __forceinline__ void ln_regs_stage2(ln_row_regs<NLN> & r, int64_t n, 
 }
 template <int ACT, int NLN>
 __device__ __forceinline__ void ln_regs_stage3(const ln_row_regs<NLN> & r, const ln_row_regs<NLN> & wr, const ln_row_regs<NLN> & br,
-                                               int64_t n, int nt, const act_image_ptr & o, const double * red) {
-    const int tid = threadIdx.x;
+                                               int64_t n, int nt, const act_image_ptr & o, const double * red, int tid_ = -1) {
+    const int tid = tid_ < 0 ? (int) threadIdx.x : tid_;
     const int64_t nv = n >> 2;
     const double s2 = waves_combine(red + 16, nt >> 6, op_add());
     const float variance = (float)(s2 / (double) n);

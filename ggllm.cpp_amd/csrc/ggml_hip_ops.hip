@@ -133,7 +133,7 @@ fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out) {
     w.row_stride = fq_il_row_stride(d, w.nblk);               // one slab, rows of row_stride bytes (fq_types.h)
     const size_t total = (size_t) M * w.row_stride;
     uint8_t * slab = nullptr;
-    HIP_CHECK(hipMalloc((void **) &slab, total + 256));        // +256: clamped tail loads never leave the allocation
+    HIP_CHECK(hipMalloc((void **) &slab, total + 2048));       // slack: clamped tail loads / the engine's last 1 KiB DMA piece never leave the allocation
     for (int p = 0; p < d.nplanes; ++p) w.plane[p] = slab;
     *slab_out = slab;
     return w;

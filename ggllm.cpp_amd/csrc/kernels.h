@@ -100,3 +100,29 @@ bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, 
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
                              int att_act_type, hipStream_t st);
+
+// kernels_engine.hip -- the persistent decode engine: one launch per token
+#include <vector>
+struct fq_engine_layer {
+    const uint8_t * qkv, * up, * down, * wo;          // row 0 of each matrix (device layout)
+    const float * ln_w, * ln_b, * ln2_w, * ln2_b;     // ln: the norm that feeds the MLP (and Wqkv of a one-norm block); ln2: the attention norm of a two-norm block
+    float * kc, * vc;                                 // this block's KV cache
+};
+struct fq_engine_sched { int qg0, qg1, ug0, ug1, r0, r1, hg0, hg1; };   // one streaming workgroup: 32-row groups of Wqkv / Wup / lm_head, rows of Wdown + Wo
+struct fq_engine_args {
+    int type, n_layers; const fq_engine_layer * layers; const fq_engine_sched * sched;     // device arrays
+    int E, FF, H, HKV, V, two_norms;
+    unsigned rsE, rsF;                                // row strides of the K = E and K = FF matrices
+    int n_attn, hpw, n_stream, attn_lds_group;        // roles: attention workgroups first (hpw heads each), then the streaming ones
+    const uint8_t * lm_head; const float * lnf_w, * lnf_b; float * logits, * argmax_val; int * argmax_idx;     // lm_head == nullptr: no head phase
+    const float * x_in;                               // residual row entering the stage (must not alias x: workgroups without phase-A work may still read it when the first rows of x are written)
+    float * x;                                        // residual row leaving every block (the last block's is the stage's output)
+    float * hidden;                                   // optional: rows 1 .. n_layers of [(n_layers + 1)][E]
+    unsigned long long * xg, * qkvg, * ffg, * attg;   // hand-off granules: E, (H + 2 HKV) 64, FF/4 + FF/16, E/4 + E/16 entries (zero-filled once)
+    const unsigned * epoch_word; unsigned * err;      // err: 0, or the code of the first wait that gave up
+    const int * n_past; int max_n_kv; const float * rope_cs; const uint16_t * exp_tab, * gelu_tab;
+};
+bool   fq_engine_plan(int type, int E, int FF, int qkv_rows, int V, bool with_head, int n_stream, std::vector<fq_engine_sched> & out, int * max_groups, int * max_rows);
+size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers);
+int    fq_engine_threads();
+bool   fq_launch_decode_engine(const fq_engine_args & a, int nslot, size_t lds_bytes, hipStream_t st);

@@ -102,8 +102,12 @@ void  falcon_hip_get_hidden(falcon_hip_context * c, float * dst_host);
 void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* capture decode steps into a hipGraph */
 /* N == 1 evals: 2 (default) = fused decode kernels, two launches per block (LayerNorm mat-vec | attention + output mat-vec,
  * when the grid fits the chip), 3 = one launch per block (the next block's LayerNorm mat-vec as a second phase of the same
- * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests). All produce the same bits. */
+ * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests), 4 = the persistent decode
+ * engine: ONE launch per token for all blocks of the stage + lm_head (csrc/kernels_engine.hip; legacy formats, one format
+ * per stage -- other models keep mode 2). All produce the same bits. */
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
+/* 1 when N == 1 evals of this context run through the persistent engine (mode 4 and a model inside its scope) */
+int   falcon_hip_context_engine_active(falcon_hip_context * c);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
 

@@ -1,0 +1,78 @@
+"""GPU: the persistent decode engine (csrc/kernels_engine.hip, falcon_hip_context_set_fused(ctx, 4): ONE launch per token --
+LDS-DMA loader wave + consumer waves per CU, attention workgroups, tagged-granule hand-offs) reproduces the op-by-op launch
+list bit for bit: logits, hidden states of every block, KV cache (through later steps), greedy tokens through the hipGraph."""
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    g.init(0)
+
+
+@pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+                                       ("gqa_q4_1", synth.HP_TINY_GQA, ob.Q4_1), ("mqa_q5_0", synth.HP_TINY_MQA, ob.Q5_0),
+                                       ("gqa_q8_0", synth.HP_TINY_GQA, ob.Q8_0)])
+def test_engine_bit_identical_to_op_list(oracle, name, hp, t):
+    w = synth.make_model(oracle, hp, t, seed=21)
+    toks = synth.tokens(11, hp["n_vocab"], seed=6)
+    outs = []
+    for mode in (0, 4):
+        m = g.FalconModel(w, n_ctx=32, n_batch=4)
+        m.set_fused(mode)
+        assert m.engine_active() == (mode == 4)
+        m.eval(toks[:4], 0)
+        r = [m.eval(toks[i:i + 1], i, want_hidden=True) for i in range(4, 11)]
+        assert m.sync_error() == 0
+        outs.append(r)
+        m.free()
+    for (la, ha), (lb, hb) in zip(*outs):
+        assert np.array_equal(ha, hb)
+        assert np.array_equal(la, lb)
+
+
+def test_engine_outside_its_scope_falls_back(oracle):
+    """k-quant weights are outside the engine's scope: mode 4 then runs the two-launch path, same bits"""
+    hp = synth.HP_TINY_GQA
+    w = synth.make_model(oracle, hp, ob.Q4_K, seed=3)
+    toks = synth.tokens(6, hp["n_vocab"], seed=1)
+    res = []
+    for mode in (2, 4):
+        m = g.FalconModel(w, n_ctx=32, n_batch=4)
+        m.set_fused(mode)
+        assert not m.engine_active()
+        m.eval(toks[:4], 0)
+        res.append([m.eval(toks[i:i + 1], i) for i in range(4, 6)])
+        m.free()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("t,two", [(ob.Q4_0, False), (ob.Q5_1, True)])
+def test_engine_full_width_greedy(oracle, t, two):
+    """Falcon-7B width (n_embd 4544 / 71 heads MQA; and a two-norm GQA variant), 3 blocks: 96 greedy steps through the
+    hipGraph with every CU streaming -- same tokens and same final logits as the three-launch form, no wait ever gave up"""
+    hp = dict(synth.HP_7B); hp["n_layer"] = 3; hp["n_vocab"] = 4096
+    if two:
+        hp.update(n_embd=4608, n_head=72, n_head_kv=2, n_ff=18432, two_norms=True)
+    w = synth.make_model_fast(hp, t, seed=5)
+    toks = synth.tokens(16, hp["n_vocab"], seed=9)
+    res = []
+    for mode in (1, 4):
+        m = g.FalconModel(w, n_ctx=256, n_batch=16)
+        m.set_fused(mode)
+        assert m.engine_active() == (mode == 4)
+        m.eval(toks, 0)
+        out = m.decode_greedy(int(toks[-1]), 16, 96, use_graph=True)
+        lg = m.eval(out[-1:], 16 + 96)
+        assert m.sync_error() == 0
+        res.append((out, lg))
+        m.free()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
