@@ -12,7 +12,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libggml_hip.so")
+LIB_PATH = os.environ.get("GGLLM_HIP_LIB") or os.path.join(PKG_DIR, "libggml_hip.so")      # (GGLLM_HIP_LIB: A/B builds of the same library)
 
 # enum ggml_type values (ggml.h:247-268)
 F32, F16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
+falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos""".split()
 
@@ -100,7 +100,7 @@ def load():
         "falcon_hip_tokenize": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int]),
         "falcon_hip_token_to_bytes": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p)]),
         "falcon_hip_token_bos": (C.c_int32, []), "falcon_hip_token_eos": (C.c_int32, []),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_plan_stages": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
@@ -366,6 +366,16 @@ class FalconModel:
 
     def engine_active(self):
         return bool(load().falcon_hip_context_engine_active(self.ctx))
+
+    def engine_debug(self):
+        """(failure records [k, 8], phase stamps [256 workgroups, 4 blocks, 8 slots]) of the engine (FALCON_HIP_ENGINE_DEBUG=1)"""
+        buf = np.zeros(4096 + 256 * 4 * 8 + 256 * 8, np.int64)
+        n = load().falcon_hip_context_engine_debug(self.ctx, buf.ctypes.data, buf.size)
+        if n == 0:
+            return None, None
+        k = int(min(buf[0], 500))
+        self.engine_counters = buf[4096 + 256 * 4 * 8:].reshape(256, 8)      # per workgroup: loader total / blocked / report-wait cycles, refills, bytes; consumer 0 wait / dot cycles, rows
+        return buf[16:16 + 8 * k].reshape(k, 8), buf[4096:4096 + 256 * 4 * 8].reshape(256, 4, 8)
 
     def sync_error(self):
         return load().falcon_hip_context_sync_error(self.ctx)

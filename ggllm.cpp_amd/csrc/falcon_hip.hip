@@ -32,6 +32,11 @@ struct falcon_hip_model {
     float * out_norm_w = nullptr, * out_norm_b = nullptr;
     std::vector<layer_weights> layers;        // local layers only
     std::vector<void *> allocs;
+    // Weight ARENA: every matrix of the stage is carved out of a few very large allocations instead of one hipMalloc per
+    // tensor. Measured on MI355X (Falcon-7B Q4_0, the persistent engine's loader alone, scripts/gpu_engine_debug.py): 131
+    // separate allocations 2680 us per token (1.45 TB/s), one arena 695 us (5.6 TB/s) -- the driver maps a large allocation
+    // with large page fragments, and a wave that streams 1 KiB pieces lives or dies by the translation reach.
+    uint8_t * arena_cur = nullptr; size_t arena_left = 0;
     size_t weight_bytes = 0;                   // quantized bytes streamed per decoded token (local layers [+ lm_head])
     bool first_stage() const { return hp.layer_begin == 0; }
     bool last_stage()  const { return hp.layer_end == hp.n_layer; }
@@ -131,12 +136,32 @@ extern "C" void falcon_hip_model_free(falcon_hip_model * m) {
     delete m;
 }
 
+static uint8_t * arena_alloc(falcon_hip_model * m, size_t bytes) {
+    bytes = (bytes + 2048 + 65535) & ~(size_t) 65535;            // slack for clamped tail loads / the engine's last DMA piece; 64 KiB granules
+    if (bytes > m->arena_left) {
+        size_t chunk = (size_t) 1 << 30;
+        if (const char * e = getenv("FALCON_HIP_ARENA_MB")) chunk = (size_t) atoll(e) << 20;
+        if (chunk < bytes) chunk = bytes;
+        void * p = nullptr;
+        HIP_CHECK(hipMalloc(&p, chunk));
+        m->allocs.push_back(p);
+        m->arena_cur = (uint8_t *) p; m->arena_left = chunk;
+    }
+    uint8_t * r = m->arena_cur;
+    m->arena_cur += bytes; m->arena_left -= bytes;
+    return r;
+}
+
 static fq_weight upload_weight(falcon_hip_model * m, int type, const void * data, int64_t K, int64_t M) {
     hip_context & c = fq_ctx();
-    void * slab = nullptr;
-    fq_weight w = fq_weight_alloc(type, K, M, &slab);
-    m->allocs.push_back(slab);
     const fq_type_desc d = fq_desc(type);
+    if (d.blck == 0 || K % d.blck != 0) { fprintf(stderr, "falcon-hip: weight type %d with K=%lld unsupported\n", type, (long long) K); exit(1); }
+    fq_weight w{};
+    w.type = type; w.K = K; w.M = M; w.nblk = K / d.blck;
+    w.bytes = (size_t) M * w.nblk * d.tsize;
+    w.row_stride = fq_il_row_stride(d, w.nblk);
+    uint8_t * slab = arena_alloc(m, (size_t) M * w.row_stride);
+    for (int p = 0; p < d.nplanes; ++p) w.plane[p] = slab;
     const size_t row_bytes = (size_t) w.nblk * d.tsize;
     int64_t rows_per_chunk = (int64_t)((256u << 20) / row_bytes);
     if (rows_per_chunk < 1) rows_per_chunk = 1;
@@ -365,6 +390,20 @@ static bool engine_prepare(falcon_hip_context * c) {
         lay[i] = { L.qkv.plane[0], L.up.plane[0], L.down.plane[0], L.wo.plane[0], L.ln_w, L.ln_b, L.ln2_w, L.ln2_b,
                    c->k_cache + i * (size_t) c->n_ctx * HKV * 64, c->v_cache + i * (size_t) c->n_ctx * HKV * 64 };
     }
+    if (getenv("FALCON_HIP_ENGINE_ONEBUF")) {           // tuning aid: every matrix inside ONE allocation (timing of the loader only; results are garbage)
+        size_t tot = 0;
+        for (const layer_weights & L : m->layers) tot += (size_t) L.qkv.M * L.qkv.row_stride + (size_t) L.up.M * L.up.row_stride + (size_t) L.down.M * L.down.row_stride + (size_t) L.wo.M * L.wo.row_stride;
+        uint8_t * big = (uint8_t *) dev_alloc(c->allocs, tot + 4096);
+        HIP_CHECK(hipMemset(big, 1, tot + 4096));
+        size_t off = 0;
+        for (size_t i = 0; i < m->layers.size(); ++i) {
+            const layer_weights & L = m->layers[i];
+            lay[i].qkv = big + off; off += (size_t) L.qkv.M * L.qkv.row_stride;
+            lay[i].up = big + off; off += (size_t) L.up.M * L.up.row_stride;
+            lay[i].down = big + off; off += (size_t) L.down.M * L.down.row_stride;
+            lay[i].wo = big + off; off += (size_t) L.wo.M * L.wo.row_stride;
+        }
+    }
     fq_engine_layer * lay_dev = (fq_engine_layer *) dev_alloc(c->allocs, lay.size() * sizeof(fq_engine_layer));
     HIP_CHECK(hipMemcpy(lay_dev, lay.data(), lay.size() * sizeof(fq_engine_layer), hipMemcpyHostToDevice));
     fq_engine_sched * sched_dev = (fq_engine_sched *) dev_alloc(c->allocs, sched.size() * sizeof(fq_engine_sched));
@@ -386,12 +425,29 @@ static bool engine_prepare(falcon_hip_context * c) {
     unsigned one = 1u;
     HIP_CHECK(hipMemcpy(c->sync_words + 2, &one, 4, hipMemcpyHostToDevice));
     a.epoch_word = c->sync_words + 2; a.err = c->sync_words + 1;
+    a.cnt = (unsigned *) dev_alloc(c->allocs, 128 * 4);
+    HIP_CHECK(hipMemset(a.cnt, 0, 128 * 4));
     a.n_past = c->n_past_dev; a.max_n_kv = c->n_ctx; a.rope_cs = c->rope_cs; a.exp_tab = hc.exp_table_attn; a.gelu_tab = hc.gelu_table;
+    if (const char * e = getenv("FALCON_HIP_ENGINE_DEBUG_MODE")) a.debug_mode = atoi(e);
+    if (const char * e = getenv("FALCON_HIP_ENGINE_COUNTERS")) a.use_counters = atoi(e);
+    if (getenv("FALCON_HIP_ENGINE_DEBUG")) {
+        a.dbg = (long long *) dev_alloc(c->allocs, (4096 + 256 * 4 * 8 + 256 * 8) * sizeof(long long));
+        HIP_CHECK(hipMemset(a.dbg, 0, (4096 + 256 * 4 * 8 + 256 * 8) * sizeof(long long)));
+    }
     c->eng_nslot = nslot; c->eng_lds = lds;
     c->eng_state = 1;
     return true;
 }
 extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c) { return c->engine && stage_fused(c) && engine_prepare(c) ? 1 : 0; }
+// tuning aid: the engine's debug buffer (FALCON_HIP_ENGINE_DEBUG=1 at context creation): n int64 to the host; returns the number copied
+extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out, int n) {
+    if (c->eng_state <= 0 || !c->eng.dbg) return 0;
+    const int total = 4096 + 256 * 4 * 8 + 256 * 8;
+    if (n > total) n = total;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, c->eng.dbg, (size_t) n * sizeof(long long), hipMemcpyDeviceToHost));
+    return n;
+}
 
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
@@ -704,6 +760,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     falcon_hip_model * m = c->m;
     hipStream_t st = hc.stream;
     if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: stage step at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); exit(1); }
+    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
     // body of one step; n_past_base >= 0: position baked into the launch arguments (plain launches), < 0: the position is
@@ -763,6 +820,7 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
     HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->tokens_dev, &first_token, 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
     auto one_step = [&](hipStream_t s, int max_kv) {

@@ -120,6 +120,10 @@ struct fq_engine_args {
     float * hidden;                                   // optional: rows 1 .. n_layers of [(n_layers + 1)][E]
     unsigned long long * xg, * qkvg, * ffg, * attg;   // hand-off granules: E, (H + 2 HKV) 64, FF/4 + FF/16, E/4 + E/16 entries (zero-filled once)
     const unsigned * epoch_word; unsigned * err;      // err: 0, or the code of the first wait that gave up
+    int use_counters;                                 // 1 (FALCON_HIP_ENGINE_COUNTERS=1): sweeps start only when an arrival counter says the producers are done
+    int debug_mode;                                   // tuning aid (FALCON_HIP_ENGINE_DEBUG_MODE): 1 = the loader alone, no arithmetic (results are garbage)
+    unsigned * cnt;                                   // 128 words: arrival counters of the hand-offs (x, qkv, GELU image, attention image at [0], [32], [64], [96])
+    long long * dbg;                                  // optional (FALCON_HIP_ENGINE_DEBUG=1): [0] failure count, records of 8 from [16], phase stamps from [4096]
     const int * n_past; int max_n_kv; const float * rope_cs; const uint16_t * exp_tab, * gelu_tab;
 };
 bool   fq_engine_plan(int type, int E, int FF, int qkv_rows, int V, bool with_head, int n_stream, std::vector<fq_engine_sched> & out, int * max_groups, int * max_rows);

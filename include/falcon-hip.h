@@ -108,6 +108,8 @@ void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* cap
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
 /* 1 when N == 1 evals of this context run through the persistent engine (mode 4 and a model inside its scope) */
 int   falcon_hip_context_engine_active(falcon_hip_context * c);
+/* tuning aid (FALCON_HIP_ENGINE_DEBUG=1): failure records and phase stamps of the engine, n int64 copied to the host */
+int   falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out_host, int n);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
 

@@ -66,7 +66,7 @@ __device__ __forceinline__ float row_dot_lds(const uint8_t * ring, long off, con
 }
 
 struct eng_args {
-    const uint8_t * w; long chunk_bytes; int rows_per_wg; int repeat; const uint8_t * image; float * out; unsigned * err;
+    const uint8_t * w; long chunk_bytes; int rows_per_wg; int repeat; const uint8_t * image; float * out; unsigned * err; long matrix_stride;   // > 0: repeat r reads chunk w of matrix r
 };
 
 // LDS: [ring RING][image IMG, 16-aligned][ctl: landed[4], done_row[32], abort]
@@ -92,8 +92,9 @@ __global__ void __launch_bounds__(64 * (NC + NL)) k_engine(eng_args a) {
         const unsigned ring_lds = (unsigned)(uintptr_t) ring;
         long k = 0;                                                       // own slots issued
         long pos = (long) wid * SLOT;                                     // source offset inside the chunk (a multiple of SLOT long)
+        long mat = 0;
         for (long s = wid; s < total_slots; s += NL, ++k, pos += (long) NL * SLOT) {
-            if (pos >= a.chunk_bytes) pos -= a.chunk_bytes;
+            if (pos >= a.chunk_bytes) { pos -= a.chunk_bytes; mat += a.matrix_stride; }
             if (s >= NSLOT) {                                             // slot s - NSLOT must have been consumed
                 const long need = (s - NSLOT + 1) * (long) SLOT;
                 bool stop = false;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(64 * (NC + NL)) k_engine(eng_args a) {
             }
             const unsigned dst = ring_lds + (unsigned)((s & (NSLOT - 1)) * SLOT);
 #pragma unroll
-            for (int p = 0; p < PIECES; ++p) glds16<NT>(chunk + pos + p * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+            for (int p = 0; p < PIECES; ++p) glds16<NT>(chunk + mat + pos + p * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + p * 1024));
             if (k >= 2) {                                                 // own slots 0 .. k-2 have landed
                 asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
                 if (lane == 0) lds_st(landed + 4 * wid, (unsigned)(k - 1));
@@ -196,7 +197,8 @@ int main(int argc, char ** argv) {
     const int rows_per_wg = argc > 1 ? atoi(argv[1]) : 1632;            // multiple of 32 -> chunk is whole slots
     const int repeat = argc > 2 ? atoi(argv[2]) : 4;
     const long chunk = (long) rows_per_wg * ROW;
-    const long total = chunk * ncu;
+    const bool matrices = argc > 3 && atoi(argv[3]) != 0;           // engine-like: `repeat` matrices of ncu chunks each
+    const long total = chunk * ncu * (matrices ? repeat : 1);
     printf("%s: %d CUs; %d rows (%.2f MB) per workgroup x %d repeats; %.2f GB unique, %.2f GB streamed per launch\n", prop.name, ncu, rows_per_wg,
            chunk / 1e6, repeat, total / 1e9, total * (double) repeat / 1e9);
     uint8_t * w; CK(hipMalloc(&w, total + 65536));
@@ -234,7 +236,7 @@ int main(int argc, char ** argv) {
         fflush(stdout);
         if (eh) CK(hipMemset(err, 0, 64));
     };
-    eng_args a{ w, chunk, rows_per_wg, repeat, dimg, nullptr, err };
+    eng_args a{ w, chunk, rows_per_wg, repeat, dimg, nullptr, err, matrices ? chunk * ncu : 0 };
 
     // ---- reference: register streaming
 #define REGS(NW, R, G) { char n[96]; snprintf(n, 96, "registers  %2d waves x %d rows", NW, R); \
@@ -274,7 +276,7 @@ int main(int argc, char ** argv) {
         const size_t lds = (size_t) NSLOT * SLOT + ((IMG + 15) & ~15) + 256; \
         CK(hipFuncSetAttribute((const void *) k_engine<NC, NL, NSLOT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
         run(n, [&](float * o) { eng_args b = a; b.out = o; hipLaunchKernelGGL((k_engine<NC, NL, NSLOT, NT>), dim3(G), dim3(64 * (NC + NL)), lds, 0, b); }, out1, G); \
-        if (G == ncu) engine_cmp(n); }
+        if (G == ncu && !matrices) engine_cmp(n); }
     ENG(11, 1, 8, true, ncu) ENG(11, 1, 8, false, ncu) ENG(11, 1, 4, true, ncu) ENG(7, 1, 8, true, ncu) ENG(15, 1, 8, true, ncu) ENG(3, 1, 8, true, ncu)
     ENG(10, 2, 8, true, ncu) ENG(14, 2, 8, true, ncu) ENG(6, 2, 8, true, ncu) ENG(10, 2, 4, true, ncu)
     ENG(11, 1, 8, true, 224) ENG(11, 1, 8, true, 192) ENG(10, 2, 8, true, 224) ENG(10, 2, 8, true, 192) ENG(10, 2, 8, true, 128)
