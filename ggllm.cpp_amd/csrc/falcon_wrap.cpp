@@ -1,0 +1,154 @@
+// falcon_wrap.cpp -- the device-resident fast path BEHIND the reference's own entry points, with the reference's sources
+// unchanged. Host C++ only; compiled by the integrator TOGETHER with the reference's libfalcon.cpp / ggml.c / the CLIs
+// (it includes the reference's libfalcon.h), linked with
+//
+//   -Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free
+//   -L<repo>/ggllm.cpp_amd -lggml_hip
+//
+// The GNU linker then sends every call that falcon_main.cpp / falcon_perplexity.cpp / falcon_common.cpp make to these six
+// functions of libfalcon.h (:165-168, :220-223, :256, :263, :172, :321) to the __wrap_ versions below, which keep the
+// reference's own objects alive (tokenizer, samplers, sessions, timings structure: everything the CLIs touch besides the
+// evaluation still is the reference's code) and run the evaluation itself on the device:
+//
+//   falcon_init_from_file   the reference loads the file as usual but with n_gpu_layers = 0 (its per-op CUDA offload is
+//                           not used: nothing is uploaded twice), then falcon_hip_model_load_ggcc puts the same file's
+//                           weights into HBM and a falcon_hip_context gets the KV cache (libfalcon.cpp:1552-1959, 3755)
+//   falcon_context_prepare  a further context over the same model (falcon_main's system-prompt context, falcon_main.cpp:169)
+//   falcon_eval             falcon_hip_eval: the whole falcon_eval_internal graph (libfalcon.cpp:2011-2588) on the device
+//   falcon_get_logits       the logits falcon_hip_eval brought back (last row, or all rows with logits_all)
+//   falcon_print_timings    the reference's report (libfalcon.cpp:4700-4714) over this path's own clocks
+//   llama_free              releases the device side, then the reference's context
+//
+// Not carried over: llama_save/load_session_file and falcon_get_embeddings still address the reference context's (unused)
+// KV cache and embedding buffer.
+#include "libfalcon.h"
+#include "../../include/falcon-hip.h"
+#include "../../include/ggml-hip-ops.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+extern "C" {
+struct falcon_context * __real_falcon_init_from_file(const char * path_model, struct falcon_context_params params);
+struct falcon_context * __real_falcon_context_prepare(falcon_context_params params, falcon_model * model, std::string context_name, bool verbose);
+int     __real_falcon_eval(struct falcon_context * ctx, const falcon_token * tokens, falcon_evaluation_config & configuration);
+float * __real_falcon_get_logits(struct falcon_context * ctx);
+void    __real_falcon_print_timings(struct falcon_context * ctx);
+void    __real_llama_free(struct falcon_context * ctx);
+}
+
+namespace {
+
+struct hip_model_ref { falcon_hip_model * m; int users; };
+struct hip_side {
+    falcon_hip_context * c = nullptr;
+    falcon_model * ref_model = nullptr;                       // key of the shared device model
+    bool logits_all = false;
+    int  n_ctx = 0, n_batch = 0;
+    int64_t t_eval_us = 0, t_p_eval_us = 0, t_start_us = 0; int n_eval = 0, n_p_eval = 0;
+};
+
+std::mutex g_mu;
+std::map<falcon_context *, hip_side> g_ctx;                   // reference context -> device side
+std::map<falcon_model *, hip_model_ref> g_model;              // reference model -> device model (shared by its contexts)
+
+int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool disabled() { const char * e = getenv("FALCON_HIP_WRAP"); return e && atoi(e) == 0; }      // FALCON_HIP_WRAP=0: the reference's own path
+
+void attach(falcon_context * ctx, falcon_hip_model * hm, const falcon_context_params & p) {
+    hip_side s;
+    s.ref_model = falcon_get_falcon_model(ctx);
+    s.logits_all = p.logits_all; s.n_ctx = p.n_ctx; s.n_batch = p.n_batch > 0 ? p.n_batch : 1;
+    s.c = falcon_hip_context_create(hm, s.n_ctx, s.n_batch, s.n_ctx);
+    s.t_start_us = now_us();
+    g_model[s.ref_model].m = hm; ++g_model[s.ref_model].users;
+    g_ctx[ctx] = s;
+}
+
+}   // namespace
+
+extern "C" {
+
+struct falcon_context * __wrap_falcon_init_from_file(const char * path_model, struct falcon_context_params params) {
+    if (disabled() || params.vocab_only) return __real_falcon_init_from_file(path_model, params);
+    falcon_context_params host = params;
+    host.n_gpu_layers = 0;                                    // the reference keeps its mmap; the weights go to HBM once, below
+    falcon_context * ctx = __real_falcon_init_from_file(path_model, host);
+    if (!ctx) return nullptr;
+    ggml_hip_init(params.main_gpu);
+    if (const char * e = getenv("GGML_HIP_REFERENCE_ORDER")) ggml_hip_reference_order(atoi(e));
+    falcon_hip_hparams hp;
+    falcon_hip_model * hm = falcon_hip_model_load_ggcc(path_model, 0, 0, &hp);
+    if (!hm) { fprintf(stderr, "falcon-hip: %s could not be loaded onto the device -- the reference's own path stays in place\n", path_model); return ctx; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    attach(ctx, hm, params);
+    fprintf(stderr, "falcon-hip: %s resident on the device (%.2f GB of weights per token); falcon_eval runs there\n", path_model,
+            falcon_hip_model_weight_bytes(hm) / 1e9);
+    return ctx;
+}
+
+struct falcon_context * __wrap_falcon_context_prepare(falcon_context_params params, falcon_model * model, std::string context_name, bool verbose) {
+    falcon_context * ctx = __real_falcon_context_prepare(params, model, context_name, verbose);
+    if (!ctx) return ctx;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_model.find(model);
+    if (it != g_model.end() && it->second.m) attach(ctx, it->second.m, params);
+    return ctx;
+}
+
+int __wrap_falcon_eval(struct falcon_context * ctx, const falcon_token * tokens, falcon_evaluation_config & configuration) {
+    hip_side * s = nullptr;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_ctx.find(ctx); if (it != g_ctx.end()) s = &it->second; }
+    if (!s) return __real_falcon_eval(ctx, tokens, configuration);
+    const int N = configuration.n_tokens, n_past = configuration.n_past;
+    if (N < 1 || N > s->n_batch || n_past + N > s->n_ctx) {
+        fprintf(stderr, "falcon-hip: falcon_eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, s->n_batch, s->n_ctx);
+        return 1;
+    }
+    const int64_t t0 = now_us();
+    const int rc = falcon_hip_eval(s->c, (const int32_t *) tokens, N, n_past, s->logits_all ? 1 : 0);
+    const int64_t dt = now_us() - t0;
+    if (N == 1) { s->t_eval_us += dt; ++s->n_eval; } else { s->t_p_eval_us += dt; s->n_p_eval += N; }     // libfalcon.cpp:2578-2585
+    return rc;
+}
+
+float * __wrap_falcon_get_logits(struct falcon_context * ctx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(ctx);
+    if (it == g_ctx.end()) return __real_falcon_get_logits(ctx);
+    return const_cast<float *>(falcon_hip_get_logits(it->second.c));
+}
+
+void __wrap_falcon_print_timings(struct falcon_context * ctx) {
+    hip_side s;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_ctx.find(ctx); if (it == g_ctx.end()) { __real_falcon_print_timings(ctx); return; } s = it->second; }
+    const int n_eval = s.n_eval > 0 ? s.n_eval : 1, n_p_eval = s.n_p_eval > 0 ? s.n_p_eval : 1;
+    fprintf(stderr, "\n");
+    fprintf(stderr, "falcon_print_timings: (device-resident path, libggml_hip.so)\n");
+    fprintf(stderr, "falcon_print_timings: batch eval time = %8.2f ms / %5d tokens (%8.2f ms per token, %8.2f tokens per second)\n",
+            1e-3 * s.t_p_eval_us, s.n_p_eval, 1e-3 * s.t_p_eval_us / n_p_eval, 1e6 / (s.t_p_eval_us > 0 ? (double) s.t_p_eval_us / n_p_eval : 1e18));
+    fprintf(stderr, "falcon_print_timings:       eval time = %8.2f ms / %5d runs   (%8.2f ms per token, %8.2f tokens per second)\n",
+            1e-3 * s.t_eval_us, s.n_eval, 1e-3 * s.t_eval_us / n_eval, 1e6 / (s.t_eval_us > 0 ? (double) s.t_eval_us / n_eval : 1e18));
+    fprintf(stderr, "falcon_print_timings:      total time = %8.2f ms\n", 1e-3 * (now_us() - s.t_start_us));
+}
+
+void __wrap_llama_free(struct falcon_context * ctx) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(ctx);
+        if (it != g_ctx.end()) {
+            falcon_hip_context_free(it->second.c);
+            auto mi = g_model.find(it->second.ref_model);
+            if (mi != g_model.end() && --mi->second.users == 0) { falcon_hip_model_free(mi->second.m); g_model.erase(mi); }
+            g_ctx.erase(it);
+        }
+    }
+    __real_llama_free(ctx);
+}
+
+}

@@ -66,6 +66,7 @@ extern "C" int ggml_hip_init(int device) {
         if (!getenv("GGML_HIP_EXP_TABLE") && fq_verify_exp_formula(g_ctx.exp_table, g_ctx.stream) == 0) g_ctx.exp_table_attn = nullptr;
         HIP_CHECK(hipMalloc((void **) &g_ctx.scalar_i32, 256));
         g_ctx.ready = true;
+        if (const char * e = getenv("GGML_HIP_REFERENCE_ORDER")) ggml_hip_reference_order(atoi(e));      // (callers that only know ggml-cuda.h)
     });
     // one process drives one GPU: a later call naming another device cannot re-bind the library
     if (device >= 0 && device < g_ctx.n_devices && device != g_ctx.device)

@@ -253,10 +253,63 @@ def gen_tiny_all():
     print("tiny_models_all.npz", os.path.getsize(os.path.join(OUT, "tiny_models_all.npz")))
 
 
+CLI_PROMPT = "The quick brown fox didn't jump"
+CLI_MAIN_ARGS = ["-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1"]
+CLI_PPL_ARGS = ["-t", "2", "-c", "32", "-b", "8", "-s", "1"]
+
+
+def cli_model(O, path):
+    """the tiny byte-level-BPE model the CLI fixtures run on (also built by tests/test_gpu_dropin.py)"""
+    import bpe_fixture
+    import ggcc_writer
+    vocab, merges = bpe_fixture.build(n_merges=308)
+    hp = dict(synth.HP_TINY_MQA)
+    hp["n_vocab"] = len(vocab)
+    w = synth.make_model(O, hp, ob.Q4_0, seed=321)
+    ggcc_writer.write_ggcc(path, w, vocab, merges)
+    return bpe_fixture
+
+
+def gen_cli():
+    """8. the reference's own command-line tools, built WITHOUT any back-end from its unchanged sources (scalar objects of
+    `make -C oracle ref_falcon` + examples/falcon/falcon_main.cpp, examples/falcon_perplexity/falcon_perplexity.cpp,
+    examples/falcon_common.cpp; build-info.h written by the reference's scripts/build-info.sh) and run on a tiny GGCC file:
+    the bytes falcon_main prints for a prompt (greedy, its default repetition penalty) and the chunk perplexities
+    falcon_perplexity prints for a text. tests/test_gpu_dropin.py runs the same tools linked against libggml_hip.so."""
+    import subprocess
+    import tempfile
+    ref = "/root/reference"
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj")
+    sc = "-march=x86-64 -mno-sse3 -mno-ssse3 -mno-avx -mno-avx2 -mno-fma -mno-f16c".split()
+    ob.build_oracle()
+    O = ob.Oracle()
+    d = {}
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.check_call("sh %s/scripts/build-info.sh > build-info.h 2>/dev/null" % ref, shell=True, cwd=td)
+        objs = [os.path.join(obj, f) for f in ("libfalcon.o", "cmpnct_unicode.o", "ggml.o", "k_quants.o")]
+        for tool, src in (("falcon_main", "examples/falcon/falcon_main.cpp"), ("falcon_perplexity", "examples/falcon_perplexity/falcon_perplexity.cpp")):
+            subprocess.check_call(["g++", "-O2", "-std=c++11", "-pthread", *sc, "-DGGML_USE_K_QUANTS", "-I" + ref, "-I" + ref + "/examples", "-I" + td,
+                                   os.path.join(ref, src), os.path.join(ref, "examples/falcon_common.cpp"), *objs, "-lm", "-o", os.path.join(td, tool)],
+                                  stderr=subprocess.DEVNULL)
+        path = os.path.join(td, "tiny_bpe.ggcc")
+        bf = cli_model(O, path)
+        r = subprocess.run([os.path.join(td, "falcon_main"), "-m", path, "-p", CLI_PROMPT, *CLI_MAIN_ARGS], capture_output=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d["main_stdout"] = np.frombuffer(r.stdout, np.uint8)
+        txt = os.path.join(td, "corpus.txt")
+        open(txt, "wb").write((bf.CORPUS * 2).encode("utf-8"))
+        r = subprocess.run([os.path.join(td, "falcon_perplexity"), "-m", path, "-f", txt, *CLI_PPL_ARGS], capture_output=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d["ppl_stdout"] = np.frombuffer(r.stdout, np.uint8)
+        print("falcon_main:", r"%r" % bytes(d["main_stdout"]))
+        print("falcon_perplexity:", r"%r" % bytes(d["ppl_stdout"]))
+    np.savez_compressed(os.path.join(OUT, "cli.npz"), **d)
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize", "tokenizer", "tiny_all"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("wquant", "model_quantize", "tokenizer", "tiny_all", "cli"):
         os.makedirs(OUT, exist_ok=True)
-        return {"wquant": gen_wquant, "model_quantize": gen_model_quantize, "tokenizer": gen_tokenizer, "tiny_all": gen_tiny_all}[sys.argv[1]]()
+        return {"wquant": gen_wquant, "model_quantize": gen_model_quantize, "tokenizer": gen_tokenizer, "tiny_all": gen_tiny_all, "cli": gen_cli}[sys.argv[1]]()
     ob.build_oracle()
     O, R, RS = ob.Oracle(), ob.Ref(), ob.Ref(scalar=True)
     os.makedirs(OUT, exist_ok=True)

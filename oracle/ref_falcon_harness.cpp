@@ -27,6 +27,14 @@ void * reff_load(const char * path, int n_ctx, int n_batch) {
     return (void *) falcon_init_from_file(path, p);
 }
 
+// the same with n_gpu_layers (the -ngl of the CLIs): only meaningful in the -DGGML_USE_CUBLAS builds of `make ref_falcon_hip`
+void * reff_load_ngl(const char * path, int n_ctx, int n_batch, int n_gpu_layers) {
+    init_once();
+    falcon_context_params p = falcon_context_default_params();
+    p.n_ctx = n_ctx; p.n_batch = n_batch; p.n_gpu_layers = n_gpu_layers; p.logits_all = true; p.f16_kv = false; p.use_mmap = true; p.seed = 1;
+    return (void *) falcon_init_from_file(path, p);
+}
+
 // falcon_model_quantize (the falcon_quantize tool's work, libfalcon.cpp:3914-3925) with one thread (deterministic)
 int reff_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor, int allow_requantize) {
     init_once();

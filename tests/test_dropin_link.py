@@ -82,6 +82,38 @@ def test_reference_libfalcon_links_against_libggml_hip(tree):
         assert sym in used, sym
 
 
+WRAP = "-Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free"
+
+
+def test_reference_clis_link_unchanged_with_the_fast_path(tree):
+    """north_star: "falcon_main / falcon_perplexity link unchanged". The reference's CLI sources -- examples/falcon/falcon_main.cpp,
+    examples/falcon_perplexity/falcon_perplexity.cpp, examples/falcon_common.cpp -- compile unchanged next to its unchanged
+    libfalcon.cpp / ggml.c (-DGGML_USE_CUBLAS, our ggml-cuda.h) and link against libggml_hip.so together with
+    csrc/falcon_wrap.cpp and the --wrap flags of INTEGRATION.md section 2: their calls of falcon_init_from_file / falcon_eval /
+    falcon_get_logits land in the device-resident path. (build-info.h is written by the reference's own scripts/build-info.sh.)"""
+    lib = os.path.dirname(g.LIB_PATH)
+    for sub in ("examples/falcon", "examples/falcon_perplexity"):
+        os.makedirs(os.path.join(tree, sub), exist_ok=True)
+    for rel in ("examples/falcon_common.cpp", "examples/falcon_common.h", "examples/falcon/falcon_main.cpp", "examples/falcon_perplexity/falcon_perplexity.cpp"):
+        if not os.path.exists(os.path.join(tree, rel)):
+            os.symlink(os.path.join(REF, rel), os.path.join(tree, rel))
+    subprocess.check_call("sh %s/scripts/build-info.sh > build-info.h 2>/dev/null" % REF, shell=True, cwd=tree)
+    defs = ["-DGGML_USE_CUBLAS", "-DGGML_USE_K_QUANTS", "-march=x86-64-v3", "-pthread"]
+    _run(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", *defs, "-c", "ggml.c", "k_quants.c"], tree)
+    _run(["g++", "-O1", "-std=c++11", *defs, "-idirafter", "stray", "-I.", "-Iexamples", "-c", "libfalcon.cpp", "cmpnct_unicode.cpp",
+          "examples/falcon_common.cpp", "examples/falcon/falcon_main.cpp", "examples/falcon_perplexity/falcon_perplexity.cpp",
+          os.path.join(ROOT, "ggllm.cpp_amd", "csrc", "falcon_wrap.cpp")], tree)
+    common = ["falcon_common.o", "libfalcon.o", "cmpnct_unicode.o", "ggml.o", "k_quants.o", "falcon_wrap.o", WRAP, "-L" + lib, "-lggml_hip", "-Wl,-rpath," + lib, "-lm", "-pthread"]
+    for tool in ("falcon_main", "falcon_perplexity"):
+        _run(["g++", tool + ".o", *common, "-o", tool + "_hip"], tree)
+        syms = subprocess.run(["nm", os.path.join(tree, tool + "_hip")], capture_output=True, text=True).stdout
+        for fn in ("falcon_init_from_file", "falcon_eval", "falcon_get_logits", "llama_free"):
+            assert re.search(r" T __wrap_%s$" % fn, syms, re.M), (tool, fn)          # the wrapper is in ...
+            assert re.search(r" T %s$" % fn, syms, re.M), (tool, fn)                 # ... and so is the reference's own function (__real_)
+        und = subprocess.run(["nm", "-u", os.path.join(tree, tool + "_hip")], capture_output=True, text=True).stdout
+        assert "falcon_hip_eval" in und and "falcon_hip_model_load_ggcc" in und and "ggml_cuda_compute_forward" in und
+
+
 def test_abi_mirror_matches_reference_header(tree):
     """include/ggml-abi.h pins the struct offsets it mirrors; re-derive them from the reference's ggml.h"""
     src = r'''

@@ -1,0 +1,120 @@
+"""GPU: the drop-in, end to end, with the REFERENCE'S OWN code on top of libggml_hip.so (artifacts of `make -C oracle
+ref_falcon_hip`, built in the dev container from the reference's unchanged sources and shipped like oracle/_ref):
+
+  libfalcon_ref_shim.so   the reference's loader, graph builder and graph executor (libfalcon.cpp, ggml.c; -DGGML_USE_CUBLAS);
+                          weights offloaded through ggml_cuda_transform_tensor, every mat-mul through ggml_cuda_compute_forward
+  libfalcon_ref_hip.so    the same plus csrc/falcon_wrap.cpp: falcon_eval runs device-resident (falcon_hip_eval)
+  falcon_main_hip, falcon_perplexity_hip   the reference's command-line tools, unchanged, with the wrap
+
+In reference order (GGML_HIP_REFERENCE_ORDER=1) all of them must reproduce what the pure-CPU reference produced -- logits of
+tests/golden/ggcc_models.npz bit for bit, the bytes falcon_main / falcon_perplexity print (tests/golden/cli.npz)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _need(name):
+    p = os.path.join(REFDIR, name)
+    if not os.path.exists(p):
+        pytest.skip("%s was not built (make -C oracle ref_falcon_hip in the dev container)" % name)
+    return p
+
+
+_LOGITS_SCRIPT = r"""
+import ctypes as C, sys, numpy as np
+so, path, nv, ngl, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+toks = np.load(sys.argv[6])
+L = C.CDLL(so)
+L.reff_load_ngl.restype = C.c_void_p; L.reff_load_ngl.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+L.reff_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+L.reff_free.argtypes = [C.c_void_p]
+ctx = L.reff_load_ngl(path.encode(), 64, 16, ngl)
+assert ctx
+pre = np.zeros((9, nv), np.float32)
+assert L.reff_eval(ctx, toks[:9].ctypes.data, 9, 0, 2, pre.ctypes.data) == 0
+dec = []
+for i in range(9, 12):
+    one = np.zeros((1, nv), np.float32)
+    assert L.reff_eval(ctx, toks[i:i + 1].ctypes.data, 1, i, 2, one.ctypes.data) == 0
+    dec.append(one)
+np.savez(out, pre=pre, dec=np.concatenate(dec))
+L.reff_free(ctx)
+"""
+
+
+@pytest.mark.parametrize("so", ["libfalcon_ref_shim.so", "libfalcon_ref_hip.so"])
+@pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
+                                       ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K)])
+def test_reference_code_on_libggml_hip_reproduces_reference_logits(oracle, golden, tmp_path, so, name, hp, t):
+    """the reference's falcon_init_from_file / falcon_eval / falcon_get_logits, with the offload (shim) or the device-resident
+    evaluation (wrap) underneath: prefill and decode logits == the pure-CPU reference's (run in a child process: the
+    reference's ggml_init starts its own CUDA-init thread and owns process-wide state)"""
+    import ggcc_writer
+    lib = _need(so)
+    gg = golden["ggcc_models"]
+    w = synth.make_model(oracle, hp, t, seed=4321)
+    path = str(tmp_path / (name + ".ggcc"))
+    ggcc_writer.write_ggcc(path, w)
+    toks = str(tmp_path / "toks.npy")
+    np.save(toks, gg[f"{name}_tokens"].astype(np.int32))
+    out = str(tmp_path / "out.npz")
+    script = str(tmp_path / "run.py")
+    open(script, "w").write(_LOGITS_SCRIPT)
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    r = subprocess.run([sys.executable, script, lib, path, str(hp["n_vocab"]), "100", out, toks], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if so.endswith("_hip.so"):
+        assert "resident on the device" in r.stderr
+    res = np.load(out)
+    assert np.array_equal(res["pre"], gg[f"{name}_prefill_logits"])
+    assert np.array_equal(res["dec"], gg[f"{name}_decode_logits"])
+
+
+def _cli_model(oracle, path):
+    import bpe_fixture
+    import ggcc_writer
+    vocab, merges = bpe_fixture.build(n_merges=308)
+    hp = dict(synth.HP_TINY_MQA)
+    hp["n_vocab"] = len(vocab)
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=321)
+    ggcc_writer.write_ggcc(path, w, vocab, merges)
+    return bpe_fixture
+
+
+def test_falcon_main_unchanged_on_the_fast_path(oracle, golden, tmp_path):
+    """the reference's falcon_main (examples/falcon/falcon_main.cpp, unchanged: its argument parser, tokenizer, repetition
+    penalty, greedy sampler, detokenizer) with falcon_eval on the device prints the same bytes as the pure-CPU build"""
+    exe = _need("falcon_main_hip")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    _cli_model(oracle, path)
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    r = subprocess.run([exe, "-m", path, "-p", "The quick brown fox didn't jump", "-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1"],
+                       capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert b"resident on the device" in r.stderr and b"device-resident path" in r.stderr
+    assert r.stdout == bytes(golden["cli"]["main_stdout"])
+
+
+def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path):
+    """the reference's falcon_perplexity tool, unchanged, with falcon_eval on the device: the chunk perplexities it prints"""
+    exe = _need("falcon_perplexity_hip")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    bf = _cli_model(oracle, path)
+    txt = str(tmp_path / "corpus.txt")
+    open(txt, "wb").write((bf.CORPUS * 2).encode("utf-8"))
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    r = subprocess.run([exe, "-m", path, "-f", txt, "-t", "2", "-c", "32", "-b", "8", "-s", "1"], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout == bytes(golden["cli"]["ppl_stdout"])
