@@ -25,7 +25,7 @@ TYPE_NAME = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0
              Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
 VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}
 
-EXPORTS_OPS = """ggml_hip_init ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
+EXPORTS_OPS = """ggml_hip_init ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
 ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
 ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_quantize_rows ggml_hip_weight_quantize ggml_hip_fp16_to_fp32_row ggml_hip_acts_alloc ggml_hip_acts_free
@@ -36,7 +36,10 @@ falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eva
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
 falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
-falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos""".split()
+falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
+falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
+falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_set_tokens
+falcon_hip_pipeline_run falcon_hip_pipeline_run_local falcon_hip_pipeline_get_history falcon_hip_pipeline_schedule""".split()
 
 
 def build(verbose=False):
@@ -74,7 +77,7 @@ def load():
         "ggml_hip_profile_begin": (None, []), "ggml_hip_profile_bracket_overhead_us": (C.c_double, []), "ggml_hip_profile_end": (None, [vp, vp, vp]),
         "ggml_hip_event_destroy": (None, [vp]), "ggml_hip_gelu_table_dev": (vp, []), "ggml_hip_exp_table_dev": (vp, []),
         "ggml_hip_weight_upload": (vp, [C.c_int, vp, i64, i64]), "ggml_hip_weight_free": (None, [vp]), "ggml_hip_weight_nbytes": (sz, [vp]),
-        "ggml_hip_dequantize_rows": (None, [vp, vp, i64, vp]), "ggml_hip_gemm_sequential": (None, [C.c_int]), "ggml_hip_reference_order": (None, [C.c_int]), "ggml_hip_get_reference_order": (C.c_int, []),
+        "ggml_hip_dequantize_rows": (None, [vp, vp, i64, vp]), "ggml_hip_gemm_sequential": (None, [C.c_int]), "ggml_hip_reference_order": (None, [C.c_int]), "ggml_hip_get_reference_order": (C.c_int, []), "ggml_hip_shim_pool_stats": (None, [vp, vp, vp]),
         "ggml_hip_quantize_rows": (C.c_int, [C.c_int, vp, i64, i64, vp, vp]), "ggml_hip_weight_quantize": (vp, [C.c_int, vp, i64, i64]),
         "ggml_hip_fp16_to_fp32_row": (None, [vp, vp, i64]),
         "ggml_hip_acts_alloc": (vp, [C.c_int, i64, i64]), "ggml_hip_acts_free": (None, [vp]),
@@ -88,6 +91,14 @@ def load():
         "falcon_hip_model_create": (vp, [C.POINTER(HParams)]), "falcon_hip_model_free": (None, [vp]),
         "falcon_hip_model_set_tensor": (C.c_int, [vp, C.c_char_p, C.c_int, vp, i64, i64]),
         "falcon_hip_model_weight_bytes": (sz, [vp]),
+        "falcon_hip_model_get_hparams": (None, [vp, vp]),
+        "falcon_hip_context_create_seqs": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_n_seq": (C.c_int, [vp]),
+        "falcon_hip_pipeline_unique_id": (C.c_int, [vp]), "falcon_hip_pipeline_create": (vp, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+        "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]),
+        "falcon_hip_pipeline_set_tokens": (C.c_int, [vp, vp]), "falcon_hip_pipeline_run": (C.c_int, [vp, C.c_int, C.c_int]),
+        "falcon_hip_pipeline_run_local": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "falcon_hip_pipeline_get_history": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+        "falcon_hip_pipeline_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_context_create": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_free": (None, [vp]),
         "falcon_hip_eval": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_eval_stage": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
@@ -387,6 +398,96 @@ class FalconModel:
         L = load()
         L.falcon_hip_context_free(self.ctx)
         L.falcon_hip_model_free(self.m)
+
+
+class SeqContext:
+    """n_seq independent sequences of one model advancing in lock step (falcon_hip_context_create_seqs): eval takes one
+    token per sequence and returns one logits row per sequence"""
+
+    def __init__(self, model, n_ctx, n_seq):
+        self.model, self.n_seq = model, n_seq
+        self.ctx = load().falcon_hip_context_create_seqs(model.m, n_ctx, n_seq, 0)
+        if not self.ctx:
+            raise RuntimeError("falcon_hip_context_create_seqs failed")
+
+    def eval(self, tokens, n_past):
+        L = load()
+        tok = np.ascontiguousarray(tokens, np.int32)
+        assert tok.size == self.n_seq
+        rc = L.falcon_hip_eval_stage(self.ctx, tok.ctypes.data, None, tok.size, n_past, 1, None)
+        if rc != 0:
+            raise RuntimeError("falcon_hip_eval_stage failed (%d)" % rc)
+        return np.ctypeslib.as_array(L.falcon_hip_get_logits(self.ctx), (self.n_seq, self.model.hp["n_vocab"])).copy()
+
+    def free(self):
+        load().falcon_hip_context_free(self.ctx)
+
+
+class Pipeline:
+    """falcon_hip_pipeline_* (csrc/falcon_pipeline.hip): rank `rank` of a `world`-stage layer pipeline over `model` (a
+    FalconModel holding that rank's blocks). unique_id: 128 bytes from Pipeline.unique_id() on rank 0 (RCCL transport), or
+    local=True for the in-process transport (all ranks in this process, see run_local)."""
+
+    def __init__(self, model, rank, world, n_groups, batch, n_ctx, unique_id=None, local=False):
+        L = load()
+        self.model, self.rank, self.world, self.G, self.B = model, rank, world, n_groups, batch
+        if local:
+            self.p = L.falcon_hip_pipeline_create_local(model.m, rank, world, n_groups, batch, n_ctx)
+        else:
+            self.p = L.falcon_hip_pipeline_create(model.m, rank, world, unique_id, n_groups, batch, n_ctx)
+        if not self.p:
+            raise RuntimeError("falcon_hip_pipeline_create failed")
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        if load().falcon_hip_pipeline_unique_id(buf) != 0:
+            raise RuntimeError("RCCL is not available")
+        return buf.raw
+
+    def set_tokens(self, tokens):
+        tok = np.ascontiguousarray(tokens, np.int32)
+        assert tok.size == self.G * self.B
+        if load().falcon_hip_pipeline_set_tokens(self.p, tok.ctypes.data) != 0:
+            raise RuntimeError("falcon_hip_pipeline_set_tokens failed")
+
+    def run(self, rounds, n_past0):
+        if load().falcon_hip_pipeline_run(self.p, rounds, n_past0) != 0:
+            raise RuntimeError("falcon_hip_pipeline_run failed")
+
+    @staticmethod
+    def run_local(ranks, rounds, n_past0):
+        arr = (C.c_void_p * len(ranks))(*[r.p for r in ranks])
+        if load().falcon_hip_pipeline_run_local(arr, len(ranks), rounds, n_past0) != 0:
+            raise RuntimeError("falcon_hip_pipeline_run_local failed")
+
+    def history(self, first_round, n_rounds):
+        """[n_rounds][n_groups * batch] sampled tokens (last rank; waits for the device); None on other ranks"""
+        out = np.zeros((n_rounds, self.G * self.B), np.int32)
+        rc = load().falcon_hip_pipeline_get_history(self.p, out.ctypes.data, first_round, n_rounds)
+        if rc == -1:
+            return None
+        if rc != 0:
+            raise RuntimeError("falcon_hip_pipeline_get_history failed (%d)" % rc)
+        return out
+
+    def free(self):
+        load().falcon_hip_pipeline_free(self.p)
+
+
+def pipeline_schedule(rank, world, n_groups, rounds):
+    """host only: the slots of one rank as [(exchange ops [(kind, group, peer)], computed group or None, round)], kinds
+    'send_hidden' 'send_token' 'recv_hidden' 'recv_token'"""
+    L = load()
+    names = ("send_hidden", "send_token", "recv_hidden", "recv_token")
+    out = (C.c_int * 9)()
+    T = L.falcon_hip_pipeline_schedule(rank, world, n_groups, rounds, -1, out)
+    slots = []
+    for t in range(T):
+        L.falcon_hip_pipeline_schedule(rank, world, n_groups, rounds, t, out)
+        ops = [(names[out[1 + 3 * i]], out[2 + 3 * i], out[3 + 3 * i]) for i in range(out[0])]
+        slots.append((ops, None if out[7] < 0 else out[7], out[8]))
+    return slots
 
 
 class Vocab:

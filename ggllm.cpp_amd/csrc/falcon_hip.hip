@@ -45,6 +45,10 @@ struct falcon_hip_model {
 struct falcon_hip_context {
     falcon_hip_model * m = nullptr;
     int n_ctx = 0, n_batch = 0, rope_n_ctx = 0;
+    // n_seq > 0: a context of n_seq independent sequences that advance in lock step (falcon_hip_context_create_seqs): every
+    // step evaluates one token of each, row t of the activations belongs to sequence t and attends to its own KV cache
+    // ([layer][seq][n_ctx][HKV][D]) -- one pass over the stage's weights serves n_seq tokens
+    int n_seq = 0;
     float * x = nullptr, * ln = nullptr, * ln2 = nullptr, * qkv = nullptr, * att = nullptr, * wo_out = nullptr, * up = nullptr;
     float * logits_dev = nullptr;
     // quantized-activation images. Each buffer holds the LARGEST image of its length (Q8_1: 1.25 bytes per element) and is
@@ -226,6 +230,7 @@ extern "C" int falcon_hip_model_set_tensor(falcon_hip_model * m, const char * na
     return -1;
 }
 
+extern "C" void falcon_hip_model_get_hparams(const falcon_hip_model * m, falcon_hip_hparams * hp_out) { *hp_out = m->hp; }
 extern "C" size_t falcon_hip_model_weight_bytes(const falcon_hip_model * m) { return m->weight_bytes; }
 
 static size_t act_col_bytes_max(int64_t K) {
@@ -239,7 +244,7 @@ static fq_act act_for(uint8_t * buf, const fq_weight & w, int64_t cols) {
     fq_act a{}; a.type = fq_desc(w.type).act_type; a.K = w.K; a.ncols = cols; a.base = buf; return a;
 }
 
-extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx) {
+static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx, int n_seq) {
     const falcon_hip_hparams & hp = m->hp;
     for (size_t i = 0; i < m->layers.size(); ++i) {
         const layer_weights & L = m->layers[i];
@@ -251,7 +256,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     if (m->last_stage() && (!m->lm_head.plane[0] || !m->out_norm_w || !m->out_norm_b)) { fprintf(stderr, "falcon-hip: missing ln_f / lm_head\n"); exit(1); }
 
     falcon_hip_context * c = new falcon_hip_context();
-    c->m = m; c->n_ctx = n_ctx; c->n_batch = n_batch; c->rope_n_ctx = rope_n_ctx > 0 ? rope_n_ctx : n_ctx;
+    c->m = m; c->n_ctx = n_ctx; c->n_batch = n_batch; c->rope_n_ctx = rope_n_ctx > 0 ? rope_n_ctx : n_ctx; c->n_seq = n_seq;
     const int64_t E = hp.n_embd, D = 64, QKV = (int64_t)(hp.n_head + 2 * hp.n_head_kv) * D, FF = hp.n_ff, B = n_batch;
     const int64_t nl = (int64_t) m->layers.size();
     c->x      = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
@@ -266,7 +271,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     c->buf_e2  = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(E) * (size_t) B + 256);
     c->buf_att = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(E) * (size_t) B + 256);
     c->buf_ff  = (uint8_t *) dev_alloc(c->allocs, act_col_bytes_max(FF) * (size_t) B + 256);
-    const size_t kvb = (size_t) nl * n_ctx * hp.n_head_kv * D * 4;
+    const size_t kvb = (size_t) nl * (n_seq > 0 ? n_seq : 1) * n_ctx * hp.n_head_kv * D * 4;
     c->k_cache = (float *) dev_alloc(c->allocs, kvb);
     c->v_cache = (float *) dev_alloc(c->allocs, kvb);
     HIP_CHECK(hipMemset(c->k_cache, 0, kvb ? kvb : 16));
@@ -297,6 +302,15 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
 }
+
+extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx) {
+    return context_create(m, n_ctx, n_batch, rope_n_ctx, 0);
+}
+extern "C" falcon_hip_context * falcon_hip_context_create_seqs(falcon_hip_model * m, int n_ctx, int n_seq, int rope_n_ctx) {
+    if (n_seq < 1 || n_seq > 64) { fprintf(stderr, "falcon-hip: a lock-step context holds 1..64 sequences, not %d\n", n_seq); return nullptr; }
+    return context_create(m, n_ctx, n_seq, rope_n_ctx, n_seq > 1 ? n_seq : 0);
+}
+extern "C" int falcon_hip_context_n_seq(const falcon_hip_context * c) { return c->n_seq > 0 ? c->n_seq : 1; }
 
 extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (!c) return;
@@ -463,6 +477,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
 
     // the fused kernels are instantiated per weight format: a model that mixes formats inside a block (e.g. the reference's
     // Q4_K_M for Falcon-7B: only the 18176-wide Wdown can hold 256-element super-blocks) takes the op list
+    const int64_t seq_stride = c->n_seq > 0 ? (int64_t) c->n_ctx * HKV * D : 0;             // lock-step sequences: one KV cache per row
+    const int64_t n_caches = c->n_seq > 0 ? c->n_seq : 1;
+    if (c->n_seq > 0 && N != c->n_seq) { fprintf(stderr, "falcon-hip: a context of %d lock-step sequences evaluates %d rows per step, not %d\n", c->n_seq, c->n_seq, N); exit(1); }
     if (N == 1 && stage_fused(c) && c->engine && !c->dual_stream && engine_prepare(c)) {
         // ---- the persistent engine: every block of the stage (+ ln_f, lm_head) in ONE launch (kernels_engine.hip)
         fq_engine_args a = c->eng;
@@ -532,8 +549,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st);
             }
             ln_done = false;
-            float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
-            float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
+            float * kc = c->k_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
+            float * vc = c->v_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
             const int att_act = fq_desc(L.wo.type).act_type;
             const bool att_q = (att_act == FQ_Q8_0 || att_act == FQ_Q8_1);      // the head's 64 outputs = two 32-blocks
             fq_gemv_out_args go{ L.down, L.wo, c->buf_ff, c->att, att_q ? c->buf_att : nullptr, c->x, c->x,
@@ -601,10 +618,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_qkv, st);
         }
         fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
-        float * kc = c->k_cache + li * (size_t) c->n_ctx * HKV * D;
-        float * vc = c->v_cache + li * (size_t) c->n_ctx * HKV * D;
-        fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st);
-        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st);
+        float * kc = c->k_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
+        float * vc = c->v_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
+        fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);
+        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride);
         const fq_act a_att = act_for(c->buf_att, L.wo, N), a_ff = act_for(c->buf_ff, L.down, N);
         fq_launch_quantize_act(c->att, E, a_att, st);
         fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
@@ -629,7 +646,8 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
                                      int n_past, int logits_all, float * hidden_out_dev) {
     hip_context & hc = fq_ctx();
     falcon_hip_model * m = c->m;
-    if (N < 1 || N > c->n_batch || n_past < 0 || n_past + N > c->n_ctx) {
+    const int adv = c->n_seq > 0 ? 1 : N;                            // lock-step sequences: N rows = one position of each of N sequences
+    if (N < 1 || N > c->n_batch || n_past < 0 || n_past + adv > c->n_ctx) {
         fprintf(stderr, "falcon-hip: eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, c->n_batch, c->n_ctx);
         exit(1);
     }
@@ -644,7 +662,7 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     if (m->first_stage()) HIP_CHECK(hipMemcpyAsync(c->tokens_dev, tokens, (size_t) N * 4, hipMemcpyHostToDevice, st));
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));        // n_past / tokens may live on the caller's stack
-    launch_stage(c, N, n_past + N, st);
+    launch_stage(c, N, n_past + adv, st);
     if (m->last_stage()) {
         const int64_t V = m->hp.n_vocab;
         if (logits_all) {
@@ -748,7 +766,26 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
 
 // ------------------------------------------------------------------------------------------------ pipeline step
 __global__ void k_set_i32(int * p, int v) { *p = v; }
-__global__ void k_copy_i32(int32_t * dst, const int32_t * src) { *dst = *src; }
+__global__ void k_copy_i32(int32_t * dst, const int32_t * src, int n = 1) { if ((int) threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
+// greedy sample of every row of a lock-step step: token[row] = argmax(logits[row]), lowest index on ties (as k_argmax_advance)
+__global__ void __launch_bounds__(1024) k_argmax_rows(const float * __restrict__ logits, int n, int32_t * __restrict__ token) {
+    __shared__ float bv[16];
+    __shared__ int   bi[16];
+    const float * vals = logits + (int64_t) blockIdx.x * n;
+    float best = -INFINITY; int idx = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = vals[i]; if (v > best || (v == best && i < idx)) { best = v; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(idx, o);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        token[blockIdx.x] = idx;
+    }
+}
 __global__ void k_inc_i32(int * p) { *p = *p + 1; }
 
 // One decode step of one pipeline stage, fully stream-ordered (no host synchronisation, no host memory): the token id
@@ -765,22 +802,25 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     c->keep_hidden = false;
     // body of one step; n_past_base >= 0: position baked into the launch arguments (plain launches), < 0: the position is
     // whatever n_past_dev holds and the step leaves n_past_dev + 1 behind (captured form, replayable)
+    const int B = c->n_seq > 0 ? c->n_seq : 1;                       // lock-step sequences: token_dev / next_token_dev hold B ids, the hidden rows are [B][n_embd]
     auto body = [&](int n_past_base, int max_kv) {
-        if (m->first_stage()) hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(1), 0, st, c->tokens_dev, token_dev);
-        else HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
-        launch_stage(c, 1, max_kv, st);
+        if (m->first_stage()) hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(64), 0, st, c->tokens_dev, token_dev, B);
+        else HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) B * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+        launch_stage(c, B, max_kv, st);
         bool advanced = false;
         if (m->last_stage()) {
             if (next_token_dev) {
                 // greedy sample; the loop-state outputs of k_argmax_advance go to scratch slots of this context
-                if (stage_fused(c))
+                if (B > 1)
+                    hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned) B), dim3(1024), 0, st, c->logits_dev, m->hp.n_vocab, next_token_dev);
+                else if (stage_fused(c))
                     hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(256), 0, st, c->argmax_val, c->argmax_idx, (m->hp.n_vocab + 31) / 32, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
                 else
                     hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, next_token_dev, c->n_past_dev, c->out_tokens_dev, n_past_base);
-                advanced = true;
+                advanced = B == 1;
             }
         } else if (hidden_out_dev) {
-            HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) B * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
         }
         if (n_past_base < 0 && !advanced) hipLaunchKernelGGL(k_inc_i32, dim3(1), dim3(1), 0, st, c->n_past_dev);
     };

@@ -1,0 +1,355 @@
+// falcon_pipeline.hip -- layer-pipelined multi-GPU decode in C++: one process per GPU, rank r holds a contiguous
+// range of Falcon blocks (falcon_hip_model with layer_begin / layer_end), and the ONLY exchange between ranks is the residual
+// rows [B][n_embd] f32 from stage to stage plus the B greedy-sampled token ids from the last stage back to stage 0 -- RCCL
+// ncclSend / ncclRecv inside one ncclGroupStart / ncclGroupEnd per slot, over xGMI, one link per hop. No all-reduce, no
+// all-gather, no host staging. What it replaces in the reference: the per-op device loop with peer copies of
+// ggml-cuda.cu:2586-2608, 2713-2732 (every mat-mul split over the devices, results gathered on the main device).
+//
+// A single decode stream is serial through the stages, so the pipeline keeps G GROUPS of B lock-step sequences in flight
+// (falcon_hip_context_create_seqs: one pass over the stage's weights serves the B tokens of a group through the N <= 4
+// mat-vec). Work item w = k * G + g is group g in round k. Two slot schedules (the same as bench_pipeline.PipelineRunner,
+// whose gloo tests pin them; falcon_hip_pipeline_schedule exposes this file's version to tests/test_pipeline_gloo.py):
+//
+//   G <  2P  rank r computes item t - r in slot t. At the start of the slot ONE grouped exchange sends the result of slot t-1
+//            to the next rank (last rank: the tokens, to rank 0) and receives the input of item t - r; all on the library stream.
+//   G >= 2P  a hop gets a whole slot: rank r computes item t - 2r in slot t; the exchange of slot t (result of slot t-1 out,
+//            input of slot t+1 in) runs on a second stream and is only waited for by the compute of slot t+1, so every
+//            transfer overlaps a stage step.
+//
+// Send and receive of a slot are posted in one group, so the ring cannot deadlock. RCCL is bound at run time (dlopen of
+// librccl.so.1, the copy already in the process if there is one): single-GPU users of libggml_hip.so do not need it.
+// A LOCAL transport (every rank a falcon_hip_pipeline of the same process and device, hand-off by device copies) runs the
+// identical schedule and stage code on one GPU: falcon_hip_pipeline_run_local, used by tests/test_gpu_pipeline.py.
+#include "../../include/falcon-hip.h"
+#include "../../include/ggml-hip-ops.h"
+#include "fq_device.h"
+#include "hip_context.h"
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ RCCL, bound at run time
+struct rccl_api {
+    void * lib = nullptr;
+    ncclResult_t (*ncclGetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*ncclCommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*ncclCommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*ncclSend)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ncclRecv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ncclGroupStart)() = nullptr;
+    ncclResult_t (*ncclGroupEnd)() = nullptr;
+    const char * (*ncclGetErrorString)(ncclResult_t) = nullptr;
+};
+
+rccl_api * rccl() {
+    static rccl_api api; static std::once_flag once; static bool ok = false;
+    std::call_once(once, [] {
+        for (const char * name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { fprintf(stderr, "falcon-hip: pipeline: librccl.so.1 not found (%s)\n", dlerror()); return; }
+        bool all = true;
+        auto bind = [&](const char * sym) { void * p = dlsym(api.lib, sym); if (!p) { fprintf(stderr, "falcon-hip: pipeline: %s missing from RCCL\n", sym); all = false; } return p; };
+        api.ncclGetUniqueId    = (decltype(api.ncclGetUniqueId))    bind("ncclGetUniqueId");
+        api.ncclCommInitRank   = (decltype(api.ncclCommInitRank))   bind("ncclCommInitRank");
+        api.ncclCommDestroy    = (decltype(api.ncclCommDestroy))    bind("ncclCommDestroy");
+        api.ncclSend           = (decltype(api.ncclSend))           bind("ncclSend");
+        api.ncclRecv           = (decltype(api.ncclRecv))           bind("ncclRecv");
+        api.ncclGroupStart     = (decltype(api.ncclGroupStart))     bind("ncclGroupStart");
+        api.ncclGroupEnd       = (decltype(api.ncclGroupEnd))       bind("ncclGroupEnd");
+        api.ncclGetErrorString = (decltype(api.ncclGetErrorString)) bind("ncclGetErrorString");
+        ok = all;
+    });
+    return ok ? &api : nullptr;
+}
+
+#define RCCL_CHECK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    fprintf(stderr, "falcon-hip: pipeline: %s failed: %s (%s:%d)\n", #call, rccl()->ncclGetErrorString(r_), __FILE__, __LINE__); abort(); } } while (0)
+
+// ------------------------------------------------------------------------------------------------ the slot schedule (host only)
+enum { OP_SEND_HIDDEN = 0, OP_SEND_TOKEN = 1, OP_RECV_HIDDEN = 2, OP_RECV_TOKEN = 3 };
+struct pipe_op   { int kind, group, peer; };
+struct pipe_slot { int n_ops = 0; pipe_op op[2]; int group = -1, round = -1; };
+
+bool overlapped(int P, int G) { return P > 1 && G >= 2 * P; }
+int  slot_count(int P, int G, int W) { return P == 1 ? W : (overlapped(P, G) ? W + 2 * P : W + P); }
+
+pipe_slot slot_of(int r, int P, int G, int W, int t) {
+    pipe_slot s;
+    if (P == 1) { s.group = t % G; s.round = t / G; return s; }
+    const bool first = r == 0, last = r == P - 1;
+    const int hop = overlapped(P, G) ? 2 : 1;                       // slots between the computes of one item on neighbouring ranks
+    const int w_prev = t - 1 - hop * r;                              // the item this rank computed in the previous slot
+    if (w_prev >= 0 && w_prev < W) s.op[s.n_ops++] = last ? pipe_op{ OP_SEND_TOKEN, w_prev % G, 0 } : pipe_op{ OP_SEND_HIDDEN, w_prev % G, r + 1 };
+    if (hop == 1) {
+        if (first) { const int x = t - P;          if (x >= 0 && x < W) s.op[s.n_ops++] = { OP_RECV_TOKEN,  x % G, P - 1 }; }
+        else       { const int w = t - r;          if (w >= 0 && w < W) s.op[s.n_ops++] = { OP_RECV_HIDDEN, w % G, r - 1 }; }
+    } else {
+        if (first) { const int x = t - 2 * P + 1;  if (x >= 0 && x < W) s.op[s.n_ops++] = { OP_RECV_TOKEN,  x % G, P - 1 }; }   // the tokens the last rank sends in this slot
+        else       { const int w = t + 1 - 2 * r;  if (w >= 0 && w < W) s.op[s.n_ops++] = { OP_RECV_HIDDEN, w % G, r - 1 }; }   // the input of the NEXT slot
+    }
+    const int w = t - hop * r;
+    if (w >= 0 && w < W) { s.group = w % G; s.round = w / G; }
+    return s;
+}
+
+}   // namespace
+
+// ------------------------------------------------------------------------------------------------ the pipeline object
+struct falcon_hip_pipeline {
+    falcon_hip_model * m = nullptr;
+    falcon_hip_hparams hp{};
+    int rank = 0, world = 1, G = 1, B = 1, n_ctx = 0;
+    bool first = true, last = true;
+    std::vector<falcon_hip_context *> ctx;                          // one lock-step context per group
+    std::vector<float *>   hidden_in, hidden_out;                   // [B][n_embd] per group
+    std::vector<int32_t *> tok_in, tok_out;                         // [B] per group
+    std::vector<float *>   mb_hidden; std::vector<int32_t *> mb_tok; // local transport: this rank's mailboxes, per group
+    int32_t * hist = nullptr;                                       // last rank: [n_ctx][G * B] sampled tokens, by round
+    int rounds_done = 0;
+    ncclComm_t comm = nullptr;                                      // world > 1 and not the local transport
+    bool local = false;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_compute[4] = {}, ev_comm[4] = {}, ev_start = nullptr;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+void * palloc(falcon_hip_pipeline * p, size_t bytes) {
+    void * d = nullptr;
+    HIP_CHECK(hipMalloc(&d, bytes ? bytes : 16));
+    HIP_CHECK(hipMemset(d, 0, bytes ? bytes : 16));
+    p->allocs.push_back(d);
+    return d;
+}
+
+void compute(falcon_hip_pipeline * p, const pipe_slot & s, int n_past0, hipStream_t st) {
+    if (s.group < 0) return;
+    const int g = s.group;
+    falcon_hip_stage_step(p->ctx[(size_t) g], p->tok_in[(size_t) g], p->hidden_in[(size_t) g], n_past0 + s.round, p->hidden_out[(size_t) g], p->tok_out[(size_t) g]);
+    if (p->last) {
+        const int slot = p->rounds_done + s.round;
+        if (slot < p->n_ctx)
+            HIP_CHECK(hipMemcpyAsync(p->hist + ((size_t) slot * p->G + g) * p->B, p->tok_out[(size_t) g], (size_t) p->B * 4, hipMemcpyDeviceToDevice, st));
+    }
+}
+
+// one grouped RCCL exchange: every send and receive of the slot between ncclGroupStart and ncclGroupEnd
+void exchange_rccl(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st) {
+    if (!s.n_ops) return;
+    rccl_api * R = rccl();
+    const size_t nh = (size_t) p->B * p->hp.n_embd, nt = (size_t) p->B;
+    RCCL_CHECK(R->ncclGroupStart());
+    for (int i = 0; i < s.n_ops; ++i) {
+        const pipe_op & o = s.op[i];
+        const size_t g = (size_t) o.group;
+        switch (o.kind) {
+            case OP_SEND_HIDDEN: RCCL_CHECK(R->ncclSend(p->hidden_out[g], nh, ncclFloat32, o.peer, p->comm, st)); break;
+            case OP_SEND_TOKEN:  RCCL_CHECK(R->ncclSend(p->tok_out[g],    nt, ncclInt32,   o.peer, p->comm, st)); break;
+            case OP_RECV_HIDDEN: RCCL_CHECK(R->ncclRecv(p->hidden_in[g],  nh, ncclFloat32, o.peer, p->comm, st)); break;
+            case OP_RECV_TOKEN:  RCCL_CHECK(R->ncclRecv(p->tok_in[g],     nt, ncclInt32,   o.peer, p->comm, st)); break;
+        }
+    }
+    RCCL_CHECK(R->ncclGroupEnd());
+}
+
+falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx) {
+    if (!m || world < 1 || rank < 0 || rank >= world || n_groups < 1 || batch < 1 || batch > 64 || n_ctx < 1) {
+        fprintf(stderr, "falcon-hip: pipeline: bad arguments (rank %d of %d, %d groups of %d sequences, n_ctx %d)\n", rank, world, n_groups, batch, n_ctx);
+        return nullptr;
+    }
+    if (world > 1 && n_groups < world) { fprintf(stderr, "falcon-hip: pipeline: %d stages need at least %d groups in flight (got %d)\n", world, world, n_groups); return nullptr; }
+    falcon_hip_pipeline * p = new falcon_hip_pipeline();
+    p->m = m; p->rank = rank; p->world = world; p->G = n_groups; p->B = batch; p->n_ctx = n_ctx;
+    falcon_hip_model_get_hparams(m, &p->hp);
+    p->first = p->hp.layer_begin == 0; p->last = p->hp.layer_end == p->hp.n_layer;
+    if ((rank == 0) != p->first || (rank == world - 1) != p->last) {
+        fprintf(stderr, "falcon-hip: pipeline: rank %d of %d holds blocks [%d, %d) of %d: the first rank must hold block 0, the last rank the last block\n",
+                rank, world, p->hp.layer_begin, p->hp.layer_end, p->hp.n_layer);
+        delete p; return nullptr;
+    }
+    const size_t E = (size_t) p->hp.n_embd;
+    for (int g = 0; g < n_groups; ++g) {
+        p->ctx.push_back(falcon_hip_context_create_seqs(m, n_ctx, batch, n_ctx));
+        p->hidden_in.push_back((float *) palloc(p, (size_t) batch * E * 4));
+        p->hidden_out.push_back((float *) palloc(p, (size_t) batch * E * 4));
+        p->tok_in.push_back((int32_t *) palloc(p, (size_t) batch * 4));
+        p->tok_out.push_back((int32_t *) palloc(p, (size_t) batch * 4));
+        p->mb_hidden.push_back((float *) palloc(p, (size_t) batch * E * 4));
+        p->mb_tok.push_back((int32_t *) palloc(p, (size_t) batch * 4));
+    }
+    if (p->last) p->hist = (int32_t *) palloc(p, (size_t) n_ctx * n_groups * batch * 4);
+    HIP_CHECK(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {
+        HIP_CHECK(hipEventCreateWithFlags(&p->ev_compute[i], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&p->ev_comm[i], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
+    return p;
+}
+
+}   // namespace
+
+extern "C" {
+
+int falcon_hip_pipeline_unique_id(void * id_out) {
+    rccl_api * R = rccl();
+    if (!R) return -1;
+    ncclUniqueId id;
+    if (R->ncclGetUniqueId(&id) != ncclSuccess) return -1;
+    memcpy(id_out, &id, FALCON_HIP_PIPELINE_ID_BYTES);
+    return 0;
+}
+
+falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank, int world, const void * unique_id, int n_groups, int batch, int n_ctx) {
+    static_assert(sizeof(ncclUniqueId) == FALCON_HIP_PIPELINE_ID_BYTES, "unique id size");
+    falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
+    if (!p || world == 1) return p;
+    rccl_api * R = rccl();
+    if (!R || !unique_id) { fprintf(stderr, "falcon-hip: pipeline: %s\n", R ? "no unique id" : "RCCL is not available"); falcon_hip_pipeline_free(p); return nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t rc = R->ncclCommInitRank(&p->comm, world, id, rank);
+    if (rc != ncclSuccess) { fprintf(stderr, "falcon-hip: pipeline: ncclCommInitRank(rank %d of %d): %s\n", rank, world, R->ncclGetErrorString(rc)); p->comm = nullptr; falcon_hip_pipeline_free(p); return nullptr; }
+    return p;
+}
+
+falcon_hip_pipeline * falcon_hip_pipeline_create_local(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx) {
+    falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
+    if (p) p->local = true;
+    return p;
+}
+
+void falcon_hip_pipeline_free(falcon_hip_pipeline * p) {
+    if (!p) return;
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+    if (p->comm_stream) HIP_CHECK(hipStreamSynchronize(p->comm_stream));
+    if (p->comm) rccl()->ncclCommDestroy(p->comm);
+    for (falcon_hip_context * c : p->ctx) falcon_hip_context_free(c);
+    for (int i = 0; i < 4; ++i) { if (p->ev_compute[i]) HIP_CHECK(hipEventDestroy(p->ev_compute[i])); if (p->ev_comm[i]) HIP_CHECK(hipEventDestroy(p->ev_comm[i])); }
+    if (p->ev_start) HIP_CHECK(hipEventDestroy(p->ev_start));
+    if (p->comm_stream) HIP_CHECK(hipStreamDestroy(p->comm_stream));
+    for (void * d : p->allocs) HIP_CHECK(hipFree(d));
+    delete p;
+}
+
+int falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * tokens) {
+    for (int i = 0; i < p->G * p->B; ++i) if (tokens[i] < 0 || tokens[i] >= p->hp.n_vocab) {
+        fprintf(stderr, "falcon-hip: pipeline: token id %d of sequence %d is outside [0, %d)\n", tokens[i], i, p->hp.n_vocab);
+        return 2;
+    }
+    hipStream_t st = fq_ctx().stream;
+    for (int g = 0; g < p->G; ++g) HIP_CHECK(hipMemcpyAsync(p->tok_in[(size_t) g], tokens + (size_t) g * p->B, (size_t) p->B * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Advance every sequence by `rounds` tokens from position n_past0: all device work is enqueued, nothing is waited for
+// (falcon_hip_pipeline_get_history or ggml_hip_synchronize waits). Every rank of the job makes the same call.
+int falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0) {
+    if (rounds < 1 || n_past0 < 0 || n_past0 + rounds > p->n_ctx) { fprintf(stderr, "falcon-hip: pipeline: %d rounds from position %d exceed n_ctx %d\n", rounds, n_past0, p->n_ctx); return 1; }
+    if (p->world > 1 && (p->local || !p->comm)) { fprintf(stderr, "falcon-hip: pipeline: this rank has no RCCL communicator (local transport: falcon_hip_pipeline_run_local)\n"); return 1; }
+    hipStream_t st = fq_ctx().stream;
+    const int P = p->world, G = p->G, W = rounds * G, T = slot_count(P, G, W);
+    if (P == 1) {
+        for (int t = 0; t < T; ++t) {
+            const pipe_slot s = slot_of(0, 1, G, W, t);
+            compute(p, s, n_past0, st);
+            HIP_CHECK(hipMemcpyAsync(p->tok_in[(size_t) s.group], p->tok_out[(size_t) s.group], (size_t) p->B * 4, hipMemcpyDeviceToDevice, st));   // the sampled tokens are the next inputs
+        }
+    } else if (!overlapped(P, G)) {
+        for (int t = 0; t < T; ++t) {
+            const pipe_slot s = slot_of(p->rank, P, G, W, t);
+            exchange_rccl(p, s, st);
+            compute(p, s, n_past0, st);
+        }
+    } else {
+        HIP_CHECK(hipEventRecord(p->ev_start, st));
+        HIP_CHECK(hipStreamWaitEvent(p->comm_stream, p->ev_start, 0));                 // everything enqueued before this call
+        for (int t = 0; t < T; ++t) {
+            const pipe_slot s = slot_of(p->rank, P, G, W, t);
+            if (t > 0) HIP_CHECK(hipStreamWaitEvent(p->comm_stream, p->ev_compute[(t - 1) & 3], 0));   // the result it sends
+            exchange_rccl(p, s, p->comm_stream);
+            HIP_CHECK(hipEventRecord(p->ev_comm[t & 3], p->comm_stream));
+            if (t > 0) HIP_CHECK(hipStreamWaitEvent(st, p->ev_comm[(t - 1) & 3], 0));                  // the input it received one slot ago
+            compute(p, s, n_past0, st);
+            HIP_CHECK(hipEventRecord(p->ev_compute[t & 3], st));
+        }
+        HIP_CHECK(hipStreamWaitEvent(st, p->ev_comm[(T - 1) & 3], 0));
+    }
+    p->rounds_done += rounds;
+    return 0;
+}
+
+// The same schedule with every rank in THIS process on one device: hand-off through the receiver's mailboxes by device copies
+// on the library stream (sends of a slot, then its receives, then its stage steps -- what one grouped exchange guarantees).
+int falcon_hip_pipeline_run_local(falcon_hip_pipeline ** ranks, int world, int rounds, int n_past0) {
+    if (world < 1) return 1;
+    const int G = ranks[0]->G, B = ranks[0]->B, W = rounds * G, T = slot_count(world, G, W);
+    for (int r = 0; r < world; ++r) {
+        falcon_hip_pipeline * p = ranks[r];
+        if (!p->local || p->world != world || p->rank != r || p->G != G || p->B != B || n_past0 + rounds > p->n_ctx || n_past0 < 0 || rounds < 1) {
+            fprintf(stderr, "falcon-hip: pipeline: run_local needs the %d local-transport ranks of one job, in rank order, with room for the rounds\n", world);
+            return 1;
+        }
+    }
+    hipStream_t st = fq_ctx().stream;
+    const size_t nh = (size_t) B * ranks[0]->hp.n_embd * 4, nt = (size_t) B * 4;
+    std::vector<pipe_slot> s((size_t) world);
+    for (int t = 0; t < T; ++t) {
+        for (int r = 0; r < world; ++r) s[(size_t) r] = slot_of(r, world, G, W, t);
+        for (int r = 0; r < world; ++r) for (int i = 0; i < s[(size_t) r].n_ops; ++i) {
+            const pipe_op & o = s[(size_t) r].op[i]; const size_t g = (size_t) o.group;
+            if (o.kind == OP_SEND_HIDDEN) HIP_CHECK(hipMemcpyAsync(ranks[o.peer]->mb_hidden[g], ranks[r]->hidden_out[g], nh, hipMemcpyDeviceToDevice, st));
+            if (o.kind == OP_SEND_TOKEN)  HIP_CHECK(hipMemcpyAsync(ranks[o.peer]->mb_tok[g],    ranks[r]->tok_out[g],    nt, hipMemcpyDeviceToDevice, st));
+        }
+        for (int r = 0; r < world; ++r) for (int i = 0; i < s[(size_t) r].n_ops; ++i) {
+            const pipe_op & o = s[(size_t) r].op[i]; const size_t g = (size_t) o.group;
+            if (o.kind == OP_RECV_HIDDEN) HIP_CHECK(hipMemcpyAsync(ranks[r]->hidden_in[g], ranks[r]->mb_hidden[g], nh, hipMemcpyDeviceToDevice, st));
+            if (o.kind == OP_RECV_TOKEN)  HIP_CHECK(hipMemcpyAsync(ranks[r]->tok_in[g],    ranks[r]->mb_tok[g],    nt, hipMemcpyDeviceToDevice, st));
+        }
+        for (int r = 0; r < world; ++r) {
+            compute(ranks[r], s[(size_t) r], n_past0, st);
+            if (world == 1) HIP_CHECK(hipMemcpyAsync(ranks[0]->tok_in[(size_t) s[0].group], ranks[0]->tok_out[(size_t) s[0].group], nt, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    for (int r = 0; r < world; ++r) ranks[r]->rounds_done += rounds;
+    return 0;
+}
+
+// last rank: the tokens sampled in rounds [first_round, first_round + n_rounds) since the pipeline was created, [round][G * B]
+// (sequence i = g * B + b). Waits for the device. Returns 0, -1 on another rank, 3 if an in-launch hand-off timed out.
+int falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, int first_round, int n_rounds) {
+    hipStream_t st = fq_ctx().stream;
+    if (!p->last) { HIP_CHECK(hipStreamSynchronize(st)); return -1; }
+    if (first_round < 0 || n_rounds < 0 || first_round + n_rounds > p->rounds_done || first_round + n_rounds > p->n_ctx) return 1;
+    HIP_CHECK(hipMemcpyAsync(out, p->hist + (size_t) first_round * p->G * p->B, (size_t) n_rounds * p->G * p->B * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (falcon_hip_context * c : p->ctx) if (falcon_hip_context_sync_error(c)) return 3;
+    return 0;
+}
+
+// host only (tests): slot `slot` of rank `rank` when `rounds` rounds of n_groups groups run over `world` ranks:
+// out[0] = number of exchange ops (<= 2), out[1 + 3 i ..] = { kind (0 send hidden, 1 send tokens, 2 recv hidden, 3 recv tokens),
+// group, peer }, out[7] = group computed in this slot (-1: none), out[8] = its round. Returns the number of slots of the run.
+int falcon_hip_pipeline_schedule(int rank, int world, int n_groups, int rounds, int slot, int * out) {
+    const int W = rounds * n_groups, T = slot_count(world, n_groups, W);
+    if (slot < 0 || slot >= T) return T;
+    const pipe_slot s = slot_of(rank, world, n_groups, W, slot);
+    for (int i = 0; i < 9; ++i) out[i] = -1;
+    out[0] = s.n_ops;
+    for (int i = 0; i < s.n_ops; ++i) { out[1 + 3 * i] = s.op[i].kind; out[2 + 3 * i] = s.op[i].group; out[3 + 3 * i] = s.op[i].peer; }
+    out[7] = s.group; out[8] = s.round;
+    return T;
+}
+
+}

@@ -12,6 +12,7 @@
 #include "hip_context.h"
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string.h>
 
@@ -93,8 +94,78 @@ extern "C" void ggml_cuda_set_tensor_split_prepare(const float * ts, int n) { fo
 extern "C" void ggml_cuda_set_tensor_split(const float * ts) { if (ts) memcpy(g_tensor_split, ts, sizeof(g_tensor_split)); }
 extern "C" void ggml_cuda_set_scratch_size(size_t s)      { g_scratch_size = s; }
 extern "C" void ggml_cuda_free_scratch(void)              { g_scratch_size = 0; }
-extern "C" void ggml_cuda_pool_reset_all_counters(int)    {}
-extern "C" int  ggml_cuda_pool_purge_buffers_with_access_count(int, int) { return 0; }
+// ---------------------------------------------------------------------------------------------- staging-buffer pool
+// The per-op staging buffers (src1 in, dst out) come from a pool instead of a hipMalloc / hipFree pair per graph node --
+// the role of ggml_cuda_pool_malloc / ggml_cuda_pool_free in the reference (ggml-cuda.cu:1738-1816). Free buffers are kept
+// in a size-ordered map: a request takes the smallest free buffer that holds it (and is not more than 4x too large, so
+// a prefill-sized buffer is not pinned under a decode-sized request), otherwise allocates with 1/16 head-room rounded up to
+// 256 KiB so that slowly growing requests (n_past) reuse the buffer. Every hand-out counts as an access; falcon_eval's
+// housekeeping (libfalcon.cpp:4573-4587) purges free buffers nobody asked for since the last reset.
+namespace {
+struct pool_buf { void * ptr; size_t size; int access; };
+struct shim_pool {
+    std::mutex mu;
+    std::multimap<size_t, pool_buf> free_;                  // by size
+    std::map<void *, pool_buf> busy_;
+    size_t n_alloc = 0, n_reuse = 0;
+};
+shim_pool & pool() { static shim_pool p; return p; }
+
+void * pool_get(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    shim_pool & P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.free_.lower_bound(bytes);
+    if (it != P.free_.end() && it->first <= 4 * bytes + (1u << 20)) {
+        pool_buf b = it->second; P.free_.erase(it);
+        ++b.access; ++P.n_reuse;
+        P.busy_[b.ptr] = b;
+        return b.ptr;
+    }
+    pool_buf b;
+    b.size = (bytes + bytes / 16 + 262143) & ~(size_t) 262143;
+    b.ptr = ggml_hip_malloc(b.size); b.access = 1;
+    ++P.n_alloc;
+    P.busy_[b.ptr] = b;
+    return b.ptr;
+}
+void pool_put(void * p) {
+    if (!p) return;
+    shim_pool & P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.busy_.find(p);
+    if (it == P.busy_.end()) { fprintf(stderr, "ggml-hip: pool_put of a pointer the pool did not hand out\n"); abort(); }
+    P.free_.emplace(it->second.size, it->second);
+    P.busy_.erase(it);
+}
+}   // namespace
+
+extern "C" void ggml_cuda_pool_reset_all_counters(int device_id) {                                  // ggml-cuda.cu:1843-1853
+    if (device_id != g_status.main_device_id) return;
+    shim_pool & P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto & kv : P.free_) kv.second.access = 0;
+    for (auto & kv : P.busy_) kv.second.access = 0;
+}
+extern "C" int ggml_cuda_pool_purge_buffers_with_access_count(int min_access_count, int device_id) { // ggml-cuda.cu:1818-1841
+    if (device_id != g_status.main_device_id) return 0;
+    shim_pool & P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    int purged = 0;
+    for (auto it = P.free_.begin(); it != P.free_.end(); ) {
+        if (it->second.access < min_access_count) { ggml_hip_free(it->second.ptr); it = P.free_.erase(it); ++purged; }
+        else ++it;
+    }
+    return purged;
+}
+// test hook: buffers allocated / hand-outs served from the pool / buffers currently free
+extern "C" void ggml_hip_shim_pool_stats(size_t * n_alloc, size_t * n_reuse, size_t * n_free) {
+    shim_pool & P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (n_alloc) *n_alloc = P.n_alloc;
+    if (n_reuse) *n_reuse = P.n_reuse;
+    if (n_free)  *n_free  = P.free_.size();
+}
 
 // ---------------------------------------------------------------------------------------------- pinned host memory
 extern "C" void * ggml_cuda_host_malloc(size_t size) {                              // ggml-cuda.cu:2079-2098
@@ -167,12 +238,12 @@ extern "C" void ggml_cuda_mul(const ggml_tensor * src0, const ggml_tensor * src1
     // dst = src0 * src1 with src1 (a [ne10] f32 weight resident in HBM) broadcast over rows; src0/dst are host f32
     hip_context & c = fq_ctx();
     const int64_t n = src0->ne[0] * src0->ne[1] * src0->ne[2] * src0->ne[3];
-    float * a = (float *) ggml_hip_malloc((size_t) n * 4), * y = (float *) ggml_hip_malloc((size_t) n * 4);
+    float * a = (float *) pool_get((size_t) n * 4), * y = (float *) pool_get((size_t) n * 4);
     ggml_hip_memcpy_h2d(a, src0->data, (size_t) n * 4);
     const float * w = (const float *) ((shim_extra *) src1->extra)->data_device[0];
     hipLaunchKernelGGL(k_mul_rows, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, c.stream, a, w, y, n, src1->ne[0]);
     ggml_hip_memcpy_d2h(dst->data, y, (size_t) n * 4);
-    ggml_hip_free(a); ggml_hip_free(y);
+    pool_put(a); pool_put(y);
 }
 
 static void shim_mul_mat(const ggml_tensor * src0, const ggml_tensor * src1, ggml_tensor * dst) {                 // ggml-cuda.cu:2931-2951 + 2520-2820
@@ -181,11 +252,11 @@ static void shim_mul_mat(const ggml_tensor * src0, const ggml_tensor * src1, ggm
         fprintf(stderr, "ggml-hip: mul_mat '%s': non-contiguous src1/dst are not supported by the shim\n", dst->name); exit(1);
     }
     const ggml_hip_weight * w = (const ggml_hip_weight *) ((shim_extra *) src0->extra)->data_device[0];
-    float * x = (float *) ggml_hip_malloc((size_t) N * K * 4), * y = (float *) ggml_hip_malloc((size_t) N * M * 4);
+    float * x = (float *) pool_get((size_t) N * K * 4), * y = (float *) pool_get((size_t) N * M * 4);
     ggml_hip_memcpy_h2d(x, src1->data, (size_t) N * K * 4);                         // reference: H2D of src1 every op (ggml-cuda.cu:2717)
     ggml_hip_mul_mat_q(w, x, K, N, y, M);
     ggml_hip_memcpy_d2h(dst->data, y, (size_t) N * M * 4);                          // reference: D2H of dst every op (ggml-cuda.cu:2787-2791)
-    ggml_hip_free(x); ggml_hip_free(y);
+    pool_put(x); pool_put(y);
     dst->meta.cuda_perf_mal_mul_type = 1;                                           // "quantized kernel" tag of the timing table
 }
 

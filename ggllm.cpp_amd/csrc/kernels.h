@@ -45,12 +45,14 @@ void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const floa
 void   fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st);
 void   fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st);
 void   fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st);
-// qkv: [N][(H+2HKV)*D] fused rows; rotates Q (in place) and K, appends K/V at positions n_past.. of the layer's cache
+// qkv: [N][(H+2HKV)*D] fused rows; rotates Q (in place) and K, appends K/V at positions n_past.. of the layer's cache.
+// seq_stride > 0 (both launchers): the N rows are N independent sequences, all at position n_past, row t with its own
+// cache at k_cache / v_cache + t * seq_stride floats
 void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs,
-                         float * k_cache, float * v_cache, hipStream_t st);
+                         float * k_cache, float * v_cache, hipStream_t st, int64_t seq_stride = 0);
 // att[N][H*D] = softmax(mask(K.Q * scale)) V, one workgroup per (head, token)
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
-                           const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st);
+                           const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride = 0);
 
 int    fq_selftest_reduce(hipStream_t st);
 int    fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st);   // number of non-NaN inputs where the formula != table   // 0 = DPP wave reductions agree with the __shfl_xor butterfly

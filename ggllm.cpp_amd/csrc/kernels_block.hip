@@ -76,8 +76,10 @@ void fq_launch_add3(const float * a, const float * b, const float * c, float * y
 // ------------------------------------------------------------------------------------------------ rope + KV append
 // thread = one rotation pair (or one V element pair). Heads 0..H-1 are Q (rotated in place), H..H+HKV-1 are K
 // (rotated into the cache), H+HKV.. are V (copied into the cache). Caches: [n_ctx][HKV][D] f32 for this layer.
+// seq_stride > 0: the N rows are N independent sequences at the SAME position n_past, row t owning the cache at
+// kc / vc + t * seq_stride (lock-step decode streams of one pipeline stage step)
 __global__ void k_rope_kv(float * __restrict__ qkv, int N, int H, int HKV, int D, const int * __restrict__ n_past_ptr, const float * __restrict__ cs,
-                          float * __restrict__ kc, float * __restrict__ vc) {
+                          float * __restrict__ kc, float * __restrict__ vc, int64_t seq_stride) {
     const int half = D >> 1;
     const int heads = H + 2 * HKV;
     const int n_past = *n_past_ptr;          // device scalar: one captured hipGraph serves every decode step
@@ -87,23 +89,25 @@ __global__ void k_rope_kv(float * __restrict__ qkv, int N, int H, int HKV, int D
         const int h = (int)((i / half) % heads);
         const int t = (int)(i / ((int64_t) half * heads));
         float * v = qkv + ((int64_t) t * heads + h) * D;
-        const int pos = n_past + t;
+        const int pos = seq_stride ? n_past : n_past + t;
+        float * kcs = kc + (int64_t) t * seq_stride, * vcs = vc + (int64_t) t * seq_stride;
         if (h < H + HKV) {
             const float c = cs[((int64_t) pos * half + k) * 2], s = cs[((int64_t) pos * half + k) * 2 + 1];
             const float x0 = v[k], x1 = v[k + half];
             const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;     // ggml.c:12974-12975
             if (h < H) { v[k] = r0; v[k + half] = r1; }
-            else { float * o = kc + ((int64_t) pos * HKV + (h - H)) * D; o[k] = r0; o[k + half] = r1; }
+            else { float * o = kcs + ((int64_t) pos * HKV + (h - H)) * D; o[k] = r0; o[k + half] = r1; }
         } else {
-            float * o = vc + ((int64_t) pos * HKV + (h - H - HKV)) * D;
+            float * o = vcs + ((int64_t) pos * HKV + (h - H - HKV)) * D;
             o[k] = v[k]; o[k + half] = v[k + half];
         }
     }
 }
-void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs, float * k_cache, float * v_cache, hipStream_t st) {
+void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs, float * k_cache, float * v_cache, hipStream_t st,
+                       int64_t seq_stride) {
     const int64_t total = (int64_t) N * (H + 2 * HKV) * (D / 2);
     const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(k_rope_kv, dim3(blocks), dim3(256), 0, st, qkv, N, H, HKV, D, n_past_dev, rope_cs, k_cache, v_cache);
+    hipLaunchKernelGGL(k_rope_kv, dim3(blocks), dim3(256), 0, st, qkv, N, H, HKV, D, n_past_dev, rope_cs, k_cache, v_cache, seq_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -112,11 +116,12 @@ void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_
 template <bool F64>
 __global__ void __launch_bounds__(256) k_attention(const float * __restrict__ qkv, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                    const float * __restrict__ kc, const float * __restrict__ vc,
-                                                   const uint16_t * __restrict__ exp_tab, float * __restrict__ att) {
+                                                   const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int64_t seq_stride) {
     constexpr int D = 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int h = blockIdx.x, t = blockIdx.y;
-    const int n_kv = *n_past_ptr + t + 1;
+    const int n_kv = *n_past_ptr + (seq_stride ? 0 : t) + 1;
+    kc += (int64_t) t * seq_stride; vc += (int64_t) t * seq_stride;
     const int heads = H + 2 * HKV;
     const int hk = h / (H / HKV);
     const attn_lds L = attn_lds_carve(smem);
@@ -175,7 +180,7 @@ static float * att_scratch(size_t bytes, hipStream_t st) {
 }
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
-                         const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st) {
+                         const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride) {
     if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
     const int p_stride = (max_n_kv + 3) & ~3;
     const size_t fixed = 16 * 4 + 16 * 64 * 8, row = (size_t) p_stride * 4, budget = 150 * 1024;
@@ -187,12 +192,13 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     static const int force = getenv("FQ_ATTN_ROWS") ? atoi(getenv("FQ_ATTN_ROWS")) : -1;      // tuning override: 0 = one token per workgroup
     const bool fit4 = fixed + 4 * row <= budget, fit2 = fixed + 2 * row <= budget;
     int R = (N >= 4 && fixed + 4 * row <= 56 * 1024) ? 4 : ((N >= 2 && fit2) ? 2 : 1);
-    if (force == 0) R = 1; else if (force == 8 && N >= 4 && fixed + 8 * row <= budget) R = 8; else if (force == 4 && N >= 4 && fit4) R = 4; else if (force == 2 && N >= 2 && fit2) R = 2;
+    if (seq_stride) R = 1;                                       // independent sequences share no key tile
+    if (force == 0 || seq_stride) R = 1; else if (force == 8 && N >= 4 && fixed + 8 * row <= budget) R = 8; else if (force == 4 && N >= 4 && fit4) R = 4; else if (force == 2 && N >= 2 && fit2) R = 2;
     // beyond ~3000 keys: 4 tokens per workgroup with the score rows in the global scratch instead of 2 with them in LDS
     // (8192-token prompt: 32 ms per block against 36-40; 8 tokens per workgroup: 38). The scratch is N x H x n_kv floats --
     // 1.2 GB for a 512-token batch at 8192 keys -- and is not used beyond FQ_ATTN_SCRATCH_GB (default 4) GiB
     static const int use_scratch = getenv("FQ_ATTN_SCRATCH") ? atoi(getenv("FQ_ATTN_SCRATCH")) : 1;
-    if (use_scratch && force < 0 && R == 2 && N >= 4) {
+    if (use_scratch && force < 0 && R == 2 && N >= 4 && !seq_stride) {
         const size_t need = (size_t)((N + 3) / 4) * (size_t) H * 4 * row;
         float * scr = att_scratch(need, st);
         if (scr) { launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed, k_cache, v_cache, exp_table, att, st, scr); return; }
@@ -210,8 +216,8 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
                 g = lds;
             }
         }
-        if (g_attn_f64) hipLaunchKernelGGL(k_attention<true>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
-        else            hipLaunchKernelGGL(k_attention<false>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att);
+        if (g_attn_f64) hipLaunchKernelGGL(k_attention<true>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, seq_stride);
+        else            hipLaunchKernelGGL(k_attention<false>, dim3((unsigned) H, (unsigned) N), dim3(256), lds, st, qkv, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, seq_stride);
     }
 }
 

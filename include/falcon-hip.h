@@ -69,10 +69,18 @@ int  falcon_hip_plan_stages(const char * path, int n_stages, int n_ctx, int n_ba
 int  falcon_hip_model_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor,
                                int allow_requantize, int64_t * hist_out);
 
+void falcon_hip_model_get_hparams(const falcon_hip_model * m, falcon_hip_hparams * hp_out);
+
 /* n_ctx: KV capacity; n_batch: largest N of one eval; rope_n_ctx: the n_ctx handed to ggml_rope
  * (n_max_real_ctx or n_ctx, libfalcon.cpp:2229-2230)                                                           */
 falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx);
 void                 falcon_hip_context_free(falcon_hip_context * c);
+/* A context of n_seq (1..64) independent sequences that advance in LOCK STEP: every falcon_hip_eval_stage / falcon_hip_stage_step
+ * evaluates n_seq rows = one token of each sequence, all at position n_past, row t attending to its own KV cache. One pass
+ * over the weights serves n_seq tokens (n_seq <= 4: the same mat-vec, the same bits per sequence as a context of its own).
+ * token_dev / next_token_dev of falcon_hip_stage_step then hold n_seq ids, the hidden rows are [n_seq][n_embd].          */
+falcon_hip_context * falcon_hip_context_create_seqs(falcon_hip_model * m, int n_ctx, int n_seq, int rope_n_ctx);
+int                  falcon_hip_context_n_seq(const falcon_hip_context * c);
 
 /* Evaluate n_tokens at position n_past (falcon_eval). Whole model in this process: tokens are host ids.
  * logits_all = 0 keeps the last row only. Returns 0.                                                           */
@@ -112,6 +120,33 @@ int   falcon_hip_context_engine_active(falcon_hip_context * c);
 int   falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out_host, int n);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
+
+/* ---- layer pipeline over several GPUs, one process per GPU (csrc/falcon_pipeline.hip). Rank r holds the blocks
+   [layer_begin, layer_end) of its falcon_hip_model (falcon_hip_plan_stages picks the ranges); n_groups groups of `batch`
+   lock-step sequences are in flight (n_groups >= world; >= 2 x world: transfers overlap stage steps); the residual rows and
+   the sampled tokens travel by RCCL ncclSend / ncclRecv (xGMI). What the reference does instead: every mat-mul split over the
+   devices with peer copies and a gather on the main device (ggml-cuda.cu:2586-2608, 2713-2732).
+     rank 0:  falcon_hip_pipeline_unique_id(id)  -> hand the 128 bytes to the other ranks (launcher's store, file, MPI ...)
+     all:     p = falcon_hip_pipeline_create(model, rank, world, id, n_groups, batch, n_ctx)
+     rank 0:  falcon_hip_pipeline_set_tokens(p, first_tokens)            n_groups * batch ids (sequence i = group * batch + b)
+     all:     falcon_hip_pipeline_run(p, rounds, n_past0)                 asynchronous; every sequence advances `rounds` tokens
+     last:    falcon_hip_pipeline_get_history(p, out, first_round, n)     the sampled tokens [round][sequence]; waits
+   world == 1 needs neither RCCL nor an id (NULL). */
+#define FALCON_HIP_PIPELINE_ID_BYTES 128
+typedef struct falcon_hip_pipeline falcon_hip_pipeline;
+int   falcon_hip_pipeline_unique_id(void * id_out);                       /* 0, or -1 when RCCL is not available */
+falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank, int world, const void * unique_id,
+                                                 int n_groups, int batch, int n_ctx);
+void  falcon_hip_pipeline_free(falcon_hip_pipeline * p);
+int   falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * tokens);
+int   falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0);
+int   falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, int first_round, int n_rounds);
+/* the same job with every rank inside ONE process on one device (hand-off by device copies instead of RCCL): the identical
+   schedule and stage code, for tests and for sizing a pipeline before the GPUs are there */
+falcon_hip_pipeline * falcon_hip_pipeline_create_local(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx);
+int   falcon_hip_pipeline_run_local(falcon_hip_pipeline ** ranks, int world, int rounds, int n_past0);
+/* host only: the slot schedule (see falcon_pipeline.hip); out: 9 ints; returns the number of slots of the run */
+int   falcon_hip_pipeline_schedule(int rank, int world, int n_groups, int rounds, int slot, int * out);
 
 /* ---- tokenizer (host only): falcon_tokenize / falcon_token_to_str (libfalcon.h:236-247, libfalcon.cpp:2594-3035, 4623-4641)
    on the vocabulary and BPE merges stored in a GGCC v10 file. Same ids as the reference for any text. */

@@ -39,6 +39,9 @@ void    ggml_hip_gemm_sequential(int on);
  * bit-identical with that reference build's (tests/test_gpu_falcon.py). A parity instrument: 10-100 x slower.             */
 void    ggml_hip_reference_order(int on);
 int     ggml_hip_get_reference_order(void);
+/* staging-buffer pool of the ggml-cuda.h boundary (ggml_cuda_compute_forward's src1 / dst device copies; the reference's
+ * ggml_cuda_pool_malloc, ggml-cuda.cu:1738-1816): buffers ever allocated, hand-outs served by reuse, buffers free now */
+void    ggml_hip_shim_pool_stats(size_t * n_alloc, size_t * n_reuse, size_t * n_free);
 int     ggml_hip_selftest(void);                  /* device self-checks (wave reductions); 0 = pass                */
 /* soft_max's fp16 EXP table entries are recomputed in the attention kernels instead of gathered when -- checked at init, for
  * every non-NaN fp16 input -- the recomputation equals the host-built table. Returns the number of mismatching inputs (0 = in

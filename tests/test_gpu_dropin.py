@@ -49,7 +49,10 @@ for i in range(9, 12):
     one = np.zeros((1, nv), np.float32)
     assert L.reff_eval(ctx, toks[i:i + 1].ctypes.data, 1, i, 2, one.ctypes.data) == 0
     dec.append(one)
-np.savez(out, pre=pre, dec=np.concatenate(dec))
+H = C.CDLL(sys.argv[7])                                # libggml_hip.so: the handle the reference code is linked against
+st = (C.c_size_t * 3)()
+H.ggml_hip_shim_pool_stats(C.byref(st, 0), C.byref(st, C.sizeof(C.c_size_t)), C.byref(st, 2 * C.sizeof(C.c_size_t)))
+np.savez(out, pre=pre, dec=np.concatenate(dec), pool=np.array(list(st), np.int64))
 L.reff_free(ctx)
 """
 
@@ -73,13 +76,20 @@ def test_reference_code_on_libggml_hip_reproduces_reference_logits(oracle, golde
     script = str(tmp_path / "run.py")
     open(script, "w").write(_LOGITS_SCRIPT)
     env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
-    r = subprocess.run([sys.executable, script, lib, path, str(hp["n_vocab"]), "100", out, toks], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([sys.executable, script, lib, path, str(hp["n_vocab"]), "100", out, toks, g.LIB_PATH], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     if so.endswith("_hip.so"):
         assert "resident on the device" in r.stderr
     res = np.load(out)
     assert np.array_equal(res["pre"], gg[f"{name}_prefill_logits"])
     assert np.array_equal(res["dec"], gg[f"{name}_decode_logits"])
+    n_alloc, n_reuse, n_free = (int(v) for v in res["pool"])
+    if so.endswith("_shim.so"):
+        # the per-node staging buffers come from the pool (ggml-cuda.cu:1738-1816's role): 4 evals x offloaded mat-muls x 2
+        # buffers were handed out, only a handful were ever allocated, and all are back in the pool
+        assert n_alloc + n_reuse >= 4 * 4 * 2 and 0 < n_alloc <= 8 and n_free == n_alloc, (n_alloc, n_reuse, n_free)
+    else:
+        assert n_alloc == 0 and n_reuse == 0                  # nothing crosses the per-op boundary on the resident path
 
 
 def _cli_model(oracle, path):

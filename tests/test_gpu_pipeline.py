@@ -1,0 +1,97 @@
+"""GPU: lock-step sequence contexts (falcon_hip_context_create_seqs) and the C++ layer pipeline (csrc/falcon_pipeline.hip)
+with its local transport -- every rank of the job in this process on the one GPU, the schedule, stage contexts, hipGraphs
+and hand-off buffers being the ones the RCCL transport uses."""
+import numpy as np
+import pytest
+
+import ggllm_cpp_amd as g
+from oracle import binding as ob
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    g.init(0)
+
+
+def _model(oracle, hp, t, n_layer, seed=17):
+    hp = dict(hp)
+    hp["n_layer"] = n_layer
+    return hp, synth.make_model(oracle, hp, t, seed=seed)
+
+
+@pytest.mark.parametrize("hp,t,B", [(synth.HP_TINY_MQA, ob.Q4_0, 3), (synth.HP_TINY_GQA, ob.Q5_1, 4), (synth.HP_TINY_GQA, ob.Q4_K, 2),
+                                    (synth.HP_TINY_MQA, ob.Q8_0, 7)])
+def test_lock_step_sequences_equal_contexts_of_their_own(oracle, hp, t, B):
+    """B sequences through ONE pass over the weights per step: each sequence's logits are those of a context of its own, bit
+    for bit for B <= 4 (the same mat-vec per column); B = 7 goes through the int8-MFMA GEMM (split sums): within the
+    documented association spread"""
+    hp, w = _model(oracle, hp, t, 2)
+    m = g.FalconModel(w, n_ctx=32, n_batch=8)
+    streams = [synth.tokens(9, hp["n_vocab"], seed=50 + b) for b in range(B)]
+    singles = []
+    for b in range(B):
+        rows = [m.eval(streams[b][i:i + 1], i)[0] for i in range(9)]       # (a context is reusable from position 0)
+        singles.append(np.stack(rows))
+    sc = g.SeqContext(m, 32, B)
+    for i in range(9):
+        lg = sc.eval([int(streams[b][i]) for b in range(B)], i)
+        for b in range(B):
+            if B <= 4:
+                assert np.array_equal(lg[b], singles[b][i]), (b, i)
+            else:
+                ref = singles[b][i]
+                assert float(np.abs(lg[b] - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean())) < 5e-2
+    sc.free()
+    m.free()
+
+
+def _greedy_reference(w, hp, first, rounds):
+    m = g.FalconModel(w, n_ctx=64, n_batch=4)
+    out = np.stack([m.decode_greedy(int(t), 0, rounds) for t in first], axis=1)      # [round][sequence]
+    m.free()
+    return out
+
+
+@pytest.mark.parametrize("world,groups,batch", [(1, 2, 2), (2, 2, 2), (2, 4, 1), (3, 3, 2), (3, 6, 2), (4, 9, 1)])
+@pytest.mark.parametrize("hp,t", [(synth.HP_TINY_MQA, ob.Q4_0), (synth.HP_TINY_GQA, ob.Q5_1)])
+def test_cpp_pipeline_reproduces_single_process_greedy_decode(oracle, hp, t, world, groups, batch):
+    """world stages x groups x batch sequences: the tokens the last stage samples, round by round, are the greedy decode of
+    each sequence on the whole model in one process -- for the simple schedule (groups < 2 x world), the overlapped one, and
+    for two consecutive run calls (warm-up + timed region)"""
+    import bench_pipeline as bp
+    hp, w = _model(oracle, hp, t, 5)
+    rounds = 7
+    first = synth.tokens(groups * batch, hp["n_vocab"], seed=8)
+    want = _greedy_reference(w, hp, first, rounds)
+    parts = bp.partition(hp["n_layer"], world)
+    stages = [g.FalconModel(w, n_ctx=8, n_batch=1, layer_begin=lb, layer_end=le) for lb, le in parts]
+    ranks = [g.Pipeline(stages[r], r, world, groups, batch, 16, local=True) for r in range(world)]
+    ranks[0].set_tokens(first)
+    g.Pipeline.run_local(ranks, 3, 0)
+    g.Pipeline.run_local(ranks, rounds - 3, 3)
+    got = ranks[-1].history(0, rounds)
+    for r in range(world - 1):
+        assert ranks[r].history(0, rounds) is None or world == 1
+    for p in ranks:
+        p.free()
+    for s in stages:
+        s.free()
+    assert np.array_equal(got, want)
+
+
+def test_cpp_pipeline_world_1_run_without_rccl(oracle):
+    """falcon_hip_pipeline_create with world 1 needs no communicator: falcon_hip_pipeline_run advances groups x batch
+    sequences on one GPU (what bench.py --force-pipeline times)"""
+    hp, w = _model(oracle, synth.HP_TINY_MQA, ob.Q4_0, 2)
+    first = synth.tokens(6, hp["n_vocab"], seed=9)
+    want = _greedy_reference(w, hp, first, 5)
+    m = g.FalconModel(w, n_ctx=8, n_batch=1)
+    p = g.Pipeline(m, 0, 1, 3, 2, 16)
+    p.set_tokens(first)
+    p.run(5, 0)
+    got = p.history(0, 5)
+    p.free(); m.free()
+    assert np.array_equal(got, want)
