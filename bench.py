@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--prefill-long", type=int, default=2048, help="also time one prompt of this many tokens (0 = skip)")
     ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
-    ap.add_argument("--streams", type=int, default=2, help="decode streams in flight for --force-pipeline at one GPU")
+    ap.add_argument("--streams", type=int, default=2, help="groups of decode streams in flight for --force-pipeline at one GPU")
+    ap.add_argument("--pipe-batch", type=int, default=4, help="pipeline: lock-step streams per group (one weight pass serves them; 1..4)")
+    ap.add_argument("--north-star", action="store_true", help="pipeline: also time Falcon-40B Q4_K (all 60 blocks) over the same GPUs, as extra keys")
     return ap.parse_args()
 
 

@@ -233,7 +233,129 @@ class HostStagedComm:
         self.finish(self.post(sends, recvs))
 
 
+def _watchdog(seconds, what):
+    """the RCCL path cannot be exercised where this is developed (one GPU per box): if `what` has not finished after
+    `seconds`, say so and leave instead of hanging the job"""
+    import threading
+    done = threading.Event()
+
+    def run():
+        if not done.wait(seconds):
+            sys.stderr.write(f"bench_pipeline: {what} did not finish within {seconds} s -- giving up\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=run, daemon=True).start()
+    return done
+
+
+def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torch, groups, batch, n_ctx, steps, warmup):
+    """one timed run of the C++ pipeline (csrc/falcon_pipeline.hip): returns (tokens/s over the job, weight bytes over all
+    ranks, blocks per stage, setup seconds) on every rank"""
+    import ggllm_cpp_amd as g
+    from ggllm_cpp_amd import synth
+    L = g.load()
+    parts = partition(hp["n_layer"], world, head_units(hp))
+    lb, le = parts[rank]
+    t0 = time.time()
+    weights = synth.make_model_fast(hp, wtype, seed=1234, layers=range(lb, le))
+    model = g.FalconModel(weights, n_ctx=8, n_batch=1, layer_begin=lb, layer_end=le)
+    del weights
+    uid = None
+    if world > 1:
+        box = [g.Pipeline.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)                   # 128 bytes over the launcher's (gloo) store
+        uid = box[0]
+    pipe = g.Pipeline(model, rank, world, groups, batch, n_ctx, unique_id=uid)
+    t_setup = time.time() - t0
+    pipe.set_tokens(synth.tokens(groups * batch, hp["n_vocab"], seed=42))
+    done = _watchdog(600, f"warm-up of the {world}-rank pipeline (RCCL channel set-up)")
+    wr = max(warmup, 1)
+    pipe.run(wr, 0)                                              # warm-up rounds (also build the RCCL P2P channels and the stage graphs)
+    L.ggml_hip_synchronize()
+    done.set()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(steps, wr)                                          # K rounds = K * groups * batch tokens, including pipeline fill and drain
+    L.ggml_hip_synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hist = pipe.history(wr, steps)                               # (last rank) also surfaces hand-off time-outs
+    if hist is not None and (hist < 0).any():
+        raise RuntimeError("pipeline produced invalid tokens")
+    dt_t = torch.tensor([dt], dtype=torch.float64)
+    wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wb_t, op=dist.ReduceOp.SUM)
+    pipe.free()
+    model.free()
+    return steps * groups * batch / float(dt_t.item()), float(wb_t.item()), [e - b for b, e in parts], t_setup, float(dt_t.item())
+
+
 def main(a, rank, world, local):
+    import torch
+    import torch.distributed as dist
+    import ggllm_cpp_amd as g
+    from ggllm_cpp_amd import synth
+
+    if os.environ.get("FALCON_PIPE_TORCH") == "1" or os.environ.get("FALCON_PIPE_DEBUG_SHARED_GPU") == "1":
+        return main_torch(a, rank, world, local)                 # the Python driver over torch.distributed P2P (kept for A/B and the shared-GPU debug transport)
+    tname = {v: k for k, v in g.TYPE_NAME.items()}
+    wtype = tname[a.quant if a.quant in tname else a.quant.replace("_k", "_K")]
+    hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B, "tiny": synth.HP_TINY_MQA}[a.model])
+    if a.layers:
+        hp["n_layer"] = a.layers
+    if not os.path.exists(g.LIB_PATH):
+        g.build()
+    torch.cuda.set_device(local)
+    g.init(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side control only (id hand-out, barrier, max over ranks); the data path is RCCL inside libggml_hip.so
+    batch = max(1, min(int(getattr(a, "pipe_batch", 4)), 4))
+    groups = max(2 * world, 2) if world > 1 else max(1, getattr(a, "streams", 2))
+    n_ctx = min(a.n_ctx, 512)
+    if a.warmup + a.steps + 1 > n_ctx:
+        raise SystemExit(f"--warmup + --steps must stay below {n_ctx} positions")
+    tok_s, wbytes, blocks, t_setup, dt = run_cpp(a, rank, world, local, hp, wtype, a.model, a.quant, dist, torch, groups, batch, n_ctx, a.steps, a.warmup)
+    extra = {}
+    if getattr(a, "north_star", False) and not (a.model == "40b" and a.quant.lower() == "q4_k"):
+        # the north-star configuration next to the headline line: Falcon-40B Q4_K, all 60 blocks, over the same GPUs
+        hp40 = dict(synth.HP_40B)
+        ns_tok_s, ns_wb, ns_blocks, ns_setup, _ = run_cpp(a, rank, world, local, hp40, tname["q4_K"], "40b", "q4_k", dist, torch, groups, batch, n_ctx,
+                                                          max(8, a.steps // 4), max(2, a.warmup // 2))
+        extra["north_star"] = {"workload": f"Falcon-40B Q4_K, 60 blocks, layer-pipelined over {world} GPU(s) ({ns_blocks} blocks per stage), "
+                                           f"{groups} groups x {batch} lock-step greedy decode streams", "value": ns_tok_s, "unit": "tokens/s",
+                               "weight_bytes_per_token": ns_wb, "effective_GBs": ns_wb * ns_tok_s / batch / 1e9, "setup_s": ns_setup}
+    if rank == 0:
+        from bench import kv_bytes_per_token, HBM_PEAK_GBS
+        S = groups * batch
+        # a weight pass serves `batch` tokens: bytes per TOKEN = weights / batch + that token's KV traffic
+        b_tok = wbytes / batch + kv_bytes_per_token(hp, a.warmup + a.steps // 2)
+        gbs = b_tok * tok_s / 1e9
+        print(json.dumps({
+            "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
+                      else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
+            "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
+            "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPU(s) "
+                                   f"({blocks} blocks per stage, balanced by bytes incl. lm_head), {groups} groups x {batch} lock-step greedy decode streams "
+                                   f"in flight, a step = one round (one token per stream); residual rows and sampled tokens by RCCL ncclSend/ncclRecv "
+                                   f"(csrc/falcon_pipeline.hip)",
+                       "streams": S, "groups": groups, "batch": batch, "weight_bytes_per_pass": wbytes, "n_past_timed": [a.warmup, a.warmup + a.steps]},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
+                         "traffic": None, "note": "whole-job view: (weight bytes / batch + KV bytes) per token x tokens/s over the summed peak of all GPUs"},
+            "cpu_baseline": None, "setup_s": t_setup, **extra,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_torch(a, rank, world, local):
     import torch
     import torch.distributed as dist
     import ggllm_cpp_amd as g

@@ -617,19 +617,51 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             a_qkv = act_for(c->buf_e2, L.qkv, N);
             fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_qkv, st);
         }
-        fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
         float * kc = c->k_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
         float * vc = c->v_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
-        fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);
-        fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride);
         const fq_act a_att = act_for(c->buf_att, L.wo, N), a_ff = act_for(c->buf_ff, L.down, N);
-        fq_launch_quantize_act(c->att, E, a_att, st);
-        fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
-        const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
-        fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
-        fq_launch_quantize_act(c->up, FF, a_ff, st);
-        const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place
-        fq_mul_mat_q_acts(L.down, a_ff, N, c->x, E, resid, st);
+        const bool att_q = (a_att.type == FQ_Q8_0 || a_att.type == FQ_Q8_1);
+        // 2..4 lock-step sequences: the block's weights in TWO launches that serve every column (kernels_cols.hip), the
+        // decode attention of all sequences in one launch between them -- same bits as the generic launches below
+        const bool cols_path = seq_stride && N >= 2 && N <= 4 && c->fused_decode && !fq_reference_order() && !fq_attn_f64() &&
+                               L.qkv.type == L.up.type && L.down.type == L.wo.type;
+        bool up_done = false, ff_quantized = false;
+        if (cols_path) {
+            const bool quant_epi = (a_ff.type == FQ_Q8_0 || a_ff.type == FQ_Q8_1) && FF % 32 == 0;
+            fq_gemv_cols_args ga{};
+            ga.nseg = 2; ga.ncols = N; ga.gelu_table = hc.gelu_table;
+            ga.seg[0] = { L.qkv, a_qkv.base, FQ_LNEPI_STORE, c->qkv, QKV, nullptr, 0, 0 };
+            ga.seg[1] = { L.up, a_up.base, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, FF, c->buf_ff, a_ff.type, 0 };
+            up_done = fq_launch_gemv_cols(ga, hc.n_cu, st);
+            ff_quantized = up_done && quant_epi;
+        }
+        if (!up_done) fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
+        if (seq_stride && !fq_reference_order() && !fq_attn_f64()) {
+            // lock-step sequences: RoPE, KV append, attention and (Q8_0 / Q8_1 consumers) the activation image of all N tokens in
+            // one launch of the decode attention (k_attn_decode's code: the same bits as the three launches below)
+            fq_launch_attn_decode_seqs(c->qkv, N, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, seq_stride, hc.exp_table_attn,
+                                       att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, a_att.type, (int64_t) fq_act_col_bytes(a_att.type, E), st);
+            if (!att_q) fq_launch_quantize_act(c->att, E, a_att, st);
+        } else {
+            fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);
+            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride);
+            fq_launch_quantize_act(c->att, E, a_att, st);
+        }
+        if (!up_done) {
+            const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
+            fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
+        }
+        if (!ff_quantized) fq_launch_quantize_act(c->up, FF, a_ff, st);
+        bool out_done = false;
+        if (cols_path) {
+            const fq_gemv_out_cols_args go{ L.down, L.wo, c->buf_ff, c->buf_att, c->x, c->x, E, N };
+            out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st);
+        }
+        if (!out_done) {
+            fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
+            const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place
+            fq_mul_mat_q_acts(L.down, a_ff, N, c->x, E, resid, st);
+        }
     }
     if (c->keep_hidden) {
         HIP_CHECK(hipMemcpyAsync(c->hidden_dev + m->layers.size() * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
@@ -638,7 +670,14 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     if (m->last_stage()) {
         const fq_act a_head = act_for(c->buf_e, m->lm_head, N);
         fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, a_head, st);
-        fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
+        bool head_done = false;
+        if (seq_stride && N >= 2 && N <= 4 && c->fused_decode && !fq_reference_order()) {
+            fq_gemv_cols_args ga{};
+            ga.nseg = 1; ga.ncols = N; ga.gelu_table = hc.gelu_table;
+            ga.seg[0] = { m->lm_head, a_head.base, FQ_LNEPI_STORE, c->logits_dev, hp.n_vocab, nullptr, 0, 0 };
+            head_done = fq_launch_gemv_cols(ga, hc.n_cu, st);
+        }
+        if (!head_done) fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
     }
 }
 

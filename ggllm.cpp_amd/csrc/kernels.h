@@ -102,6 +102,30 @@ bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, 
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
                              int att_act_type, hipStream_t st);
+// B lock-step sequences: row t of qkv / att, KV cache t (seq_stride floats apart), image column t (image_stride bytes apart)
+void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
+                                  float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
+                                  int att_act_type, int64_t image_stride, hipStream_t st);
+
+// kernels_cols.hip -- the two mat-vec launches of a block for 2..4 lock-step sequences (one weight pass serves all columns)
+struct fq_gemv_cols_seg {
+    fq_weight       w;
+    const uint8_t * act;           // ncols quantized activation columns of length w.K (column stride fq_act_col_bytes)
+    int             epi;           // FQ_LNEPI_*
+    float *         dst; int64_t ldd;      // f32 output, column c at dst + c * ldd (STORE / GELU_STORE)
+    uint8_t *       dst_image;     // Q8_0 / Q8_1 image columns of length w.M (GELU_QUANT)
+    int             next_act_type;
+    int             block_begin;   // set by the launcher
+};
+struct fq_gemv_cols_args { fq_gemv_cols_seg seg[2]; int nseg, ncols; const uint16_t * gelu_table; int npass; };
+struct fq_gemv_out_cols_args {
+    fq_weight w_down, w_wo;
+    const uint8_t * act_ff_image, * att_image;     // ncols columns each
+    const float * resid; float * dst; int64_t ld;  // residual rows [ncols][ld] (dst may alias resid)
+    int ncols;
+};
+bool   fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st);                 // false: outside its scope, nothing launched
+bool   fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st);
 
 // kernels_engine.hip -- the persistent decode engine: one launch per token
 #include <vector>

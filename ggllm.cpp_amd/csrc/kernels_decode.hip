@@ -430,6 +430,26 @@ void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past
     hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, a);
 }
 
+// the same for B lock-step sequences (falcon_hip_context_create_seqs): blockIdx.y = sequence, with its own qkv row, KV cache
+// and output column -- RoPE, KV append, attention and the Q8 image of B tokens in one launch
+__global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a, int64_t qkv_stride, int64_t seq_stride, int64_t att_stride, int64_t image_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int64_t t = blockIdx.y;
+    a.qkv += t * qkv_stride; a.kc += t * seq_stride; a.vc += t * seq_stride;
+    if (a.att) a.att += t * att_stride;
+    if (a.att_image) a.att_image += t * image_stride;
+    attn_decode_group<false>(a, (int) blockIdx.x, true, (int) threadIdx.x, smem);
+}
+void fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
+                                float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
+                                int att_act_type, int64_t image_stride, hipStream_t st) {
+    const size_t lds = attn_decode_lds(max_n_kv);
+    if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
+    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode_seqs, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
+    const fq_attn_decode_args a{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type, max_n_kv, nullptr, nullptr, nullptr, nullptr };
+    hipLaunchKernelGGL(k_attn_decode_seqs, dim3((unsigned) H, (unsigned) n_seq), dim3(256), lds, st, a, (int64_t)(H + 2 * HKV) * 64, seq_stride, (int64_t) H * 64, image_stride);
+}
+
 // =============================================================================================== k_attn_out
 // Attention and the output mat-vec of one block in ONE launch, one workgroup of 12 waves per CU:
 //   workgroups [0, n_attn)      3 query heads each (three lockstep 256-thread groups running attn_decode_group), results
