@@ -25,44 +25,32 @@
 #include "fq_device.h"
 #include "hip_context.h"
 
-#include <rccl/rccl.h>
-#include <dlfcn.h>
+#include "rccl_dyn.h"
 
 #include <mutex>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
 
-namespace {
+#include <dlfcn.h>
 
-// ------------------------------------------------------------------------------------------------ RCCL, bound at run time
-struct rccl_api {
-    void * lib = nullptr;
-    ncclResult_t (*ncclGetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*ncclCommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*ncclCommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*ncclSend)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*ncclRecv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*ncclGroupStart)() = nullptr;
-    ncclResult_t (*ncclGroupEnd)() = nullptr;
-    const char * (*ncclGetErrorString)(ncclResult_t) = nullptr;
-};
-
-rccl_api * rccl() {
+// ------------------------------------------------------------------------------------------------ RCCL, bound at run time (rccl_dyn.h)
+rccl_api * fq_rccl() {
     static rccl_api api; static std::once_flag once; static bool ok = false;
     std::call_once(once, [] {
         for (const char * name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
             api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (api.lib) break;
         }
-        if (!api.lib) { fprintf(stderr, "falcon-hip: pipeline: librccl.so.1 not found (%s)\n", dlerror()); return; }
+        if (!api.lib) { fprintf(stderr, "ggml-hip: librccl.so.1 not found (%s)\n", dlerror()); return; }
         bool all = true;
-        auto bind = [&](const char * sym) { void * p = dlsym(api.lib, sym); if (!p) { fprintf(stderr, "falcon-hip: pipeline: %s missing from RCCL\n", sym); all = false; } return p; };
+        auto bind = [&](const char * sym) { void * p = dlsym(api.lib, sym); if (!p) { fprintf(stderr, "ggml-hip: %s missing from RCCL\n", sym); all = false; } return p; };
         api.ncclGetUniqueId    = (decltype(api.ncclGetUniqueId))    bind("ncclGetUniqueId");
         api.ncclCommInitRank   = (decltype(api.ncclCommInitRank))   bind("ncclCommInitRank");
         api.ncclCommDestroy    = (decltype(api.ncclCommDestroy))    bind("ncclCommDestroy");
         api.ncclSend           = (decltype(api.ncclSend))           bind("ncclSend");
         api.ncclRecv           = (decltype(api.ncclRecv))           bind("ncclRecv");
+        api.ncclAllGather      = (decltype(api.ncclAllGather))      bind("ncclAllGather");
         api.ncclGroupStart     = (decltype(api.ncclGroupStart))     bind("ncclGroupStart");
         api.ncclGroupEnd       = (decltype(api.ncclGroupEnd))       bind("ncclGroupEnd");
         api.ncclGetErrorString = (decltype(api.ncclGetErrorString)) bind("ncclGetErrorString");
@@ -71,8 +59,7 @@ rccl_api * rccl() {
     return ok ? &api : nullptr;
 }
 
-#define RCCL_CHECK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
-    fprintf(stderr, "falcon-hip: pipeline: %s failed: %s (%s:%d)\n", #call, rccl()->ncclGetErrorString(r_), __FILE__, __LINE__); abort(); } } while (0)
+namespace {
 
 // ------------------------------------------------------------------------------------------------ the slot schedule (host only)
 enum { OP_SEND_HIDDEN = 0, OP_SEND_TOKEN = 1, OP_RECV_HIDDEN = 2, OP_RECV_TOKEN = 3 };
@@ -146,7 +133,7 @@ void compute(falcon_hip_pipeline * p, const pipe_slot & s, int n_past0, hipStrea
 // one grouped RCCL exchange: every send and receive of the slot between ncclGroupStart and ncclGroupEnd
 void exchange_rccl(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st) {
     if (!s.n_ops) return;
-    rccl_api * R = rccl();
+    rccl_api * R = fq_rccl();
     const size_t nh = (size_t) p->B * p->hp.n_embd, nt = (size_t) p->B;
     RCCL_CHECK(R->ncclGroupStart());
     for (int i = 0; i < s.n_ops; ++i) {
@@ -202,7 +189,7 @@ falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_gr
 extern "C" {
 
 int falcon_hip_pipeline_unique_id(void * id_out) {
-    rccl_api * R = rccl();
+    rccl_api * R = fq_rccl();
     if (!R) return -1;
     ncclUniqueId id;
     if (R->ncclGetUniqueId(&id) != ncclSuccess) return -1;
@@ -214,7 +201,7 @@ falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank,
     static_assert(sizeof(ncclUniqueId) == FALCON_HIP_PIPELINE_ID_BYTES, "unique id size");
     falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
     if (!p || world == 1) return p;
-    rccl_api * R = rccl();
+    rccl_api * R = fq_rccl();
     if (!R || !unique_id) { fprintf(stderr, "falcon-hip: pipeline: %s\n", R ? "no unique id" : "RCCL is not available"); falcon_hip_pipeline_free(p); return nullptr; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
@@ -233,7 +220,7 @@ void falcon_hip_pipeline_free(falcon_hip_pipeline * p) {
     if (!p) return;
     HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
     if (p->comm_stream) HIP_CHECK(hipStreamSynchronize(p->comm_stream));
-    if (p->comm) rccl()->ncclCommDestroy(p->comm);
+    if (p->comm) fq_rccl()->ncclCommDestroy(p->comm);
     for (falcon_hip_context * c : p->ctx) falcon_hip_context_free(c);
     for (int i = 0; i < 4; ++i) { if (p->ev_compute[i]) HIP_CHECK(hipEventDestroy(p->ev_compute[i])); if (p->ev_comm[i]) HIP_CHECK(hipEventDestroy(p->ev_comm[i])); }
     if (p->ev_start) HIP_CHECK(hipEventDestroy(p->ev_start));

@@ -183,17 +183,43 @@ extern "C" void * ggml_cuda_host_malloc(size_t size) {                          
 extern "C" void ggml_cuda_host_free(void * p) { if (p) HIP_CHECK(hipHostFree(p)); }
 
 // ---------------------------------------------------------------------------------------------- weights
-struct shim_extra : ggml_tensor_extra_gpu { bool is_weight; size_t bytes; };
+struct shim_extra : ggml_tensor_extra_gpu { bool is_weight; size_t bytes; bool split; int64_t row_low[GGML_CUDA_MAX_DEVICES], row_high[GGML_CUDA_MAX_DEVICES]; };
+
+// Row-split tensor parallelism over several PROCESSES (one per GPU, every process running the same reference graph): once
+// ggml_hip_split_configure has joined this process to a job, GGML_BACKEND_GPU_SPLIT tensors are uploaded as this rank's row
+// range of the `-ts` proportions (ggml_cuda_set_tensor_split) and their mat-muls exchange output rows by RCCL
+// (csrc/split_tp.hip). Not configured (the default): the whole matrix lives on this process's device.
+static ggml_hip_split_comm * g_split = nullptr;
+static int g_split_rank = 0, g_split_world = 1;
+extern "C" int ggml_hip_split_configure(int rank, int world, const void * unique_id) {
+    if (g_split) { ggml_hip_split_comm_free(g_split); g_split = nullptr; }
+    g_split_rank = 0; g_split_world = 1;
+    if (world <= 1) return 0;
+    if (world > GGML_CUDA_MAX_DEVICES) { fprintf(stderr, "ggml-hip: split: at most %d ranks\n", GGML_CUDA_MAX_DEVICES); return 1; }
+    ggml_init_cublas(false);
+    g_split = ggml_hip_split_comm_create(rank, world, unique_id);
+    if (!g_split) return 1;
+    g_split_rank = rank; g_split_world = world;
+    return 0;
+}
 
 extern "C" void ggml_cuda_transform_tensor(void * data, ggml_tensor * t) {          // ggml-cuda.cu:3030-3073
     if (!on_device(t)) return;
     ggml_init_cublas(false);
     shim_extra * ex = new shim_extra();
     memset(ex->data_device, 0, sizeof(ex->data_device));
+    ex->split = false;
     if (is_quantized(t->type)) {
-        // the whole matrix goes to this process's device: the north star shards by LAYER (one process per GPU), not by
-        // rows, so GPU_SPLIT tensors are not row-split here (the reference's -ts row split is a "next" row)
-        ex->data_device[0] = ggml_hip_weight_upload((int) t->type, data, t->ne[0], t->ne[1] * t->ne[2] * t->ne[3]);
+        const int64_t nrows = t->ne[1] * t->ne[2] * t->ne[3];
+        if (t->backend == GGML_BACKEND_GPU_SPLIT && g_split) {
+            // this rank's rows of the -ts split (ggml-cuda.cu:3044-3066); an empty range holds nothing
+            ggml_hip_tensor_split_rows(g_tensor_split, g_split_world, nrows, ex->row_low, ex->row_high);
+            ex->data_device[0] = ggml_hip_weight_upload_rows((int) t->type, data, t->ne[0], nrows, ex->row_low[g_split_rank], ex->row_high[g_split_rank]);
+            ex->split = true;
+        } else {
+            // the whole matrix on this process's device: the north star shards by LAYER (one process per GPU)
+            ex->data_device[0] = ggml_hip_weight_upload((int) t->type, data, t->ne[0], nrows);
+        }
         ex->is_weight = true;
     } else if (t->type == GGML_TYPE_F32) {
         const size_t n = (size_t) t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3] * 4;
@@ -210,7 +236,7 @@ extern "C" void ggml_cuda_transform_tensor(void * data, ggml_tensor * t) {      
 extern "C" void ggml_cuda_free_data(ggml_tensor * t) {                              // ggml-cuda.cu:3075-3092
     if (!t || !on_device(t) || !t->extra) return;
     shim_extra * ex = (shim_extra *) t->extra;
-    if (ex->is_weight) ggml_hip_weight_free((ggml_hip_weight *) ex->data_device[0]);
+    if (ex->is_weight) { if (ex->data_device[0]) ggml_hip_weight_free((ggml_hip_weight *) ex->data_device[0]); }
     else               ggml_hip_free(ex->data_device[0]);
     delete ex;
     t->extra = nullptr;
@@ -251,10 +277,12 @@ static void shim_mul_mat(const ggml_tensor * src0, const ggml_tensor * src1, ggm
     if (src1->ne[0] != K || src1->nb[0] != 4 || dst->nb[0] != 4 || src1->nb[1] != (size_t) K * 4 || dst->nb[1] != (size_t) M * 4) {
         fprintf(stderr, "ggml-hip: mul_mat '%s': non-contiguous src1/dst are not supported by the shim\n", dst->name); exit(1);
     }
-    const ggml_hip_weight * w = (const ggml_hip_weight *) ((shim_extra *) src0->extra)->data_device[0];
+    const shim_extra * ex = (const shim_extra *) src0->extra;
+    const ggml_hip_weight * w = (const ggml_hip_weight *) ex->data_device[0];
     float * x = (float *) pool_get((size_t) N * K * 4), * y = (float *) pool_get((size_t) N * M * 4);
     ggml_hip_memcpy_h2d(x, src1->data, (size_t) N * K * 4);                         // reference: H2D of src1 every op (ggml-cuda.cu:2717)
-    ggml_hip_mul_mat_q(w, x, K, N, y, M);
+    if (ex->split) { if (ggml_hip_mul_mat_q_split(g_split, w, x, K, N, y, M, ex->row_low, ex->row_high) != 0) exit(1); }   // rows exchanged by RCCL (reference: peer copies, :2779-2788)
+    else ggml_hip_mul_mat_q(w, x, K, N, y, M);
     ggml_hip_memcpy_d2h(dst->data, y, (size_t) N * M * 4);                          // reference: D2H of dst every op (ggml-cuda.cu:2787-2791)
     pool_put(x); pool_put(y);
     dst->meta.cuda_perf_mal_mul_type = 1;                                           // "quantized kernel" tag of the timing table

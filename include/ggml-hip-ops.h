@@ -39,6 +39,27 @@ void    ggml_hip_gemm_sequential(int on);
  * bit-identical with that reference build's (tests/test_gpu_falcon.py). A parity instrument: 10-100 x slower.             */
 void    ggml_hip_reference_order(int on);
 int     ggml_hip_get_reference_order(void);
+/* ---- row-split tensor parallelism, one process per GPU (csrc/split_tp.hip): the reference's `-ts` / GGML_BACKEND_GPU_SPLIT.
+ * ggml_hip_tensor_split_rows: the row range of every device for a matrix of nrows rows, with the reference's arithmetic
+ *   (ggml_cuda_set_tensor_split ggml-cuda.cu:2050-2077, ggml_cuda_transform_tensor :3044-3052); host only.
+ * ggml_hip_weight_upload_rows: rows [row_low, row_high) of the ggml block bytes onto this process's device (NULL: empty range).
+ * ggml_hip_mul_mat_q_split: every rank multiplies its rows, then the ranks exchange them by RCCL send/recv (in place of the
+ *   host-side gather on the main device, :2779-2788); dst [N][M] is complete on every rank and bit-identical to the unsplit
+ *   ggml_hip_mul_mat_q. unique_id: 128 bytes of falcon_hip_pipeline_unique_id (world == 1: NULL, no RCCL).
+ * ggml_hip_mul_mat_q_split_local: all ranks' parts in one process on one device (tests).                                   */
+typedef struct ggml_hip_split_comm ggml_hip_split_comm;
+/* joins this process to a row-split job at the ggml-cuda.h boundary: from now on ggml_cuda_transform_tensor uploads this
+ * rank's rows of GGML_BACKEND_GPU_SPLIT tensors (proportions: ggml_cuda_set_tensor_split) and their mat-muls inside
+ * ggml_cuda_compute_forward exchange rows by RCCL. world <= 1 leaves / restores the default (whole matrices). Returns 0. */
+int     ggml_hip_split_configure(int rank, int world, const void * unique_id);
+void    ggml_hip_tensor_split_rows(const float * tensor_split, int n_devices, int64_t nrows, int64_t * row_low, int64_t * row_high);
+ggml_hip_weight * ggml_hip_weight_upload_rows(int type, const void * host_blocks, int64_t K, int64_t nrows, int64_t row_low, int64_t row_high);
+ggml_hip_split_comm * ggml_hip_split_comm_create(int rank, int world, const void * unique_id);
+void    ggml_hip_split_comm_free(ggml_hip_split_comm * c);
+int     ggml_hip_mul_mat_q_split(ggml_hip_split_comm * c, const ggml_hip_weight * w_rows, const float * x_dev, int64_t K, int64_t N,
+                                 float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
+int     ggml_hip_mul_mat_q_split_local(ggml_hip_weight * const * parts, int world, const float * x_dev, int64_t K, int64_t N,
+                                       float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
 /* staging-buffer pool of the ggml-cuda.h boundary (ggml_cuda_compute_forward's src1 / dst device copies; the reference's
  * ggml_cuda_pool_malloc, ggml-cuda.cu:1738-1816): buffers ever allocated, hand-outs served by reuse, buffers free now */
 void    ggml_hip_shim_pool_stats(size_t * n_alloc, size_t * n_reuse, size_t * n_free);
