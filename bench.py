@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
     ap.add_argument("--streams", type=int, default=2, help="groups of decode streams in flight for --force-pipeline at one GPU")
     ap.add_argument("--pipe-batch", type=int, default=4, help="pipeline: lock-step streams per group (one weight pass serves them; 1..4)")
-    ap.add_argument("--north-star", action="store_true", help="pipeline: also time Falcon-40B Q4_K (all 60 blocks) over the same GPUs, as extra keys")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the extra keys of the north-star configuration (Falcon-40B Q4_K, all 60 blocks, on the same GPUs)")
+    ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     return ap.parse_args()
 
 
@@ -256,6 +257,27 @@ def main():
     if long_ms:
         prefill["long"] = prefill_roof(a.prefill_long, long_ms)
 
+    # ---- extra keys (not `value`): 8 decode streams on the same weights, 4 lock-step streams per weight pass
+    # (falcon_hip_pipeline at world 1: csrc/falcon_pipeline.hip + kernels_cols.hip), same greedy sampler
+    lock_step = None
+    if not a.no_lock_step:
+        G, B, R = 2, 4, min(a.steps, 64)
+        pipe = g.Pipeline(model, 0, 1, G, B, min(a.n_ctx, 512))
+        pipe.set_tokens(synth.tokens(G * B, hp["n_vocab"], seed=42))
+        pipe.run(8, 0)
+        L.ggml_hip_synchronize()
+        t0 = time.perf_counter()
+        pipe.run(R, 8)
+        L.ggml_hip_synchronize()
+        dtp = time.perf_counter() - t0
+        pipe.history(8, R)
+        pipe.free()
+        ls_tok_s = R * G * B / dtp
+        ls_bytes = wbytes / B + kv_bytes_per_token(hp, 8 + R // 2)
+        lock_step = {"workload": f"{G} groups x {B} lock-step greedy decode streams on the same resident weights (one weight pass serves {B} tokens), positions 8..{8 + R}",
+                     "value": ls_tok_s, "unit": "tokens/s", "streams": G * B, "ms_per_weight_pass": dtp / (R * G) * 1e3,
+                     "vs_single_stream": ls_tok_s / tok_s, "effective_GBs": ls_bytes * ls_tok_s / 1e9}
+
     cpu = None
     if not a.no_cpu:
         cpu = cpu_baseline(weights, hp, wbytes, a.prompt, a.cpu_tokens, toks)
@@ -275,9 +297,44 @@ def main():
         "roofline": roof, "cpu_baseline": cpu,
         "max_rel_logit_err_vs_cpu": parity["max_rel_logit_err_vs_cpu"] if parity else None, "parity": parity,
         "setup_s": {"synthesize": t_gen, "upload": t_up},
+        "lock_step_streams": lock_step,
     }
-    print(json.dumps(line))
     model.free()
+    del weights
+    # ---- extra keys: the north-star configuration on this GPU (Falcon-40B Q4_K, all 60 blocks resident, single-stream greedy decode)
+    if not a.no_north_star and a.model == "7b" and a.quant == "q4_0" and valid:
+        line["north_star_1gpu"] = north_star_1gpu(g, synth, L, tname, a)
+    print(json.dumps(line))
+
+
+def north_star_1gpu(g, synth, L, tname, a):
+    hp = dict(synth.HP_40B)
+    t0 = time.time()
+    weights = synth.make_model_fast(hp, tname["q4_K"], seed=1234)
+    model = g.FalconModel(weights, n_ctx=512, n_batch=128)
+    del weights
+    t_setup = time.time() - t0
+    wbytes = model.weight_bytes()
+    toks = synth.tokens(136, hp["n_vocab"], seed=42)
+    e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
+    model.eval(toks[:128], 0, logits_all=False)
+    L.ggml_hip_event_record(e0)
+    lg = model.eval(toks[:128], 0, logits_all=False)
+    L.ggml_hip_event_record(e1)
+    prefill_ms = L.ggml_hip_event_elapsed_ms(e0, e1)
+    out_w = model.decode_greedy(int(lg[0].argmax()), 128, 4, use_graph=not a.no_graph)
+    K = 32
+    L.ggml_hip_synchronize()
+    t0 = time.perf_counter()
+    model.decode_greedy(int(out_w[-1]), 132, K, use_graph=not a.no_graph)
+    L.ggml_hip_synchronize()
+    dt = time.perf_counter() - t0
+    model.free()
+    tok_s = K / dt
+    b_tok = wbytes + kv_bytes_per_token(hp, 132 + K // 2)
+    return {"workload": "Falcon-40B Q4_K (60 blocks, GQA 128/8, 8192 wide) fully resident on ONE GPU, 128-token prompt + 32 greedy decode steps",
+            "value": tok_s, "unit": "tokens/s", "ms_per_step": dt / K * 1e3, "prefill_tok_s": 128 / (prefill_ms * 1e-3),
+            "weight_bytes_per_token": wbytes, "step_achieved_GBs": b_tok * tok_s / 1e9, "step_frac": b_tok * tok_s / 1e9 / HBM_PEAK_GBS, "setup_s": t_setup}
 
 
 if __name__ == "__main__":

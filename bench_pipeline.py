@@ -322,7 +322,7 @@ def main(a, rank, world, local):
         raise SystemExit(f"--warmup + --steps must stay below {n_ctx} positions")
     tok_s, wbytes, blocks, t_setup, dt = run_cpp(a, rank, world, local, hp, wtype, a.model, a.quant, dist, torch, groups, batch, n_ctx, a.steps, a.warmup)
     extra = {}
-    if getattr(a, "north_star", False) and not (a.model == "40b" and a.quant.lower() == "q4_k"):
+    if not getattr(a, "no_north_star", False) and world > 1 and a.model == "7b" and not a.layers:
         # the north-star configuration next to the headline line: Falcon-40B Q4_K, all 60 blocks, over the same GPUs
         hp40 = dict(synth.HP_40B)
         ns_tok_s, ns_wb, ns_blocks, ns_setup, _ = run_cpp(a, rank, world, local, hp40, tname["q4_K"], "40b", "q4_k", dist, torch, groups, batch, n_ctx,

@@ -36,6 +36,7 @@ struct ggcc_file {
 };
 
 size_t tensor_bytes(int type, int64_t ne0, int64_t ne1) {
+    if (ne0 <= 0 || ne1 <= 0 || ne0 > ((int64_t) 1 << 31) || ne1 > ((int64_t) 1 << 31) || ne0 > ((int64_t) 1 << 60) / ne1) return 0;   // (sizes of a hostile file must not wrap)
     if (type == FQ_F32) return (size_t) ne0 * ne1 * 4;
     if (type == 1 /* GGML_TYPE_F16 */) return (size_t) ne0 * ne1 * 2;
     const fq_type_desc d = fq_desc(type);
@@ -70,6 +71,10 @@ bool ggcc_open(const char * path, ggcc_file & f) {
     f.hp.layer_begin = 0; f.hp.layer_end = f.hp.n_layer;
     if (f.hp.n_embd <= 0 || f.hp.n_head <= 0 || f.hp.n_embd != 64 * f.hp.n_head || f.hp.n_head_kv <= 0 || f.hp.n_head % f.hp.n_head_kv) {
         f.error = "implausible hparams (head_dim must be 64)"; return false;
+    }
+    if (f.hp.n_vocab <= 0 || f.hp.n_vocab > (1 << 24) || f.hp.n_layer <= 0 || f.hp.n_layer > 4096 || f.hp.n_embd > (1 << 20)) {
+        f.error = "implausible hparams (n_vocab " + std::to_string(f.hp.n_vocab) + ", n_layer " + std::to_string(f.hp.n_layer) + ", n_embd " + std::to_string(f.hp.n_embd) + ")";
+        return false;
     }
     f.vocab_begin = pos;
     for (int i = 0; i < f.hp.n_vocab; ++i) {                     // vocabulary: len, bytes, f32 score
@@ -140,6 +145,25 @@ extern "C" falcon_hip_model * falcon_hip_model_load_ggcc(const char * path, int 
             const bool mine = (t.name == "lm_head.weight" && hp.layer_end == hp.n_layer) || (t.name == "transformer.word_embeddings.weight" && hp.layer_begin == 0);
             if (mine) { fprintf(stderr, "falcon-hip: %s: %s is f16; quantize it (falcon_quantize quantizes the output tensor by default)\n", path, t.name.c_str()); falcon_hip_model_free(m); return nullptr; }
             continue;
+        }
+        {   // shapes are checked HERE (a bad file is an error return, not the exit(1) of the in-memory upload path)
+            const int64_t E = hp.n_embd, QKV = (int64_t)(hp.n_head + 2 * hp.n_head_kv) * 64, FF = hp.n_ff, V = hp.n_vocab;
+            const std::string & n = t.name;
+            auto ends = [&](const char * suf) { const size_t l = strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
+            int64_t e0 = -1, e1 = -1;
+            if (n == "transformer.word_embeddings.weight" || n == "lm_head.weight") { e0 = E; e1 = V; }
+            else if (ends("self_attention.query_key_value.weight")) { e0 = E; e1 = QKV; }
+            else if (ends("self_attention.dense.weight")) { e0 = E; e1 = E; }
+            else if (ends("mlp.dense_h_to_4h.weight")) { e0 = E; e1 = FF; }
+            else if (ends("mlp.dense_4h_to_h.weight")) { e0 = FF; e1 = E; }
+            else if (t.n_dims == 1) { e0 = E; e1 = 1; }                       // the norms
+            const int64_t n1 = t.n_dims > 1 ? t.ne[1] : 1;
+            if (e0 >= 0 && (t.ne[0] != e0 || n1 != e1 || (e1 > 1 && t.type == 0))) {
+                fprintf(stderr, "falcon-hip: %s: tensor %s is [%lld x %lld] of type %d, expected [%lld x %lld]%s\n", path, n.c_str(), (long long) t.ne[0], (long long) n1, t.type,
+                        (long long) e0, (long long) e1, (e1 > 1 && t.type == 0) ? " quantized (f32 matrices are not on this path: run falcon_quantize)" : "");
+                falcon_hip_model_free(m);
+                return nullptr;
+            }
         }
         if (falcon_hip_model_set_tensor(m, t.name.c_str(), t.type, f.base + t.offset, t.ne[0], t.n_dims > 1 ? t.ne[1] : 1) == 0) ++used;
     }

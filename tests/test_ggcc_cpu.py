@@ -85,7 +85,11 @@ def test_scan_refuses_damaged_files(files, tmp_path):
     for mutated in (struct.pack("<I", 0x67676a74) + blob[4:],        # GGJT magic
                     blob[:4] + struct.pack("<I", 3) + blob[8:],       # wrong version
                     blob[:len(blob) - 1000],                          # truncated tensor data
-                    blob[:30]):                                       # truncated header
+                    blob[:30],                                        # truncated header
+                    blob[:8] + struct.pack("<I", 0) + blob[12:],      # n_vocab 0
+                    blob[:8] + struct.pack("<I", 0x7FFFFFFF) + blob[12:],   # n_vocab absurd
+                    blob[:24] + struct.pack("<I", 0) + blob[28:],     # n_layer 0
+                    blob[:24] + struct.pack("<I", 1 << 20) + blob[28:]):    # n_layer absurd
         bad.write_bytes(mutated)
         with pytest.raises(RuntimeError):
             g.ggcc_scan(str(bad))
