@@ -26,6 +26,14 @@
 #include "kernels.h"
 #include <type_traits>
 
+// GQ_PACKED=1: the scaling epilogue with v_pk_mul_f32 / v_pk_add_f32, two results per instruction (356 instead of 640 f32 VALU
+// instructions in <Q4_0,2,4,2>, the same bits). Measured on MI355X (Falcon-7B Q4_0, A/B of two builds in one gpurun call):
+// 128-token prompt 9.90 ms against 9.72 scalar, 2048 tokens 145.5 ms against 140.2 -- the packed f32 operations issue at half
+// rate next to the MFMAs, so the instruction count they save buys nothing. OFF.
+#ifndef GQ_PACKED
+#define GQ_PACKED 0
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i  __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -428,13 +436,14 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         }
     };
 
-    float acc[RB][NR];
+    v2f acc2[RB][NR / 2];                                                // the f32 results in pairs (packed scaling epilogue)
+#define ACC(rb_, i_) acc2[rb_][(i_) >> 1][(i_) & 1]
     int iacc[RB][KINT ? NR : 1];                                         // k-quants: integer sums of the current super-block
     v16i chi[RB], clo[RB];                                               // ... and of its mins term (wave sw == S - 1)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { acc[rb][r] = 0.0f; chi[rb][r] = 0; clo[rb][r] = 0; }
+        for (int r = 0; r < NR; ++r) { ACC(rb, r) = 0.0f; chi[rb][r] = 0; clo[rb][r] = 0; }
 #pragma unroll
         for (int r = 0; r < (KINT ? NR : 1); ++r) iacc[rb][r] = 0;
     }
@@ -499,6 +508,20 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
                     // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
                     // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
+#if GQ_PACKED
+                    // the same IEEE operations two results at a time (v_pk_mul_f32 / v_pk_add_f32; no contraction: -ffp-contract=off)
+                    const v2f dw2 = { dw, dw }, mw2 = { mw, mw };
+#pragma unroll
+                    for (int i = 0; i < NR; i += 2) {
+                        const v2f ci = { (float) c[i], (float) c[i + 1] };
+                        const v2f dx = { dxv[i], dxv[i + 1] };
+                        v2f t;
+                        if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw2) * dx;                       // ggml.c:2606
+                        else if constexpr (!HAS_MIN)                            t = (dw2 * dx) * ci;                       // ggml.c:2972, 3325; Q3_K, Q6_K
+                        else { const v2f sx = { sxv[i], sxv[i + 1] };           t = (dw2 * dx) * ci + mw2 * sx; }          // ggml.c:2731, 3227; k-quants
+                        acc2[rb][i >> 1] = acc2[rb][i >> 1] + t;
+                    }
+#else
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         const float ci = (float) c[i];
@@ -507,8 +530,9 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
                         else if constexpr (!HAS_MIN)                            t = (dw * dxv[i]) * ci;                    // Q3_K, Q6_K
                         else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
-                        acc[rb][i] = acc[rb][i] + t;
+                        ACC(rb, i) = ACC(rb, i) + t;
                     }
+#endif
                 }
             }
         }
@@ -550,7 +574,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                             if constexpr (HAS_MIN) {       // (the oracle's / reference's expression: sumf += d isum - dmin msum)
                                 if (sw == S - 1) { t = t - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]); chi[rb][i] = 0; clo[rb][i] = 0; }
                             }
-                            acc[rb][i] = acc[rb][i] + t;
+                            ACC(rb, i) = ACC(rb, i) + t;
                         }
                     }
                 }
@@ -592,14 +616,14 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) xch[((tt * RB + rb) * NR + i) * 64 + lane] = acc[rb][i];
+                    for (int i = 0; i < NR; ++i) xch[((tt * RB + rb) * NR + i) * 64 + lane] = ACC(rb, i);
             }
             __syncthreads();
             if (sw == 0) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) acc[rb][i] = acc[rb][i] + xch[((tt * RB + rb) * NR + i) * 64 + lane];
+                    for (int i = 0; i < NR; ++i) ACC(rb, i) = ACC(rb, i) + xch[((tt * RB + rb) * NR + i) * 64 + lane];
             }
         }
         if (sw != 0) return;
@@ -612,7 +636,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         for (int i = 0; i < NR; ++i) {
             const int64_t n = n0 + 32 * tt + rot + (i & 3) + 8 * (i >> 2) + 4 * half;
             if (n < N && m < M) {
-                float v = acc[rb][i];
+                float v = ACC(rb, i);
                 if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
                 else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
                 dst[n * ldd + m] = v;
