@@ -153,6 +153,145 @@ static void launch_attention_rows_t(const float * qkv, int N, int H, int HKV, co
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_rows<R, F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     hipLaunchKernelGGL((k_attention_rows<R, F64>), dim3((unsigned) H, (unsigned)((N + R - 1) / R)), dim3(256), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, p_stride, p_scratch);
 }
+// ---- prefill attention on the f32 matrix pipe (N >= 32) ----------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 performs, per output element, ONE fused multiply-add per k step in ascending k
+// (scripts/microbench/mb_mfma_f32.hip: 0 of 1024 outputs differ from the fmaf chain over 64 steps) -- the arithmetic of the
+// reference's SIMD builds (f32 FMA accumulation, ggml.c:2270-2294) with a SEQUENTIAL association the oracle restates in two
+// lines (oracle_falcon.c dot_qk_mfma / dot_pv_mfma):
+//   score(i, j) = chain over s = 0..31 of  q[s] k[s],  q[32 + s] k[32 + s]            (lanes 0-31 feed dims 0..31, lanes 32-63 dims 32..63)
+//   out(i, d)   = E + O,  E / O = chains over the even / odd 32-key tiles, in a tile over s = 0..15 of  p[s] v[s],  p[16 + s] v[16 + s]
+// One workgroup = one head x 32 query tokens, 4 waves: the waves split the key tiles of K.Q (one 32 x 32 score tile = 32
+// MFMAs), the soft_max rows (max, fp16-table exp, f64 sum -- exact in any order: <= 2^13 fp16-valued terms --, scaling), and
+// V.P as (dim half) x (tile parity). Scores / probabilities live in the workgroup's slice of the global scratch (L2).
+typedef float v16f __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_attention_mfma(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                        const float * __restrict__ kc, const float * __restrict__ vc,
+                                                        const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int p_stride,
+                                                        float * __restrict__ p_scratch) {
+    __shared__ float xch[2][16][64];
+    __shared__ float rmax[4][32], rinv[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, hf = lane >> 5;
+    const int h = blockIdx.x, i0 = blockIdx.y * 32, hk = h / (H / HKV), heads = H + 2 * HKV;
+    const int n_past = *n_past_ptr;
+    const int nrows = N - i0 < 32 ? N - i0 : 32;
+    const int n_kv_max = n_past + i0 + nrows;                       // keys the tile's last token sees
+    const int n_rows_cache = n_past + N;                            // key / value rows that exist
+    const int ntile = (n_kv_max + 31) >> 5;
+    float * p = p_scratch + ((size_t) blockIdx.y * gridDim.x + blockIdx.x) * (size_t) 32 * (size_t) p_stride;
+    // The score matrix makes FOUR trips through the scratch (written here, read + rewritten as exp() by the soft_max, read by V.P):
+    // the row maxima are taken from the MFMA results in registers, and the 1 / sum scaling is applied to the operand V.P loads
+    // (p = e * inv, the soft_max's own rounding) -- the scratch of a 2048-token prompt is 1.2 GB and does not stay in the caches.
+    // ---- scores
+    {
+        f32x4 q8[8];
+        const float * qrow = qkv + ((int64_t)(i0 + (li < nrows ? li : nrows - 1)) * heads + h) * 64 + 32 * hf;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) q8[v] = ((const f32x4 *) qrow)[v];
+        auto load_k = [&](int T, f32x4 (&k8)[8]) {
+            const int j = 32 * T + li;
+            const float * krow = kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hf;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) k8[v] = ((const f32x4 *) krow)[v];
+        };
+        f32x4 ka[8], kb[8];
+        float mx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+        if (wid < ntile) load_k(wid, ka);
+        for (int T = wid; T < ntile; T += 4) {
+            if (T + 4 < ntile) load_k(T + 4, kb);
+            v16f c = {0};
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].x, ka[v].x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].y, ka[v].y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].z, ka[v].z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].w, ka[v].w, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const float sc = c[r] * 0.125f;
+                p[(size_t) ir * p_stride + 32 * T + li] = sc;
+                mx[r] = fq_max_f32(mx[r], (ir < nrows && 32 * T + li <= n_past + i0 + ir) ? sc : -INFINITY);
+            }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m = reduce32(mx[r], op_max());
+            if (li == 0) rmax[wid][(r & 3) + 8 * (r >> 2) + 4 * hf] = m;
+        }
+    }
+    __syncthreads();
+    // ---- soft_max: wave w takes rows w, w + 4, ...: exp() of the visible keys, zeros up to the last tile, 1 / sum kept aside
+    for (int ir = wid; ir < 32; ir += 4) {
+        float * pr = p + (size_t) ir * p_stride;
+        const int n_kv = ir < nrows ? n_past + i0 + ir + 1 : 0;
+        const float m = fq_max_f32(fq_max_f32(rmax[0][ir], rmax[1][ir]), fq_max_f32(rmax[2][ir], rmax[3][ir]));
+        double lsum = 0.0;
+#pragma unroll 4
+        for (int j = 4 * lane; j < 32 * ntile; j += 256) {
+            const f32x4 x = *(const f32x4 *)(pr + j);
+            f32x4 e;
+            e.x = j     < n_kv ? soft_max_exp(exp_tab, x.x - m) : 0.0f;
+            e.y = j + 1 < n_kv ? soft_max_exp(exp_tab, x.y - m) : 0.0f;
+            e.z = j + 2 < n_kv ? soft_max_exp(exp_tab, x.z - m) : 0.0f;
+            e.w = j + 3 < n_kv ? soft_max_exp(exp_tab, x.w - m) : 0.0f;
+            *(f32x4 *)(pr + j) = e;
+            lsum += (double) e.x; lsum += (double) e.y; lsum += (double) e.z; lsum += (double) e.w;     // (exact in any order)
+        }
+        lsum = wave_sum(lsum);
+        if (lane == 0) rinv[ir] = (float)(1.0 / lsum);
+    }
+    __syncthreads();
+    // ---- V.P: wave = (dim half, tile parity)
+    {
+        const int dh = wid & 1, par = wid >> 1;
+        const float * prow = p + (size_t) li * p_stride + 16 * hf;
+        const float inv = rinv[li];
+        auto load_pv = [&](int T, f32x4 (&p4)[4], float (&v16)[16]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) p4[v] = ((const f32x4 *)(prow + 32 * T))[v];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int j = 32 * T + 16 * hf + s;
+                v16[s] = vc[((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * dh + li];
+            }
+        };
+        f32x4 pa[4], pb[4]; float va[16], vb[16];
+        if (par < ntile) load_pv(par, pa, va);
+        v16f c = {0};
+        for (int T = par; T < ntile; T += 2) {
+            if (T + 2 < ntile) load_pv(T + 2, pb, vb);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[v].x * inv, va[4 * v + 0], c, 0, 0, 0);      // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32)
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[v].y * inv, va[4 * v + 1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[v].z * inv, va[4 * v + 2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[v].w * inv, va[4 * v + 3], c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pa[v] = pb[v];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) va[s] = vb[s];
+        }
+        if (par == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[dh][r][lane] = c[r];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (ir < nrows) att[(int64_t)(i0 + ir) * H * 64 + (int64_t) h * 64 + 32 * dh + li] = c[r] + xch[dh][r][lane];
+            }
+        }
+    }
+}
+
 // 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
 static int g_attn_f64 = 0;
 void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
@@ -197,6 +336,18 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     // beyond ~3000 keys: 4 tokens per workgroup with the score rows in the global scratch instead of 2 with them in LDS
     // (8192-token prompt: 32 ms per block against 36-40; 8 tokens per workgroup: 38). The scratch is N x H x n_kv floats --
     // 1.2 GB for a 512-token batch at 8192 keys -- and is not used beyond FQ_ATTN_SCRATCH_GB (default 4) GiB
+    static const int use_mfma = getenv("FQ_ATTN_MFMA") ? atoi(getenv("FQ_ATTN_MFMA")) : 1;
+    if (use_mfma && N >= 32 && !g_attn_f64 && !seq_stride && force < 0) {
+        const int ps = (max_n_kv + 31) & ~31;
+        float * scr = att_scratch((size_t)((N + 31) / 32) * (size_t) H * 32 * (size_t) ps * 4, st);
+        if (scr) {
+            // (a 128-token-per-workgroup form with the key / value tiles shared through LDS was built and measured: 124 ms against
+            // 112 ms for a 2048-token Falcon-7B prompt -- a barrier per tile and idle waves at the causal edge cost more than the
+            // L2 traffic it saves)
+            hipLaunchKernelGGL(k_attention_mfma, dim3((unsigned) H, (unsigned)((N + 31) / 32)), dim3(256), 0, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, ps, scr);
+            return;
+        }
+    }
     static const int use_scratch = getenv("FQ_ATTN_SCRATCH") ? atoi(getenv("FQ_ATTN_SCRATCH")) : 1;
     if (use_scratch && force < 0 && R == 2 && N >= 4 && !seq_stride) {
         const size_t need = (size_t)((N + 3) / 4) * (size_t) H * 4 * row;

@@ -155,6 +155,30 @@ static float dot_pv_backend(const float * v, const float * p, int64_t n, int64_t
     return o;
 }
 
+/* The backend's prefill attention for N >= 32 tokens runs on the f32 matrix pipe (k_attention_mfma, kernels_block.hip):
+ * v_mfma_f32_32x32x2_f32 is one fused multiply-add per k step and output element, k ascending (measured bit for bit,
+ * scripts/microbench/mb_mfma_f32.hip), so the association is sequential:
+ *   K.Q  one chain over s = 0..31 of dims s, 32 + s
+ *   V.P  two chains, over the even and the odd 32-key tiles (keys 32 T .. 32 T + 31, inside a tile s = 0..15 of keys s, 16 + s),
+ *        added at the end; a masked key has weight 0 and leaves its chain unchanged (the chain never holds -0) */
+#define ORC_ATTN_MFMA_MIN_N 32
+static float dot_qk_mfma(const float * k, const float * q) {
+    float c = 0.0f;
+    for (int s = 0; s < 32; ++s) { c = fmaf(q[s], k[s], c); c = fmaf(q[32 + s], k[32 + s], c); }
+    return c;
+}
+static float dot_pv_mfma(const float * v, const float * p, int64_t n, int64_t stride_v) {
+    float c[2] = { 0.0f, 0.0f };
+    for (int64_t t0 = 0; t0 < n; t0 += 32) {
+        float * a = &c[(t0 >> 5) & 1];
+        for (int s = 0; s < 16; ++s) {
+            if (t0 + s < n)      *a = fmaf(p[t0 + s], v[(t0 + s) * stride_v], *a);
+            if (t0 + 16 + s < n) *a = fmaf(p[t0 + 16 + s], v[(t0 + 16 + s) * stride_v], *a);
+        }
+    }
+    return c[0] + c[1];
+}
+
 void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_past, int n_threads,
                      int flavour, float * logits_out, float * hidden_out) {
     orc_tables_init();
@@ -205,12 +229,14 @@ void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_p
 
         const float kq_scale = 1.0f / sqrtf((float) D);
         const int backend_attn = orc_attn_backend_order() && D == 64;
+        const int mfma_attn = backend_attn && N >= ORC_ATTN_MFMA_MIN_N;
         for (int t = 0; t < N; ++t) {
             for (int h = 0; h < H; ++h) {
                 const int hk = h / group;
                 const float * q = qrot + ((size_t) t * H + h) * D;
                 for (int64_t s = 0; s < n_kv; ++s) {
-                    float v = (backend_attn ? dot_qk_backend(kc + ((size_t) s * HKV + hk) * D, q)
+                    float v = (mfma_attn ? dot_qk_mfma(kc + ((size_t) s * HKV + hk) * D, q)
+                               : backend_attn ? dot_qk_backend(kc + ((size_t) s * HKV + hk) * D, q)
                                             : dot_f32(kc + ((size_t) s * HKV + hk) * D, q, D, 1)) * kq_scale;  /* K.Q then scale */
                     if (s > n_past + t) v = -INFINITY;                                    /* ggml.c:12341-12347 */
                     p[s] = v;
@@ -218,7 +244,9 @@ void orc_falcon_eval(const orc_model * m, const int32_t * tokens, int N, int n_p
                 orc_softmax_rows(p, n_kv, 1);
                 float * o = att + (size_t) t * E + (size_t) h * D;                        /* merged [n_embd, N] */
                 for (int64_t d = 0; d < D; ++d) {
-                    o[d] = backend_attn ? dot_pv_backend(vc + (size_t) hk * D + d, p, n_kv, HKV * D)
+                    /* (masked keys carry p = 0: the chains of the matrix-pipe form run over the visible keys only) */
+                    o[d] = mfma_attn ? dot_pv_mfma(vc + (size_t) hk * D + d, p, n_past + t + 1, HKV * D)
+                         : backend_attn ? dot_pv_backend(vc + (size_t) hk * D + d, p, n_kv, HKV * D)
                                         : dot_f32(vc + (size_t) hk * D + d, p, n_kv, HKV * D);    /* V^T row . P row */
                 }
             }
@@ -255,18 +283,21 @@ static void * att_worker(void * arg) {
     const int group = (int)(H / HKV);
     const float kq_scale = 1.0f / sqrtf((float) D);
     const int backend_attn = orc_attn_backend_order() && D == 64;
+    const int mfma_attn = backend_attn && j->N >= ORC_ATTN_MFMA_MIN_N;
     float * p = (float *) malloc(sizeof(float) * (size_t)(j->pos0 + j->N));
     for (int64_t w = j->ith; w < (int64_t) j->ns * H; w += j->nth) {
         const int si = (int)(w / H), h = (int)(w % H), hk = h / group;
         const int64_t n_kv = (int64_t) j->pos0 + j->sample[si] + 1;
         const float * q = j->q + ((size_t) si * H + h) * D;
         for (int64_t s = 0; s < n_kv; ++s)
-            p[s] = (backend_attn ? dot_qk_backend(j->kc + ((size_t) s * HKV + hk) * D, q)
+            p[s] = (mfma_attn ? dot_qk_mfma(j->kc + ((size_t) s * HKV + hk) * D, q)
+                    : backend_attn ? dot_qk_backend(j->kc + ((size_t) s * HKV + hk) * D, q)
                                  : dot_f32(j->kc + ((size_t) s * HKV + hk) * D, q, D, 1)) * kq_scale;
         orc_softmax_rows(p, n_kv, 1);
         float * o = j->att + (size_t) si * E + (size_t) h * D;
         for (int64_t d = 0; d < D; ++d)
-            o[d] = backend_attn ? dot_pv_backend(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D)
+            o[d] = mfma_attn ? dot_pv_mfma(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D)
+                 : backend_attn ? dot_pv_backend(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D)
                                 : dot_f32(j->vc + (size_t) hk * D + d, p, n_kv, HKV * D);
     }
     free(p);
