@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
     ap.add_argument("--streams", type=int, default=2, help="groups of decode streams in flight for --force-pipeline at one GPU")
-    ap.add_argument("--pipe-batch", type=int, default=4, help="pipeline: lock-step streams per group (one weight pass serves them; 1..4)")
+    ap.add_argument("--pipe-batch", type=int, default=8, help="pipeline: lock-step streams per group (one weight pass serves them; 1..64, beyond 4 through the int8-MFMA GEMM)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra keys of the north-star configuration (Falcon-40B Q4_K, all 60 blocks, on the same GPUs)")
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     return ap.parse_args()
@@ -257,11 +257,11 @@ def main():
     if long_ms:
         prefill["long"] = prefill_roof(a.prefill_long, long_ms)
 
-    # ---- extra keys (not `value`): 8 decode streams on the same weights, 4 lock-step streams per weight pass
+    # ---- extra keys (not `value`): 16 decode streams on the same weights, 8 lock-step streams per weight pass (two chunks of 4 columns)
     # (falcon_hip_pipeline at world 1: csrc/falcon_pipeline.hip + kernels_cols.hip), same greedy sampler
     lock_step = None
     if not a.no_lock_step:
-        G, B, R = 2, 4, min(a.steps, 64)
+        G, B, R = 2, 8, min(a.steps, 64)
         pipe = g.Pipeline(model, 0, 1, G, B, min(a.n_ctx, 512))
         pipe.set_tokens(synth.tokens(G * B, hp["n_vocab"], seed=42))
         pipe.run(8, 0)

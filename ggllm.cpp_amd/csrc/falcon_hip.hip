@@ -466,6 +466,7 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
+#define FQ_COLS_MAX_N 12
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
     const falcon_hip_hparams & hp = m->hp;
@@ -623,16 +624,22 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         const bool att_q = (a_att.type == FQ_Q8_0 || a_att.type == FQ_Q8_1);
         // 2..4 lock-step sequences: the block's weights in TWO launches that serve every column (kernels_cols.hip), the
         // decode attention of all sequences in one launch between them -- same bits as the generic launches below
-        const bool cols_path = seq_stride && N >= 2 && N <= 4 && c->fused_decode && !fq_reference_order() && !fq_attn_f64() &&
+        // up to FQ_COLS_MAX_N sequences in chunks of 4 columns (beyond that the int8-MFMA GEMM's one pass is cheaper: measured
+        // 8.3-9.2 ms per Falcon-7B pass for any N in 8..64 against 2.0 ms per 4-column pass)
+        const bool cols_path = seq_stride && N >= 2 && N <= FQ_COLS_MAX_N && c->fused_decode && !fq_reference_order() && !fq_attn_f64() &&
                                L.qkv.type == L.up.type && L.down.type == L.wo.type;
         bool up_done = false, ff_quantized = false;
         if (cols_path) {
             const bool quant_epi = (a_ff.type == FQ_Q8_0 || a_ff.type == FQ_Q8_1) && FF % 32 == 0;
-            fq_gemv_cols_args ga{};
-            ga.nseg = 2; ga.ncols = N; ga.gelu_table = hc.gelu_table;
-            ga.seg[0] = { L.qkv, a_qkv.base, FQ_LNEPI_STORE, c->qkv, QKV, nullptr, 0, 0 };
-            ga.seg[1] = { L.up, a_up.base, quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE, c->up, FF, c->buf_ff, a_ff.type, 0 };
-            up_done = fq_launch_gemv_cols(ga, hc.n_cu, st);
+            up_done = true;
+            for (int c0 = 0; c0 < N && up_done; c0 += 4) {
+                fq_gemv_cols_args ga{};
+                ga.nseg = 2; ga.ncols = N - c0 < 4 ? N - c0 : 4; ga.gelu_table = hc.gelu_table;
+                ga.seg[0] = { L.qkv, a_qkv.base + (size_t) c0 * fq_act_col_bytes(a_qkv.type, E), FQ_LNEPI_STORE, c->qkv + (size_t) c0 * QKV, QKV, nullptr, 0, 0 };
+                ga.seg[1] = { L.up, a_up.base + (size_t) c0 * fq_act_col_bytes(a_up.type, E), quant_epi ? FQ_LNEPI_GELU_QUANT : FQ_LNEPI_GELU_STORE,
+                              c->up + (size_t) c0 * FF, FF, c->buf_ff + (size_t) c0 * fq_act_col_bytes(a_ff.type, FF), a_ff.type, 0 };
+                up_done = fq_launch_gemv_cols(ga, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
+            }
             ff_quantized = up_done && quant_epi;
         }
         if (!up_done) fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
@@ -654,8 +661,12 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         if (!ff_quantized) fq_launch_quantize_act(c->up, FF, a_ff, st);
         bool out_done = false;
         if (cols_path) {
-            const fq_gemv_out_cols_args go{ L.down, L.wo, c->buf_ff, c->buf_att, c->x, c->x, E, N };
-            out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st);
+            out_done = true;
+            for (int c0 = 0; c0 < N && out_done; c0 += 4) {
+                const fq_gemv_out_cols_args go{ L.down, L.wo, c->buf_ff + (size_t) c0 * fq_act_col_bytes(a_ff.type, FF), c->buf_att + (size_t) c0 * fq_act_col_bytes(a_att.type, E),
+                                                c->x + (size_t) c0 * E, c->x + (size_t) c0 * E, E, N - c0 < 4 ? N - c0 : 4 };
+                out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
+            }
         }
         if (!out_done) {
             fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
@@ -671,11 +682,14 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         const fq_act a_head = act_for(c->buf_e, m->lm_head, N);
         fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, a_head, st);
         bool head_done = false;
-        if (seq_stride && N >= 2 && N <= 4 && c->fused_decode && !fq_reference_order()) {
-            fq_gemv_cols_args ga{};
-            ga.nseg = 1; ga.ncols = N; ga.gelu_table = hc.gelu_table;
-            ga.seg[0] = { m->lm_head, a_head.base, FQ_LNEPI_STORE, c->logits_dev, hp.n_vocab, nullptr, 0, 0 };
-            head_done = fq_launch_gemv_cols(ga, hc.n_cu, st);
+        if (seq_stride && N >= 2 && N <= FQ_COLS_MAX_N && c->fused_decode && !fq_reference_order()) {
+            head_done = true;
+            for (int c0 = 0; c0 < N && head_done; c0 += 4) {
+                fq_gemv_cols_args ga{};
+                ga.nseg = 1; ga.ncols = N - c0 < 4 ? N - c0 : 4; ga.gelu_table = hc.gelu_table;
+                ga.seg[0] = { m->lm_head, a_head.base + (size_t) c0 * fq_act_col_bytes(a_head.type, E), FQ_LNEPI_STORE, c->logits_dev + (size_t) c0 * hp.n_vocab, hp.n_vocab, nullptr, 0, 0 };
+                head_done = fq_launch_gemv_cols(ga, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
+            }
         }
         if (!head_done) fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
     }

@@ -245,7 +245,7 @@ void launch_out_cols_t(const fq_gemv_out_cols_args & a, unsigned blocks, int nw,
 // both launchers return false (nothing launched) when the shape is outside their scope; the caller keeps the op list
 bool fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st) {
     (void) n_cu;
-    if (a.ncols < 2 || a.ncols > 4 || a.nseg < 1 || a.nseg > 2) return false;
+    if (a.ncols < 1 || a.ncols > 4 || a.nseg < 1 || a.nseg > 2) return false;
     const int type = a.seg[0].w.type;
     const int act = fq_desc(type).act_type;
     a.npass = 4;                                                        // 12 waves x 4 passes x 2 rows = 96 rows per workgroup
@@ -271,7 +271,7 @@ bool fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st) {
 }
 
 bool fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st) {
-    if (a.ncols < 2 || a.ncols > 4 || a.w_down.type != a.w_wo.type || a.w_down.M != a.w_wo.M) return false;
+    if (a.ncols < 1 || a.ncols > 4 || a.w_down.type != a.w_wo.type || a.w_down.M != a.w_wo.M) return false;
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
     const int nc = a.ncols > 2 ? 4 : 2;
