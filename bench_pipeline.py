@@ -310,6 +310,8 @@ def main(a, rank, world, local):
         hp["n_layer"] = a.layers
     if not os.path.exists(g.LIB_PATH):
         g.build()
+    if os.environ.get("FALCON_PIPE_SAME_DEVICE") == "1":         # debug: every rank on GPU 0 (RCCL normally refuses two ranks on one device)
+        local = 0
     torch.cuda.set_device(local)
     g.init(local)
     if world > 1:

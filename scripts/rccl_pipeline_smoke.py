@@ -27,6 +27,8 @@ def main():
     from ggllm_cpp_amd import synth
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("FALCON_PIPE_SAME_DEVICE") == "1":         # debug: every rank on GPU 0
+        local = 0
     torch.cuda.set_device(local)
     g.init(local)
     dist.init_process_group("gloo", rank=rank, world_size=world)
