@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r2t
 cd /root/repo
 export PYTHONUNBUFFERED=1
 python -m pytest tests/test_gpu_block_ops.py tests/test_gpu_falcon.py tests/test_gpu_configs.py -x -q > gpurun_out/r2t/tests.log 2>&1; tail -15 gpurun_out/r2t/tests.log
-for m in 1 0 2; do
+for m in 1 0; do
   W=512; [ $m == 2 ] && W=1000000
   FQ_ATTN_MFMA_WIDE=$W FQ_ATTN_MFMA=$(( m > 0 ? 1 : 0 )) python bench.py --no-cpu --steps 16 --repeats 1 --no-north-star --no-lock-step > gpurun_out/r2t/bench_mfma$m.json 2> gpurun_out/r2t/bench_mfma$m.err
   python -c "
