@@ -188,6 +188,32 @@ def _both_orders(oracle, w, toks, n_pre, n_ctx):
     return relrms(out[2], out[0])
 
 
+@pytest.mark.parametrize("hp,t", [(synth.HP_TINY_MQA, ob.Q4_0), (synth.HP_TINY_GQA, ob.Q5_1), (synth.HP_TINY_GQA, ob.Q4_K)])
+@pytest.mark.parametrize("n_past,N", [(0, 32), (0, 33), (0, 45), (0, 100), (5, 64), (40, 33), (37, 95), (64, 32)])
+def test_matrix_pipe_attention_ragged_prompts(oracle, hp, t, n_past, N):
+    """prompts of 32 tokens and more take the prefill attention on the f32 matrix pipe (k_attention_mfma: 32-token query tiles,
+    32-key tiles): ragged last tiles, a context that does not start at 0 (the first chunk through whichever kernel its length
+    selects), MQA and GQA -- hidden states and logits of the chunk bit-identical to the oracle's restatement of the sequential
+    multiply-add chains (oracle_falcon.c dot_qk_mfma / dot_pv_mfma)"""
+    w = synth.make_model(oracle, hp, t, seed=31)
+    toks = synth.tokens(n_past + N, hp["n_vocab"], seed=12)
+    m = g.FalconModel(w, n_ctx=160, n_batch=100)
+    if n_past:
+        m.eval(toks[:n_past], 0)
+    lg, hid = m.eval(toks[n_past:], n_past, want_hidden=True)
+    m.free()
+    oracle.lib.orc_set_sum_order(2)
+    try:
+        mo = oracle.model(w, 160)
+        if n_past:
+            mo.eval(toks[:n_past], 0, 8)
+        lo, ho = mo.eval(toks[n_past:], n_past, 8, want_hidden=True)
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    assert np.array_equal(hid, ho)
+    assert np.array_equal(lg, lo)
+
+
 def test_falcon7b_shaped_layer_vs_oracle(oracle):
     """one block with the real 7B dimensions (n_embd 4544, 71 heads MQA, n_ff 18176), small vocab: bit-exact in both orders"""
     hp = dict(n_vocab=1024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=1, n_ff=18176, two_norms=False)
