@@ -700,9 +700,9 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     hip_context & hc = fq_ctx();
     falcon_hip_model * m = c->m;
     const int adv = c->n_seq > 0 ? 1 : N;                            // lock-step sequences: N rows = one position of each of N sequences
-    if (N < 1 || N > c->n_batch || n_past < 0 || n_past + adv > c->n_ctx) {
-        fprintf(stderr, "falcon-hip: eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, c->n_batch, c->n_ctx);
-        exit(1);
+    if (N < 1 || N > c->n_batch || n_past < 0 || n_past + adv > c->n_ctx || (m->first_stage() && !tokens) || (!m->first_stage() && !hidden_in_dev)) {
+        fprintf(stderr, "falcon-hip: eval of %d tokens at n_past %d: needs 1 <= n_tokens <= n_batch (%d), n_past + n_tokens <= n_ctx (%d) and its input\n", N, n_past, c->n_batch, c->n_ctx);
+        return 1;                                                    // (falcon_eval's convention: non-zero = failed to eval, libfalcon.cpp:4588-4591)
     }
     if (m->first_stage()) {
         for (int i = 0; i < N; ++i) if (tokens[i] < 0 || tokens[i] >= m->hp.n_vocab) {

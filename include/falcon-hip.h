@@ -83,7 +83,8 @@ falcon_hip_context * falcon_hip_context_create_seqs(falcon_hip_model * m, int n_
 int                  falcon_hip_context_n_seq(const falcon_hip_context * c);
 
 /* Evaluate n_tokens at position n_past (falcon_eval). Whole model in this process: tokens are host ids.
- * logits_all = 0 keeps the last row only. Returns 0.                                                           */
+ * logits_all = 0 keeps the last row only. Returns 0; 1 for an empty / oversized batch or a position past n_ctx (nothing is
+ * evaluated), 2 for a token id outside the vocabulary, 3 if an in-launch hand-off timed out (results invalid).          */
 int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, int n_tokens, int n_past, int logits_all);
 /* Pipeline-stage form: hidden_in_dev / hidden_out_dev are device [n_tokens][n_embd] f32 (NULL where the stage
  * embeds tokens / produces logits).                                                                             */

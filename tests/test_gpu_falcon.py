@@ -214,6 +214,25 @@ def test_matrix_pipe_attention_ragged_prompts(oracle, hp, t, n_past, N):
     assert np.array_equal(lg, lo)
 
 
+def test_eval_rejects_bad_batches(oracle):
+    """an empty batch, a batch larger than n_batch, a position past n_ctx and a token id outside the vocabulary are refused with
+    falcon_eval's non-zero return (libfalcon.cpp:4588-4591) -- nothing is evaluated, the context stays usable"""
+    hp = synth.HP_TINY_MQA
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=5)
+    m = g.FalconModel(w, n_ctx=16, n_batch=4)
+    toks = synth.tokens(8, hp["n_vocab"], seed=1)
+    good = m.eval(toks[:4], 0)
+    L = g.load()
+    for bad_toks, n_past in ((toks[:0], 0), (toks[:5], 0), (toks[:4], 13), (toks[:1], 16), (np.array([hp["n_vocab"]], np.int32), 4), (np.array([-1], np.int32), 4)):
+        t = np.ascontiguousarray(bad_toks, np.int32)
+        rc = L.falcon_hip_eval(m.ctx, t.ctypes.data if t.size else None, t.size, n_past, 1)
+        assert rc in (1, 2), (t.size, n_past, rc)
+        with pytest.raises(RuntimeError):
+            m.eval(bad_toks, n_past)
+    assert np.array_equal(m.eval(toks[:4], 0), good)
+    m.free()
+
+
 def test_falcon7b_shaped_layer_vs_oracle(oracle):
     """one block with the real 7B dimensions (n_embd 4544, 71 heads MQA, n_ff 18176), small vocab: bit-exact in both orders"""
     hp = dict(n_vocab=1024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=1, n_ff=18176, two_norms=False)
