@@ -629,8 +629,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // decode attention of all sequences in one launch between them -- same bits as the generic launches below
         // up to FQ_COLS_MAX_N sequences in chunks of 4 columns (beyond that the int8-MFMA GEMM's one pass is cheaper: measured
         // 8.3-9.2 ms per Falcon-7B pass for any N in 8..64 against 2.0 ms per 4-column pass)
+        const int cw_out = (L.down.type == L.wo.type) ? fq_gemv_out_cols_width(L.wo.type, FF, E) : 0;      // Falcon-40B width: 2 columns per output launch
         const bool cols_path = seq_stride && N >= 2 && N <= FQ_COLS_MAX_N && c->fused_decode && !fq_reference_order() && !fq_attn_f64() &&
-                               L.qkv.type == L.up.type && L.down.type == L.wo.type;
+                               L.qkv.type == L.up.type && cw_out > 0;
         bool up_done = false, ff_quantized = false;
         if (cols_path) {
             const bool quant_epi = (a_ff.type == FQ_Q8_0 || a_ff.type == FQ_Q8_1) && FF % 32 == 0;
@@ -691,9 +692,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         bool out_done = false;
         if (cols_path) {
             out_done = true;
-            for (int c0 = 0; c0 < N && out_done; c0 += 4) {
+            for (int c0 = 0; c0 < N && out_done; c0 += cw_out) {
                 const fq_gemv_out_cols_args go{ L.down, L.wo, c->buf_ff + (size_t) c0 * fq_act_col_bytes(a_ff.type, FF), c->buf_att + (size_t) c0 * fq_act_col_bytes(a_att.type, E),
-                                                c->x + (size_t) c0 * E, c->x + (size_t) c0 * E, E, N - c0 < 4 ? N - c0 : 4 };
+                                                c->x + (size_t) c0 * E, c->x + (size_t) c0 * E, E, N - c0 < cw_out ? N - c0 : cw_out };
                 out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
             }
         }

@@ -126,6 +126,7 @@ struct fq_gemv_out_cols_args {
 };
 bool   fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st);                 // false: outside its scope, nothing launched
 bool   fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st);
+int    fq_gemv_out_cols_width(int type, int64_t K_down, int64_t K_wo);      // columns per launch that fit its LDS: 4, 2 or 0
 
 // kernels_engine.hip -- the persistent decode engine: one launch per token
 #include <vector>

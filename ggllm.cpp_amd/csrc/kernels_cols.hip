@@ -270,6 +270,12 @@ bool fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st) {
     return true;
 }
 
+// widest column chunk (4 or 2; 0: none) whose two activation column sets fit the LDS of k_gemv_out_cols
+int fq_gemv_out_cols_width(int type, int64_t K_down, int64_t K_wo) {
+    const int act = fq_desc(type).act_type;
+    const size_t per = fq_act_col_bytes(act, K_down) + fq_act_col_bytes(act, K_wo);
+    return per * 4 + 16 <= 160 * 1024 ? 4 : (per * 2 + 16 <= 160 * 1024 ? 2 : 0);
+}
 bool fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st) {
     if (a.ncols < 1 || a.ncols > 4 || a.w_down.type != a.w_wo.type || a.w_down.M != a.w_wo.M) return false;
     const int type = a.w_wo.type;

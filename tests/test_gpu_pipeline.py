@@ -48,6 +48,24 @@ def test_lock_step_sequences_equal_contexts_of_their_own(oracle, hp, t, B):
     m.free()
 
 
+def test_lock_step_at_falcon40b_width(oracle):
+    """one 40B-shaped block (n_embd 8192, n_ff 32768, GQA 128/8, two norms, Q4_K): the output launch takes two columns at a time
+    (four would not fit its LDS) -- still one context's bits per sequence"""
+    hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
+    w = synth.make_model(oracle, hp, ob.Q4_K, seed=10)
+    m = g.FalconModel(w, n_ctx=16, n_batch=4)
+    B = 4
+    streams = [synth.tokens(5, hp["n_vocab"], seed=70 + b) for b in range(B)]
+    singles = [np.stack([m.eval(streams[b][i:i + 1], i)[0] for i in range(5)]) for b in range(B)]
+    sc = g.SeqContext(m, 16, B)
+    for i in range(5):
+        lg = sc.eval([int(streams[b][i]) for b in range(B)], i)
+        for b in range(B):
+            assert np.array_equal(lg[b], singles[b][i]), (b, i)
+    sc.free()
+    m.free()
+
+
 def _greedy_reference(w, hp, first, rounds):
     m = g.FalconModel(w, n_ctx=64, n_batch=4)
     out = np.stack([m.decode_greedy(int(t), 0, rounds) for t in first], axis=1)      # [round][sequence]
