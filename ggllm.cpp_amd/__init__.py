@@ -383,14 +383,19 @@ class FalconModel:
         return bool(load().falcon_hip_context_engine_active(self.ctx))
 
     def engine_debug(self):
-        """(failure records [k, 8], phase stamps [256 workgroups, 4 blocks, 8 slots]) of the engine (FALCON_HIP_ENGINE_DEBUG=1)"""
-        buf = np.zeros(4096 + 256 * 4 * 8 + 256 * 8, np.int64)
+        """(failure records [k, 8], phase stamps of consumer 0 / the attention workgroups [256 workgroups, 4 blocks, 8 slots]) of the engine
+        (FALCON_HIP_ENGINE_DEBUG=1); also sets engine_gstamps (the gatherer wave's stamps) and engine_counters [256, 16]
+        (kernels.h FQ_ENG_DBG_*: loader total / blocked / report-wait cycles, refills, bytes; consumer 0: wait-landed, dot cycles, rows,
+        waits for statistics / image / GELU image / attention image, gather; gatherer: gather, epilogues, wait for statistics)"""
+        S, NS = 4096, 256 * 4 * 8
+        buf = np.zeros(S + 2 * NS + 256 * 16, np.int64)
         n = load().falcon_hip_context_engine_debug(self.ctx, buf.ctypes.data, buf.size)
         if n == 0:
             return None, None
         k = int(min(buf[0], 500))
-        self.engine_counters = buf[4096 + 256 * 4 * 8:].reshape(256, 8)      # per workgroup: loader total / blocked / report-wait cycles, refills, bytes; consumer 0 wait / dot cycles, rows
-        return buf[16:16 + 8 * k].reshape(k, 8), buf[4096:4096 + 256 * 4 * 8].reshape(256, 4, 8)
+        self.engine_gstamps = buf[S + NS:S + 2 * NS].reshape(256, 4, 8)
+        self.engine_counters = buf[S + 2 * NS:].reshape(256, 16)
+        return buf[16:16 + 8 * k].reshape(k, 8), buf[S:S + NS].reshape(256, 4, 8)
 
     def sync_error(self):
         return load().falcon_hip_context_sync_error(self.ctx)

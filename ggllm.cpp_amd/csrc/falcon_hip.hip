@@ -383,7 +383,7 @@ static bool engine_prepare(falcon_hip_context * c) {
     if (m->last_stage() && m->lm_head.type != type) return false;
     if (type != FQ_Q4_0 && type != FQ_Q4_1 && type != FQ_Q5_0 && type != FQ_Q5_1 && type != FQ_Q8_0) return false;
     const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, HKV = hp.n_head_kv, QKVR = (H + 2 * HKV) * 64, V = hp.n_vocab;
-    if (E > 4 * 3 * 64 * 11) return false;                                  // the LayerNorm row must fit the consumers' registers
+    if (E > 4 * 3 * 64 * 11) return false;                                  // the LayerNorm weights of the row must fit the helper waves' registers
     int hpw = 2;
     if (const char * e = getenv("FALCON_HIP_ENGINE_HPW")) hpw = atoi(e) >= 3 ? 3 : (atoi(e) <= 1 ? 1 : 2);
     const int n_attn = (H + hpw - 1) / hpw, n_stream = hc.n_cu - n_attn;
@@ -393,8 +393,8 @@ static bool engine_prepare(falcon_hip_context * c) {
     if (!fq_engine_plan(type, E, FF, QKVR, V, m->last_stage(), n_stream, sched, &mg, &mr)) return false;
     const size_t attn_group = (768 + 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) c->n_ctx * 4 + 15) & ~(size_t) 15) + 15) & ~(size_t) 15;
     int nslot = 0; size_t lds = 0;
-    for (int ns : { 8, 6, 4 }) {
-        const size_t need = fq_engine_lds_bytes(type, ns, E, FF, (int) m->layers.size());
+    for (int ns : { 8, 7, 6, 4 }) {
+        const size_t need = fq_engine_lds_bytes(type, ns, E, FF, (int) m->layers.size(), hp.two_norms ? 1 : 0);
         if (need <= 160 * 1024) { nslot = ns; lds = need; break; }
     }
     if (!nslot) return false;
@@ -442,14 +442,13 @@ static bool engine_prepare(falcon_hip_context * c) {
     unsigned one = 1u;
     HIP_CHECK(hipMemcpy(c->sync_words + 2, &one, 4, hipMemcpyHostToDevice));
     a.epoch_word = c->sync_words + 2; a.err = c->sync_words + 1;
-    a.cnt = (unsigned *) dev_alloc(c->allocs, 128 * 4);
-    HIP_CHECK(hipMemset(a.cnt, 0, 128 * 4));
     a.n_past = c->n_past_dev; a.max_n_kv = c->n_ctx; a.rope_cs = c->rope_cs; a.exp_tab = hc.exp_table_attn; a.gelu_tab = hc.gelu_table;
     if (const char * e = getenv("FALCON_HIP_ENGINE_DEBUG_MODE")) a.debug_mode = atoi(e);
-    if (const char * e = getenv("FALCON_HIP_ENGINE_COUNTERS")) a.use_counters = atoi(e);
+    a.thin_loader = 1;
+    if (const char * e = getenv("FALCON_HIP_ENGINE_THIN")) a.thin_loader = atoi(e) != 0;
     if (getenv("FALCON_HIP_ENGINE_DEBUG")) {
-        a.dbg = (long long *) dev_alloc(c->allocs, (4096 + 256 * 4 * 8 + 256 * 8) * sizeof(long long));
-        HIP_CHECK(hipMemset(a.dbg, 0, (4096 + 256 * 4 * 8 + 256 * 8) * sizeof(long long)));
+        a.dbg = (long long *) dev_alloc(c->allocs, (size_t) FQ_ENG_DBG_WORDS * sizeof(long long));
+        HIP_CHECK(hipMemset(a.dbg, 0, (size_t) FQ_ENG_DBG_WORDS * sizeof(long long)));
     }
     c->eng_nslot = nslot; c->eng_lds = lds;
     c->eng_state = 1;
@@ -459,7 +458,7 @@ extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c) { return
 // tuning aid: the engine's debug buffer (FALCON_HIP_ENGINE_DEBUG=1 at context creation): n int64 to the host; returns the number copied
 extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out, int n) {
     if (c->eng_state <= 0 || !c->eng.dbg) return 0;
-    const int total = 4096 + 256 * 4 * 8 + 256 * 8;
+    const int total = FQ_ENG_DBG_WORDS;
     if (n > total) n = total;
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, c->eng.dbg, (size_t) n * sizeof(long long), hipMemcpyDeviceToHost));

@@ -26,9 +26,10 @@ template <bool PUBLISH, typename T> __device__ __forceinline__ void out_store(T 
     if constexpr (PUBLISH) __hip_atomic_store(pub.gran + word, ((unsigned long long) pub.epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else base[word] = v;
 }
-template <bool PUBLISH>
-__device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr,
-                                                  const fq_publish pub = fq_publish{ nullptr, 0u }) {
+// PRE: the first key / value rows were requested by the caller (attn_prefetch with the same arguments) before q was known and sit in P
+template <bool PUBLISH, bool PRE>
+__device__ __forceinline__ void attn_decode_group_p(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg,
+                                                    const fq_publish pub, attn_pre & P) {
     constexpr int D = 64, HALF = 32;
     const int H = a.H, HKV = a.HKV;
     const int group = H / HKV, hk = h / group;
@@ -48,8 +49,7 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
     const float x0 = src[k], x1 = src[k + HALF];
     const float c = csr[2 * k], s = csr[2 * k + 1];
     const float vnew = vh[tid & (D - 1)];
-    attn_pre P;
-    attn_prefetch(a.kc, a.vc, HKV, hk, a.cache_rows, tid, P);
+    if constexpr (!PRE) attn_prefetch(a.kc, a.vc, HKV, hk, a.cache_rows, tid, P);
     FQ_STAMP(dbg, 1);
     const bool append = live && h % group == 0;
     if (tid < 2 * HALF) {
@@ -92,6 +92,13 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
             }
         }
     }
+}
+
+template <bool PUBLISH>
+__device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr,
+                                                  const fq_publish pub = fq_publish{ nullptr, 0u }) {
+    attn_pre P;
+    attn_decode_group_p<PUBLISH, false>(a, h, live, tid, smem, dbg, pub, P);
 }
 
 // the barriers of attn_decode_group (1 after the rope + attn_head_block's), for waves of the same workgroup that sit a group out

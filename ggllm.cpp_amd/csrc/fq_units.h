@@ -94,10 +94,10 @@ FQ_HD uint16_t ld_u16(const void * p) { return *(const uint16_t *) p; }
 
 FQ_HD uint32_t spread4(uint32_t bits4) { return ((bits4 & 0xFu) * 0x00204081u) & 0x01010101u; }   // bit k -> byte k bit 0
 
-FQ_HD int dot16(const fq_u4 & a, const int8_t * x) {     // 16 int8 x 16 int8
-    const fq_u4 b = ld_u4(x);
+FQ_HD int dot16r(const fq_u4 & a, const fq_u4 & b) {     // 16 int8 x 16 int8, both in registers
     int s = fq_dot4(a.x, b.x, 0); s = fq_dot4(a.y, b.y, s); s = fq_dot4(a.z, b.z, s); return fq_dot4(a.w, b.w, s);
 }
+FQ_HD int dot16(const fq_u4 & a, const int8_t * x) { return dot16r(a, ld_u4(x)); }     // 16 int8 x 16 int8
 FQ_HD fq_u4 and4(const fq_u4 & a, uint32_t m) { return { a.x & m, a.y & m, a.z & m, a.w & m }; }
 FQ_HD fq_u4 shr4(const fq_u4 & a, int s)      { return { a.x >> s, a.y >> s, a.z >> s, a.w >> s }; }
 FQ_HD fq_u4 or4 (const fq_u4 & a, const fq_u4 & b) { return { a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w }; }
@@ -113,18 +113,28 @@ struct fq_unit_regs {
 
 template <int TYPE> struct fq_unit;
 
+// the activation slice of one 32-element unit of the legacy formats, in registers: the 32 int8, the block's d, and its aux word
+// (Q8_0: i32 sum of the block's quants; Q8_1: f32 s = d * sum). dot_x() below is THE arithmetic of each legacy format's unit; dot()
+// loads the slice and calls it, the persistent engine loads all slices of a pass first (one LDS round trip) and calls it directly.
+struct fq_act32 { fq_u4 x0, x1; float d; uint32_t aux; };
+FQ_HD fq_act32 fq_act32_load(const fq_actcol & a, int u) {
+    const int8_t * x = a.qs + 32 * (size_t) u;
+    return { ld_u4(x), ld_u4(x + 16), a.d[u], ((const uint32_t *) a.aux)[u] };
+}
+FQ_HD float fq_bits2f(uint32_t b) { float f; __builtin_memcpy(&f, &b, 4); return f; }
+
 // ---------------------------------------------------------------- Q4_0  (ggml.c:2591-2609)
 template <> struct fq_unit<FQ_Q4_0> {
     static constexpr int ELEMS = 32;
     FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_0, 0>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q4_0, 1>(k, ju)); return r;
     }
-    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
-        const int8_t * x = a.qs + 32 * (size_t) u;
-        int s = dot16(and4(r.q, 0x0F0F0F0Fu), x) + dot16(and4(shr4(r.q, 4), 0x0F0F0F0Fu), x + 16);
-        s -= 8 * ((const int32_t *) a.aux)[u];
-        return ((float) s * fq_h2f((uint16_t) r.dm)) * a.d[u];
+    FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
+        int s = dot16r(and4(r.q, 0x0F0F0F0Fu), y.x0) + dot16r(and4(shr4(r.q, 4), 0x0F0F0F0Fu), y.x1);
+        s -= 8 * (int32_t) y.aux;
+        return ((float) s * fq_h2f((uint16_t) r.dm)) * y.d;
     }
+    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) { return dot_x(r, fq_act32_load(a, u)); }
 };
 // ---------------------------------------------------------------- Q4_1  (ggml.c:2716-2735)
 template <> struct fq_unit<FQ_Q4_1> {
@@ -132,11 +142,11 @@ template <> struct fq_unit<FQ_Q4_1> {
     FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_1, 0>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q4_1, 1>(k, ju)); return r;
     }
-    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
-        const int8_t * x = a.qs + 32 * (size_t) u;
-        const int s = dot16(and4(r.q, 0x0F0F0F0Fu), x) + dot16(and4(shr4(r.q, 4), 0x0F0F0F0Fu), x + 16);
-        return (fq_h2f((uint16_t) r.dm) * a.d[u]) * (float) s + fq_h2f((uint16_t)(r.dm >> 16)) * ((const float *) a.aux)[u];
+    FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
+        const int s = dot16r(and4(r.q, 0x0F0F0F0Fu), y.x0) + dot16r(and4(shr4(r.q, 4), 0x0F0F0F0Fu), y.x1);
+        return (fq_h2f((uint16_t) r.dm) * y.d) * (float) s + fq_h2f((uint16_t)(r.dm >> 16)) * fq_bits2f(y.aux);
     }
+    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) { return dot_x(r, fq_act32_load(a, u)); }
 };
 // 5th bits of a Q5 block: element j <- bit j of qh, element j+16 <- bit j+16   (ggml.c:1550-1574)
 FQ_HD fq_u4 q5_hi(uint32_t qh, int base) {
@@ -148,12 +158,12 @@ template <> struct fq_unit<FQ_Q5_0> {
     FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_0, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_0, 1>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q5_0, 2>(k, ju)); return r;
     }
-    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
-        const int8_t * x = a.qs + 32 * (size_t) u;
-        int s = dot16(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), x) + dot16(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), x + 16);
-        s -= 16 * ((const int32_t *) a.aux)[u];
-        return (fq_h2f((uint16_t) r.dm) * a.d[u]) * (float) s;
+    FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
+        int s = dot16r(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), y.x0) + dot16r(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), y.x1);
+        s -= 16 * (int32_t) y.aux;
+        return (fq_h2f((uint16_t) r.dm) * y.d) * (float) s;
     }
+    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) { return dot_x(r, fq_act32_load(a, u)); }
 };
 // ---------------------------------------------------------------- Q5_1  (ggml.c:3207-3228)
 template <> struct fq_unit<FQ_Q5_1> {
@@ -161,11 +171,11 @@ template <> struct fq_unit<FQ_Q5_1> {
     FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_1, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_1, 1>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q5_1, 2>(k, ju)); return r;
     }
-    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
-        const int8_t * x = a.qs + 32 * (size_t) u;
-        const int s = dot16(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), x) + dot16(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), x + 16);
-        return (fq_h2f((uint16_t) r.dm) * a.d[u]) * (float) s + fq_h2f((uint16_t)(r.dm >> 16)) * ((const float *) a.aux)[u];
+    FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
+        const int s = dot16r(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), y.x0) + dot16r(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), y.x1);
+        return (fq_h2f((uint16_t) r.dm) * y.d) * (float) s + fq_h2f((uint16_t)(r.dm >> 16)) * fq_bits2f(y.aux);
     }
+    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) { return dot_x(r, fq_act32_load(a, u)); }
 };
 // ---------------------------------------------------------------- Q8_0  (ggml.c:3317-3329)  unit = whole block (2 x 16 B)
 template <> struct fq_unit<FQ_Q8_0> {
@@ -173,11 +183,11 @@ template <> struct fq_unit<FQ_Q8_0> {
     FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; const uint8_t * q = fq_cp<FQ_Q8_0, 0>(k, ju); r.q = ld_w4(q); r.q2 = ld_w4(q + 16); r.dm = ld_u16(fq_cp<FQ_Q8_0, 1>(k, ju)); return r;
     }
-    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) {
-        const int8_t * x = a.qs + 32 * (size_t) u;
-        const int s = dot16(r.q, x) + dot16(r.q2, x + 16);
-        return (float) s * (fq_h2f((uint16_t) r.dm) * a.d[u]);
+    FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
+        const int s = dot16r(r.q, y.x0) + dot16r(r.q2, y.x1);
+        return (float) s * (fq_h2f((uint16_t) r.dm) * y.d);
     }
+    FQ_HDM static float dot(const fq_unit_regs & r, const fq_actcol & a, int u) { return dot_x(r, fq_act32_load(a, u)); }
 };
 // ---------------------------------------------------------------- Q2_K  (k_quants.c:1267-1306)
 // unit u: super-block sb=u>>2, 128-half hf=(u>>1)&1, 16-byte group g=u&1; covers elements 128hf+32j+16g+l, j=0..3

@@ -147,13 +147,18 @@ struct fq_engine_args {
     float * hidden;                                   // optional: rows 1 .. n_layers of [(n_layers + 1)][E]
     unsigned long long * xg, * qkvg, * ffg, * attg;   // hand-off granules: E, (H + 2 HKV) 64, FF/4 + FF/16, E/4 + E/16 entries (zero-filled once)
     const unsigned * epoch_word; unsigned * err;      // err: 0, or the code of the first wait that gave up
-    int use_counters;                                 // 1 (FALCON_HIP_ENGINE_COUNTERS=1): sweeps start only when an arrival counter says the producers are done
-    int debug_mode;                                   // tuning aid (FALCON_HIP_ENGINE_DEBUG_MODE): 1 = the loader alone, no arithmetic (results are garbage)
-    unsigned * cnt;                                   // 128 words: arrival counters of the hand-offs (x, qkv, GELU image, attention image at [0], [32], [64], [96])
-    long long * dbg;                                  // optional (FALCON_HIP_ENGINE_DEBUG=1): [0] failure count, records of 8 from [16], phase stamps from [4096]
+    int thin_loader;                                  // 1 (default; FALCON_HIP_ENGINE_THIN=0 clears): the loader keeps 16 instead of 48 pieces in flight while its workgroup gathers a hand-off
+    int debug_mode;                                   // tuning aid (FALCON_HIP_ENGINE_DEBUG_MODE; results are garbage): 1 = the loader alone; bits: 2 = no row dots, 4 / 8 / 16 / 32 = do not wait for the x / qkv / GELU-image / attention-image hand-off
+    long long * dbg;                                  // optional (FALCON_HIP_ENGINE_DEBUG=1), FQ_ENG_DBG_WORDS int64: [0] failure count, records of 8 from [16], then the regions below
     const int * n_past; int max_n_kv; const float * rope_cs; const uint16_t * exp_tab, * gelu_tab;
 };
+// debug buffer regions (int64 indices): phase stamps of consumer 0 / the attention workgroups [256 workgroups][4 blocks][8 slots], the
+// same of the gatherer wave, per-workgroup counters [256][16]
+#define FQ_ENG_DBG_STAMPS   4096
+#define FQ_ENG_DBG_GSTAMPS  (FQ_ENG_DBG_STAMPS + 256 * 4 * 8)
+#define FQ_ENG_DBG_COUNTERS (FQ_ENG_DBG_GSTAMPS + 256 * 4 * 8)
+#define FQ_ENG_DBG_WORDS    (FQ_ENG_DBG_COUNTERS + 256 * 16)
 bool   fq_engine_plan(int type, int E, int FF, int qkv_rows, int V, bool with_head, int n_stream, std::vector<fq_engine_sched> & out, int * max_groups, int * max_rows);
-size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers);
+size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers, int two_norms);
 int    fq_engine_threads();
 bool   fq_launch_decode_engine(const fq_engine_args & a, int nslot, size_t lds_bytes, hipStream_t st);

@@ -1,28 +1,34 @@
-// kernels_engine.hip -- the PERSISTENT decode engine: one launch per generated token (gfx950, wave64).
+// kernels_engine.hip -- the PERSISTENT decode engine, second form: one launch per generated token (gfx950, wave64).
 //
 // Replaces the per-token launch list of the fused decode path (2 launches per block + lm_head: k_gemv_ln / k_attn_out,
 // kernels_decode.hip) -- i.e. one N = 1 pass of falcon_eval_internal's graph (libfalcon.cpp:2115-2466) whose mat-muls are
 // ggml_compute_forward_mul_mat_q_f32 (ggml.c:11318-11529) -- by ONE kernel of one workgroup per CU (12 waves) that stays
-// resident for all blocks of the stage. What a launch boundary costs this workload is not the ~1.7 us gap itself but the
-// empty memory pipeline on either side of it (4.8 us per launch in which nothing streams, 65 launches
-// per token); here the weight stream never stops:
+// resident for all blocks of the stage. Built to the chip's measured recipe (MI355X_MICROARCH.md, rows engine-vs-launches,
+// gather-pass, polling-cost, allgather, prefetch-credit):
 //
-//   streaming workgroups   wave 0 = LOADER: streams the workgroup's byte ranges of [Wqkv | Wup | Wdown | Wo] of every block
-//                          (then lm_head), in the order they will be used, into a RING of LDS with global_load_lds_dwordx4
-//                          (1 KiB per wave-instruction, non-temporal, no registers held), limited only by ring space: it
-//                          runs up to ~128 KiB ahead of the arithmetic and keeps streaming across every dependency stall.
-//                          waves 1..11 = CONSUMERS: take the landed rows round-robin, run the row dots out of LDS (the
-//                          fq_units.h arithmetic, lane l = units l, l+64, ..: bit-identical to the other paths), LayerNorm
-//                          + Q8 images, GELU + Q8 epilogues, residual update. They synchronise among themselves with
-//                          counters in LDS (the loader never reaches a barrier, so s_barrier cannot be used).
-//   attention workgroups   2 query heads each (attn_decode_group, the code of k_attn_decode / k_attn_out): RoPE, KV append,
-//                          K.Q, soft_max, V.P, Q8 image of the output.
-//   between workgroups     8-byte {tag, value} granules written with single agent-scope stores and swept by the readers
-//                          (the hand-off k_attn_out already uses; MI355X_MICROARCH.md "handoff" / "allgather" rows):
+//   streaming workgroups   wave 0 = LOADER: streams the workgroup's byte ranges of [Wqkv | Wup | Wdown | Wo] of every block (then
+//                          lm_head), in the order they will be used, into a RING of LDS with global_load_lds_dwordx4 (1 KiB per
+//                          wave-instruction, non-temporal, no registers held), limited only by ring space: up to ~112 KiB (~4.5 us of
+//                          stream) ahead of the arithmetic, across every dependency stall. The ring's first 2 KiB are mirrored behind
+//                          its end, so a reader never wraps inside a 1-1.5 KiB column of a row. While the workgroup gathers a
+//                          hand-off the loader thins itself to 16 pieces in flight.
+//                          wave 1 = GATHERER: the Wup epilogues (GELU, Q8 block, publish) of the workgroup's 32-row groups as they
+//                          complete, and its share of the gathering of the cross-workgroup hand-offs into LDS.
+//                          waves 2..11 = CONSUMERS: take the landed rows round-robin and run the row dots out of LDS (the fq_units.h
+//                          arithmetic, lane l = units l, l+64, ..: bit-identical to the other paths); when they run out of rows they
+//                          gather their share of the next hand-off.
+//                          No barrier anywhere after the roles split (the loader could never reach one): every dependency inside the
+//                          workgroup is a MONOTONIC counter or flag in LDS (value = a function of the block index), polled with s_sleep.
+//   attention workgroups   2 query heads each (attn_decode_group, the code of k_attn_decode / k_attn_out): the block's first key /
+//                          value rows are requested BEFORE q exists, then RoPE, KV append, K.Q, soft_max, V.P, Q8 image.
+//   between workgroups     8-byte {tag, value} granules written with single agent-scope stores, gathered in chunks of 1024 (16 loads
+//                          in flight per lane = one memory round trip per attempt) by ONE wave per chunk and workgroup:
 //                          residual row x (4 hops per block: x -> LN -> [qkv, up] -> attention / GELU image -> down, wo -> x).
+//   LayerNorm              the gathering waves leave the f32 row in LDS with one f64 partial sum per chunk; the LAST of them to
+//                          arrive adds the partial sums (chunk order), takes the second pass over the row alone (f64, as ggml.c:
+//                          10577-10591) and publishes {mean, scale}: no barrier. All 11 waves then normalise and quantize their
+//                          share (quant_q8_quad: the k_gemv_ln arithmetic).
 //
-// scripts/microbench/mb_engine.hip measures the engine's core alone (no dependencies): 6.9 TB/s with 1 loader + 11 consumer
-// waves per CU against 5.4 TB/s inside a k_gemv_ln launch.
 // Scope: legacy formats (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 -> Q8_0 / Q8_1 activations), one format per stage; everything
 // else keeps the two-launch path (fq_launch_decode_engine returns false).
 #include "fq_block_dev.h"
@@ -34,18 +40,15 @@
 #include <type_traits>
 #include <vector>
 
-#ifndef ENG_OPT_NLN2
-#define ENG_OPT_NLN2 0
-#endif
-#ifndef ENG_OPT_PREFETCH_ATT
-#define ENG_OPT_PREFETCH_ATT 0
-#endif
-
 namespace {
 
-constexpr int ENG_NC = 11;                 // consumer waves
-constexpr int ENG_NT = 64 * (ENG_NC + 1);  // 768 threads
+constexpr int ENG_NH = 11;                 // helper waves: the gatherer (helper 0) + the consumers (helpers 1..10)
+constexpr int ENG_NC = ENG_NH - 1;         // consumer waves
+constexpr int ENG_NT = 64 * (ENG_NH + 1);  // 768 threads
+constexpr int ENG_HT = 64 * ENG_NH;        // 704 helper threads
 constexpr int ENG_SLOT = 16384;
+constexpr int ENG_MIRROR = 2048;           // bytes of the ring's start repeated behind its end (>= the largest column: 1536 B, Q5_1)
+constexpr int ENG_CHUNK = 1024;            // granules per gather chunk: 16 per lane
 constexpr unsigned ENG_SPIN_MAX = 1u << 17;
 
 template <int TYPE> struct eng_act { static constexpr int value = (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1) ? FQ_Q8_1 : FQ_Q8_0; };
@@ -56,16 +59,38 @@ __device__ __forceinline__ void lds_st(unsigned addr, unsigned v) { asm volatile
 __device__ __forceinline__ void lds_add(unsigned addr, unsigned v) { asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ unsigned lds_ld_u(unsigned addr) { return __builtin_amdgcn_readfirstlane(lds_ld(addr)); }
 __device__ __forceinline__ unsigned lds_add_rtn(unsigned addr, unsigned v) { unsigned o; asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o) : "v"(addr), "v"(v) : "memory"); return o; }
-// arrival counters of the four hand-offs (device words 128 bytes apart, zeroed before every launch). They only say WHEN a sweep
-// is worth starting -- thousands of waves re-reading 40 KB of granules while they wait take a large share of the L2 bandwidth the
-// weight stream needs; the tagged granules remain what makes a hand-off correct.
-enum { ENG_CNT_X = 0, ENG_CNT_QKV = 32, ENG_CNT_FF = 64, ENG_CNT_ATT = 96 };
-__device__ __forceinline__ void cnt_add(unsigned * cnt, unsigned v) { __hip_atomic_fetch_add(cnt, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned cnt_ld(const unsigned * cnt) { return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long lds_ld64(unsigned addr) {
+    unsigned long long v; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory"); return v;
+}
+__device__ __forceinline__ void lds_st64(unsigned addr, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void glds16_nt(const void * gsrc, unsigned lds_dst) {       // 64 lanes x 16 B -> 1 KiB of LDS at lds_dst
+// ---- LDS-DMA of the loader wave. Source = scalar base (64-bit) + per-lane 32-bit offset (+ immediate), destination = M0 (wave-uniform
+// LDS byte address, the lanes' 16 bytes land side by side: 1 KiB per instruction). No vector ALU work per piece.
+// one piece: 1 KiB at base (+ voff = lane * 16) -> LDS at lds_dst
+__device__ __forceinline__ void glds_piece(const void * base, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+// sixteen pieces: 16 KiB at base -> the ring from LDS address ml on (wrapping from mend to mstart); ml is advanced. v[p] = lane * 16 +
+// p KiB (an instruction offset would be added to the LDS address as well). Also samples the LDS word at flag_addr (returned; the
+// read overlaps the issue).
+struct eng_voff { unsigned v[16]; };
+#define ENG_DMA1(P) "s_mov_b32 m0, %[ml]\n\ts_add_u32 %[ml], %[ml], 0x400\n\tglobal_load_lds_dwordx4 %[v" #P "], %[base] nt\n\t" \
+                    "s_cmp_lt_u32 %[ml], %[mend]\n\ts_cselect_b32 %[ml], %[ml], %[mstart]\n\t"
+__device__ __forceinline__ unsigned glds_batch16(const void * base, const eng_voff & o, unsigned & ml, unsigned mstart, unsigned mend, unsigned flag_addr) {
+    unsigned keep, flag;
+    asm volatile("ds_read_b32 %[flag], %[fa]\n\ts_mov_b32 %[keep], m0\n\ts_nop 4\n\t"
+                 ENG_DMA1(0) ENG_DMA1(1) ENG_DMA1(2) ENG_DMA1(3) ENG_DMA1(4) ENG_DMA1(5) ENG_DMA1(6) ENG_DMA1(7)
+                 ENG_DMA1(8) ENG_DMA1(9) ENG_DMA1(10) ENG_DMA1(11) ENG_DMA1(12) ENG_DMA1(13) ENG_DMA1(14) ENG_DMA1(15)
+                 "s_mov_b32 m0, %[keep]\n\ts_waitcnt lgkmcnt(0)"
+                 : [keep] "=&s"(keep), [ml] "+s"(ml), [flag] "=&v"(flag)
+                 : [v0] "v"(o.v[0]), [v1] "v"(o.v[1]), [v2] "v"(o.v[2]), [v3] "v"(o.v[3]), [v4] "v"(o.v[4]), [v5] "v"(o.v[5]), [v6] "v"(o.v[6]), [v7] "v"(o.v[7]),
+                   [v8] "v"(o.v[8]), [v9] "v"(o.v[9]), [v10] "v"(o.v[10]), [v11] "v"(o.v[11]), [v12] "v"(o.v[12]), [v13] "v"(o.v[13]), [v14] "v"(o.v[14]), [v15] "v"(o.v[15]),
+                   [base] "s"(base), [mstart] "s"(mstart), [mend] "s"(mend), [fa] "v"(flag_addr)
+                 : "memory", "scc");
+    return flag;
 }
 
 __device__ __forceinline__ unsigned long long gran_ld(const unsigned long long * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -75,59 +100,68 @@ __device__ __forceinline__ void eng_fail(unsigned * err, unsigned code) { __hip_
 
 // control block (byte offsets from its base; the base is 16-byte aligned)
 struct eng_ctl {
-    static constexpr unsigned RED = 0;            // 32 doubles: LayerNorm partial sums
-    static constexpr unsigned OUT = 256;          // 384 floats: dots of up to twelve 32-row groups (phase A / lm_head)
+    static constexpr unsigned PSUM = 0;           // 16 doubles: per gather chunk, the f64 sum of its values (residual row)
+    static constexpr unsigned STAT = 128;         // mean, scale (f32) of the current LayerNorm
+    static constexpr unsigned OUT = 144;          // 384 floats: dots of up to twelve 32-row groups (phase A / lm_head)
     static constexpr unsigned CNT = OUT + 1536;   // 16 words: rows finished per group (all blocks: a group's count grows by 32 per block)
     static constexpr unsigned CNTH = CNT + 64;    // 16 words: the same for the lm_head groups
     static constexpr unsigned OUTB = CNTH + 64;   // 64 floats: down-projection dots of the workgroup's rows
     static constexpr unsigned XRES = OUTB + 256;  // 64 floats: residual values of the workgroup's rows
     static constexpr unsigned LANDED = XRES + 256;
-    static constexpr unsigned LOW = LANDED + 4;   // ENG_NC words: per consumer, stream position below which it needs nothing
-    static constexpr unsigned CBAR = LOW + 4 * 16;
-    static constexpr unsigned EPI = CBAR + 4;     // Wup epilogues finished (all blocks)
-    static constexpr unsigned BDONE = CBAR + 8;   // consumers that finished their Wo rows (all blocks)
-    static constexpr unsigned QDONE = CBAR + 12;  // consumers that finished their Wqkv rows (all blocks)
-    static constexpr unsigned GO = CBAR + 16;     // 4 words: the last target each hand-off counter was seen to reach
-    static constexpr unsigned PTRS = GO + 16;     // per block 4 x 8 bytes: this workgroup's first byte of Wqkv, Wup, Wdown, Wo; then lm_head's
-    static constexpr unsigned BYTES = PTRS;       // + 32 * n_layers + 8
+    static constexpr unsigned LOW = LANDED + 4;   // 16 words: per consumer, stream position below which it needs nothing
+    // monotonic flags / counters (targets are functions of the block index)
+    static constexpr unsigned XG_DONE = LOW + 64; // residual-row chunks gathered
+    static constexpr unsigned LN_STAT = XG_DONE + 4;   // = index of the LayerNorm whose {mean, scale} are in STAT, + 1
+    static constexpr unsigned IMG_DONE = XG_DONE + 8;  // helper waves that wrote their share of the LayerNorm image(s)
+    static constexpr unsigned A_DONE = XG_DONE + 12;   // consumers that finished their phase-A rows
+    static constexpr unsigned FG_DONE = XG_DONE + 16;  // GELU-image chunks gathered
+    static constexpr unsigned B1_DONE = XG_DONE + 20;  // consumers that finished their Wdown rows
+    static constexpr unsigned AG_DONE = XG_DONE + 24;  // attention-image chunks gathered
+    static constexpr unsigned B2_DONE = XG_DONE + 28;  // consumers that finished their Wo rows
+    static constexpr unsigned THIN = XG_DONE + 32;     // != 0: the loader keeps at most 16 pieces in flight
+    static constexpr unsigned LN_MEAN = XG_DONE + 36;  // = index of the LayerNorm whose mean is in STAT, + 1
+    static constexpr unsigned S2_DONE = XG_DONE + 40;  // helper waves that left their partial sum of squares
+    static constexpr unsigned PSQ = XG_DONE + 64;      // 16 doubles: per helper wave, the f64 sum of its squared deviations
+    static constexpr unsigned PTRS = PSQ + 128;        // per block 4 x 8 bytes: this workgroup's first byte of Wqkv, Wup, Wdown, Wo; then lm_head's
+    static constexpr unsigned BYTES = PTRS;            // + 32 * n_layers + 8
 };
-__device__ __forceinline__ unsigned long long lds_ld64(unsigned addr) {
-    unsigned long long v; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory"); return v;
-}
-__device__ __forceinline__ void lds_st64(unsigned addr, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 
-// one unit (32 weights) of a row out of the ring. u0 = first unit of the pass (a multiple of 64), the lane takes unit u0 + lane
-// clamped to the row's last. For the formats with 64 blocks per column the column -- its ring offset, its block count -- is
-// wave-uniform: scalar arithmetic, only the lane's own offset and the wrap are vector work.
-template <int TYPE, int RING>
-__device__ __forceinline__ fq_unit_regs eng_unit_load(const uint8_t * ring, unsigned pos, int u0, int lane, int nblk) {
-    constexpr int CB = fq_lay<TYPE>::CB, TS = fq_lay<TYPE>::TS;
+// one unit (32 weights) of a row out of the ring. cb = ring offset of the unit's column (a column never wraps: the mirror),
+// nbc = blocks in the column; both wave-uniform for the formats with 64 blocks per column, so only the lane's own offset is
+// vector work.
+template <int TYPE>
+__device__ __forceinline__ fq_unit_regs eng_unit_load_col(const uint8_t * ring, unsigned cb, int nbc, int lane) {
     constexpr fq_type_desc D = fq_desc(TYPE);
-    auto wrap = [](unsigned o) { const unsigned m = o - (unsigned) RING; return m < o ? m : o; };      // o in [0, 2 RING): one v_min_u32 after the subtract
+    static_assert(fq_lay<TYPE>::CB == 64, "64 blocks per column");
     fq_unit_regs r{};
-    if constexpr (CB == 64) {
-        const int c = u0 >> 6;                                             // scalar
-        const int rem = nblk - 64 * c, nbc = rem < 64 ? rem : 64;
-        const int j = lane < nbc ? lane : nbc - 1;
-        const unsigned cb = pos + (unsigned)(c * 64 * TS);                 // < 2 RING: a row is shorter than the ring
-        r.q = *(const fq_u4 *)(ring + wrap(cb + (unsigned)(j * 16)));
-        const unsigned p1 = wrap(cb + (unsigned)(nbc * 16) + (unsigned)(j * D.plane[1].bytes));
-        if constexpr (TYPE == FQ_Q4_0)      r.dm = *(const uint16_t *)(ring + p1);
-        else if constexpr (TYPE == FQ_Q4_1) r.dm = *(const uint32_t *)(ring + p1);
-        else {                                                               // Q5_0 / Q5_1: plane 1 = qh, plane 2 = d (,m)
-            r.s0 = *(const uint32_t *)(ring + p1);
-            const unsigned p2 = wrap(cb + (unsigned)(nbc * (16 + D.plane[1].bytes)) + (unsigned)(j * D.plane[2].bytes));
-            if constexpr (TYPE == FQ_Q5_0) r.dm = *(const uint16_t *)(ring + p2); else r.dm = *(const uint32_t *)(ring + p2);
-        }
-    } else {                                                                 // Q8_0: 32 blocks of 32 + 2 bytes per column
-        const int u = u0 + lane, uc = u < nblk ? u : nblk - 1;
-        const int c = uc / CB, j = uc - c * CB;
-        const int rem = nblk - c * CB, nbc = rem < CB ? rem : CB;
-        const unsigned cb = pos + (unsigned)(c * CB * TS);
-        r.q  = *(const fq_u4 *)(ring + wrap(cb + (unsigned)(j * 32)));
-        r.q2 = *(const fq_u4 *)(ring + wrap(cb + (unsigned)(j * 32 + 16)));
-        r.dm = *(const uint16_t *)(ring + wrap(cb + (unsigned)(nbc * 32 + j * 2)));
+    const int j = lane < nbc ? lane : nbc - 1;
+    const uint8_t * c0 = (const uint8_t *) __builtin_assume_aligned(ring + cb, 16);      // rows and columns start on 16-byte boundaries
+    typedef unsigned int u32x4_ld __attribute__((ext_vector_type(4)));
+    const u32x4_ld q = *(const u32x4_ld *)(c0 + j * 16);                                   // one ds_read_b128
+    r.q = fq_u4{ q.x, q.y, q.z, q.w };
+    const uint8_t * p1 = c0 + nbc * 16 + j * D.plane[1].bytes;
+    if constexpr (TYPE == FQ_Q4_0)      r.dm = *(const uint16_t *) p1;
+    else if constexpr (TYPE == FQ_Q4_1) r.dm = *(const uint32_t *) p1;
+    else {                                                               // Q5_0 / Q5_1: plane 1 = qh, plane 2 = d (,m)
+        r.s0 = *(const uint32_t *) p1;
+        const uint8_t * p2 = c0 + nbc * (16 + D.plane[1].bytes) + j * D.plane[2].bytes;
+        if constexpr (TYPE == FQ_Q5_0) r.dm = *(const uint16_t *) p2; else r.dm = *(const uint32_t *) p2;
     }
+    return r;
+}
+// Q8_0: 32 blocks of 32 + 2 bytes per column, the 64 lanes of a pass sit in two columns: the column base is per lane
+template <int RING>
+__device__ __forceinline__ fq_unit_regs eng_unit_load_q8(const uint8_t * ring, unsigned pos, int u0, int lane, int nblk) {
+    constexpr int CB = fq_lay<FQ_Q8_0>::CB, TS = fq_lay<FQ_Q8_0>::TS;
+    fq_unit_regs r{};
+    const int u = u0 + lane, uc = u < nblk ? u : nblk - 1;
+    const int c = uc / CB, j = uc - c * CB;
+    const int rem = nblk - c * CB, nbc = rem < CB ? rem : CB;
+    unsigned cb = pos + (unsigned)(c * CB * TS);
+    cb = cb >= (unsigned) RING ? cb - (unsigned) RING : cb;             // a row is shorter than the ring
+    r.q  = *(const fq_u4 *)(ring + cb + (unsigned)(j * 32));
+    r.q2 = *(const fq_u4 *)(ring + cb + (unsigned)(j * 32 + 16));
+    r.dm = *(const uint16_t *)(ring + cb + (unsigned)(nbc * 32 + j * 2));
     return r;
 }
 // U passes (of 64 units) of R rows: all loads first, then the dots -- per lane the units are still added in ascending order
@@ -136,39 +170,39 @@ __device__ __forceinline__ void eng_pass_group(const uint8_t * ring, const unsig
     fq_unit_regs regs[U][R];
 #pragma unroll
     for (int p = 0; p < U; ++p) {
+        if constexpr (fq_lay<TYPE>::CB == 64) {
+            constexpr unsigned COLB = 64u * (unsigned) fq_lay<TYPE>::TS;
+            const int c = (u0 >> 6) + p;                                   // scalar
+            const int rem = nblk - 64 * c, nbc = rem < 64 ? rem : 64;
 #pragma unroll
-        for (int r = 0; r < R; ++r) regs[p][r] = eng_unit_load<TYPE, RING>(ring, pos[r], u0 + 64 * p, lane, nblk);
+            for (int r = 0; r < R; ++r) {
+                unsigned cb = pos[r] + (unsigned) c * COLB;               // scalar; < 2 RING: a row is shorter than the ring
+                cb = cb >= (unsigned) RING ? cb - (unsigned) RING : cb;
+                regs[p][r] = eng_unit_load_col<TYPE>(ring, cb, nbc, lane);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) regs[p][r] = eng_unit_load_q8<RING>(ring, pos[r], u0 + 64 * p, lane, nblk);
+        }
     }
+    // the activation slices of all U passes as well, before any arithmetic: one LDS round trip per pass group instead of three per unit
+    fq_act32 act[U];
+#pragma unroll
+    for (int p = 0; p < U; ++p) { const int u = u0 + 64 * p + lane; act[p] = fq_act32_load(col, u < nblk ? u : nblk - 1); }
 #pragma unroll
     for (int p = 0; p < U; ++p) {
-        const int u = u0 + 64 * p + lane; const bool ok = u < nblk; const int uc = ok ? u : nblk - 1;
+        const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[p][r], col, uc); acc[r] += ok ? v : 0.0f; }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
     }
 }
-// the dots of R rows out of the ring. pos[r] = the row's stream position reduced modulo RING (wave-uniform)
-template <int TYPE, int RING, int R>
-__device__ __forceinline__ void eng_rows_dot(const uint8_t * ring, const unsigned (&pos)[R], int nblk, const fq_actcol & col, int lane, float (&out)[R]) {
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-    const int npass = (nblk + 63) >> 6;
-    int p0 = 0;
-    for (; p0 + 3 <= npass; p0 += 3) eng_pass_group<TYPE, RING, R, 3>(ring, pos, nblk, 64 * p0, col, lane, acc);
-    if (npass - p0 == 2)      eng_pass_group<TYPE, RING, R, 2>(ring, pos, nblk, 64 * p0, col, lane, acc);
-    else if (npass - p0 == 1) eng_pass_group<TYPE, RING, R, 1>(ring, pos, nblk, 64 * p0, col, lane, acc);
-#pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r]);
-}
-
 struct eng_wait {                 // per-wave state of the bounded waits
     unsigned * err; bool dead; long long * dbg; int blk;
     __device__ __forceinline__ bool spin(unsigned & spins, unsigned code, unsigned x0 = 0, unsigned x1 = 0) {      // true = keep waiting
         if (dead) return false;
         ++spins;
         if ((spins & 255u) == 0u && eng_failed(err)) { dead = true; return false; }
-        // (the consumer barrier gets 16 x the patience of the waits it may be waiting behind, so that the culprit reports first)
-        if (spins > (code == 3u ? 16u * ENG_SPIN_MAX : ENG_SPIN_MAX)) {
+        if (spins > ENG_SPIN_MAX) {
             if ((threadIdx.x & 63) == 0) {
                 eng_fail(err, code);
                 if (dbg) {                                                 // failure record: who gave up, where, on what
@@ -180,50 +214,85 @@ struct eng_wait {                 // per-wave state of the bounded waits
         }
         return true;
     }
+    // wait until the LDS word at `addr` has reached `target` (monotonic counters and flags)
+    __device__ __forceinline__ void until(unsigned addr, unsigned target, unsigned code) {
+        for (unsigned spins = 0; (int)(lds_ld_u(addr) - target) < 0;) { if (!spin(spins, code, addr, target)) break; __builtin_amdgcn_s_sleep(1); }
+    }
 };
-#define ENG_STAMP(slot) do { if (a.dbg && c == 0 && lane == 0 && (b < 3 || b == a.n_layers - 1)) \
-        a.dbg[4096 + ((size_t) blockIdx.x * 4 + (b < 3 ? b : 3)) * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
-// barrier among the consumer waves (generation counter in LDS)
-__device__ __forceinline__ void eng_cbar(unsigned ctl, unsigned & gen, eng_wait & w) {
-    ++gen;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // this wave's LDS stores are done before it arrives
-    if ((threadIdx.x & 63) == 0) lds_add(ctl + eng_ctl::CBAR, 1u);
-    const unsigned target = gen * (unsigned) ENG_NC;
-    for (unsigned spins = 0; lds_ld_u(ctl + eng_ctl::CBAR) < target;) { if (!w.spin(spins, 3u)) break; __builtin_amdgcn_s_sleep(1); }
-}
+// failure / wait codes
+enum { ENG_W_RING = 1, ENG_W_LAND = 2, ENG_W_QKV = 4, ENG_W_XG = 5, ENG_W_GROUP = 6, ENG_W_FG = 7, ENG_W_AG = 8,
+       ENG_W_STAT = 12, ENG_W_IMG = 13, ENG_W_ADONE = 14, ENG_W_B1 = 15, ENG_W_B2 = 16, ENG_W_FGD = 17, ENG_W_AGD = 18 };
 
-// the consumers' share of a granule buffer: words [0, nwords) -> LDS (dst) once every granule carries `tag`. All NG loads of a
-// thread are in flight together: an attempt costs ONE memory round trip (~2 us while the chip streams).
-template <int NG>
-__device__ __forceinline__ void eng_sweep(const unsigned long long * gran, unsigned tag, int nwords, unsigned * dst, int ctid, eng_wait & w, unsigned code) {
-    constexpr int CT = 64 * ENG_NC;
-    for (int base = 0; base < nwords; base += NG * CT) {
-        unsigned v[NG];
+// one helper's chunks of a granule buffer: chunk k (k = h, h + stride, ..) = words [1024 k, 1024 k + 1024) -> dst (LDS words) once
+// every granule of the chunk carries `tag`. All 16 loads of a lane are in flight together: an attempt costs ONE memory round trip.
+// SUM: the chunk's values are floats; their f64 sum goes to psum[k] (lane order, then the wave butterfly).
+// Returns the number of chunks this helper owned.
+template <bool SUM>
+__device__ __forceinline__ unsigned eng_gather(const unsigned long long * gran, unsigned tag, int nwords, unsigned * dst, int h, int lane, eng_wait & w,
+                                               unsigned code, bool nowait, unsigned psum_addr, int stride = ENG_NH) {
+    const int nchunks = (nwords + ENG_CHUNK - 1) / ENG_CHUNK;
+    unsigned own = 0;
+    for (int k = h; k < nchunks; k += stride) {
+        const int base = k * ENG_CHUNK;
+        unsigned v[16];
         for (unsigned spins = 0;;) {
-            unsigned long long x[NG];
+            unsigned long long x[16];
 #pragma unroll
-            for (int k = 0; k < NG; ++k) { const int i = base + k * CT + ctid; x[k] = gran_ld(gran + (i < nwords ? i : nwords - 1)); }
+            for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; x[j] = gran_ld(gran + (i < nwords ? i : nwords - 1)); }
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < NG; ++k) { v[k] = (unsigned) x[k]; ok = ok && (unsigned)(x[k] >> 32) == tag; }
-            if (__all(ok)) break;
+            for (int j = 0; j < 16; ++j) { v[j] = (unsigned) x[j]; ok = ok && (unsigned)(x[j] >> 32) == tag; }
+            if (nowait || __all(ok)) break;
             if (!w.spin(spins, code, (unsigned) base, tag)) break;
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
-        for (int k = 0; k < NG; ++k) { const int i = base + k * CT + ctid; if (i < nwords) dst[i] = v[k]; }
+        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) dst[i] = v[j]; }
+        if constexpr (SUM) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) s += (double) __builtin_bit_cast(float, v[j]); }
+            s = wave_sum(s);
+            if (lane == 0) lds_st64(psum_addr + 8u * (unsigned) k, (unsigned long long) __builtin_bit_cast(long long, s));
+        }
+        ++own;
     }
+    return own;
+}
+// the same chunks of a plain f32 row in memory (the residual row entering the stage)
+__device__ __forceinline__ unsigned eng_gather_mem(const float * x, int nwords, unsigned * dst, int h, int lane, unsigned psum_addr) {
+    const int nchunks = (nwords + ENG_CHUNK - 1) / ENG_CHUNK;
+    unsigned own = 0;
+    for (int k = h; k < nchunks; k += ENG_NH) {
+        const int base = k * ENG_CHUNK;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; v[j] = x[i < nwords ? i : nwords - 1]; }
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) { dst[i] = __builtin_bit_cast(unsigned, v[j]); s += (double) v[j]; } }
+        s = wave_sum(s);
+        if (lane == 0) lds_st64(psum_addr + 8u * (unsigned) k, (unsigned long long) __builtin_bit_cast(long long, s));
+        ++own;
+    }
+    return own;
 }
 
-// LDS of a streaming workgroup: [ring][R][ATT][control block + pointer table]. R holds the LayerNorm image(s) during phase A and
-// the GELU image during phase B1 (a consumer barrier separates the two uses), ATT the attention output image.
+// LDS of a streaming workgroup: [ring][mirror][R][S][control block + pointer table].
+//   R: the f32 residual row while it is gathered and normalised, then the GELU image (phase B1)
+//   S: the LayerNorm image(s) during phase A, then the attention output image (phase B2)
 __host__ __device__ inline size_t eng_region_r(int act, int64_t E, int64_t FF) {
-    const size_t ff = fq_act_col_bytes(act, FF), e2 = 2 * fq_act_col_bytes(act, E);
-    return ff > e2 ? ff : e2;
+    const size_t ff = fq_act_col_bytes(act, FF), x = ((size_t) E * 4 + 15) & ~(size_t) 15;
+    return ff > x ? ff : x;
 }
+__host__ __device__ inline size_t eng_region_s(int act, int64_t E, int two_norms) { return (two_norms ? 2 : 1) * fq_act_col_bytes(act, E); }
 
 }   // namespace
+
+#define ENG_NSTAMP_BLK 4
+#define ENG_STAMP_AT(sbase, slot) do { if (a.dbg && lane == 0 && b >= 0 && (b < 3 || b == a.n_layers - 1)) \
+        a.dbg[(sbase) + ((size_t) blockIdx.x * ENG_NSTAMP_BLK + (b < 3 ? b : 3)) * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
 // =============================================================================================== the kernel
 template <int TYPE, int NSLOT>
@@ -232,9 +301,10 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
     constexpr int ACT = eng_act<TYPE>::value;
     constexpr int RING = NSLOT * ENG_SLOT;
     constexpr int TS = fq_desc(TYPE).tsize;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform for the compiler too: scalar address arithmetic)
     const unsigned epoch0 = *a.epoch_word;
     const int E = a.E, FF = a.FF;
+    const bool nodots = (a.debug_mode & 2) != 0;
 
     if ((int) blockIdx.x < a.n_attn) {
         if (a.debug_mode == 1) return;
@@ -251,17 +321,20 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
         for (int b = 0; b < a.n_layers; ++b) {
             w.blk = b;
             const unsigned tag = epoch0 + (unsigned) b + 1u;
-#define ENG_ASTAMP(slot) do { if (a.dbg && tid == 0 && (b < 3 || b == a.n_layers - 1)) a.dbg[4096 + ((size_t) blockIdx.x * 4 + (b < 3 ? b : 3)) * 8 + (slot)] = (long long) wall_clock64(); } while (0)
+            const fq_engine_layer & L = a.layers[b];
+#define ENG_ASTAMP(slot) do { if (a.dbg && tid == 0 && (b < 3 || b == a.n_layers - 1)) a.dbg[FQ_ENG_DBG_STAMPS + ((size_t) blockIdx.x * ENG_NSTAMP_BLK + (b < 3 ? b : 3)) * 8 + (slot)] = (long long) wall_clock64(); } while (0)
             ENG_ASTAMP(0);
+            // the block's first key / value rows are on their way while q / k / v are still being computed elsewhere
+            attn_pre P;
+            if (!idle) attn_prefetch(L.kc, L.vc, a.HKV, hk, a.max_n_kv, gtid, P);
             if (!idle && gtid < 192) {
-                for (unsigned spins = 0; a.use_counters && cnt_ld(a.cnt + ENG_CNT_QKV) < (unsigned)((a.H + 2 * a.HKV) * 64) * (unsigned)(b + 1);) { if (!w.spin(spins, 9u)) break; __builtin_amdgcn_s_sleep(8); }
                 const int part = gtid >> 6, d = gtid & 63;
                 const int row = (part == 0 ? h : (part == 1 ? a.H + hk : a.H + a.HKV + hk)) * 64 + d;
                 unsigned long long x = 0;
                 for (unsigned spins = 0;;) {
                     x = gran_ld(a.qkvg + row);
-                    if (__all((unsigned)(x >> 32) == tag)) break;
-                    if (!w.spin(spins, 4u, (unsigned) row, (unsigned)(x >> 32))) break;
+                    if ((a.debug_mode & 8) || __all((unsigned)(x >> 32) == tag)) break;
+                    if (!w.spin(spins, ENG_W_QKV, (unsigned) row, (unsigned)(x >> 32))) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
                 stage[gtid] = __builtin_bit_cast(float, (unsigned) x);
@@ -269,7 +342,6 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
             __syncthreads();
             ENG_ASTAMP(1);
             if (idle) { attn_decode_group_idle(); continue; }
-            const fq_engine_layer & L = a.layers[b];
             // (qkv is not used when q / k / v sources are given; it must be a GLOBAL pointer all the same -- with an LDS-derived or
             //  null one hipcc 7.2's InstCombine crashes on the selects between the two sources)
             fq_attn_decode_args at{ a.rope_cs, a.H, a.HKV, a.n_past, a.rope_cs, L.kc, L.vc, a.exp_tab, nullptr, (uint8_t *) a.attg, ACT, a.max_n_kv, nullptr,
@@ -279,12 +351,8 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
             int gt2 = gtid, h2 = h;
             asm volatile("" : "+v"(gt2), "+v"(h2));
             h2 = __builtin_amdgcn_readfirstlane(h2);
-            attn_decode_group<true>(at, h2, live, gt2, gbase + 768, nullptr, fq_publish{ a.attg, tag });
+            attn_decode_group_p<true, true>(at, h2, live, gt2, gbase + 768, nullptr, fq_publish{ a.attg, tag }, P);
             ENG_ASTAMP(2);
-            if (gtid < 64) {                                               // (the group's first wave stored the image)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (gtid == 0 && live && a.use_counters) cnt_add(a.cnt + ENG_CNT_ATT, 1u);
-            }
         }
         return;
     }
@@ -293,13 +361,15 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
     const int sw = (int) blockIdx.x - a.n_attn;
     const fq_engine_sched sc = a.sched[sw];
     uint8_t * ring    = smem;
-    uint8_t * img_ff  = smem + RING;                                       // region R: GELU image (phase B1) ...
-    uint8_t * img_e   = img_ff;                                            // ... LN image feeding Wup (and Wqkv with one norm) (phase A)
-    uint8_t * img_e2  = img_e + fq_act_col_bytes(ACT, E);                  // ... attention-norm image of a two-norm block (phase A)
-    uint8_t * img_att = img_ff + eng_region_r(ACT, E, FF);                 // attention output image (phase B2)
-    uint8_t * ctlp = img_att + fq_act_col_bytes(ACT, E);
+    uint8_t * reg_r   = smem + RING + ENG_MIRROR;                          // f32 residual row, then the GELU image
+    uint8_t * reg_s   = reg_r + eng_region_r(ACT, E, FF);                  // LayerNorm image(s), then the attention output image
+    uint8_t * ctlp    = reg_s + eng_region_s(ACT, E, a.two_norms);
+    float   * xrow    = (float *) reg_r;
+    uint8_t * img_ff  = reg_r;
+    uint8_t * img_e   = reg_s;                                             // LN image feeding Wup (and Wqkv with one norm)
+    uint8_t * img_e2  = reg_s + fq_act_col_bytes(ACT, E);                  // attention-norm image of a two-norm block
+    uint8_t * img_att = reg_s;
     const unsigned ctl = (unsigned)(uintptr_t) ctlp;
-    double * red  = (double *)(ctlp + eng_ctl::RED);
     // (dots, residual values and counters of the control block are touched with explicit DS instructions: in order with the
     //  counter updates that publish them)
     auto ldsf_st = [&](unsigned off, float v) { lds_st(ctl + off, __builtin_bit_cast(unsigned, v)); };
@@ -330,8 +400,8 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
     }
     if (tid < 32) lds_st(ctl + eng_ctl::CNT + 4 * tid, 0u);                 // CNT and CNTH
     if (tid < 16) lds_st(ctl + eng_ctl::LOW + 4 * tid, tid < ENG_NC ? 0u : 0xFFFFFFFFu);
-    if (tid == 0) { lds_st(ctl + eng_ctl::LANDED, 0u); lds_st(ctl + eng_ctl::CBAR, 0u); lds_st(ctl + eng_ctl::EPI, 0u); lds_st(ctl + eng_ctl::BDONE, 0u); lds_st(ctl + eng_ctl::QDONE, 0u); }
-    if (tid < 4) lds_st(ctl + eng_ctl::GO + 4 * tid, 0u);
+    if (tid < 16) lds_st(ctl + eng_ctl::XG_DONE + 4 * tid, 0u);             // all flags and counters (XG_DONE .. S2_DONE)
+    if (tid == 0) lds_st(ctl + eng_ctl::LANDED, 0u);
     __syncthreads();                                                       // the only workgroup barrier: before the roles split
 
     if (wid == 0) {
@@ -340,64 +410,98 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
         eng_wait w{ a.err, false, a.dbg, 0 };
         // pos = bytes issued, reported = bytes known to have landed (published in LANDED), freed = cached low-water mark; rp = ring
         // piece index. ALL of it is wave-uniform and kept scalar on purpose: one wave executes this loop, a dependent instruction
-        // costs it ~8 cycles, and a per-piece loop of ~45 vector instructions was measured at 350 cycles per 1 KiB piece (6.6 GB/s per
-        // CU); pieces are therefore issued 16 at a time, unrolled, with scalar addressing (~90 cycles per piece as in mb_engine.hip).
-        // At most 48 pieces are in flight; s_waitcnt vmcnt(N) = "all but my N newest pieces have landed".
+        // costs it ~8 cycles; pieces are issued 16 at a time, unrolled, with scalar addressing. At most 48 pieces are in flight;
+        // s_waitcnt vmcnt(N) = "all but my N newest DMA operations have landed" -- up to two of those may be mirror copies, so a
+        // report claims two pieces fewer than the count suggests.
         constexpr unsigned NP = (unsigned)(NSLOT * 16);
+        constexpr unsigned MIRP = (unsigned)(ENG_MIRROR / 1024);
         unsigned pos = 0, rp = 0, freed = 0, reported = 0;
         unsigned long long t_blocked = 0, t_report = 0, n_blocked = 0, t_start = __builtin_amdgcn_s_memtime();
-        auto report = [&](unsigned upto) { if (upto > reported) { reported = upto; if (lane == 0) lds_st(ctl + eng_ctl::LANDED, upto); } };
+        auto report = [&](unsigned upto) { if ((int)(upto - reported) > 0) { reported = upto; if (lane == 0) lds_st(ctl + eng_ctl::LANDED, upto); } };
+        auto report_keep = [&](unsigned keep_kb) { const unsigned back = (keep_kb + MIRP) * 1024u; if (pos > back) report(pos - back); };
         // make room for `bytes` (<= one slot) more: while the ring is full let the pieces in flight land step by step and report them
+        auto low_water = [&]() {
+            unsigned v = lds_ld(ctl + eng_ctl::LOW + 4 * (lane < 16 ? lane : 0));
+            v = (unsigned) wave_reduce((int) v, [](int x, int y) { return (unsigned) x < (unsigned) y ? x : y; });
+            return (unsigned) __builtin_amdgcn_readfirstlane(v);
+        };
+        // make room for `bytes` (<= one slot) more. While the ring is full the pieces in flight are let land and reported in SMALL steps
+        // (4 pieces), with a look at the consumers' low-water mark after every step: a consumer may be waiting for exactly those pieces,
+        // and space freed meanwhile must be refilled at once (waiting for everything to land first -- 1.5 us -- held the refill rate of a
+        // full ring at 10 GB/s per CU).
         auto wait_space = [&](unsigned bytes) {
+            if (pos + bytes - freed <= (unsigned) RING) return;
+            freed = low_water();
             if (pos + bytes - freed <= (unsigned) RING) return;
             const unsigned long long tb0 = __builtin_amdgcn_s_memtime(); ++n_blocked;
             for (unsigned spins = 0;;) {
                 const unsigned inflight = pos - reported;
-                if (inflight > 32u * 1024u)      { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); report(pos - 32u * 1024u); }
-                else if (inflight > 16u * 1024u) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); report(pos - 16u * 1024u); }
-                else if (inflight > 0u)          { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  report(pos); }
-                unsigned v = lds_ld(ctl + eng_ctl::LOW + 4 * (lane < 16 ? lane : 0));
-                v = (unsigned) wave_reduce((int) v, [](int x, int y) { return (unsigned) x < (unsigned) y ? x : y; });
-                freed = __builtin_amdgcn_readfirstlane(v);
-                if (pos + (unsigned) ENG_SLOT - freed <= (unsigned) RING) break;      // resume with a whole slot of space
-                if (!w.spin(spins, 1u, pos, freed)) break;
-                __builtin_amdgcn_s_sleep(1);
+#define ENG_LAND_STEP(N) if (inflight > (N + MIRP) * 1024u) { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); report_keep(N); } else
+                ENG_LAND_STEP(44) ENG_LAND_STEP(40) ENG_LAND_STEP(36) ENG_LAND_STEP(32) ENG_LAND_STEP(28) ENG_LAND_STEP(24) ENG_LAND_STEP(20) ENG_LAND_STEP(16)
+                ENG_LAND_STEP(12) ENG_LAND_STEP(8) ENG_LAND_STEP(4)
+                if (inflight > 0u) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); report(pos); }
+                else __builtin_amdgcn_s_sleep(1);
+#undef ENG_LAND_STEP
+                freed = low_water();
+                if (pos + bytes - freed <= (unsigned) RING) break;
+                if (!w.spin(spins, ENG_W_RING, pos, freed)) break;
             }
-            freed = __builtin_amdgcn_readfirstlane(freed);
             t_blocked += __builtin_amdgcn_s_memtime() - tb0;
         };
-        auto after_issue = [&]() {
-            if (pos - reported >= 48u * 1024u) {
+        const unsigned voff0 = (unsigned) lane * 16u;
+        eng_voff vo;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) vo.v[p] = voff0 + 1024u * (unsigned) p;
+        const unsigned mstart = __builtin_amdgcn_readfirstlane(ring_lds), mend = mstart + (unsigned) RING;
+        unsigned ml = mstart;                                              // LDS address of ring piece rp
+        auto after_issue = [&](unsigned thin) {
+            // gather-pass: while this CU gathers a hand-off its own DMA burst is what the gather's loads queue behind
+            if (thin != 0u) {
+                if (pos - reported > 18u * 1024u) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); report_keep(16u); }
+            } else if (pos - reported >= 50u * 1024u) {
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
-                asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); report(pos - 32u * 1024u);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); report_keep(32u);
                 t_report += __builtin_amdgcn_s_memtime() - tr0;
             }
         };
+        // the ring's first MIRP pieces a second time, behind its end: k = index inside the run of n pieces just issued from src
+        auto mirror = [&](const uint8_t * src, unsigned rp0, unsigned n) {
+#pragma unroll
+            for (unsigned t = 0; t < MIRP; ++t) {
+                unsigned k = t + NP - rp0; k = k >= NP ? k - NP : k;
+                if (k < n) glds_piece(src + k * 1024u, voff0, mstart + (NP + t) * 1024u);
+            }
+        };
+        const unsigned thin_addr = ctl + eng_ctl::THIN;
         auto seg = [&](const uint8_t * src, unsigned padded) {
-            const uint8_t * sl = src + lane * 16;                          // this lane's 16 bytes of every piece
             const unsigned nfull = padded >> 14, ntail = (padded >> 10) & 15u;
             for (unsigned k = 0; k < nfull; ++k) {
                 wait_space((unsigned) ENG_SLOT);
                 if (w.dead) return;
-#pragma unroll
-                for (unsigned p = 0; p < 16; ++p) {
-                    unsigned q = rp + p; q = q >= NP ? q - NP : q;
-                    glds16_nt(sl + p * 1024u, __builtin_amdgcn_readfirstlane(ring_lds + q * 1024u));
-                }
-                sl += ENG_SLOT; pos += (unsigned) ENG_SLOT;
+                mirror(src, rp, 16u);                                      // (first: a mirror copy is then never newer than its piece, see report_keep)
+                const unsigned thin = __builtin_amdgcn_readfirstlane(glds_batch16(src, vo, ml, mstart, mend, thin_addr));
+                src += ENG_SLOT; pos += (unsigned) ENG_SLOT;
                 rp += 16u; rp = rp >= NP ? rp - NP : rp;
-                after_issue();
+                after_issue(a.thin_loader ? thin : 0u);
             }
-            for (unsigned p = 0; p < ntail; ++p) {
-                wait_space(1024u);
+            if (ntail) {
+                wait_space(ntail * 1024u);
                 if (w.dead) return;
-                glds16_nt(sl, __builtin_amdgcn_readfirstlane(ring_lds + rp * 1024u));
-                sl += 1024; pos += 1024u;
-                if (++rp == NP) rp = 0;
-                after_issue();
+                mirror(src, rp, ntail);
+                for (unsigned p = 0; p < ntail; ++p) {
+                    glds_piece(src + p * 1024u, voff0, ml);
+                    ml += 1024u; ml = ml >= mend ? mstart : ml;
+                }
+                pos += ntail * 1024u;
+                rp += ntail; rp = rp >= NP ? rp - NP : rp;
+                after_issue(0u);
             }
         };
-        auto src = [&](int i) { return (const uint8_t *)(uintptr_t) lds_ld64(ctl + eng_ctl::PTRS + 8 * (unsigned) i); };
+        auto src = [&](int i) {                                             // (wave-uniform by construction; made so for the compiler)
+            const unsigned long long v = lds_ld64(ctl + eng_ctl::PTRS + 8 * (unsigned) i);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (const uint8_t *)(uintptr_t)(((unsigned long long) hi << 32) | lo);
+        };
         for (int b = 0; b < a.n_layers && !w.dead; ++b) {
             seg(src(4 * b), pA1);
             seg(src(4 * b + 1), pA2);
@@ -408,21 +512,29 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         report(pos);
         if (a.dbg && lane == 0) {
-            long long * r = a.dbg + 4096 + 256 * 4 * 8 + (size_t) blockIdx.x * 8;
+            long long * r = a.dbg + FQ_ENG_DBG_COUNTERS + (size_t) blockIdx.x * 16;
             r[0] = (long long)(__builtin_amdgcn_s_memtime() - t_start); r[1] = (long long) t_blocked; r[2] = (long long) t_report; r[3] = (long long) n_blocked; r[4] = pos;
         }
         return;
     }
 
-    // ==================================================================================== consumers
-    const int c = wid - 1, ctid = tid - 64;
-    constexpr int CT = 64 * ENG_NC;
-    constexpr int NLN = 3;                                                 // float4 of the row per consumer thread: n_embd <= 8448
+    // ==================================================================================== helpers: the gatherer (h = 0) and the consumers (c = h - 1)
+    const int h = wid - 1, c = h - 1, ht = tid - 64;
+    const bool isG = h == 0;
+    constexpr int NLN = 3;                                                 // float4 of the row per helper thread: n_embd <= 8448
     eng_wait w{ a.err, false, a.dbg, 0 };
-    unsigned long long t_wait_land = 0, t_dot = 0, n_rows = 0;
-    unsigned gen = 0;                                                      // consumer barrier generation
+    unsigned long long t_wait_land = 0, t_dot = 0, n_rows = 0, t_w_stat = 0, t_w_img = 0, t_w_ff = 0, t_w_att = 0, t_gather = 0, t_epi = 0;
     const int nblkE = E / 32, nblkF = FF / 32;
-    const int64_t nv = E >> 2;
+    const int nv = E >> 2;
+    const int nwords_ff = (FF >> 2) + 2 * (FF >> 5), nwords_e = (E >> 2) + 2 * (E >> 5);
+    const unsigned nx = (unsigned)((E + ENG_CHUNK - 1) / ENG_CHUNK), nf = (unsigned)((nwords_ff + ENG_CHUNK - 1) / ENG_CHUNK), na = (unsigned)((nwords_e + ENG_CHUNK - 1) / ENG_CHUNK);
+    const size_t stamp_base = isG ? FQ_ENG_DBG_GSTAMPS : FQ_ENG_DBG_STAMPS;
+    const bool stamps = isG || c == 0;
+    auto timed_until = [&](unsigned addr, unsigned target, unsigned code, unsigned long long & acc) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        w.until(addr, target, code);
+        acc += __builtin_amdgcn_s_memtime() - t0;
+    };
 
     // rows [0, nrows) of a segment that starts at stream position seg_pos, dealt in runs of R consecutive rows: mine are
     // [R (c + NC k), R (c + NC k) + R), k = 0, 1, .. -- R rows share every activation read, and a wave only ever waits for ONE
@@ -433,32 +545,38 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
         // nothing below my first run is needed by me (without this the loader would wait for rows of OTHER consumers to be
         // released by a wave that is itself waiting for its first rows to land)
         if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, R * c < nrows ? seg_pos + (unsigned)(R * c) * rs : seg_pos + padded);
+        const int npass = (nblk + 63) >> 6;                                // passes of 64 units = 64 blocks = 64 TS bytes of a row
         for (int i = R * c; i < nrows; i += R * ENG_NC) {
             const int last = i + R - 1 < nrows ? i + R - 1 : nrows - 1;
-            const unsigned need = seg_pos + (unsigned) last * rs + row_bytes;
-            const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
-            for (unsigned spins = 0; lds_ld_u(ctl + eng_ctl::LANDED) < need;) { if (!w.spin(spins, 2u, need, lds_ld_u(ctl + eng_ctl::LANDED))) break; __builtin_amdgcn_s_sleep(1); }
-            const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
-            unsigned pr[R]; float v[R];
-            const unsigned p0 = (seg_pos + (unsigned) i * rs) % (unsigned) RING;
+            const unsigned row0 = seg_pos + (unsigned) i * rs, rowl = seg_pos + (unsigned) last * rs;
+            unsigned pr[R]; float v[R], acc[R];
+            const unsigned p0 = row0 % (unsigned) RING;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rs; pr[r] = q >= (unsigned) RING ? q - (unsigned) RING : q; }
-            eng_rows_dot<TYPE, RING, R>(ring, pr, nblk, col, lane, v);
-            t_wait_land += tw1 - tw0; t_dot += __builtin_amdgcn_s_memtime() - tw1; n_rows += R;
+            for (int r = 0; r < R; ++r) { const unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rs; pr[r] = q >= (unsigned) RING ? q - (unsigned) RING : q; acc[r] = 0.0f; }
+            // a long row is taken three passes at a time as they land, and given back as it is consumed (ten 10 KB rows in progress would
+            // otherwise BE the ring: nothing could be loaded ahead). The lane's units are added in the same ascending order.
+            for (int ps = 0; ps < npass; ps += 3) {
+                const int np = npass - ps < 3 ? npass - ps : 3;
+                const unsigned upto = (unsigned)((ps + np) * 64 * TS);
+                const unsigned need = rowl + (upto < row_bytes ? upto : row_bytes);
+                const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+                for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) < 0;) { if (!w.spin(spins, ENG_W_LAND, need, lds_ld_u(ctl + eng_ctl::LANDED))) break; __builtin_amdgcn_s_sleep(1); }
+                const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+                if (!nodots) {                                             // (tuning aid: no arithmetic, the hand-offs alone)
+                    if (np == 3)      eng_pass_group<TYPE, RING, R, 3>(ring, pr, nblk, 64 * ps, col, lane, acc);
+                    else if (np == 2) eng_pass_group<TYPE, RING, R, 2>(ring, pr, nblk, 64 * ps, col, lane, acc);
+                    else              eng_pass_group<TYPE, RING, R, 1>(ring, pr, nblk, 64 * ps, col, lane, acc);
+                }
+                t_wait_land += tw1 - tw0; t_dot += __builtin_amdgcn_s_memtime() - tw1;
+                if (ps + 3 < npass && lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, row0 + upto);
+            }
+            n_rows += R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[r]);
 #pragma unroll
             for (int r = 0; r < R; ++r) if (i + r <= last) sink(i + r, v[r]);
-            const int nx = i + R * ENG_NC;
-            if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx < nrows ? seg_pos + (unsigned) nx * rs : seg_pos + padded);
-        }
-    };
-    // wait until hand-off counter e has reached target: ONE consumer wave polls the device word, the others the word it leaves in LDS
-    auto edge_wait = [&](int e, unsigned target) {
-        if (!a.use_counters) return;
-        if (c == 0) {
-            for (unsigned spins = 0; cnt_ld(a.cnt + e) < target;) { if (!w.spin(spins, 10u, (unsigned) e, target)) break; __builtin_amdgcn_s_sleep(8); }
-            if (lane == 0) lds_st(ctl + eng_ctl::GO + (unsigned) e / 8u, target);
-        } else {
-            for (unsigned spins = 0; lds_ld_u(ctl + eng_ctl::GO + (unsigned) e / 8u) < target;) { if (!w.spin(spins, 11u, (unsigned) e, target)) break; __builtin_amdgcn_s_sleep(2); }
+            const int nx_ = i + R * ENG_NC;
+            if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rs : seg_pos + padded);
         }
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
@@ -471,79 +589,119 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
     auto rows_f = [&](unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, auto && sink) {
         rows(R1, seg_pos, padded, nrows, rsF, nblkF, col, sink);
     };
-    // LayerNorm (+ the second norm of a two-norm block) of the residual row -> Q8 images; the row comes from memory (first
-    // block of the stage) or from the granules the previous block's owners published. Also keeps x[r0 .. r1) for phase B.
-    auto layer_norm_images = [&](bool from_mem, unsigned tag, unsigned x_target, const float * w1, const float * b1, uint8_t * img1,
-                                 const float * w2, const float * b2, uint8_t * img2) {
-        ln_row_regs<NLN> xr, wr, br;
-        ln_regs_issue_wb(w1, b1, E, CT, wr, br, ctid);
-        if (!from_mem) edge_wait(ENG_CNT_X, x_target);
-        if (from_mem) {
-#pragma unroll
-            for (int k = 0; k < NLN; ++k) { const int64_t i = (int64_t) k * CT + ctid, j = i < nv ? i : nv - 1; xr.t[k] = ((const float4 *) a.x_in)[j]; }
-        } else {
-            for (unsigned spins = 0;;) {                                   // all 4 NLN granules of the thread in flight together
-                unsigned long long g[NLN][4];
-#pragma unroll
-                for (int k = 0; k < NLN; ++k) {
-                    const int64_t i = (int64_t) k * CT + ctid, j = i < nv ? i : nv - 1;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[k][q] = gran_ld(a.xg + 4 * j + q);
-                }
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < NLN; ++k) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(g[k][q] >> 32) == tag;
-                    xr.t[k] = make_float4(__builtin_bit_cast(float, (unsigned) g[k][0]), __builtin_bit_cast(float, (unsigned) g[k][1]),
-                                          __builtin_bit_cast(float, (unsigned) g[k][2]), __builtin_bit_cast(float, (unsigned) g[k][3]));
-                }
-                if (__all(ok)) break;
-                if (!w.spin(spins, 5u, 0u, tag)) break;
-                __builtin_amdgcn_s_sleep(4);
+
+    // ---- the residual row of LayerNorm number `li` (block li, or ln_f for li = n_layers) -> LDS -> Q8 image(s).
+    // Every helper gathers its chunks; the last one to arrive takes the statistics; every helper normalises its share.
+    // b: the block index for the phase stamps (-1: none)
+    auto layer_norm_images = [&](int li, const float * w1, const float * b1, uint8_t * img1, const float * w2, const float * b2, uint8_t * img2, int b) {
+        const bool from_mem = li == 0;
+        const unsigned xtag = epoch0 + (unsigned) li;
+        ln_row_regs<NLN> wr, br;
+        ln_regs_issue_wb(w1, b1, E, ENG_HT, wr, br, ht);                   // (on their way while the row is gathered)
+        // the row goes where the previous block's GELU image was: every consumer must be done with its Wdown rows
+        if (li > 0) w.until(ctl + eng_ctl::B1_DONE, (unsigned) ENG_NC * (unsigned) li, ENG_W_B1);
+        const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+        if (isG && a.thin_loader) lds_st(ctl + eng_ctl::THIN, 1u);
+        const unsigned own = from_mem ? eng_gather_mem(a.x_in, E, (unsigned *) xrow, h, lane, ctl + eng_ctl::PSUM)
+                                      : eng_gather<true>(a.xg, xtag, E, (unsigned *) xrow, h, lane, w, ENG_W_XG, (a.debug_mode & 4) != 0, ctl + eng_ctl::PSUM);
+        t_gather += __builtin_amdgcn_s_memtime() - tg0;
+        if (stamps) ENG_STAMP_AT(stamp_base, 1);
+        if (own) {
+            lds_drain();                                                   // this wave's row values and partial sums are in LDS before it counts itself in
+            unsigned old = 0;
+            if (lane == 0) old = lds_add_rtn(ctl + eng_ctl::XG_DONE, own);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old + own == nx * (unsigned)(li + 1)) {
+                // ---- the last chunk has arrived: the row's mean by this wave (ggml.c:10577-10582), chunk sums in chunk order
+                double s = 0.0;
+                const unsigned long long pk = lds_ld64(ctl + eng_ctl::PSUM + 8u * (unsigned)(lane < (int) nx ? lane : 0));
+                for (unsigned k = 0; k < nx; ++k) s += lane_get(__builtin_bit_cast(double, (long long) pk), (int) k);
+                const float mean = (float)(s / (double) E);
+                if (lane < nB) ldsf_st(eng_ctl::XRES + 4 * lane, xrow[sc.r0 + lane]);      // residual values of this workgroup's phase-B rows
+                if (lane == 0) ldsf_st(eng_ctl::STAT, mean);
+                lds_drain();
+                if (lane == 0) lds_st(ctl + eng_ctl::LN_MEAN, (unsigned)(li + 1));
+                if (a.thin_loader && lane == 0) lds_st(ctl + eng_ctl::THIN, 0u);
             }
         }
+        timed_until(ctl + eng_ctl::LN_MEAN, (unsigned)(li + 1), ENG_W_STAT, t_w_stat);
+        if (stamps) ENG_STAMP_AT(stamp_base, 2);
+        // ---- second pass (ggml.c:10585-10591): every helper wave over its share of the row, which it keeps for the normalisation
+        const float mean = ldsf_ld(eng_ctl::STAT);
+        float4 xv[NLN];
+        {
+            double s2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NLN; ++k) {                                    // residual values of this workgroup's phase-B rows
-            const int64_t i = (int64_t) k * CT + ctid;
-            if (i < nv) {
-                const int e0 = (int)(4 * i);
-                const float t4[4] = { xr.t[k].x, xr.t[k].y, xr.t[k].z, xr.t[k].w };
+            for (int k = 0; k < NLN; ++k) {
+                const int q4 = k * ENG_HT + ht;
+                float4 v = ((const float4 *) xrow)[q4 < nv ? q4 : nv - 1];
+                v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+                xv[k] = v;
+                if (q4 < nv) { s2 += (double)(v.x * v.x); s2 += (double)(v.y * v.y); s2 += (double)(v.z * v.z); s2 += (double)(v.w * v.w); }
+            }
+            s2 = wave_sum(s2);
+            if (lane == 0) lds_st64(ctl + eng_ctl::PSQ + 8u * (unsigned) h, (unsigned long long) __builtin_bit_cast(long long, s2));
+            lds_drain();
+            unsigned old2 = 0;
+            if (lane == 0) old2 = lds_add_rtn(ctl + eng_ctl::S2_DONE, 1u);
+            old2 = __builtin_amdgcn_readfirstlane(old2);
+            if (old2 + 1u == (unsigned) ENG_NH * (unsigned)(li + 1)) {     // the last wave: partial sums in wave order -> scale
+                const unsigned long long pk = lds_ld64(ctl + eng_ctl::PSQ + 8u * (unsigned)(lane < ENG_NH ? lane : 0));
+                double t = 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int e = e0 + q; if (e >= sc.r0 && e < sc.r1) ldsf_st(eng_ctl::XRES + 4 * (e - sc.r0), t4[q]); }
+                for (int k = 0; k < ENG_NH; ++k) t += lane_get(__builtin_bit_cast(double, (long long) pk), k);
+                const float variance = (float)(t / (double) E);
+                const float scale = 1.0f / sqrtf(variance + 1e-5f);
+                if (lane == 0) ldsf_st(eng_ctl::STAT + 4, scale);
+                lds_drain();
+                if (lane == 0) lds_st(ctl + eng_ctl::LN_STAT, (unsigned)(li + 1));
             }
         }
-        ln_regs_stage1(xr, E, CT, red, ctid);
-        eng_cbar(ctl, gen, w);
-        ln_regs_stage2(xr, E, CT, red, ctid);
-        eng_cbar(ctl, gen, w);
-        ln_regs_stage3<ACT>(xr, wr, br, E, CT, act_image_at(img1, ACT, E), red, ctid);
+        timed_until(ctl + eng_ctl::LN_STAT, (unsigned)(li + 1), ENG_W_STAT, t_w_stat);
+        // the image(s) go where the previous block's attention image was: every consumer must be done with its Wo rows
+        if (li > 0) w.until(ctl + eng_ctl::B2_DONE, (unsigned) ENG_NC * (unsigned) li, ENG_W_B2);
+        const float scale = ldsf_ld(eng_ctl::STAT + 4);
+        auto norm_quant = [&](const ln_row_regs<NLN> & wq, const ln_row_regs<NLN> & bq, uint8_t * img) {
+            const act_image_ptr o = act_image_at(img, ACT, E);
+#pragma unroll
+            for (int k = 0; k < NLN; ++k) {
+                const int q4 = k * ENG_HT + ht;
+                if ((q4 & ~63) < nv) {                                     // wave-uniform
+                    const bool lv = q4 < nv; const int j = lv ? q4 : nv - 1;
+                    float4 v = xv[k];
+                    const float4 ww = wq.t[k], bb = bq.t[k];
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
+                    quant_q8_quad<ACT>(v, j, o, lv);
+                }
+            }
+        };
+        norm_quant(wr, br, img1);
         if (w2) {
             ln_row_regs<NLN> w2r, b2r;
-            ln_regs_issue_wb(w2, b2, E, CT, w2r, b2r, ctid);
-            ln_regs_stage3<ACT>(xr, w2r, b2r, E, CT, act_image_at(img2, ACT, E), red, ctid);
+            ln_regs_issue_wb(w2, b2, E, ENG_HT, w2r, b2r, ht);
+            norm_quant(w2r, b2r, img2);
         }
-        eng_cbar(ctl, gen, w);
+        lds_drain();
+        if (lane == 0) lds_add(ctl + eng_ctl::IMG_DONE, 1u);
+        timed_until(ctl + eng_ctl::IMG_DONE, (unsigned) ENG_NH * (unsigned)(li + 1), ENG_W_IMG, t_w_img);
+        if (stamps) ENG_STAMP_AT(stamp_base, 3);
     };
 
-    // the 32 rows of a finished group, by one wave (lanes 32..63 mirror 0..31): waits until all of them are in outA
-    auto group_ready = [&](unsigned cnt, int gl, unsigned target) {
-        for (unsigned spins = 0; lds_ld_u(ctl + cnt + 4 * gl) < target;) { if (!w.spin(spins, 6u, (unsigned) gl, lds_ld_u(ctl + cnt + 4 * gl))) break; __builtin_amdgcn_s_sleep(1); }
-    };
     const fq_actcol col_e  = { (const int8_t *) img_e,  (const float *)(img_e + fq_act_d_off(ACT, E)),  (const void *)(img_e + fq_act_aux_off(ACT, E)) };
     const fq_actcol col_e2 = { (const int8_t *) img_e2, (const float *)(img_e2 + fq_act_d_off(ACT, E)), (const void *)(img_e2 + fq_act_aux_off(ACT, E)) };
     const fq_actcol col_att = { (const int8_t *) img_att, (const float *)(img_att + fq_act_d_off(ACT, E)), (const void *)(img_att + fq_act_aux_off(ACT, E)) };
     const fq_actcol col_ff = { (const int8_t *) img_ff, (const float *)(img_ff + fq_act_d_off(ACT, FF)), (const void *)(img_ff + fq_act_aux_off(ACT, FF)) };
-    const int nwords_ff = (FF >> 2) + 2 * (FF >> 5), nwords_e = (E >> 2) + 2 * (E >> 5);
 
     if (a.debug_mode == 1) {                                               // tuning aid: the loader alone -- rows are released as soon as they land
+        if (isG) return;
         auto drain = [&](unsigned seg_pos, unsigned padded, int nrows, unsigned rs, int nblk) {
             const unsigned row_bytes = (unsigned)(nblk * TS);
             for (int i = c; i < nrows; i += ENG_NC) {
                 const unsigned need = seg_pos + (unsigned) i * rs + row_bytes;
-                for (unsigned spins = 0; lds_ld_u(ctl + eng_ctl::LANDED) < need;) { if (!w.spin(spins, 2u, need, 0)) break; __builtin_amdgcn_s_sleep(1); }
-                const int nx = i + ENG_NC;
-                if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx < nrows ? seg_pos + (unsigned) nx * rs : seg_pos + padded);
+                for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) < 0;) { if (!w.spin(spins, ENG_W_LAND, need, 0)) break; __builtin_amdgcn_s_sleep(1); }
+                const int nx_ = i + ENG_NC;
+                if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rs : seg_pos + padded);
             }
             if (c >= nrows && lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, seg_pos + padded);
         };
@@ -555,114 +713,140 @@ __global__ void __launch_bounds__(ENG_NT) k_decode_engine(fq_engine_args a) {
         if (a.lm_head) drain((unsigned) a.n_layers * p_blk, pH, nH, rsE, nblkE);
         return;
     }
+
+#define ENG_STAMP(slot) do { if (stamps) ENG_STAMP_AT(stamp_base, slot); } while (0)
     for (int b = 0; b < a.n_layers; ++b) {
         const fq_engine_layer & L = a.layers[b];
         const unsigned base = (unsigned) b * p_blk;
         const unsigned tag = epoch0 + (unsigned) b + 1u;                   // tag of everything block b publishes
+        const unsigned bp1 = (unsigned)(b + 1);
         w.blk = b;
         ENG_STAMP(0);
         // ---- residual row -> LayerNorm image(s)
-        layer_norm_images(b == 0, epoch0 + (unsigned) b, (unsigned) E * (unsigned) b, L.ln_w, L.ln_b, img_e, a.two_norms ? L.ln2_w : nullptr, L.ln2_b, img_e2);
-        ENG_STAMP(1);
-        // ---- phase A: rows of Wqkv (norm image: the attention norm when the block has two) and Wup
-        const unsigned cnt_target = 32u * (unsigned)(b + 1);
+        layer_norm_images(b, L.ln_w, L.ln_b, img_e, a.two_norms ? L.ln2_w : nullptr, L.ln2_b, img_e2, b);
         const int gA = nA2 / 32;
-        auto epilogue = [&](int gl) {                                      // a finished Wup group: GELU, Q8 block of 32 (kernels_decode.hip, k_gemv_ln epilogue)
-            group_ready(eng_ctl::CNT, gl, cnt_target);
-            const int j = lane & 31;
-            float v = ldsf_ld(eng_ctl::OUT + 4 * (32 * gl + j));
-            const int g = sc.ug0 + gl;                                     // block index in the FF-long image
-            v = h2f_bits(a.gelu_tab[f2h_bits(v)]);                         // ggml.c:3477-3484
-            const float amax = reduce32(fabsf(v), op_max());
-            const float d  = amax / 127.0f;
-            const float id = d ? 1.0f / d : 0.0f;
-            const int q = round_half_away(v * id);
-            const int s = reduce32(q, op_add());
-            unsigned wq = (unsigned) q & 0xFFu;                            // 4 lanes -> one word of qs
-            wq |= ((unsigned) __shfl_down((int) wq, 1) & 0xFFu) << 8;
-            wq |= ((unsigned) __shfl_down((int) wq, 2) & 0xFFFFu) << 16;
-            if (lane < 32 && (lane & 3) == 0) gran_st(a.ffg + 8 * g + (lane >> 2), tag, wq);
-            if (lane == 0) {
-                const int wd = (FF >> 2) + g, wa = wd + (FF >> 5);
-                if (ACT == FQ_Q8_0) { gran_st(a.ffg + wd, tag, __builtin_bit_cast(unsigned, h2f_bits(f2h_bits(d)))); gran_st(a.ffg + wa, tag, (unsigned) s); }
-                else                { gran_st(a.ffg + wd, tag, __builtin_bit_cast(unsigned, d)); gran_st(a.ffg + wa, tag, __builtin_bit_cast(unsigned, (float) s * d)); }
+        const unsigned cnt_target = 32u * bp1;
+        if (isG) {
+            // ---- the Wup epilogues of this workgroup's groups, in the order their rows are dealt (kernels_decode.hip, k_gemv_ln epilogue)
+            const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+            for (int gl = 0; gl < gA;) {
+                for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::CNT + 4 * gl) - cnt_target) < 0;) { if (!w.spin(spins, ENG_W_GROUP, (unsigned) gl, lds_ld_u(ctl + eng_ctl::CNT + 4 * gl))) break; __builtin_amdgcn_s_sleep(1); }
+                // lanes 0..31: group gl; lanes 32..63: group gl + 1 if it is complete as well (one table round trip for both), else a mirror
+                const bool two = gl + 1 < gA && (int)(lds_ld_u(ctl + eng_ctl::CNT + 4 * (gl + 1)) - cnt_target) >= 0;
+                const int j = lane & 31, half = lane >> 5;
+                const int myg = gl + (two ? half : 0);
+                const bool st = two || half == 0;
+                float v = ldsf_ld(eng_ctl::OUT + 4 * (32 * myg + j));
+                const int g = sc.ug0 + myg;                                // block index in the FF-long image
+                v = h2f_bits(a.gelu_tab[f2h_bits(v)]);                     // ggml.c:3477-3484
+                const float amax = reduce32(fabsf(v), op_max());
+                const float d  = amax / 127.0f;
+                const float id = d ? 1.0f / d : 0.0f;
+                const int q = round_half_away(v * id);
+                const int s = reduce32(q, op_add());
+                unsigned wq = (unsigned) q & 0xFFu;                        // 4 lanes -> one word of qs
+                wq |= ((unsigned) __shfl_down((int) wq, 1) & 0xFFu) << 8;
+                wq |= ((unsigned) __shfl_down((int) wq, 2) & 0xFFFFu) << 16;
+                if (st && (j & 3) == 0) gran_st(a.ffg + 8 * g + (j >> 2), tag, wq);
+                if (st && j == 0) {
+                    const int wd = (FF >> 2) + g, wa = wd + (FF >> 5);
+                    if (ACT == FQ_Q8_0) { gran_st(a.ffg + wd, tag, __builtin_bit_cast(unsigned, h2f_bits(f2h_bits(d)))); gran_st(a.ffg + wa, tag, (unsigned) s); }
+                    else                { gran_st(a.ffg + wd, tag, __builtin_bit_cast(unsigned, d)); gran_st(a.ffg + wa, tag, __builtin_bit_cast(unsigned, (float) s * d)); }
+                }
+                gl += two ? 2 : 1;
             }
-            if (a.use_counters) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0 && lds_add_rtn(ctl + eng_ctl::EPI, 1u) + 1u == (unsigned) gA * (unsigned)(b + 1))
-                    cnt_add(a.cnt + ENG_CNT_FF, (unsigned) gA);            // the workgroup's last Wup epilogue: one device atomic per workgroup
-            }
-        };
-        // Wqkv rows: q / k / v values go out one by one, before the Wup rows (the attention starts as early as it can)
-        rows_e(base, pA1, nA1, a.two_norms ? col_e2 : col_e, [&](int i, float v) { if (lane == 0) gran_st(a.qkvg + sc.qg0 + i, tag, __builtin_bit_cast(unsigned, v)); });
-        if (a.use_counters) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0 && lds_add_rtn(ctl + eng_ctl::QDONE, 1u) + 1u == (unsigned) ENG_NC * (unsigned)(b + 1) && nA1 > 0) cnt_add(a.cnt + ENG_CNT_QKV, (unsigned) nA1);
+            t_epi += __builtin_amdgcn_s_memtime() - te0;
+            ENG_STAMP(4);
+        } else {
+            // ---- phase A: rows of Wqkv (norm image: the attention norm when the block has two) and Wup
+            // Wqkv rows: q / k / v values go out one by one, before the Wup rows (the attention starts as early as it can)
+            rows_e(base, pA1, nA1, a.two_norms ? col_e2 : col_e, [&](int i, float v) { if (lane == 0) gran_st(a.qkvg + sc.qg0 + i, tag, __builtin_bit_cast(unsigned, v)); });
+            rows_e(base + pA1, pA2, nA2, col_e, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
+            if (lane == 0) lds_add(ctl + eng_ctl::A_DONE, 1u);
+            ENG_STAMP(4);
         }
-        rows_e(base + pA1, pA2, nA2, col_e, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
-        for (int gl = c; gl < gA; gl += ENG_NC) epilogue(gl);
-        ENG_STAMP(2);
-        // ---- the whole GELU image -> LDS (over the LayerNorm images: every consumer must be done with phase A), then Wdown
-        eng_cbar(ctl, gen, w);
-        ENG_STAMP(3);
-        edge_wait(ENG_CNT_FF, (unsigned)(FF / 32) * (unsigned)(b + 1));
-        eng_sweep<9>(a.ffg, tag, nwords_ff, (unsigned *) img_ff, ctid, w, 7u);
-        eng_cbar(ctl, gen, w);
-        ENG_STAMP(4);
-        rows_f(base + pA1 + pA2, pB1, nB, col_ff, [&](int i, float v) { if (lane == 0) ldsf_st(eng_ctl::OUTB + 4 * i, v); });
+        // ---- the whole GELU image -> LDS (where the f32 row was: every helper has passed IMG_DONE), one chunk per helper
+        {
+            const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+            if (isG && a.thin_loader && lane == 0) lds_st(ctl + eng_ctl::THIN, 1u);
+            const unsigned own = eng_gather<false>(a.ffg, tag, nwords_ff, (unsigned *) img_ff, h, lane, w, ENG_W_FG, (a.debug_mode & 16) != 0, 0u);
+            t_gather += __builtin_amdgcn_s_memtime() - tg0;
+            if (own) { lds_drain(); if (lane == 0) lds_add(ctl + eng_ctl::FG_DONE, own); }
+            timed_until(ctl + eng_ctl::FG_DONE, nf * bp1, ENG_W_FGD, t_w_ff);
+            if (isG && a.thin_loader && lane == 0) lds_st(ctl + eng_ctl::THIN, 0u);
+        }
         ENG_STAMP(5);
-        // ---- the attention output image -> LDS, then the rows of Wo
-        edge_wait(ENG_CNT_ATT, (unsigned) a.H * (unsigned)(b + 1));
-        eng_sweep<3>(a.attg, tag, nwords_e, (unsigned *) img_att, ctid, w, 8u);
-        eng_cbar(ctl, gen, w);
-        ENG_STAMP(6);
-        rows_e(base + pA1 + pA2 + pB1, pB2, nB, col_att, [&](int i, float v) {
-            if (lane == 0) {
-                const float xn = (ldsf_ld(eng_ctl::OUTB + 4 * i) + v) + ldsf_ld(eng_ctl::XRES + 4 * i);     // libfalcon.cpp:2399-2400
-                const int row = sc.r0 + i;
-                gran_st(a.xg + row, tag, __builtin_bit_cast(unsigned, xn));
-                a.x[row] = xn;
-                if (a.hidden) a.hidden[(size_t)(b + 1) * E + row] = xn;
-            }
-        });
-        if (a.use_counters) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's rows of x are out: count the workgroup in once
-            if (lane == 0 && lds_add_rtn(ctl + eng_ctl::BDONE, 1u) + 1u == (unsigned) ENG_NC * (unsigned)(b + 1) && nB > 0) cnt_add(a.cnt + ENG_CNT_X, (unsigned) nB);
+        if (!isG) {
+            rows_f(base + pA1 + pA2, pB1, nB, col_ff, [&](int i, float v) { if (lane == 0) ldsf_st(eng_ctl::OUTB + 4 * i, v); });
+            lds_drain();
+            if (lane == 0) lds_add(ctl + eng_ctl::B1_DONE, 1u);
         }
-        ENG_STAMP(7);
-    }
-    if (a.dbg && c == 0 && lane == 0) {
-        long long * r = a.dbg + 4096 + 256 * 4 * 8 + (size_t) blockIdx.x * 8;
-        r[5] = (long long) t_wait_land; r[6] = (long long) t_dot; r[7] = (long long) n_rows;
+        ENG_STAMP(6);
+        // ---- the attention output image -> LDS (where the LayerNorm images were: every consumer must be done with phase A)
+        {
+            w.until(ctl + eng_ctl::A_DONE, (unsigned) ENG_NC * bp1, ENG_W_ADONE);
+            const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+            if (isG && a.thin_loader && lane == 0) lds_st(ctl + eng_ctl::THIN, 1u);
+            // (the gatherer has nothing else to do while the Wdown rows are dotted: all chunks are its)
+            const unsigned own = isG ? eng_gather<false>(a.attg, tag, nwords_e, (unsigned *) img_att, 0, lane, w, ENG_W_AG, (a.debug_mode & 32) != 0, 0u, 1) : 0u;
+            t_gather += __builtin_amdgcn_s_memtime() - tg0;
+            if (own) { lds_drain(); if (lane == 0) lds_add(ctl + eng_ctl::AG_DONE, own); }
+            if (isG && a.thin_loader) { w.until(ctl + eng_ctl::AG_DONE, na * bp1, ENG_W_AGD); if (lane == 0) lds_st(ctl + eng_ctl::THIN, 0u); }
+        }
+        if (!isG) {
+            timed_until(ctl + eng_ctl::AG_DONE, na * bp1, ENG_W_AGD, t_w_att);
+            w.until(ctl + eng_ctl::B1_DONE, (unsigned) ENG_NC * bp1, ENG_W_B1);      // (a row's down-projection dot was left by another wave)
+            ENG_STAMP(7);
+            rows_e(base + pA1 + pA2 + pB1, pB2, nB, col_att, [&](int i, float v) {
+                if (lane == 0) {
+                    const float xn = (ldsf_ld(eng_ctl::OUTB + 4 * i) + v) + ldsf_ld(eng_ctl::XRES + 4 * i);     // libfalcon.cpp:2399-2400
+                    const int row = sc.r0 + i;
+                    gran_st(a.xg + row, tag, __builtin_bit_cast(unsigned, xn));
+                    a.x[row] = xn;
+                    if (a.hidden) a.hidden[(size_t)(b + 1) * E + row] = xn;
+                }
+            });
+            lds_drain();
+            if (lane == 0) lds_add(ctl + eng_ctl::B2_DONE, 1u);
+        } else ENG_STAMP(7);
     }
     // ---- ln_f + lm_head (last stage): logits and the per-32-row greedy candidates
     if (a.lm_head) {
-        layer_norm_images(a.n_layers == 0, epoch0 + (unsigned) a.n_layers, (unsigned) E * (unsigned) a.n_layers, a.lnf_w, a.lnf_b, img_e, nullptr, nullptr, nullptr);
+        w.blk = a.n_layers;
+        layer_norm_images(a.n_layers, a.lnf_w, a.lnf_b, img_e, nullptr, nullptr, nullptr, -1);
         const unsigned hbase = (unsigned) a.n_layers * p_blk;
         const int ngroups = (nH + 31) / 32;
-        rows_e(hbase, pH, nH, col_e, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNTH + 4 * (i >> 5), 1u); } });
-        // (a partial last group: its missing rows never arrive -- count them in)
-        if (c == 0 && lane == 0 && (nH & 31)) lds_add(ctl + eng_ctl::CNTH + 4 * (nH >> 5), (unsigned)(32 - (nH & 31)));
-        for (int gl = c; gl < ngroups; gl += ENG_NC) {
-            group_ready(eng_ctl::CNTH, gl, 32u);
-            const int j = lane & 31;
-            const int row = sc.hg0 * 32 + 32 * gl + j;
-            const float v = ldsf_ld(eng_ctl::OUT + 4 * (32 * gl + j));
-            if (lane < 32 && row < a.V) a.logits[row] = v;
-            float bv = row < a.V ? v : -INFINITY; int bi = row;
+        if (!isG) {
+            rows_e(hbase, pH, nH, col_e, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNTH + 4 * (i >> 5), 1u); } });
+        } else {
+            // (a partial last group: its missing rows never arrive -- count them in)
+            if (lane == 0 && (nH & 31)) lds_add(ctl + eng_ctl::CNTH + 4 * (nH >> 5), (unsigned)(32 - (nH & 31)));
+            for (int gl = 0; gl < ngroups; ++gl) {
+                for (unsigned spins = 0; lds_ld_u(ctl + eng_ctl::CNTH + 4 * gl) < 32u;) { if (!w.spin(spins, ENG_W_GROUP, (unsigned) gl, lds_ld_u(ctl + eng_ctl::CNTH + 4 * gl))) break; __builtin_amdgcn_s_sleep(1); }
+                const int j = lane & 31;
+                const int row = sc.hg0 * 32 + 32 * gl + j;
+                const float v = ldsf_ld(eng_ctl::OUT + 4 * (32 * gl + j));
+                if (lane < 32 && row < a.V) a.logits[row] = v;
+                float bv = row < a.V ? v : -INFINITY; int bi = row;
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                for (int o = 1; o < 32; o <<= 1) {
+                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { a.argmax_val[sc.hg0 + gl] = bv; a.argmax_idx[sc.hg0 + gl] = bi; }
             }
-            if (lane == 0) { a.argmax_val[sc.hg0 + gl] = bv; a.argmax_idx[sc.hg0 + gl] = bi; }
         }
+    }
+    if (a.dbg && lane == 0 && (isG || c == 0)) {
+        long long * r = a.dbg + FQ_ENG_DBG_COUNTERS + (size_t) blockIdx.x * 16;
+        if (isG) { r[13] = (long long) t_gather; r[14] = (long long) t_epi; r[15] = (long long) t_w_stat; }
+        else { r[5] = (long long) t_wait_land; r[6] = (long long) t_dot; r[7] = (long long) n_rows; r[8] = (long long) t_w_stat; r[9] = (long long) t_w_img;
+               r[10] = (long long) t_w_ff; r[11] = (long long) t_w_att; r[12] = (long long) t_gather; }
     }
 }
 
-// ---- the tag of a launch's hand-offs: advanced before every launch (never 0); also clears nothing else -- granules carry their tag
-__global__ void k_engine_epoch(unsigned * epoch_word, unsigned step, unsigned * cnt) {
-    if (threadIdx.x < 4) cnt[32 * threadIdx.x] = 0u;
+// ---- the tag of a launch's hand-offs: advanced before every launch (never 0); granules carry their tag, nothing else is cleared
+__global__ void k_engine_epoch(unsigned * epoch_word, unsigned step) {
     if (threadIdx.x == 0) {
         unsigned e = *epoch_word + step;
         if (e < step + 1u) e = 1u;              // wrapped
@@ -671,10 +855,6 @@ __global__ void k_engine_epoch(unsigned * epoch_word, unsigned step, unsigned * 
 }
 
 // =============================================================================================== host side
-struct fq_engine_plan_impl {
-    std::vector<fq_engine_sched> sched;
-};
-
 // Work split of one block over `n_stream` workgroups (host): 32-row groups of [Wqkv | Wup] and rows of [Wdown, Wo] so that every
 // workgroup streams about the same number of bytes per block; the first group of as many workgroups as there are Wqkv
 // groups is a Wqkv group, so that q / k / v are complete -- and the attention can start -- after the first group round.
@@ -714,9 +894,9 @@ bool fq_engine_plan(int type, int E, int FF, int qkv_rows, int V, bool with_head
     return mg <= 12 && mr <= 64;
 }
 
-size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers) {
+size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers, int two_norms) {
     const int act = fq_desc(type).act_type;
-    return (size_t) nslot * ENG_SLOT + eng_region_r(act, E, FF) + fq_act_col_bytes(act, E) + eng_ctl::BYTES + 32 * (size_t) n_layers + 16;
+    return (size_t) nslot * ENG_SLOT + ENG_MIRROR + eng_region_r(act, E, FF) + eng_region_s(act, E, two_norms) + eng_ctl::BYTES + 32 * (size_t) n_layers + 16;
 }
 
 int fq_engine_threads() { return ENG_NT; }
@@ -724,18 +904,18 @@ int fq_engine_threads() { return ENG_NT; }
 // launches the pre-kernel (tag) and the engine; false = this configuration is not supported (nothing launched)
 bool fq_launch_decode_engine(const fq_engine_args & a, int nslot, size_t lds_bytes, hipStream_t st) {
     const int grid = a.n_attn + a.n_stream;
-    if ((a.type != FQ_Q4_0 && a.type != FQ_Q4_1 && a.type != FQ_Q5_0 && a.type != FQ_Q5_1 && a.type != FQ_Q8_0) || (nslot != 8 && nslot != 6 && nslot != 4) ||
-        a.E > 4 * 3 * 64 * ENG_NC) return false;
-    hipLaunchKernelGGL(k_engine_epoch, dim3(1), dim3(64), 0, st, const_cast<unsigned *>(a.epoch_word), (unsigned)(a.n_layers + 2), a.cnt);
+    if ((a.type != FQ_Q4_0 && a.type != FQ_Q4_1 && a.type != FQ_Q5_0 && a.type != FQ_Q5_1 && a.type != FQ_Q8_0) || (nslot != 8 && nslot != 7 && nslot != 6 && nslot != 4) ||
+        a.E > 4 * 3 * ENG_HT || a.E > 16 * ENG_CHUNK) return false;
+    hipLaunchKernelGGL(k_engine_epoch, dim3(1), dim3(64), 0, st, const_cast<unsigned *>(a.epoch_word), (unsigned)(a.n_layers + 2));
 #define FQ_ENG_LAUNCH(T, NS) { \
         static size_t g = 0; if (lds_bytes > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_decode_engine<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes)); g = lds_bytes; } \
         hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_); \
         if (e0_) hipExtLaunchKernelGGL((k_decode_engine<T, NS>), dim3((unsigned) grid), dim3(ENG_NT), lds_bytes, st, e0_, e1_, 0, a); \
         else     hipLaunchKernelGGL((k_decode_engine<T, NS>), dim3((unsigned) grid), dim3(ENG_NT), lds_bytes, st, a); }
 #ifdef ENG_TUNE_ONLY_Q4_0
-#define FQ_ENG_CASE(T) case T: if (T == FQ_Q4_0 && nslot == 8) FQ_ENG_LAUNCH(FQ_Q4_0, 8) else return false; break;
+#define FQ_ENG_CASE(T) case T: if (T == FQ_Q4_0 && nslot == 7) FQ_ENG_LAUNCH(FQ_Q4_0, 7) else return false; break;
 #else
-#define FQ_ENG_CASE(T) case T: if (nslot == 8) FQ_ENG_LAUNCH(T, 8) else if (nslot == 6) FQ_ENG_LAUNCH(T, 6) else if (nslot == 4) FQ_ENG_LAUNCH(T, 4) else return false; break;
+#define FQ_ENG_CASE(T) case T: if (nslot == 8) FQ_ENG_LAUNCH(T, 8) else if (nslot == 7) FQ_ENG_LAUNCH(T, 7) else if (nslot == 6) FQ_ENG_LAUNCH(T, 6) else if (nslot == 4) FQ_ENG_LAUNCH(T, 4) else return false; break;
 #endif
     switch (a.type) {
         FQ_ENG_CASE(FQ_Q4_0) FQ_ENG_CASE(FQ_Q4_1) FQ_ENG_CASE(FQ_Q5_0) FQ_ENG_CASE(FQ_Q5_1) FQ_ENG_CASE(FQ_Q8_0)

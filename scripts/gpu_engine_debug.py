@@ -12,8 +12,9 @@ os.environ["FALCON_HIP_ENGINE_DEBUG"] = "1"
 import ggllm_cpp_amd as g          # noqa: E402
 from ggllm_cpp_amd import synth    # noqa: E402
 
-CODES = {1: "loader: ring space", 2: "consumer: row landed", 3: "consumer barrier", 4: "attention: qkv granules", 5: "LN: x granules",
-         6: "group rows", 7: "sweep GELU image", 8: "sweep attention image", 9: "attention: qkv counter", 10: "edge counter (device)", 11: "edge counter (LDS)"}
+CODES = {1: "loader: ring space", 2: "consumer: row landed", 4: "attention: qkv granules", 5: "gather: x granules", 6: "group rows", 7: "gather: GELU image",
+         8: "gather: attention image", 12: "LN statistics flag", 13: "LN image counter", 14: "phase A counter", 15: "Wdown counter", 16: "Wo counter",
+         17: "GELU image counter", 18: "attention image counter"}
 
 
 def run(tname, shape, layers, steps=8, timeline=True):
@@ -46,21 +47,27 @@ def run(tname, shape, layers, steps=8, timeline=True):
         dt = time.perf_counter() - t0
         print("  64 steps: %.1f us / token, %.1f tok/s" % (dt / 64 * 1e6, 64 / dt))
         rec, st = m.engine_debug()
+        gs = m.engine_gstamps
         n_attn = (hp["n_head"] + 1) // 2
         s = st[n_attn:256].astype(np.float64) / 100.0      # us (100 MHz wall clock)
-        names = ["LN", "A rows+epi", "cbar", "FF sweep", "B1 rows", "att sweep", "B2 rows"]
+        gg = gs[n_attn:256].astype(np.float64) / 100.0
+        cn = ["start", "x chunk in", "LN stats", "image done", "A rows done", "GELU image in", "Wdown rows done", "attention image in (Wo starts)"]
+        gn = ["start", "x chunk in", "LN stats", "image done", "epilogues done", "GELU image in", "-", "attention image in"]
         for bi, bl in enumerate(["block 0", "block 1", "block 2", "last block"]):
             d = s[:, bi, :]
             ok = d[:, 0] > 0
             if not ok.any():
                 continue
-            d = d[ok]
+            d = d[ok]; dg = gg[ok][:, bi, :]
             t0 = d[:, 0].min()
-            print("  %s: start spread %.1f us; phase durations (us) median [min..max] over %d workgroups" % (bl, d[:, 0].max() - t0, len(d)))
-            for k, nm in enumerate(names):
-                x = d[:, k + 1] - d[:, k]
-                print("     %-12s %6.2f [%6.2f .. %6.2f]   ends at %.1f" % (nm, np.median(x), x.min(), x.max(), np.median(d[:, k + 1]) - t0))
-            print("     whole block %.2f us (median), first start -> last end %.2f us" % (np.median(d[:, 7] - d[:, 0]), d[:, 7].max() - t0))
+            print("  %s: start spread %.1f us; stamps (us after the first workgroup starts the block) median [min..max] over %d workgroups: consumer 0 | gatherer" % (bl, d[:, 0].max() - t0, len(d)))
+            for k in range(8):
+                x = d[:, k] - t0; y = dg[:, k] - t0
+                print("     %-32s %6.2f [%6.2f .. %6.2f]   | %-22s %6.2f [%6.2f .. %6.2f]" % (cn[k], np.median(x), x.min(), x.max(), gn[k], np.median(y), y.min(), y.max()))
+        for bi in range(3):
+            a0, a1 = s[:, bi, 0], s[:, bi + 1, 0]
+            if a0.max() > 0 and a1.max() > 0 and bi + 1 < 3:
+                print("  block %d start -> block %d start: %.2f us (first workgroup), %.2f us (median)" % (bi, bi + 1, a1[a1 > 0].min() - a0[a0 > 0].min(), np.median(a1[a1 > 0]) - np.median(a0[a0 > 0])))
         sa = st[:n_attn].astype(np.float64) / 100.0
         for bi, bl in enumerate(["block 0", "block 1", "block 2", "last block"]):
             d = sa[:, bi, :]
@@ -68,13 +75,14 @@ def run(tname, shape, layers, steps=8, timeline=True):
                 t0 = s[s[:, bi, 0] > 0, bi, 0].min()
                 print("  attention workgroups, %s (us after the block's first streaming workgroup starts): wait begins %.1f, q/k/v gathered %.1f [%.1f..%.1f], image published %.1f [%.1f..%.1f]"
                       % (bl, np.median(d[:, 0]) - t0, np.median(d[:, 1]) - t0, d[:, 1].min() - t0, d[:, 1].max() - t0, np.median(d[:, 2]) - t0, d[:, 2].min() - t0, d[:, 2].max() - t0))
-        cn = m.engine_counters[n_attn:256].astype(np.float64)
-        clk = float(np.median(cn[:, 0])) / (dt / 64 * 1e6)                # s_memtime ticks per us, from the loader's whole-launch count
+        cnt = m.engine_counters[n_attn:256].astype(np.float64)
+        clk = float(np.median(cnt[:, 0])) / (dt / 64 * 1e6)                # s_memtime ticks per us, from the loader's whole-launch count
+        med = lambda k: np.median(cnt[:, k]) / clk
         print("  loader (per token, median over workgroups): total %.0f us, blocked on ring space %.0f us in %.0f refills, waiting in vmcnt(32) %.0f us; %.1f MB"
-              % (np.median(cn[:, 0]) / clk, np.median(cn[:, 1]) / clk, np.median(cn[:, 3]), np.median(cn[:, 2]) / clk, np.median(cn[:, 4]) / 1e6))
-        print("  consumer 0 (blocks only): waiting for rows to land %.0f us, in dots %.0f us, %d rows" % (np.median(cn[:, 5]) / clk, np.median(cn[:, 6]) / clk, np.median(cn[:, 7])))
-        if st[n_attn:256, 1, 0].max() > 0 and st[n_attn:256, 0, 0].max() > 0:
-            print("  block 0 start -> block 1 start: %.2f us" % ((st[n_attn:256, 1, 0].min() - st[n_attn:256, 0, 0].min()) / 100.0))
+              % (med(0), med(1), np.median(cnt[:, 3]), med(2), np.median(cnt[:, 4]) / 1e6))
+        print("  consumer 0 (per token): rows to land %.0f us, dots %.0f us (%d rows), waits: LN statistics %.0f, image %.0f, GELU image %.0f, attention image %.0f; own gathers %.0f us"
+              % (med(5), med(6), np.median(cnt[:, 7]), med(8), med(9), med(10), med(11), med(12)))
+        print("  gatherer (per token): gathers %.0f us, epilogues (incl. waiting for rows) %.0f us, wait for LN statistics %.0f us" % (med(13), med(14), med(15)))
     m.free()
 
 
