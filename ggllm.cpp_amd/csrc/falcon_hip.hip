@@ -468,7 +468,9 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
-#define FQ_COLS_MAX_N 12
+// lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides)
+static int fq_cols_max_n() { static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 12; return v; }
+#define FQ_COLS_MAX_N fq_cols_max_n()
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
     const falcon_hip_hparams & hp = m->hp;

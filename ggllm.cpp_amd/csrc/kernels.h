@@ -39,6 +39,9 @@ void   fq_attn_set_f64(int on);
 int    fq_attn_f64();
 void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd,
                       const fq_gemv_epi & ep, int n_cu, hipStream_t st);
+// kernels_gemm_skinny.hip -- N <= 16 columns of a legacy format at weight-stream speed; S = K split (1, 2, 4: k_gemm_q's association);
+// false = outside its scope, nothing launched
+bool   fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st);
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);

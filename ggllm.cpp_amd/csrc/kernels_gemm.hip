@@ -692,6 +692,9 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // -> four partial sums per row below 4 x #CU tiles, two above; one (the reference's order) only on request
     const int64_t tiles = ((w.M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
     int cfg = g_gemm_sequential ? 0 : (tiles < 4 * (int64_t) n_cu ? 2 : 3);
+    // small batches: the streaming form (kernels_gemm_skinny.hip), same K split -> same bits (FQ_GEMM_SKINNY=0: this kernel for every N)
+    static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0);
+    if (skinny && N <= 16 && !getenv("FQ_GEMM_CFG") && fq_launch_gemm_skinny(w, act, N, dst, ldd, ep, cfg == 0 ? 1 : (cfg == 2 ? 4 : 2), st)) return;
     // 64-row workgroups (RB = 2) where there are tiles enough to fill the chip with them: two partial sums as <2,4> above,
     // or four (<4,4,2>: 16 waves) for the formats whose 64-row kernel stays within 128 VGPRs
     static const int64_t rb_min = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : 32;      // x #CU tiles; 0 = never

@@ -1,0 +1,283 @@
+// kernels_gemm_skinny.hip -- the quantized mat-mul for SMALL batches (5 <= N <= 16 columns) at weight-stream speed (gfx950).
+//
+// ggml_compute_forward_mul_mat_q_f32 (ggml.c:11318-11529; CUDA twin for every N > 1: dequantize + cublasGemmEx,
+// ggml-cuda.cu:2353-2403, 2931-2951) for the case that serving produces all the time -- a handful of lock-step sequences, a short
+// prompt chunk: the matrix is streamed ONCE, the int8 matrix pipe takes the N columns, the exact per-32-group f32 scaling of the CPU
+// path runs on the vector ALU underneath the stream (4 results per lane and group). kernels_gemm.hip's 128-token tiles cost the same
+// 8-9 ms per Falcon-7B pass whatever N is (a barrier and a register round trip per 128 of K); this form is bound by HBM.
+//
+//   workgroup   32 weight rows (two 16-row tiles) x all of K. Wave 0 is the LOADER: per stage (32 blocks of K = half a column of the
+//               device layout, fq_types.h) ONE global_load_lds per row moves the row's raw blocks -- 512 B of quants and the 64-128 B of
+//               its scale planes, gathered by the lanes of the same instruction -- into the stage buffer: no registers, no decode, three
+//               stages deep. The 2 S consumer waves = (tile t, K share sw) stage the N activation columns of the stage the same way (qs,
+//               d, aux of the Q8 images the decode path uses), transpose the token scales once per stage, and run
+//               v_mfma_i32_16x16x32_i8 per group: A = 16 tokens x 32 k, B = 16 rows x 32 k (nibbles unpacked on the way out of LDS:
+//               two shifts and two masks per lane), C starts at -8 isum[token] (Q4_0; -16 for Q5_0), so the int32 result is exactly
+//               the CPU's sumi; then the reference's scalar per-block expression per result.
+//   association the S waves of a tile split K exactly like k_gemm_q (group g -> partial sum g mod S, partial sums added as
+//               ((P0 + P1) + P2) + P3; S chosen by the same rule): results are bit-identical to kernels_gemm.hip's, and the
+//               oracle's split orders (orc_set_sum_order 2 / 3 / 4 / 5) apply unchanged.
+// Scope: the legacy formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0); k-quants keep kernels_gemm.hip.
+#include "fq_block_dev.h"
+#include "kernels.h"
+
+typedef int  sk_v4i __attribute__((ext_vector_type(4)));
+typedef int  sk_v2i __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int SK_TM = 32;                  // weight rows per workgroup (two 16-row tiles)
+constexpr int SK_TN = 16;                  // columns
+constexpr int SK_GS = 32;                  // blocks (32-element groups) per stage
+constexpr int SK_TOKB = 1024 + 128 + 160;  // LDS bytes per token and stage: [qs 1024 | d 128 | aux 144 (the source is read from a 16-byte boundary: LDS-DMA ignores the low address bits) | pad]
+
+template <int TYPE> struct sk_fmt {
+    static constexpr fq_type_desc D = fq_desc(TYPE);
+    static constexpr int QB = D.plane[0].bytes, PB1 = D.plane[1].bytes, PB2 = D.nplanes > 2 ? D.plane[2].bytes : 0;
+    static constexpr int CB = 1024 / QB, SPC = CB / SK_GS;      // blocks per column of the device layout (64; Q8_0: 32), stages per column
+    static constexpr int P2PAD = PB2 ? 16 : 0;                  // plane 2 of a partial column starts on a 4-byte boundary only: read from the 16-byte boundary below
+    static constexpr int ROWB = SK_GS * (QB + PB1 + PB2) + P2PAD;      // LDS bytes of a row's stage: [quants | plane 1 | plane 2 (+ 16)]
+    static constexpr int NL = ROWB / 16;                        // 16-byte lanes of the row's gather
+    static constexpr bool HAS_MIN = (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1);
+    static constexpr int NBUF = ROWB > 800 ? 2 : 3;             // stage buffers (Q8_0: two fit)
+};
+
+__device__ __forceinline__ void sk_dma(const void * base, unsigned voff, unsigned lds_dst) {      // active lanes: 16 B at base + voff -> LDS lds_dst + 16 lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+// sixteen rows in one statement: row i's active lanes read 16 B at base + v[i], LDS destination ml + i * rowb (+ 16 lane); ml is advanced
+struct sk_voff16 { unsigned v[16]; };
+#define SK_DMA1(P) "s_mov_b32 m0, %[ml]\n\ts_add_u32 %[ml], %[ml], %[rowb]\n\tglobal_load_lds_dwordx4 %[v" #P "], %[base]\n\t"
+__device__ __forceinline__ void sk_dma16(const void * base, const sk_voff16 & o, unsigned & ml, unsigned rowb) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_nop 4\n\t"
+                 SK_DMA1(0) SK_DMA1(1) SK_DMA1(2) SK_DMA1(3) SK_DMA1(4) SK_DMA1(5) SK_DMA1(6) SK_DMA1(7)
+                 SK_DMA1(8) SK_DMA1(9) SK_DMA1(10) SK_DMA1(11) SK_DMA1(12) SK_DMA1(13) SK_DMA1(14) SK_DMA1(15)
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep), [ml] "+s"(ml)
+                 : [v0] "v"(o.v[0]), [v1] "v"(o.v[1]), [v2] "v"(o.v[2]), [v3] "v"(o.v[3]), [v4] "v"(o.v[4]), [v5] "v"(o.v[5]), [v6] "v"(o.v[6]), [v7] "v"(o.v[7]),
+                   [v8] "v"(o.v[8]), [v9] "v"(o.v[9]), [v10] "v"(o.v[10]), [v11] "v"(o.v[11]), [v12] "v"(o.v[12]), [v13] "v"(o.v[13]), [v14] "v"(o.v[14]), [v15] "v"(o.v[15]),
+                   [base] "s"(base), [rowb] "s"(rowb)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ unsigned sk_lds(const void * p) { return (unsigned)(uintptr_t) p; }
+__device__ __forceinline__ const uint8_t * sk_uniform(const uint8_t * p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const uint8_t *)(uintptr_t)(((unsigned long long) hi << 32) | lo);
+}
+
+}   // namespace
+
+template <int TYPE, int S>
+__global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef sk_fmt<TYPE> F;
+    constexpr int ACT = fq_act_of(TYPE);
+    constexpr int NCW = 2 * S, NBUF = F::NBUF;
+    constexpr int STAGE = SK_TM * F::ROWB + SK_TN * SK_TOKB;
+    constexpr int WOPS = (F::NL + 63) / 64;                                // loader instructions per row and stage
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nblk = (int) w.nblk;
+    const int nstages = (nblk + SK_GS - 1) / SK_GS;
+    const int64_t m0 = (int64_t) blockIdx.x * SK_TM;
+    const size_t img = fq_act_col_bytes(ACT, K);
+    uint8_t * dxT = smem + (size_t) NBUF * STAGE;                          // [32 groups][16 tokens] f32: the tokens' d
+    uint8_t * ciT = dxT + SK_GS * SK_TN * 4;                               // [32][16]: C start values (int) or the tokens' s (f32)
+    auto wbuf = [&](int s) { return smem + (size_t)(s % NBUF) * STAGE; };
+    auto tbuf = [&](int s) { return smem + (size_t)(s % NBUF) * STAGE + SK_TM * F::ROWB; };
+
+    // ---- staging (LDS-DMA). Stage s = blocks [32 s, 32 s + 32) of every row = half hf = s & 1 of column c = s >> 1.
+    auto issue_weights = [&](int s) {                                      // the loader wave
+        const int c = s / F::SPC, hf = s % F::SPC;
+        const int rem = nblk - F::CB * c, nbc = rem < F::CB ? rem : F::CB;
+        const unsigned colb = (unsigned) c * (unsigned)(F::CB * F::D.tsize);
+        // the lane's 16 bytes of the LDS row -> where they are in the device layout (fq_types.h: planes back to back per column).
+        // Every source address is a multiple of 16 (the DMA ignores the low bits): plane 2 is read from the boundary below it.
+        auto src_of = [&](int l) {
+            const int p = 16 * l;
+            unsigned o;
+            if (p < SK_GS * F::QB)                   o = colb + (unsigned)(SK_GS * hf * F::QB + p);
+            else if (p < SK_GS * (F::QB + F::PB1))   o = colb + (unsigned)(nbc * F::QB + SK_GS * hf * F::PB1 + (p - SK_GS * F::QB));
+            else                                     o = colb + (unsigned)(((nbc * (F::QB + F::PB1)) & ~15) + SK_GS * hf * F::PB2 + (p - SK_GS * (F::QB + F::PB1)));
+            return o;
+        };
+        const unsigned v0 = src_of(lane), v1 = src_of(lane + 64 < F::NL ? lane + 64 : F::NL - 1);
+        const unsigned wb = __builtin_amdgcn_readfirstlane(sk_lds(wbuf(s)));
+        if (m0 + SK_TM <= M) {
+            // a whole tile: the rows are row_stride apart -- per-row offsets in registers, one scalar base, 3 scalar instructions per row
+            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) m0 * w.row_stride);
+            const unsigned rs = (unsigned) w.row_stride;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sk_voff16 o;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o.v[i] = v0 + (unsigned)(16 * h + i) * rs;
+                unsigned ml = wb + (unsigned)(16 * h * F::ROWB);
+                if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma16(base, o, ml, (unsigned) F::ROWB);
+                if constexpr (WOPS > 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o.v[i] = v1 + (unsigned)(16 * h + i) * rs;
+                    unsigned ml2 = wb + (unsigned)(16 * h * F::ROWB + 1024);
+                    if (lane + 64 < F::NL) sk_dma16(base, o, ml2, (unsigned) F::ROWB);
+                }
+            }
+            return;
+        }
+        for (int r = 0; r < SK_TM; ++r) {                                  // the matrix's last, partial tile: rows beyond M re-read row M - 1
+            const int64_t row = m0 + r < M ? m0 + r : M - 1;
+            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) row * w.row_stride);
+            if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma(base, v0, wb + (unsigned)(r * F::ROWB));
+            if constexpr (WOPS > 1) { if (lane + 64 < F::NL) sk_dma(base, v1, wb + (unsigned)(r * F::ROWB + 1024)); }
+        }
+    };
+    auto issue_tokens = [&](int s, int cw) {                               // consumer wave cw: its share of the 16 columns
+        const unsigned tb = sk_lds(tbuf(s));
+        const unsigned last = (unsigned)(img - 16);
+        unsigned vq = (unsigned)(SK_GS * 32 * s + 16 * lane);              // qs: 1024 bytes
+        vq = vq < last ? vq : last;
+        const size_t nd4 = fq_act_d_elems(ACT, K) * 4;
+        // d: 128 bytes (K is a multiple of 32: aligned); aux: 144 bytes from the 16-byte boundary below it
+        unsigned vs = (unsigned)(lane < 8 ? (size_t) K + 4 * SK_GS * s + 16 * lane : (((size_t) K + nd4) & ~(size_t) 15) + 4 * SK_GS * s + 16 * (lane - 8));
+        vs = vs < last ? vs : last;
+        for (int t = cw; t < SK_TN; t += NCW) {
+            const uint8_t * base = act.base + (size_t)(t < N ? t : N - 1) * img;
+            sk_dma(base, vq, tb + (unsigned)(t * SK_TOKB));
+            if (lane < 17) sk_dma(base, vs, tb + (unsigned)(t * SK_TOKB + 1024));
+        }
+    };
+    constexpr int TOPS = 2 * ((SK_TN + NCW - 1) / NCW);                    // DMA instructions a consumer wave issues per stage
+    constexpr int LOPS = SK_TM * WOPS;                                     // ... and the loader
+
+    const int aux_delta = (int)(((size_t) K + fq_act_d_elems(ACT, K) * 4) & 15);     // the aux array's offset from the 16-byte boundary its DMA starts at
+    const bool loader = wid == 0;
+    const int cw = wid - 1, tile = cw & 1, sw = cw >> 1;
+    const int l16 = lane & 15, kq = lane >> 4;
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+
+    // ---- prologue: the first NBUF - 1 stages
+    for (int s = 0; s < NBUF - 1; ++s) {
+        if (s < nstages) { if (loader) issue_weights(s); else issue_tokens(s, cw); }
+    }
+    for (int s = 0; s < nstages; ++s) {
+        // stage s has landed (every issuing wave waits for its own DMA before it arrives), and nobody reads stage s - 1 any more
+        if (NBUF == 3 && s + 1 < nstages) { if (loader) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOPS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TOPS) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + NBUF - 1 < nstages) { if (loader) issue_weights(s + NBUF - 1); else issue_tokens(s + NBUF - 1, cw); }
+        const uint8_t * W = wbuf(s), * T = tbuf(s);
+        if (!loader) {
+            // the tokens' scales of the stage, transposed to [group][token] (a lane needs 4 consecutive tokens of one group)
+            for (int e = cw * 64 + lane; e < SK_GS * SK_TN; e += NCW * 64) {
+                const int gi = e >> 4, tok = e & 15;
+                const uint8_t * tp = T + tok * SK_TOKB + 1024;
+                const float d = ((const float *) tp)[gi];
+                const uint32_t aux = ((const uint32_t *)(tp + 128 + aux_delta))[gi];
+                ((float *) dxT)[e] = d;
+                uint32_t cv;
+                if constexpr (TYPE == FQ_Q4_0)      cv = (uint32_t)(-8 * (int32_t) aux);         // sum (nib - 8) x = sum nib x - 8 sum x
+                else if constexpr (TYPE == FQ_Q5_0) cv = (uint32_t)(-16 * (int32_t) aux);
+                else if constexpr (F::HAS_MIN)      cv = aux;                                       // y.s (f32)
+                else                                cv = 0u;
+                ((uint32_t *) ciT)[e] = cv;
+            }
+        }
+        __syncthreads();
+        if (loader) continue;
+        const int ng = nblk - SK_GS * s < SK_GS ? nblk - SK_GS * s : SK_GS;
+        const int cst = s / F::SPC, remc = nblk - F::CB * cst, nbcs = remc < F::CB ? remc : F::CB;
+        const int p2d = (nbcs * (F::QB + F::PB1)) & 15;                    // plane 2's offset from the boundary its DMA started at
+        const uint8_t * wr = W + (16 * tile + l16) * F::ROWB;              // the lane's weight row
+        const uint8_t * tq = T + l16 * SK_TOKB;                            // the lane's token (A operand)
+        for (int gi = sw; gi < ng; gi += S) {
+            // ---- operands: 8 k-bytes per lane, k = 8 kq + b on both sides
+            const sk_v2i xa = *(const sk_v2i *)(tq + 32 * gi + 8 * kq);
+            sk_v2i wb2;
+            float dw, mw = 0.0f;
+            if constexpr (TYPE == FQ_Q8_0) {
+                wb2 = *(const sk_v2i *)(wr + 32 * gi + 8 * kq);
+                dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 32 + 2 * gi));
+            } else {
+                const sk_v2i raw = *(const sk_v2i *)(wr + 16 * gi + 8 * (kq & 1));
+                const int sh = 4 * (kq >> 1);                              // elements 0..15: low nibbles, 16..31: high nibbles (ggml.c:1509-1601)
+                wb2 = sk_v2i{ (int)(((uint32_t) raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) raw.y >> sh) & 0x0F0F0F0Fu) };
+                if constexpr (TYPE == FQ_Q4_0) dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 16 + 2 * gi));
+                else if constexpr (TYPE == FQ_Q4_1) { const uint32_t dm = *(const uint32_t *)(wr + SK_GS * 16 + 4 * gi); dw = fq_h2f((uint16_t) dm); mw = fq_h2f((uint16_t)(dm >> 16)); }
+                else {
+                    const uint32_t qh = *(const uint32_t *)(wr + SK_GS * 16 + 4 * gi);
+                    const uint32_t hb = qh >> (8 * kq);                    // bit e of qh = 5th bit of element e
+                    wb2.x |= (int)(spread4(hb) << 4); wb2.y |= (int)(spread4(hb >> 4) << 4);
+                    if constexpr (TYPE == FQ_Q5_0) dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 20 + p2d + 2 * gi));
+                    else { const uint32_t dm = *(const uint32_t *)(wr + SK_GS * 20 + p2d + 4 * gi); dw = fq_h2f((uint16_t) dm); mw = fq_h2f((uint16_t)(dm >> 16)); }
+                }
+            }
+            const float4 dx4 = *(const float4 *)(dxT + (gi * SK_TN + 4 * kq) * 4);
+            sk_v4i c = { 0, 0, 0, 0 };
+            float sxv[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if constexpr (F::HAS_MIN) { const float4 s4 = *(const float4 *)(ciT + (gi * SK_TN + 4 * kq) * 4); sxv[0] = s4.x; sxv[1] = s4.y; sxv[2] = s4.z; sxv[3] = s4.w; }
+            else c = *(const sk_v4i *)(ciT + (gi * SK_TN + 4 * kq) * 4);
+            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, xa), __builtin_bit_cast(long, wb2), c, 0, 0, 0);
+            // ---- f32 epilogue of the group: the reference's scalar per-block expression (as k_gemm_q)
+            const float dxv[4] = { dx4.x, dx4.y, dx4.z, dx4.w };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ci = (float) c[r];
+                float t;
+                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                acc[r] = acc[r] + t;
+            }
+        }
+    }
+    if (loader) return;
+    // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free: every wave is past the loop)
+    if constexpr (S > 1) {
+        float * xch = (float *) smem;                                      // [tile][lane][4]
+        for (int r = 1; r < S; ++r) {
+            asm volatile("s_barrier" ::: "memory");                        // (consumer waves only: the loader has left; s_barrier counts the waves still alive)
+            if (sw == r) *(float4 *)(xch + (tile * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sw == 0) {
+                const float4 p = *(const float4 *)(xch + (tile * 64 + lane) * 4);
+                acc[0] = acc[0] + p.x; acc[1] = acc[1] + p.y; acc[2] = acc[2] + p.z; acc[3] = acc[3] + p.w;
+            }
+        }
+        if (sw != 0) return;
+    }
+    const int64_t m = m0 + 16 * tile + l16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 4 * kq + r;
+        if (n < N && m < M) {
+            float v = acc[r];
+            if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+            else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+            dst[n * ldd + m] = v;
+        }
+    }
+}
+
+// true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
+bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
+    if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
+    if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
+    const unsigned grid = (unsigned)((w.M + SK_TM - 1) / SK_TM);
+#define FQ_SK_LAUNCH(T, SS) { \
+        typedef sk_fmt<T> F; \
+        const size_t lds = (size_t) F::NBUF * (SK_TM * F::ROWB + SK_TN * SK_TOKB) + 2 * SK_GS * SK_TN * 4; \
+        static bool set = false; \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny<T, SS>), dim3(grid), dim3(64 * (1 + 2 * SS)), lds, st, w, act, (int) N, dst, ldd, ep); }
+#define FQ_SK_CASE(T) case T: if (S == 1) FQ_SK_LAUNCH(T, 1) else if (S == 2) FQ_SK_LAUNCH(T, 2) else FQ_SK_LAUNCH(T, 4) break;
+    switch (w.type) {
+        FQ_SK_CASE(FQ_Q4_0) FQ_SK_CASE(FQ_Q4_1) FQ_SK_CASE(FQ_Q5_0) FQ_SK_CASE(FQ_Q5_1) FQ_SK_CASE(FQ_Q8_0)
+        default: return false;
+    }
+#undef FQ_SK_CASE
+#undef FQ_SK_LAUNCH
+    return true;
+}
