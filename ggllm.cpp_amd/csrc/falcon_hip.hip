@@ -469,7 +469,7 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
 // lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides)
-static int fq_cols_max_n() { static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 12; return v; }
+static int fq_cols_max_n() { static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 8; return v; }
 #define FQ_COLS_MAX_N fq_cols_max_n()
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
@@ -628,8 +628,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         const bool att_q = (a_att.type == FQ_Q8_0 || a_att.type == FQ_Q8_1);
         // 2..4 lock-step sequences: the block's weights in TWO launches that serve every column (kernels_cols.hip), the
         // decode attention of all sequences in one launch between them -- same bits as the generic launches below
-        // up to FQ_COLS_MAX_N sequences in chunks of 4 columns (beyond that the int8-MFMA GEMM's one pass is cheaper: measured
-        // 8.3-9.2 ms per Falcon-7B pass for any N in 8..64 against 2.0 ms per 4-column pass)
+        // up to FQ_COLS_MAX_N (8) sequences in chunks of 4 columns; beyond that one pass of the streaming small-batch mat-mul
+        // (kernels_gemm_skinny.hip, N <= 16) is cheaper: measured on Falcon-7B Q4_0 3.6 ms per pass of 8 in two chunks, 4.0 ms for 12
+        // and 4.1 ms for 16 in one pass (the 128-token tile GEMM beyond 16: 8.3-9.2 ms for any N up to 64)
         const int cw_out = (L.down.type == L.wo.type) ? fq_gemv_out_cols_width(L.wo.type, FF, E) : 0;      // Falcon-40B width: 2 columns per output launch
         const bool cols_path = seq_stride && N >= 2 && N <= FQ_COLS_MAX_N && c->fused_decode && !fq_reference_order() && !fq_attn_f64() &&
                                L.qkv.type == L.up.type && cw_out > 0;

@@ -33,7 +33,8 @@ void   fq_launch_mul_mat_ref(const fq_weight & w, const fq_act & act, int64_t N,
 
 // kernels_gemm.hip -- int8 MFMA mat-mul for N > 4 columns
 bool   fq_gemm_supported(int type);
-void   fq_gemm_debug_mode(int m);
+void   fq_gemm_debug_mode(int m);       // tuning aid. bit 1: no MFMA / scaling; kernels_gemm_skinny.hip: 4 = no token DMA, 8 = no weight DMA, 16 = no arithmetic
+int    fq_gemm_debug_get();
 void   fq_gemm_set_sequential(int on);
 void   fq_attn_set_f64(int on);
 int    fq_attn_f64();

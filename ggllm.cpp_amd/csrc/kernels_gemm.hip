@@ -275,7 +275,9 @@ template <> struct gemm_kint<FQ_Q6_K> { static constexpr bool value = true; };
 // tuning aid (ggml_hip_debug_gemm_mode): bit 1 = no MFMA / scaling (timing only: what the staging alone costs). Bit 0 (no
 // global loads) went with the role-specialised pipeline, whose loads are unconditional on purpose.
 __device__ int g_gemm_dbg = 0;
-void fq_gemm_debug_mode(int m) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
+static int g_gemm_dbg_host = 0;
+void fq_gemm_debug_mode(int m) { g_gemm_dbg_host = m; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
+int  fq_gemm_debug_get() { return g_gemm_dbg_host; }
 
 // LDS buffer of one K stage
 template <bool HAS_MIN, int TN, int SUB, int TM> struct gemm_lds {   // TN = tokens, TM = weight rows per workgroup, SUB = scale sub-groups per group

@@ -6,10 +6,10 @@
 // path runs on the vector ALU underneath the stream (4 results per lane and group). kernels_gemm.hip's 128-token tiles cost the same
 // 8-9 ms per Falcon-7B pass whatever N is (a barrier and a register round trip per 128 of K); this form is bound by HBM.
 //
-//   workgroup   32 weight rows (two 16-row tiles) x all of K. Wave 0 is the LOADER: per stage (32 blocks of K = half a column of the
+//   workgroup   32 weight rows (two 16-row tiles) x all of K. Waves 0-1 are the LOADERS (16 rows each): per stage (32 blocks of K = half a column of the
 //               device layout, fq_types.h) ONE global_load_lds per row moves the row's raw blocks -- 512 B of quants and the 64-128 B of
 //               its scale planes, gathered by the lanes of the same instruction -- into the stage buffer: no registers, no decode, three
-//               stages deep. The 2 S consumer waves = (tile t, K share sw) stage the N activation columns of the stage the same way (qs,
+//               stages ahead of the arithmetic (the columns, L2 hits, one stage ahead). The 2 S consumer waves = (tile t, K share sw) stage the N activation columns of the stage the same way (qs,
 //               d, aux of the Q8 images the decode path uses), transpose the token scales once per stage, and run
 //               v_mfma_i32_16x16x32_i8 per group: A = 16 tokens x 32 k, B = 16 rows x 32 k (nibbles unpacked on the way out of LDS:
 //               two shifts and two masks per lane), C starts at -8 isum[token] (Q4_0; -16 for Q5_0), so the int32 result is exactly
@@ -39,7 +39,9 @@ template <int TYPE> struct sk_fmt {
     static constexpr int ROWB = SK_GS * (QB + PB1 + PB2) + P2PAD;      // LDS bytes of a row's stage: [quants | plane 1 | plane 2 (+ 16)]
     static constexpr int NL = ROWB / 16;                        // 16-byte lanes of the row's gather
     static constexpr bool HAS_MIN = (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1);
-    static constexpr int NBUF = ROWB > 800 ? 2 : 3;             // stage buffers (Q8_0: two fit)
+    // stage buffers: the weights (HBM: long latency) run NBW - 1 stages ahead, the columns (L2 hits) NBT - 1
+    static constexpr int NBW = ROWB > 800 ? 2 : 4, NBT = 2;
+    static constexpr int LDS = NBW * SK_TM * ROWB + NBT * SK_TN * SK_TOKB + 2 * SK_GS * SK_TN * 4;
 };
 
 __device__ __forceinline__ void sk_dma(const void * base, unsigned voff, unsigned lds_dst) {      // active lanes: 16 B at base + voff -> LDS lds_dst + 16 lane
@@ -49,7 +51,7 @@ __device__ __forceinline__ void sk_dma(const void * base, unsigned voff, unsigne
 }
 // sixteen rows in one statement: row i's active lanes read 16 B at base + v[i], LDS destination ml + i * rowb (+ 16 lane); ml is advanced
 struct sk_voff16 { unsigned v[16]; };
-#define SK_DMA1(P) "s_mov_b32 m0, %[ml]\n\ts_add_u32 %[ml], %[ml], %[rowb]\n\tglobal_load_lds_dwordx4 %[v" #P "], %[base]\n\t"
+#define SK_DMA1(P) "s_mov_b32 m0, %[ml]\n\ts_add_u32 %[ml], %[ml], %[rowb]\n\tglobal_load_lds_dwordx4 %[v" #P "], %[base] nt\n\t"
 __device__ __forceinline__ void sk_dma16(const void * base, const sk_voff16 & o, unsigned & ml, unsigned rowb) {
     unsigned keep;
     asm volatile("s_mov_b32 %[keep], m0\n\ts_nop 4\n\t"
@@ -72,12 +74,12 @@ __device__ __forceinline__ const uint8_t * sk_uniform(const uint8_t * p) {
 }   // namespace
 
 template <int TYPE, int S>
-__global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep) {
+__global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny(fq_weight w, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef sk_fmt<TYPE> F;
     constexpr int ACT = fq_act_of(TYPE);
-    constexpr int NCW = 2 * S, NBUF = F::NBUF;
-    constexpr int STAGE = SK_TM * F::ROWB + SK_TN * SK_TOKB;
+    constexpr int NCW = 2 * S, NBW = F::NBW, NBT = F::NBT, NLW = 2;        // consumer waves, buffers, loader waves (16 rows each)
+    constexpr int WSTAGE = SK_TM * F::ROWB, TSTAGE = SK_TN * SK_TOKB;
     constexpr int WOPS = (F::NL + 63) / 64;                                // loader instructions per row and stage
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t K = w.K, M = w.M;
@@ -85,13 +87,13 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
     const int nstages = (nblk + SK_GS - 1) / SK_GS;
     const int64_t m0 = (int64_t) blockIdx.x * SK_TM;
     const size_t img = fq_act_col_bytes(ACT, K);
-    uint8_t * dxT = smem + (size_t) NBUF * STAGE;                          // [32 groups][16 tokens] f32: the tokens' d
+    uint8_t * dxT = smem + (size_t) NBW * WSTAGE + (size_t) NBT * TSTAGE;   // [32 groups][16 tokens] f32: the tokens' d
     uint8_t * ciT = dxT + SK_GS * SK_TN * 4;                               // [32][16]: C start values (int) or the tokens' s (f32)
-    auto wbuf = [&](int s) { return smem + (size_t)(s % NBUF) * STAGE; };
-    auto tbuf = [&](int s) { return smem + (size_t)(s % NBUF) * STAGE + SK_TM * F::ROWB; };
+    auto wbuf = [&](int s) { return smem + (size_t)(s % NBW) * WSTAGE; };
+    auto tbuf = [&](int s) { return smem + (size_t) NBW * WSTAGE + (size_t)(s % NBT) * TSTAGE; };
 
     // ---- staging (LDS-DMA). Stage s = blocks [32 s, 32 s + 32) of every row = half hf = s & 1 of column c = s >> 1.
-    auto issue_weights = [&](int s) {                                      // the loader wave
+    auto issue_weights = [&](int s, int lw) {                                // loader wave lw: rows 16 lw .. 16 lw + 15 of the tile
         const int c = s / F::SPC, hf = s % F::SPC;
         const int rem = nblk - F::CB * c, nbc = rem < F::CB ? rem : F::CB;
         const unsigned colb = (unsigned) c * (unsigned)(F::CB * F::D.tsize);
@@ -111,8 +113,8 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
             // a whole tile: the rows are row_stride apart -- per-row offsets in registers, one scalar base, 3 scalar instructions per row
             const uint8_t * base = sk_uniform(w.plane[0] + (size_t) m0 * w.row_stride);
             const unsigned rs = (unsigned) w.row_stride;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            {
+                const int h = lw;
                 sk_voff16 o;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o.v[i] = v0 + (unsigned)(16 * h + i) * rs;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
             }
             return;
         }
-        for (int r = 0; r < SK_TM; ++r) {                                  // the matrix's last, partial tile: rows beyond M re-read row M - 1
+        for (int r = 16 * lw; r < 16 * lw + 16; ++r) {                     // the matrix's last, partial tile: rows beyond M re-read row M - 1
             const int64_t row = m0 + r < M ? m0 + r : M - 1;
             const uint8_t * base = sk_uniform(w.plane[0] + (size_t) row * w.row_stride);
             if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma(base, v0, wb + (unsigned)(r * F::ROWB));
@@ -146,28 +148,37 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
         for (int t = cw; t < SK_TN; t += NCW) {
             const uint8_t * base = act.base + (size_t)(t < N ? t : N - 1) * img;
             sk_dma(base, vq, tb + (unsigned)(t * SK_TOKB));
-            if (lane < 17) sk_dma(base, vs, tb + (unsigned)(t * SK_TOKB + 1024));
+            if (lane < 17 && !(dbg & 64)) sk_dma(base, vs, tb + (unsigned)(t * SK_TOKB + 1024));
         }
     };
     constexpr int TOPS = 2 * ((SK_TN + NCW - 1) / NCW);                    // DMA instructions a consumer wave issues per stage
-    constexpr int LOPS = SK_TM * WOPS;                                     // ... and the loader
+    constexpr int LOPS = 16 * WOPS;                                        // ... and a loader wave
 
     const int aux_delta = (int)(((size_t) K + fq_act_d_elems(ACT, K) * 4) & 15);     // the aux array's offset from the 16-byte boundary its DMA starts at
-    const bool loader = wid == 0;
-    const int cw = wid - 1, tile = cw & 1, sw = cw >> 1;
+    const bool loader = wid < NLW;
+    const int cw = wid - NLW, tile = cw & 1, sw = cw >> 1;
     const int l16 = lane & 15, kq = lane >> 4;
     float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 
-    // ---- prologue: the first NBUF - 1 stages
-    for (int s = 0; s < NBUF - 1; ++s) {
-        if (s < nstages) { if (loader) issue_weights(s); else issue_tokens(s, cw); }
-    }
+    // ---- prologue: the first NBW - 1 stages of weights, NBT - 1 of columns
+    if (loader) { for (int s = 0; s < NBW - 1 && s < nstages; ++s) if (!(dbg & 8)) issue_weights(s, wid); }
+    else        { for (int s = 0; s < NBT - 1 && s < nstages; ++s) if (!(dbg & 4)) issue_tokens(s, cw); }
+    unsigned long long tm[5] = { 0, 0, 0, 0, 0 }, tprev = __builtin_amdgcn_s_memtime();
+#define SK_TM_MARK(i) do { if (dbg & 128) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tm[i] += tn_ - tprev; tprev = tn_; } } while (0)
     for (int s = 0; s < nstages; ++s) {
-        // stage s has landed (every issuing wave waits for its own DMA before it arrives), and nobody reads stage s - 1 any more
-        if (NBUF == 3 && s + 1 < nstages) { if (loader) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOPS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TOPS) : "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage s has landed (every issuing wave waits for its own DMA before it arrives: all but the stages issued after it), and
+        // nobody reads stage s - 1 any more
+        if (loader) {
+            const int ahead = nstages - 1 - s < NBW - 2 ? nstages - 1 - s : NBW - 2;      // later stages already issued
+            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LOPS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOPS) : "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (NBT = 2: the columns of stage s were this wave's newest DMA)
+        SK_TM_MARK(0);
         __syncthreads();
-        if (s + NBUF - 1 < nstages) { if (loader) issue_weights(s + NBUF - 1); else issue_tokens(s + NBUF - 1, cw); }
+        SK_TM_MARK(1);
+        if (loader) { if (s + NBW - 1 < nstages && !(dbg & 8)) issue_weights(s + NBW - 1, wid); }
+        else        { if (s + NBT - 1 < nstages && !(dbg & 4)) issue_tokens(s + NBT - 1, cw); }
         const uint8_t * W = wbuf(s), * T = tbuf(s);
         if (!loader) {
             // the tokens' scales of the stage, transposed to [group][token] (a lane needs 4 consecutive tokens of one group)
@@ -185,43 +196,67 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
                 ((uint32_t *) ciT)[e] = cv;
             }
         }
+        SK_TM_MARK(2);
         __syncthreads();
+        SK_TM_MARK(3);
         if (loader) continue;
         const int ng = nblk - SK_GS * s < SK_GS ? nblk - SK_GS * s : SK_GS;
         const int cst = s / F::SPC, remc = nblk - F::CB * cst, nbcs = remc < F::CB ? remc : F::CB;
         const int p2d = (nbcs * (F::QB + F::PB1)) & 15;                    // plane 2's offset from the boundary its DMA started at
         const uint8_t * wr = W + (16 * tile + l16) * F::ROWB;              // the lane's weight row
         const uint8_t * tq = T + l16 * SK_TOKB;                            // the lane's token (A operand)
-        for (int gi = sw; gi < ng; gi += S) {
-            // ---- operands: 8 k-bytes per lane, k = 8 kq + b on both sides
-            const sk_v2i xa = *(const sk_v2i *)(tq + 32 * gi + 8 * kq);
-            sk_v2i wb2;
-            float dw, mw = 0.0f;
-            if constexpr (TYPE == FQ_Q8_0) {
-                wb2 = *(const sk_v2i *)(wr + 32 * gi + 8 * kq);
-                dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 32 + 2 * gi));
-            } else {
-                const sk_v2i raw = *(const sk_v2i *)(wr + 16 * gi + 8 * (kq & 1));
-                const int sh = 4 * (kq >> 1);                              // elements 0..15: low nibbles, 16..31: high nibbles (ggml.c:1509-1601)
-                wb2 = sk_v2i{ (int)(((uint32_t) raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) raw.y >> sh) & 0x0F0F0F0Fu) };
-                if constexpr (TYPE == FQ_Q4_0) dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 16 + 2 * gi));
-                else if constexpr (TYPE == FQ_Q4_1) { const uint32_t dm = *(const uint32_t *)(wr + SK_GS * 16 + 4 * gi); dw = fq_h2f((uint16_t) dm); mw = fq_h2f((uint16_t)(dm >> 16)); }
+        // ---- one group = operands out of LDS (8 k-bytes per lane, k = 8 kq + b on both sides) -> matrix instruction -> f32 epilogue.
+        // The three steps of consecutive groups are software-pipelined by hand (hipcc keeps them in program order): the reads of group
+        // k + 1 are in flight while group k's operand is unpacked and its matrix instruction issued, whose latency group k - 1's scaling covers.
+        struct sk_ops { sk_v2i xa, raw; uint32_t s1, s2; float4 dx4, sx4; sk_v4i ci4; };
+        // (lane bases once per stage; a group's operands sit at compile-time offsets from them in the unrolled loop: no address arithmetic per group)
+        // (gi = sw + goff: the wave's share is folded into the bases, goff is a compile-time constant in the unrolled loop)
+        const uint8_t * tqb = tq + 8 * kq + 32 * sw, * wrq = wr + (TYPE == FQ_Q8_0 ? 8 * kq + 32 * sw : 8 * (kq & 1) + 16 * sw);
+        const uint8_t * dxb = dxT + 16 * kq + sw * SK_TN * 4, * cib = ciT + 16 * kq + sw * SK_TN * 4;
+        const uint8_t * wr2 = wr + 2 * sw, * wr4 = wr + 4 * sw;
+        auto load_ops = [&](int gi) __attribute__((always_inline)) {
+            sk_ops o;
+            o.xa = *(const sk_v2i *)(tqb + 32 * gi);
+            o.s2 = 0u;
+            if constexpr (TYPE == FQ_Q8_0) { o.raw = *(const sk_v2i *)(wrq + 32 * gi); o.s1 = *(const uint16_t *)(wr2 + SK_GS * 32 + 2 * gi); }
+            else {
+                o.raw = *(const sk_v2i *)(wrq + 16 * gi);
+                if constexpr (TYPE == FQ_Q4_0)      o.s1 = *(const uint16_t *)(wr2 + SK_GS * 16 + 2 * gi);
+                else if constexpr (TYPE == FQ_Q4_1) o.s1 = *(const uint32_t *)(wr4 + SK_GS * 16 + 4 * gi);
                 else {
-                    const uint32_t qh = *(const uint32_t *)(wr + SK_GS * 16 + 4 * gi);
-                    const uint32_t hb = qh >> (8 * kq);                    // bit e of qh = 5th bit of element e
-                    wb2.x |= (int)(spread4(hb) << 4); wb2.y |= (int)(spread4(hb >> 4) << 4);
-                    if constexpr (TYPE == FQ_Q5_0) dw = fq_h2f(*(const uint16_t *)(wr + SK_GS * 20 + p2d + 2 * gi));
-                    else { const uint32_t dm = *(const uint32_t *)(wr + SK_GS * 20 + p2d + 4 * gi); dw = fq_h2f((uint16_t) dm); mw = fq_h2f((uint16_t)(dm >> 16)); }
+                    o.s1 = *(const uint32_t *)(wr4 + SK_GS * 16 + 4 * gi);                      // qh
+                    if constexpr (TYPE == FQ_Q5_0) o.s2 = *(const uint16_t *)(wr2 + SK_GS * 20 + p2d + 2 * gi);
+                    else                           o.s2 = *(const uint32_t *)(wr4 + SK_GS * 20 + p2d + 4 * gi);
                 }
             }
-            const float4 dx4 = *(const float4 *)(dxT + (gi * SK_TN + 4 * kq) * 4);
-            sk_v4i c = { 0, 0, 0, 0 };
-            float sxv[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if constexpr (F::HAS_MIN) { const float4 s4 = *(const float4 *)(ciT + (gi * SK_TN + 4 * kq) * 4); sxv[0] = s4.x; sxv[1] = s4.y; sxv[2] = s4.z; sxv[3] = s4.w; }
-            else c = *(const sk_v4i *)(ciT + (gi * SK_TN + 4 * kq) * 4);
-            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, xa), __builtin_bit_cast(long, wb2), c, 0, 0, 0);
-            // ---- f32 epilogue of the group: the reference's scalar per-block expression (as k_gemm_q)
-            const float dxv[4] = { dx4.x, dx4.y, dx4.z, dx4.w };
+            o.dx4 = *(const float4 *)(dxb + gi * SK_TN * 4);
+            if constexpr (F::HAS_MIN) { o.sx4 = *(const float4 *)(cib + gi * SK_TN * 4); o.ci4 = sk_v4i{ 0, 0, 0, 0 }; }     // (two typed loads: a bit_cast of the int vector's elements is miscompiled by hipcc 7.2)
+            else { o.ci4 = *(const sk_v4i *)(cib + gi * SK_TN * 4); o.sx4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            return o;
+        };
+        auto run_mfma = [&](const sk_ops & o, float & dw, float & mw) __attribute__((always_inline)) {
+            sk_v2i wb2;
+            mw = 0.0f;
+            if constexpr (TYPE == FQ_Q8_0) { wb2 = o.raw; dw = fq_h2f((uint16_t) o.s1); }
+            else {
+                const int sh = 4 * (kq >> 1);                              // elements 0..15: low nibbles, 16..31: high nibbles (ggml.c:1509-1601)
+                wb2 = sk_v2i{ (int)(((uint32_t) o.raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw.y >> sh) & 0x0F0F0F0Fu) };
+                if constexpr (TYPE == FQ_Q4_0) dw = fq_h2f((uint16_t) o.s1);
+                else if constexpr (TYPE == FQ_Q4_1) { dw = fq_h2f((uint16_t) o.s1); mw = fq_h2f((uint16_t)(o.s1 >> 16)); }
+                else {
+                    const uint32_t hb = o.s1 >> (8 * kq);                  // bit e of qh = 5th bit of element e
+                    wb2.x |= (int)(spread4(hb) << 4); wb2.y |= (int)(spread4(hb >> 4) << 4);
+                    dw = fq_h2f((uint16_t) o.s2);
+                    if constexpr (TYPE == FQ_Q5_1) mw = fq_h2f((uint16_t)(o.s2 >> 16));
+                }
+            }
+            sk_v4i c = o.ci4;                                              // (Q4_0 / Q5_0: -8 / -16 times the token's block sum; else 0)
+            return __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa), __builtin_bit_cast(long, wb2), c, 0, 0, 0);
+        };
+        // the reference's scalar per-block expression per result (as k_gemm_q)
+        auto scale = [&](const sk_v4i & c, const sk_ops & o, float dw, float mw) __attribute__((always_inline)) {
+            const float dxv[4] = { o.dx4.x, o.dx4.y, o.dx4.z, o.dx4.w };
+            const float sxv[4] = { o.sx4.x, o.sx4.y, o.sx4.z, o.sx4.w };
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ci = (float) c[r];
@@ -231,8 +266,33 @@ __global__ void __launch_bounds__(64 * (1 + 2 * S)) k_gemm_skinny(fq_weight w, f
                 else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
                 acc[r] = acc[r] + t;
             }
+        };
+        if (dbg & 16) continue;
+        if (ng == SK_GS) {
+            constexpr int NG = SK_GS / S;
+            sk_ops o[NG]; sk_v4i c[NG]; float dwv[NG], mwv[NG];
+            o[0] = load_ops(0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                if (k + 1 < NG) o[k + 1] = load_ops((k + 1) * S);
+                c[k] = run_mfma(o[k], dwv[k], mwv[k]);
+                __builtin_amdgcn_sched_barrier(0);                         // (the matrix instruction first: the scaling below hides its latency)
+                if (k > 0) scale(c[k - 1], o[k - 1], dwv[k - 1], mwv[k - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            scale(c[NG - 1], o[NG - 1], dwv[NG - 1], mwv[NG - 1]);
+        } else {
+            for (int gi = sw; gi < ng; gi += S) {
+                const sk_ops o = load_ops(gi - sw);
+                float dw, mw;
+                const sk_v4i c = run_mfma(o, dw, mw);
+                scale(c, o, dw, mw);
+            }
         }
+        SK_TM_MARK(4);
     }
+    if ((dbg & 128) && blockIdx.x == 1 && cw == 0 && lane == 0)
+        printf("skinny wg 1 consumer 0: %d stages; cycles (100 MHz): dma wait %llu, barrier 1 %llu, issue + prep %llu, barrier 2 %llu, compute %llu\n", nstages, tm[0], tm[1], tm[2], tm[3], tm[4]);
     if (loader) return;
     // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free: every wave is past the loop)
     if constexpr (S > 1) {
@@ -268,10 +328,10 @@ bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, f
     const unsigned grid = (unsigned)((w.M + SK_TM - 1) / SK_TM);
 #define FQ_SK_LAUNCH(T, SS) { \
         typedef sk_fmt<T> F; \
-        const size_t lds = (size_t) F::NBUF * (SK_TM * F::ROWB + SK_TN * SK_TOKB) + 2 * SK_GS * SK_TN * 4; \
+        const size_t lds = (size_t) F::LDS; \
         static bool set = false; \
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; } \
-        hipLaunchKernelGGL((k_gemm_skinny<T, SS>), dim3(grid), dim3(64 * (1 + 2 * SS)), lds, st, w, act, (int) N, dst, ldd, ep); }
+        hipLaunchKernelGGL((k_gemm_skinny<T, SS>), dim3(grid), dim3(64 * (2 + 2 * SS)), lds, st, w, act, (int) N, dst, ldd, ep, fq_gemm_debug_get()); }
 #define FQ_SK_CASE(T) case T: if (S == 1) FQ_SK_LAUNCH(T, 1) else if (S == 2) FQ_SK_LAUNCH(T, 2) else FQ_SK_LAUNCH(T, 4) break;
     switch (w.type) {
         FQ_SK_CASE(FQ_Q4_0) FQ_SK_CASE(FQ_Q4_1) FQ_SK_CASE(FQ_Q5_0) FQ_SK_CASE(FQ_Q5_1) FQ_SK_CASE(FQ_Q8_0)

@@ -1,32 +1,43 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, smoke, bench, rocprof. Everything lands in gpurun_out/.
-# usage: scripts/gpu_round.sh [tests|bench|prof|all]   (default all)
+# One gpurun call of a round: every -m gpu test, smoke, the bench line the driver reads; optionally rocprofv3 kernel trace + PMC passes.
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|all ...]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export TMPDIR=/tmp
-OUT=gpurun_out
+R=$PWD
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+TAG=${1:-r03x}; shift || true
+WHAT=" ${*:-tests bench} "
+OUT=gpurun_out/$TAG
 mkdir -p $OUT
-WHAT=${1:-all}
-rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
-nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/gpu.txt
-if [[ $WHAT == all || $WHAT == tests ]]; then
-  for f in test_gpu_quant test_gpu_mul_mat test_gpu_block_ops test_gpu_falcon test_gpu_shim test_gpu_wquant test_gpu_model_quantize; do
-    timeout 600 python -m pytest tests/$f.py -m gpu -q -x --no-header -p no:cacheprovider -s > $OUT/$f.log 2>&1
-    echo "$f exit $?" | tee -a $OUT/summary.txt
-    tail -3 $OUT/$f.log
-  done
+has() { [[ $WHAT == *" $1 "* || $WHAT == *" all "* ]]; }
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x > $OUT/pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?" | tee -a $OUT/summary.txt
+  tail -5 $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as e; e.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/summary.txt; tail -2 $OUT/smoke.log
 fi
-if [[ $WHAT == all || $WHAT == bench ]]; then
-  timeout 300 python bench.py --layers 4 --steps 32 --no-cpu > $OUT/bench_4layers.json 2> $OUT/bench_4layers.err; echo "bench4 exit $?" | tee -a $OUT/summary.txt; tail -c 1500 $OUT/bench_4layers.json
-  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" | tee -a $OUT/summary.txt; tail -c 2500 $OUT/bench.json; tail -5 $OUT/bench.err
-  timeout 600 python bench.py --no-graph --no-cpu > $OUT/bench_nograph.json 2> $OUT/bench_nograph.err; echo "bench-nograph exit $?" | tee -a $OUT/summary.txt; tail -c 1200 $OUT/bench_nograph.json
+if has bench; then
+  ( time timeout 1200 python bench.py ${BENCH_ARGS:-} ) > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" | tee -a $OUT/summary.txt; python scripts/bench_brief.py < $OUT/bench.json 2>/dev/null || tail -c 1500 $OUT/bench.json; tail -4 $OUT/bench.err
 fi
-if [[ $WHAT == all || $WHAT == prof ]]; then
+if has prof; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o r1 -- python $OLDPWD/bench.py --steps 64 --no-cpu > $OLDPWD/$OUT/prof_run.log 2>&1
-  echo "rocprof exit $?" | tee -a $OLDPWD/$OUT/summary.txt
-  cd $OLDPWD
-  find $OUT/prof -name "*stats*" | head; 
-  for f in $(find $OUT/prof -name "*kernel_stats*csv" | head -1); do head -25 $f; done
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o decode -- python $R/bench.py --steps 64 --no-cpu --no-graph --no-north-star --no-lock-step > $R/$OUT/prof_run.log 2>&1
+  echo "rocprof exit $?" | tee -a $R/$OUT/summary.txt
+  cd $R
+  db=$(find $OUT/prof -name "*results.db" | head -1)
+  [ -n "$db" ] && python scripts/prof_summary.py $db $OUT/decode_7b_q4_0 > /dev/null 2>&1 && head -12 $OUT/decode_7b_q4_0_kernel_stats.md | cut -c1-170
+  find $OUT/prof -name "*.db" -delete
 fi
+if has pmc; then
+  mkdir -p $OUT/pmc
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+    timeout 900 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc -o $n -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-graph --no-north-star --no-lock-step > $R/$OUT/pmc/$n.log 2>&1
+    echo "$c rc=$?"
+  done
+  cd $R
+  fdb=$(find $OUT/pmc -name "fetch*results.db" | head -1); wdb=$(find $OUT/pmc -name "write*results.db" | head -1)
+  python scripts/pmc_summary.py $fdb $wdb $OUT/pmc_traffic.json > $OUT/pmc_summary.log 2>&1; tail -5 $OUT/pmc_summary.log
+  find $OUT/pmc -name "*.db" -delete
+fi
+cat $OUT/summary.txt

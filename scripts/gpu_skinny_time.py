@@ -7,6 +7,9 @@ import ggllm_cpp_amd as g
 from ggllm_cpp_amd import synth
 g.init(0); L = g.load()
 Ns = [int(a) for a in sys.argv[1:]] or [8, 16]
+import ctypes as C
+L.ggml_hip_debug_gemm_mode.argtypes = [C.c_int]
+L.ggml_hip_debug_gemm_mode(int(os.environ.get("SK_DBG", "0")))
 rng = np.random.default_rng(0)
 tot = {n: 0.0 for n in Ns}
 for name, K, M in (("qkv", 4544, 4672), ("wo", 4544, 4544), ("up", 4544, 18176), ("down", 18176, 4544), ("head", 4544, 65024)):
