@@ -56,7 +56,27 @@ def parse():
     ap.add_argument("--pipe-batch", type=int, default=8, help="pipeline: lock-step streams per group (one weight pass serves them; 1..64, beyond 4 through the int8-MFMA GEMM)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra keys of the north-star configuration (Falcon-40B Q4_K, all 60 blocks, on the same GPUs)")
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
+    ap.add_argument("--no-cli", action="store_true", help="skip the reference_cli key (the reference's own falcon_main, linked against libggml_hip.so, on a written GGCC file)")
     return ap.parse_args()
+
+
+def spawn_ranks(n, argv=None, script=None):
+    """start n ranks of this script on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run
+    sets them) and wait; rank 0 prints the JSON line. Returns the largest exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *(sys.argv[1:] if argv is None else argv)], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    if rc:
+        raise SystemExit(rc)
+    return rc
 
 
 def kv_bytes_per_token(hp, n_past):
@@ -64,33 +84,64 @@ def kv_bytes_per_token(hp, n_past):
     return hp["n_layer"] * 2 * (n_past + 1) * hp["n_head_kv"] * 64 * 4 + hp["n_layer"] * 2 * hp["n_head_kv"] * 64 * 4
 
 
-def host_cores():
-    """(physical cores of ONE socket, sockets) of this host"""
-    phys = set()
+def host_topology():
+    """{socket: [one logical cpu per physical core, in core order]} of this host (first hardware thread of every core)"""
+    cores = {}
     try:
-        pid = cid = None
+        cpu = pid = cid = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
                 pid = int(line.split(":")[1])
             elif line.startswith("core id"):
                 cid = int(line.split(":")[1])
             elif not line.strip():
-                if pid is not None and cid is not None:
-                    phys.add((pid, cid))
-                pid = cid = None
+                if cpu is not None and pid is not None and cid is not None:
+                    cores.setdefault(pid, {}).setdefault(cid, cpu)
+                cpu = pid = cid = None
     except OSError:
         pass
-    if not phys:
-        return max(1, (os.cpu_count() or 2) // 2), 1
-    sockets = len({p for p, _ in phys})
-    return max(1, len(phys) // sockets), sockets
+    if not cores:
+        n = max(1, (os.cpu_count() or 2) // 2)
+        return {0: list(range(n))}
+    return {p: [c[k] for k in sorted(c)] for p, c in cores.items()}
+
+
+def host_cores():
+    """(physical cores of ONE socket, sockets) of this host"""
+    topo = host_topology()
+    return max(1, len(topo[min(topo)])), len(topo)
+
+
+class pinned:
+    """run the body with this thread (and the worker threads it creates: they inherit the mask) restricted to `n` physical cores of
+    socket 0, one logical cpu per core -- the reference creates its spin-barrier pool per graph compute (ggml.c:17251+), so its
+    threads land on distinct cores of ONE socket instead of roaming over both (threads pinned)"""
+    def __init__(self, n):
+        topo = host_topology()
+        avail = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set()
+        want = [c for c in topo[min(topo)] if not avail or c in avail]
+        self.cpus = set(want[:max(1, n)]) if want else None
+    def __enter__(self):
+        self.old = os.sched_getaffinity(0) if self.cpus and hasattr(os, "sched_getaffinity") else None
+        if self.old is not None:
+            try:
+                os.sched_setaffinity(0, self.cpus)
+            except OSError:
+                self.old = None
+        return self
+    def __exit__(self, *exc):
+        if self.old is not None:
+            os.sched_setaffinity(0, self.old)
+        return False
 
 
 def cpu_baseline(weights, hp, wbytes, prompt, n_tokens, tokens):
-    """The same workload on the host cores: the prompt as one batch, then n_tokens timed decode steps -- with the
-    threads of one socket's physical cores, and again with the reference's default -t 4 (examples/falcon_common.cpp:115-118).
-    Runs the REAL reference (oracle/_ref/libggml_ref.so, its AVX2 build: what a user of the reference executes) when the .so
-    travelled, else the oracle port (scalar)."""
+    """The same workload on the host cores: the prompt as one batch, then n_tokens timed decode steps -- at the
+    reference's default -t 4 (examples/falcon_common.cpp:115-118) and at 8 / 16 / 32 / all physical cores of ONE socket, every run
+    pinned to that many distinct cores of socket 0. `value` = the best of them (which one: `cores`). Runs the REAL reference
+    (oracle/_ref/libggml_ref.so, its AVX2 build: what a user of the reference executes) when the .so travelled, else the oracle port."""
     from oracle import binding as ob
     cores, sockets = host_cores()
     ob.build_oracle()
@@ -98,26 +149,88 @@ def cpu_baseline(weights, hp, wbytes, prompt, n_tokens, tokens):
         runner, kind = ob.Ref().model(weights, prompt + n_tokens + 8), "reference"
     else:
         runner, kind = ob.Oracle().model(weights, prompt + n_tokens + 8), "port"
-    t0 = time.time()
-    lg = runner.eval(tokens[:prompt], 0, cores)
-    t_prompt = time.time() - t0
-    cur = int(lg[-1].argmax())
-    seq = []
-    for i in range(3):                                                   # 3 warm-up steps
-        cur = int(runner.eval(np.array([cur], np.int32), prompt + i, cores)[0].argmax()); seq.append(cur)
-    res = {}
-    for threads in (cores, 4):
+    with pinned(cores):
         t0 = time.time()
-        c = seq[-1]
-        for i in range(n_tokens):
-            c = int(runner.eval(np.array([c], np.int32), prompt + 3 + i, threads)[0].argmax())
-        res[threads] = n_tokens / (time.time() - t0)
-    return dict(value=res[cores], unit="tokens/s", cores=cores, kind=kind,
-                effective_GBs=wbytes * res[cores] / 1e9,
-                t4_value=res[4], t4_effective_GBs=wbytes * res[4] / 1e9,
-                prefill_tok_s=prompt / t_prompt, sockets=sockets,
-                sample=f"{prompt}-token prompt as one batch, 3 warm-up + {n_tokens} timed greedy decode steps of the same synthetic model; "
-                       f"{cores} threads (the physical cores of one of {sockets} sockets) and the reference's default -t 4")
+        lg = runner.eval(tokens[:prompt], 0, cores)
+        t_prompt = time.time() - t0
+        cur = int(lg[-1].argmax())
+        seq = []
+        for i in range(3):                                               # 3 warm-up steps
+            cur = int(runner.eval(np.array([cur], np.int32), prompt + i, cores)[0].argmax()); seq.append(cur)
+    res = {}
+    for threads in sorted({4, 8, 16, 32, cores} & set(range(1, cores + 1)) | {min(4, cores)}):
+        with pinned(threads):
+            t0 = time.time()
+            c = seq[-1]
+            for i in range(n_tokens):
+                c = int(runner.eval(np.array([c], np.int32), prompt + 3 + i, threads)[0].argmax())
+            res[threads] = n_tokens / (time.time() - t0)
+    best = max(res, key=lambda k: res[k])
+    t4 = res[min(4, cores)]
+    return dict(value=res[best], unit="tokens/s", cores=best, kind=kind,
+                effective_GBs=wbytes * res[best] / 1e9,
+                t4_value=t4, t4_effective_GBs=wbytes * t4 / 1e9,
+                by_threads={str(k): v for k, v in sorted(res.items())}, pinned="one logical cpu per physical core of socket 0 (sched_setaffinity before the reference creates its threads)",
+                prefill_tok_s=prompt / t_prompt, sockets=sockets, socket_cores=cores,
+                sample=f"{prompt}-token prompt as one batch ({cores} threads), 3 warm-up + {n_tokens} timed greedy decode steps of the same synthetic model per thread count "
+                       f"{sorted(res)}; value = the best ({best} threads), t4_value = the reference's default -t 4")
+
+
+def reference_cli(g, weights, hp, n_prompt, n_predict, n_ctx):
+    """The reference's OWN entry point: examples/falcon/falcon_main.cpp, unchanged, linked against libggml_hip.so (csrc/falcon_wrap.cpp:
+    its falcon_eval runs on the device) -- on this model written as a GGCC v10 file, default summation order, batch 128; the numbers are
+    the ones its falcon_print_timings prints (libfalcon.cpp:4700-4714: batch eval = calls with more than one token, eval = one token)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "falcon_main_hip")
+    if not os.path.exists(exe):
+        return None
+    import bpe_fixture
+    import ggcc_writer
+    vocab, merges = bpe_fixture.build(n_merges=308)
+    vocab = list(vocab) + [b"<|unused%d|>" % i for i in range(len(vocab), hp["n_vocab"])]      # (ids the byte-level BPE never produces; the model's logits cover them)
+    td = tempfile.mkdtemp(prefix="falcon_cli_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        path = os.path.join(td, "falcon_synth.ggcc")
+        t0 = time.time()
+        ggcc_writer.write_ggcc(path, weights, vocab, merges)
+        t_write = time.time() - t0
+        # a prompt of exactly n_prompt tokens: the longest prefix of the (repeated) fixture corpus that tokenizes to it
+        voc = g.Vocab(path)
+        text = (bpe_fixture.CORPUS * 8)
+        lo, hi = 1, len(text)
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if len(voc.tokenize(text[:mid])) <= n_prompt:
+                lo = mid
+            else:
+                hi = mid - 1
+        prompt = text[:lo]
+        n_tok = len(voc.tokenize(prompt))
+        voc.free() if hasattr(voc, "free") else None
+        env = dict(os.environ)
+        env.pop("GGML_HIP_REFERENCE_ORDER", None)
+        t0 = time.time()
+        r = subprocess.run([exe, "-m", path, "-p", prompt, "-n", str(n_predict), "--temp", "0", "-t", "4", "-c", str(n_ctx), "-b", "128", "--ignore-eos", "-s", "1"],
+                           capture_output=True, env=env, timeout=600)
+        wall = time.time() - t0
+        err = r.stderr.decode("utf-8", "replace")
+        if r.returncode != 0:
+            return {"error": "falcon_main_hip exited %d" % r.returncode, "stderr_tail": err[-600:]}
+        out = {"workload": f"oracle/_ref/falcon_main_hip -m <this model as GGCC v10> -p <{n_tok} tokens> -n {n_predict} --temp 0 -t 4 -c {n_ctx} -b 128 --ignore-eos "
+                           f"(the reference's falcon_main.cpp + libfalcon.cpp + ggml.c, unchanged, with falcon_eval on the device; default order)",
+               "prompt_tokens": n_tok, "wall_s": wall, "ggcc_write_s": t_write, "on_device": "resident on the device" in err}
+        m = re.search(r"batch eval time\s*=\s*([0-9.]+) ms /\s*(\d+) tokens \(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
+        if m:
+            out.update(batch_eval_ms=float(m.group(1)), batch_eval_tokens=int(m.group(2)), batch_eval_tok_s=float(m.group(4)))
+        m = re.search(r"[^h] eval time\s*=\s*([0-9.]+) ms /\s*(\d+) runs\s*\(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
+        if m:
+            out.update(eval_ms=float(m.group(1)), eval_runs=int(m.group(2)), eval_ms_per_token=float(m.group(3)), eval_tok_s=float(m.group(4)))
+        return out
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def parity_sample(model, weights, toks, L):
@@ -132,6 +245,11 @@ def parity_sample(model, weights, toks, L):
         runner, kind = ob.Oracle().model(weights, 8), "port (order 0 == the reference's scalar build, tests/test_oracle_vs_golden.py)"
     th = min(32, os.cpu_count() or 4)
     ref = [runner.eval(toks[i:i + 1], i, th)[0] for i in range(2)]
+    # the reference against itself: its AVX2 build (what a user runs) against its scalar build, same model, same steps
+    simd = None
+    if ob.Ref.available(scalar=True) and ob.Ref.available():
+        r2 = ob.Ref().model(weights, 8)
+        simd = [r2.eval(toks[i:i + 1], i, th)[0] for i in range(2)]
 
     def rel(a, b):
         return float(np.abs(a.astype(np.float64) - b).max() / np.sqrt((b.astype(np.float64) ** 2).mean()))
@@ -142,14 +260,21 @@ def parity_sample(model, weights, toks, L):
     finally:
         L.ggml_hip_reference_order(0)
     return dict(max_rel_logit_err_vs_cpu=max(rel(exact[i], ref[i]) for i in range(2)),
-                assoc_spread_default_order_vs_cpu=max(rel(fast[i], ref[i]) for i in range(2)), cpu=kind)
+                assoc_spread_default_order_vs_cpu=max(rel(fast[i], ref[i]) for i in range(2)),
+                reference_avx2_vs_scalar_spread=(max(rel(simd[i], ref[i]) for i in range(2)) if simd else None),
+                assoc_spread_default_order_vs_reference_avx2=(max(rel(fast[i], simd[i]) for i in range(2)) if simd else None), cpu=kind)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)                 # `python bench.py --gpus N` on its own: one process per GPU, as torch.distributed.run would start them
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, a.gpus):
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks\n")
+        raise SystemExit(2)
     if a.gpus > 1 or world > 1 or a.force_pipeline:
         import bench_pipeline                      # layer-sharded multi-GPU path (RCCL hand-off)
         return bench_pipeline.main(a, rank, world, local)
@@ -300,6 +425,12 @@ def main():
         "lock_step_streams": lock_step,
     }
     model.free()
+    # ---- extra key: the same model through the reference's own CLI on top of the library
+    if not a.no_cli and a.model == "7b" and valid:
+        try:
+            line["reference_cli"] = reference_cli(g, weights, hp, a.prompt, 128, a.n_ctx)
+        except Exception as e:                                          # (never lose the bench line to the extra key)
+            line["reference_cli"] = {"error": repr(e)}
     del weights
     # ---- extra keys: the north-star configuration on this GPU (Falcon-40B Q4_K, all 60 blocks resident, single-stream greedy decode)
     if not a.no_north_star and a.model == "7b" and a.quant == "q4_0" and valid:

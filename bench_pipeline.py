@@ -266,6 +266,7 @@ def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torc
         dist.broadcast_object_list(box, src=0)                   # 128 bytes over the launcher's (gloo) store
         uid = box[0]
     pipe = g.Pipeline(model, rank, world, groups, batch, n_ctx, unique_id=uid)
+    rccl_ranks = int(L.falcon_hip_pipeline_rccl_ranks(pipe.p))      # ncclCommCount of the communicator the hand-offs use
     t_setup = time.time() - t0
     pipe.set_tokens(synth.tokens(groups * batch, hp["n_vocab"], seed=42))
     done = _watchdog(600, f"warm-up of the {world}-rank pipeline (RCCL channel set-up)")
@@ -292,6 +293,7 @@ def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torc
         dist.all_reduce(wb_t, op=dist.ReduceOp.SUM)
     pipe.free()
     model.free()
+    run_cpp.rccl_ranks = rccl_ranks
     return steps * groups * batch / float(dt_t.item()), float(wb_t.item()), [e - b for b, e in parts], t_setup, float(dt_t.item())
 
 
@@ -323,7 +325,26 @@ def main(a, rank, world, local):
     if a.warmup + a.steps + 1 > n_ctx:
         raise SystemExit(f"--warmup + --steps must stay below {n_ctx} positions")
     tok_s, wbytes, blocks, t_setup, dt = run_cpp(a, rank, world, local, hp, wtype, a.model, a.quant, dist, torch, groups, batch, n_ctx, a.steps, a.warmup)
-    extra = {}
+    rccl_ranks = getattr(run_cpp, "rccl_ranks", None)
+    if world > 1 and rccl_ranks != world:
+        raise SystemExit(f"bench_pipeline: RCCL communicator has {rccl_ranks} ranks, launched {world}")
+    extra = {"rccl_ranks": rccl_ranks}
+
+    def one_gpu_same_workload(hp1, wt1, mname, qname, steps, warmup):
+        # the denominator of the scaling figure: the SAME workload (groups x batch lock-step streams, all blocks) on rank 0's GPU alone,
+        # measured in the same job while the other ranks wait (None when the model does not fit one GPU's budget)
+        val = None
+        if rank == 0:
+            try:
+                t1, _, _, _, _ = run_cpp(a, 0, 1, local, hp1, wt1, mname, qname, dist, torch, groups, batch, n_ctx, steps, warmup)
+                val = t1
+            except Exception as e:                                   # (out of memory on a smaller part: report, do not fail the line)
+                sys.stderr.write(f"bench_pipeline: one-GPU run of {mname} {qname} failed: {e}\n")
+        if world > 1:
+            dist.barrier()
+        return val
+    if world > 1 and not a.layers:
+        extra["same_workload_1gpu_tok_s"] = one_gpu_same_workload(hp, wtype, a.model, a.quant, max(8, a.steps // 2), max(2, a.warmup // 2))
     if not getattr(a, "no_north_star", False) and world > 1 and a.model == "7b" and not a.layers:
         # the north-star configuration next to the headline line: Falcon-40B Q4_K, all 60 blocks, over the same GPUs
         hp40 = dict(synth.HP_40B)
@@ -332,6 +353,9 @@ def main(a, rank, world, local):
         extra["north_star"] = {"workload": f"Falcon-40B Q4_K, 60 blocks, layer-pipelined over {world} GPU(s) ({ns_blocks} blocks per stage), "
                                            f"{groups} groups x {batch} lock-step greedy decode streams", "value": ns_tok_s, "unit": "tokens/s",
                                "weight_bytes_per_token": ns_wb, "effective_GBs": ns_wb * ns_tok_s / batch / 1e9, "setup_s": ns_setup}
+        ns1 = one_gpu_same_workload(hp40, tname["q4_K"], "40b", "q4_k", max(8, a.steps // 4), max(2, a.warmup // 2))
+        extra["north_star"]["same_workload_1gpu_tok_s"] = ns1
+        extra["north_star"]["scaling_vs_1gpu"] = (ns_tok_s / ns1) if ns1 else None
     if rank == 0:
         from bench import kv_bytes_per_token, HBM_PEAK_GBS
         S = groups * batch

@@ -32,13 +32,13 @@ ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_qu
 ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
-falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy
+falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_set_rope_n_ctx
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
 falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
-falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_set_tokens
+falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_rccl_ranks falcon_hip_pipeline_set_tokens
 falcon_hip_pipeline_run falcon_hip_pipeline_run_local falcon_hip_pipeline_get_history falcon_hip_pipeline_schedule""".split()
 
 
@@ -98,7 +98,7 @@ def load():
         "falcon_hip_model_get_hparams": (None, [vp, vp]),
         "falcon_hip_context_create_seqs": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_n_seq": (C.c_int, [vp]),
         "falcon_hip_pipeline_unique_id": (C.c_int, [vp]), "falcon_hip_pipeline_create": (vp, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
-        "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]),
+        "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]), "falcon_hip_pipeline_rccl_ranks": (C.c_int, [vp]),
         "falcon_hip_pipeline_set_tokens": (C.c_int, [vp, vp]), "falcon_hip_pipeline_run": (C.c_int, [vp, C.c_int, C.c_int]),
         "falcon_hip_pipeline_run_local": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_pipeline_get_history": (C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -107,6 +107,7 @@ def load():
         "falcon_hip_eval": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_eval_stage": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_decode_greedy": (C.c_int, [vp, i32, C.c_int, C.c_int, vp]),
+        "falcon_hip_eval_token": (C.c_int, [vp, i32, C.c_int]), "falcon_hip_context_set_rope_n_ctx": (None, [vp, C.c_int]),
         "falcon_hip_stage_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
@@ -358,6 +359,19 @@ class FalconModel:
             L.falcon_hip_context_keep_hidden(self.ctx, 0)
             return lg, hid
         return lg
+
+    def eval_token(self, token, n_past):
+        """one token through the captured graph, no host round trip; logits() fetches the row"""
+        rc = load().falcon_hip_eval_token(self.ctx, int(token), int(n_past))
+        if rc != 0:
+            raise RuntimeError("falcon_hip_eval_token failed (%d)" % rc)
+
+    def logits(self):
+        n = self.hp["n_vocab"]
+        return np.ctypeslib.as_array(load().falcon_hip_get_logits(self.ctx), shape=(n,)).copy()
+
+    def set_rope_n_ctx(self, n):
+        load().falcon_hip_context_set_rope_n_ctx(self.ctx, int(n))
 
     def decode_greedy(self, first_token, n_past, n_steps, use_graph=False):
         L = load()

@@ -65,6 +65,9 @@ struct falcon_hip_context {
     bool keep_hidden = false;
     int  hidden_tokens = 0;
     std::vector<float> logits_host;
+    bool logits_pending = false;               // falcon_hip_eval_token: the row is still on the device (copied by falcon_hip_get_logits)
+    hipGraphExec_t token_graph = nullptr;      // falcon_hip_eval_token's captured step
+    int token_sig = -1;
     std::vector<void *> allocs;
     bool use_graph = false;
     // fused decode: MLP-up GEMV on a side stream, concurrent with QKV GEMV + attention. Measured on MI355X (Falcon-7B
@@ -318,6 +321,7 @@ extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (!c) return;
     if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
     if (c->step_graph) HIP_CHECK(hipGraphExecDestroy(c->step_graph));
+    if (c->token_graph) HIP_CHECK(hipGraphExecDestroy(c->token_graph));
     for (hipEvent_t e : c->ev_fork) HIP_CHECK(hipEventDestroy(e));
     for (hipEvent_t e : c->ev_join) HIP_CHECK(hipEventDestroy(e));
     for (hipEvent_t e : c->ev_attn) HIP_CHECK(hipEventDestroy(e));
@@ -345,6 +349,7 @@ extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1
 extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one, 4 the persistent engine (one per token)
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
     if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
+    if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
     c->two_phase = mode == 3;
@@ -743,6 +748,7 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
         }
     }
     hipStream_t st = hc.stream;
+    c->logits_pending = false;
     HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
     if (m->first_stage()) HIP_CHECK(hipMemcpyAsync(c->tokens_dev, tokens, (size_t) N * 4, hipMemcpyHostToDevice, st));
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
@@ -771,7 +777,68 @@ extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, i
     return falcon_hip_eval_stage(c, tokens, nullptr, n_tokens, n_past, logits_all, nullptr);
 }
 
-extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) { return c->logits_host.data(); }
+extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
+    if (c->logits_pending) {                                         // the last falcon_hip_eval_token left its row on the device
+        hipStream_t st = fq_ctx().stream;
+        const size_t V = (size_t) c->m->hp.n_vocab;
+        c->logits_host.resize(V);
+        HIP_CHECK(hipMemcpyAsync(c->logits_host.data(), c->logits_dev, V * 4, hipMemcpyDeviceToHost, st));
+        fetch_sync_error(c, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        c->logits_pending = false;
+        (void) report_sync_error(c, "eval");
+    }
+    return c->logits_host.data();
+}
+
+__global__ void k_set_i32(int * p, int v);
+// One token at n_past (falcon_eval with n_tokens = 1, libfalcon.cpp:4566), asynchronous: the fused decode launches are replayed
+// from a hipGraph (captured on first use, position read from device memory), nothing is copied back and the host does not wait --
+// falcon_hip_get_logits fetches the row when, and only when, the caller asks for it. Returns 0, or 1 / 2 as falcon_hip_eval.
+extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int n_past) {
+    hip_context & hc = fq_ctx();
+    falcon_hip_model * m = c->m;
+    if (!m->first_stage() || !m->last_stage() || c->n_seq > 0) { fprintf(stderr, "falcon-hip: falcon_hip_eval_token needs the whole model in one process and a single sequence\n"); exit(1); }
+    if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: eval of one token at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); return 1; }
+    if (token < 0 || token >= m->hp.n_vocab) { fprintf(stderr, "falcon-hip: token id %d is outside [0, %d)\n", token, m->hp.n_vocab); return 2; }
+    hipStream_t st = hc.stream;
+    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, (int *) c->tokens_dev, (int) token);
+    const bool was_keep = c->keep_hidden;
+    c->keep_hidden = false;
+    if (stage_fused(c) && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
+        if (!c->token_graph || c->token_sig != graph_signature(c)) {
+            if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
+            hipGraph_t g;
+            HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            launch_stage(c, 1, c->n_ctx, st);
+            HIP_CHECK(hipStreamEndCapture(st, &g));
+            HIP_CHECK(hipGraphInstantiate(&c->token_graph, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            c->token_sig = graph_signature(c);
+        }
+        HIP_CHECK(hipGraphLaunch(c->token_graph, st));
+    } else {
+        launch_stage(c, 1, n_past + 1, st);
+    }
+    c->keep_hidden = was_keep;
+    c->logits_pending = true;
+    return 0;
+}
+
+// The n_ctx handed to ggml_rope may change from call to call (falcon_evaluation_config::n_max_real_ctx, libfalcon.cpp:2229-2230):
+// the NTK factor only depends on n_ctx / 2048 (ggml.c:12880-12887), so the table is rebuilt -- in place, after the stream has
+// drained -- only when that bucket changes.
+extern "C" void falcon_hip_context_set_rope_n_ctx(falcon_hip_context * c, int rope_n_ctx) {
+    if (rope_n_ctx <= 0) rope_n_ctx = c->n_ctx;
+    const int old_b = c->rope_n_ctx >= 2048 ? c->rope_n_ctx / 2048 : 0, new_b = rope_n_ctx >= 2048 ? rope_n_ctx / 2048 : 0;
+    c->rope_n_ctx = rope_n_ctx;
+    if (old_b == new_b || !c->rope_cs) return;
+    HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+    const std::vector<float> cs = fq_rope_table_host(64, c->n_ctx, rope_n_ctx);
+    HIP_CHECK(hipMemcpy(c->rope_cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+}
 
 // ------------------------------------------------------------------------------------------------ perplexity
 // The reference's perplexity loop (examples/falcon_perplexity/falcon_perplexity.cpp:28-124), same chunking and the same

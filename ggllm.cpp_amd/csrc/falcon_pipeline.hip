@@ -48,6 +48,7 @@ rccl_api * fq_rccl() {
         api.ncclGetUniqueId    = (decltype(api.ncclGetUniqueId))    bind("ncclGetUniqueId");
         api.ncclCommInitRank   = (decltype(api.ncclCommInitRank))   bind("ncclCommInitRank");
         api.ncclCommDestroy    = (decltype(api.ncclCommDestroy))    bind("ncclCommDestroy");
+        api.ncclCommCount      = (decltype(api.ncclCommCount))      bind("ncclCommCount");
         api.ncclSend           = (decltype(api.ncclSend))           bind("ncclSend");
         api.ncclRecv           = (decltype(api.ncclRecv))           bind("ncclRecv");
         api.ncclAllGather      = (decltype(api.ncclAllGather))      bind("ncclAllGather");
@@ -214,6 +215,15 @@ falcon_hip_pipeline * falcon_hip_pipeline_create_local(falcon_hip_model * m, int
     falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
     if (p) p->local = true;
     return p;
+}
+
+// ranks of the RCCL communicator the pipeline exchanges over (ncclCommCount): 1 for a one-rank pipeline, 0 for the local transport
+int falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p) {
+    if (!p || p->local) return 0;
+    if (!p->comm) return 1;
+    int n = -1;
+    if (fq_rccl()->ncclCommCount(p->comm, &n) != ncclSuccess) return -1;
+    return n;
 }
 
 void falcon_hip_pipeline_free(falcon_hip_pipeline * p) {

@@ -3,6 +3,7 @@
 // (it includes the reference's libfalcon.h), linked with
 //
 //   -Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free
+//   -Wl,--wrap=llama_load_session_file,--wrap=llama_save_session_file,--wrap=falcon_copy_state_data,--wrap=falcon_set_state_data,--wrap=falcon_get_embeddings
 //   -L<repo>/ggllm.cpp_amd -lggml_hip
 //
 // The GNU linker then sends every call that falcon_main.cpp / falcon_perplexity.cpp / falcon_common.cpp make to these six
@@ -19,8 +20,10 @@
 //   falcon_print_timings    the reference's report (libfalcon.cpp:4700-4714) over this path's own clocks
 //   llama_free              releases the device side, then the reference's context
 //
-// Not carried over: llama_save/load_session_file and falcon_get_embeddings still address the reference context's (unused)
-// KV cache and embedding buffer.
+//   llama_load_session_file, llama_save_session_file, falcon_copy_state_data, falcon_set_state_data, falcon_get_embeddings
+//                           address the reference context's host KV cache / embedding buffer, which this path does not fill: for a
+//                           context with a device side they FAIL LOUDLY (false / 0 / NULL after a message) instead of silently
+//                           restoring or saving an empty cache (libfalcon.h:205-214, 267)
 #include "libfalcon.h"
 #include "../../include/falcon-hip.h"
 #include "../../include/ggml-hip-ops.h"
@@ -37,6 +40,11 @@ struct falcon_context * __real_falcon_init_from_file(const char * path_model, st
 struct falcon_context * __real_falcon_context_prepare(falcon_context_params params, falcon_model * model, std::string context_name, bool verbose);
 int     __real_falcon_eval(struct falcon_context * ctx, const falcon_token * tokens, falcon_evaluation_config & configuration);
 float * __real_falcon_get_logits(struct falcon_context * ctx);
+bool    __real_llama_load_session_file(struct falcon_context * ctx, const char * path_session, falcon_token * tokens_out, size_t n_token_capacity, size_t * n_token_count_out);
+bool    __real_llama_save_session_file(struct falcon_context * ctx, const char * path_session, const falcon_token * tokens, size_t n_token_count);
+size_t  __real_falcon_copy_state_data(struct falcon_context * ctx, uint8_t * dst);
+size_t  __real_falcon_set_state_data(struct falcon_context * ctx, uint8_t * src);
+float * __real_falcon_get_embeddings(struct falcon_context * ctx);
 void    __real_falcon_print_timings(struct falcon_context * ctx);
 void    __real_llama_free(struct falcon_context * ctx);
 }
@@ -48,6 +56,7 @@ struct hip_side {
     falcon_hip_context * c = nullptr;
     falcon_model * ref_model = nullptr;                       // key of the shared device model
     bool logits_all = false;
+    bool pending_one = false;                                 // the last eval was a single token whose logits are still on the device
     int  n_ctx = 0, n_batch = 0;
     int64_t t_eval_us = 0, t_p_eval_us = 0, t_start_us = 0; int n_eval = 0, n_p_eval = 0;
 };
@@ -110,8 +119,20 @@ int __wrap_falcon_eval(struct falcon_context * ctx, const falcon_token * tokens,
         fprintf(stderr, "falcon-hip: falcon_eval of %d tokens at n_past %d exceeds n_batch %d / n_ctx %d\n", N, n_past, s->n_batch, s->n_ctx);
         return 1;
     }
+    // the n_ctx the reference hands to ggml_rope: n_max_real_ctx when the caller has set it (libfalcon.cpp:2229-2230; falcon_main
+    // does for non-interactive runs, falcon_main.cpp:836), else the context's -- it selects the dynamic-NTK factor
+    falcon_hip_context_set_rope_n_ctx(s->c, configuration.n_max_real_ctx ? configuration.n_max_real_ctx : s->n_ctx);
     const int64_t t0 = now_us();
-    const int rc = falcon_hip_eval(s->c, (const int32_t *) tokens, N, n_past, s->logits_all ? 1 : 0);
+    int rc;
+    if (N == 1 && !s->logits_all) {
+        // one token: the captured graph, no copy, no wait -- falcon_get_logits fetches the row if (and when) the caller samples from it;
+        // the time until then is booked there
+        rc = falcon_hip_eval_token(s->c, (int32_t) tokens[0], n_past);
+        s->pending_one = rc == 0;
+    } else {
+        rc = falcon_hip_eval(s->c, (const int32_t *) tokens, N, n_past, s->logits_all ? 1 : 0);
+        s->pending_one = false;
+    }
     const int64_t dt = now_us() - t0;
     if (N == 1) { s->t_eval_us += dt; ++s->n_eval; } else { s->t_p_eval_us += dt; s->n_p_eval += N; }     // libfalcon.cpp:2578-2585
     return rc;
@@ -121,7 +142,10 @@ float * __wrap_falcon_get_logits(struct falcon_context * ctx) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ctx.find(ctx);
     if (it == g_ctx.end()) return __real_falcon_get_logits(ctx);
-    return const_cast<float *>(falcon_hip_get_logits(it->second.c));
+    const int64_t t0 = now_us();
+    float * lg = const_cast<float *>(falcon_hip_get_logits(it->second.c));
+    if (it->second.pending_one) { it->second.t_eval_us += now_us() - t0; it->second.pending_one = false; }     // (the step's device time ends here)
+    return lg;
 }
 
 void __wrap_falcon_print_timings(struct falcon_context * ctx) {
@@ -135,6 +159,35 @@ void __wrap_falcon_print_timings(struct falcon_context * ctx) {
     fprintf(stderr, "falcon_print_timings:       eval time = %8.2f ms / %5d runs   (%8.2f ms per token, %8.2f tokens per second)\n",
             1e-3 * s.t_eval_us, s.n_eval, 1e-3 * s.t_eval_us / n_eval, 1e6 / (s.t_eval_us > 0 ? (double) s.t_eval_us / n_eval : 1e18));
     fprintf(stderr, "falcon_print_timings:      total time = %8.2f ms\n", 1e-3 * (now_us() - s.t_start_us));
+}
+
+// ---- state that lives in the reference context's host buffers, which the device path neither fills nor reads
+static bool has_device_side(falcon_context * ctx, const char * what) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx.find(ctx) == g_ctx.end()) return false;
+    fprintf(stderr, "falcon-hip: %s is not supported for a context evaluated on the device (its KV cache and embeddings are not in the reference's host buffers); "
+                    "run with FALCON_HIP_WRAP=0 to use it\n", what);
+    return true;
+}
+bool __wrap_llama_load_session_file(struct falcon_context * ctx, const char * path_session, falcon_token * tokens_out, size_t n_token_capacity, size_t * n_token_count_out) {
+    if (has_device_side(ctx, "llama_load_session_file")) { if (n_token_count_out) *n_token_count_out = 0; return false; }
+    return __real_llama_load_session_file(ctx, path_session, tokens_out, n_token_capacity, n_token_count_out);
+}
+bool __wrap_llama_save_session_file(struct falcon_context * ctx, const char * path_session, const falcon_token * tokens, size_t n_token_count) {
+    if (has_device_side(ctx, "llama_save_session_file")) return false;
+    return __real_llama_save_session_file(ctx, path_session, tokens, n_token_count);
+}
+size_t __wrap_falcon_copy_state_data(struct falcon_context * ctx, uint8_t * dst) {
+    if (has_device_side(ctx, "falcon_copy_state_data")) return 0;
+    return __real_falcon_copy_state_data(ctx, dst);
+}
+size_t __wrap_falcon_set_state_data(struct falcon_context * ctx, uint8_t * src) {
+    if (has_device_side(ctx, "falcon_set_state_data")) return 0;
+    return __real_falcon_set_state_data(ctx, src);
+}
+float * __wrap_falcon_get_embeddings(struct falcon_context * ctx) {
+    if (has_device_side(ctx, "falcon_get_embeddings")) return nullptr;
+    return __real_falcon_get_embeddings(ctx);
 }
 
 void __wrap_llama_free(struct falcon_context * ctx) {

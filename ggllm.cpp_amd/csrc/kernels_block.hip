@@ -292,6 +292,131 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const float * __restrict
     }
 }
 
+// ---- the same arithmetic with the score rows in LDS: one head x 16 query tokens per workgroup, v_mfma_f32_16x16x4_f32 ------------
+// v_mfma_f32_16x16x4_f32 is the same fused chain, four k steps per instruction in ascending k (scripts/microbench/mb_mfma_f32_16.hip:
+// 0 of 2048 outputs differ), so the chains above are kept term for term by feeding k = 0..3 of instruction m with
+//   K.Q : dims  2m, 32 + 2m, 2m + 1, 33 + 2m     (m = 0..15)        V.P : keys  2m, 16 + 2m, 2m + 1, 17 + 2m  of a 32-key tile (m = 0..7)
+// i.e. lane group kq = lane >> 4 holds the even (kq < 2) or odd elements of the low (kq even) or high (kq odd) half. Results are
+// bit-identical to k_attention_mfma (and to the oracle's dot_qk_mfma / dot_pv_mfma). 16 rows x n_kv floats fit the LDS up to ~2400
+// keys (128 KiB at 2048): the score matrix never leaves the CU -- the 32-row form moves 2.5 GB of HBM traffic per 2048-token
+// launch for it. 8 waves: K.Q by 16-key sub-tiles, soft_max two rows per wave, V.P as (16-dim tile) x (32-key tile parity).
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(512) k_attention_mfma16(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                          const float * __restrict__ kc, const float * __restrict__ vc,
+                                                          const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int ps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float * p = (float *) smem;                                     // [16][ps], ps = 32 ntile_max + 4
+    float * rmax = p + 16 * ps;                                     // [8 waves][16 rows]
+    float * rinv = rmax + 8 * 16;                                   // [16]
+    float * xch  = rinv + 16;                                       // [4 dim tiles][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int h = blockIdx.x, i0 = blockIdx.y * 16, hk = h / (H / HKV), heads = H + 2 * HKV;
+    const int n_past = *n_past_ptr;
+    const int nrows = N - i0 < 16 ? N - i0 : 16;
+    const int n_kv_max = n_past + i0 + nrows;                       // keys the tile's last token sees
+    const int n_rows_cache = n_past + N;                            // key / value rows that exist
+    const int ntile = (n_kv_max + 31) >> 5, nsub = 2 * ntile;
+    const int eo = kq >> 1, hi = kq & 1;                            // the lane group's elements: odd (1) / even (0) ones of the high (1) / low (0) half
+    // ---- scores
+    {
+        float q16[16];
+        {
+            const float * qrow = qkv + ((int64_t)(i0 + (l16 < nrows ? l16 : nrows - 1)) * heads + h) * 64 + 32 * hi;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { const f32x4 t = ((const f32x4 *) qrow)[v]; q16[2 * v] = eo ? t.y : t.x; q16[2 * v + 1] = eo ? t.w : t.z; }
+        }
+        auto load_k = [&](int U, float (&k16)[16]) {
+            const int j = 16 * U + l16;
+            const float * krow = kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hi;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { const f32x4 t = ((const f32x4 *) krow)[v]; k16[2 * v] = eo ? t.y : t.x; k16[2 * v + 1] = eo ? t.w : t.z; }
+        };
+        float ka[16], kb[16];
+        float mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        if (wid < nsub) load_k(wid, ka);
+        for (int U = wid; U < nsub; U += 8) {
+            if (U + 8 < nsub) load_k(U + 8, kb);
+            v4f_ c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 16; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(q16[m], ka[m], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = 4 * kq + r, j = 16 * U + l16;
+                const float sc = c[r] * 0.125f;
+                p[ir * ps + j] = sc;
+                mx[r] = fq_max_f32(mx[r], (ir < nrows && j <= n_past + i0 + ir) ? sc : -INFINITY);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ka[v] = kb[v];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = reduce16(mx[r], op_max());
+            if (l16 == 0) rmax[wid * 16 + 4 * kq + r] = m;
+        }
+    }
+    __syncthreads();
+    // ---- soft_max: wave w takes rows w and w + 8: exp() of the visible keys, zeros up to the last tile, 1 / sum kept aside
+    for (int ir = wid; ir < 16; ir += 8) {
+        float * pr = p + ir * ps;
+        const int n_kv = ir < nrows ? n_past + i0 + ir + 1 : 0;
+        float m = rmax[ir];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) m = fq_max_f32(m, rmax[w2 * 16 + ir]);
+        double lsum = 0.0;
+        for (int j = 4 * lane; j < 32 * ntile; j += 256) {
+            const f32x4 x = *(const f32x4 *)(pr + j);
+            f32x4 e;
+            e.x = j     < n_kv ? soft_max_exp(exp_tab, x.x - m) : 0.0f;
+            e.y = j + 1 < n_kv ? soft_max_exp(exp_tab, x.y - m) : 0.0f;
+            e.z = j + 2 < n_kv ? soft_max_exp(exp_tab, x.z - m) : 0.0f;
+            e.w = j + 3 < n_kv ? soft_max_exp(exp_tab, x.w - m) : 0.0f;
+            *(f32x4 *)(pr + j) = e;
+            lsum += (double) e.x; lsum += (double) e.y; lsum += (double) e.z; lsum += (double) e.w;     // (exact in any order)
+        }
+        lsum = wave_sum(lsum);
+        if (lane == 0) rinv[ir] = (float)(1.0 / lsum);
+    }
+    __syncthreads();
+    // ---- V.P: wave = (16-dim tile dt, tile parity par)
+    {
+        const int dt = wid & 3, par = wid >> 2;
+        const float * prow = p + l16 * ps + 16 * hi;                // keys 16 hi .. 16 hi + 15 of a tile: the even or the odd ones
+        const float inv = rinv[l16];
+        auto load_pv = [&](int T, float (&p8)[8], float (&v8)[8]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const f32x4 t = ((const f32x4 *)(prow + 32 * T))[v]; p8[2 * v] = eo ? t.y : t.x; p8[2 * v + 1] = eo ? t.w : t.z; }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int j = 32 * T + 16 * hi + 2 * m + eo;
+                v8[m] = vc[((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 16 * dt + l16];
+            }
+        };
+        float pa[8], pb[8], va[8], vb[8];
+        if (par < ntile) load_pv(par, pa, va);
+        v4f_ c = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int T = par; T < ntile; T += 2) {
+            if (T + 2 < ntile) load_pv(T + 2, pb, vb);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[m] * inv, va[m], c, 0, 0, 0);      // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { pa[m] = pb[m]; va[m] = vb[m]; }
+        }
+        if (par == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[(dt * 4 + r) * 64 + lane] = c[r];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = 4 * kq + r;
+                if (ir < nrows) att[(int64_t)(i0 + ir) * H * 64 + (int64_t) h * 64 + 16 * dt + l16] = c[r] + xch[(dt * 4 + r) * 64 + lane];
+            }
+        }
+    }
+}
+
 // 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
 static int g_attn_f64 = 0;
 void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
@@ -338,6 +463,17 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     // 1.2 GB for a 512-token batch at 8192 keys -- and is not used beyond FQ_ATTN_SCRATCH_GB (default 4) GiB
     static const int use_mfma = getenv("FQ_ATTN_MFMA") ? atoi(getenv("FQ_ATTN_MFMA")) : 1;
     if (use_mfma && N >= 32 && !g_attn_f64 && !seq_stride && force < 0) {
+        // the score rows of 16 query tokens in LDS while they fit (~2400 keys); beyond that 32 tokens per workgroup and the global scratch
+        static const int use_16 = getenv("FQ_ATTN_MFMA16") ? atoi(getenv("FQ_ATTN_MFMA16")) : 0;      // (measured slower than the scratch form at every prompt length: one 8-wave workgroup per CU; kept for its tests)
+        static const int max_kv16 = getenv("FQ_ATTN_MFMA16_MAXKV") ? atoi(getenv("FQ_ATTN_MFMA16_MAXKV")) : 4096;
+        const int ps16 = ((max_n_kv + 31) & ~31) + 4;
+        const size_t lds16 = ((size_t) 16 * ps16 + 8 * 16 + 16 + 4 * 4 * 64) * 4;
+        if (use_16 && lds16 <= 158 * 1024 && max_n_kv <= max_kv16) {
+            static size_t g16 = 0;
+            if (lds16 > 64 * 1024 && lds16 > g16) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_mfma16, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds16)); g16 = lds16; }
+            hipLaunchKernelGGL(k_attention_mfma16, dim3((unsigned) H, (unsigned)((N + 15) / 16)), dim3(512), lds16, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, ps16);
+            return;
+        }
         const int ps = (max_n_kv + 31) & ~31;
         float * scr = att_scratch((size_t)((N + 31) / 32) * (size_t) H * 32 * (size_t) ps * 4, st);
         if (scr) {

@@ -99,6 +99,12 @@ int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * token_dev, con
  * tokens (falcon_main --temp 0, falcon_main.cpp:958-960); out_tokens receives n_steps ids. No host sync per step. */
 int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens);
 
+/* falcon_eval with n_tokens = 1 (libfalcon.cpp:4566) without a host round trip: the fused decode launches are replayed from a
+ * hipGraph, the logits stay on the device until falcon_hip_get_logits is called (libfalcon.h:256, 263). Returns as falcon_hip_eval. */
+int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int n_past);
+/* the n_ctx ggml_rope is given may change per call (falcon_evaluation_config::n_max_real_ctx, libfalcon.cpp:2229-2230);
+ * the table is rebuilt when the dynamic-NTK bucket n_ctx / 2048 changes (<= 0: the context's n_ctx)                       */
+void falcon_hip_context_set_rope_n_ctx(falcon_hip_context * c, int rope_n_ctx);
 const float * falcon_hip_get_logits(falcon_hip_context * c);        /* host, n_vocab (or n_tokens*n_vocab) floats */
 /* The reference's perplexity loop (falcon_perplexity.cpp:28-124) over a token stream: chunks of n_ctx tokens evaluated
  * from an empty context in batches of n_batch, NLL of the second half of every chunk (host soft_max as in :12-27).
@@ -139,6 +145,7 @@ int   falcon_hip_pipeline_unique_id(void * id_out);                       /* 0, 
 falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank, int world, const void * unique_id,
                                                  int n_groups, int batch, int n_ctx);
 void  falcon_hip_pipeline_free(falcon_hip_pipeline * p);
+int   falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p);           /* ncclCommCount of its communicator (1: one rank, 0: local transport) */
 int   falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * tokens);
 int   falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0);
 int   falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, int first_round, int n_rounds);

@@ -256,6 +256,9 @@ def gen_tiny_all():
 CLI_PROMPT = "The quick brown fox didn't jump"
 CLI_MAIN_ARGS = ["-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1"]
 CLI_PPL_ARGS = ["-t", "2", "-c", "32", "-b", "8", "-s", "1"]
+# -c 4096 with a short real context: falcon_main sets n_max_real_ctx = min(n_ctx, prompt + n_predict) (falcon_main.cpp:836), so the
+# rope sees a small n_ctx (NTK factor 1) although the context was created for 4096 (factor 3)
+CLI_MAIN_ARGS_C4096 = ["-n", "8", "--temp", "0", "-t", "2", "-c", "4096", "-b", "8", "--ignore-eos", "-s", "1"]
 
 
 def cli_model(O, path):
@@ -296,6 +299,10 @@ def gen_cli():
         r = subprocess.run([os.path.join(td, "falcon_main"), "-m", path, "-p", CLI_PROMPT, *CLI_MAIN_ARGS], capture_output=True)
         assert r.returncode == 0, r.stderr[-2000:]
         d["main_stdout"] = np.frombuffer(r.stdout, np.uint8)
+        r = subprocess.run([os.path.join(td, "falcon_main"), "-m", path, "-p", CLI_PROMPT, *CLI_MAIN_ARGS_C4096], capture_output=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d["main_c4096_stdout"] = np.frombuffer(r.stdout, np.uint8)
+        print("falcon_main -c 4096:", r"%r" % bytes(d["main_c4096_stdout"]))
         txt = os.path.join(td, "corpus.txt")
         open(txt, "wb").write((bf.CORPUS * 2).encode("utf-8"))
         r = subprocess.run([os.path.join(td, "falcon_perplexity"), "-m", path, "-f", txt, *CLI_PPL_ARGS], capture_output=True)

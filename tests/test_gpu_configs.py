@@ -87,6 +87,51 @@ def test_config3_kquant_prefill_2048(oracle, shape, hp, t):
     m.free()
 
 
+def test_config2_falcon7b_q4_0_full_depth(oracle):
+    """BASELINE config 2 at its OWN size and depth: Falcon-7B Q4_0, all 32 blocks, vocabulary 65024, a 128-token prompt as one batch,
+    then 128 greedy decode steps (fused decode kernels). Every block of both phases is checked bit for bit on sampled tokens against
+    the oracle in the backend's order (prompt: the GEMM's K split; decode: the mat-vec kernels' wave order), the decode phase against
+    the K / V rows the prompt phase left, and the sampled logits rows of both phases against the oracle's head."""
+    hp = dict(synth.HP_7B)
+    w = synth.make_model_fast(hp, ob.Q4_0, seed=1234)
+    NP, ND, L = 128, 128, hp["n_layer"]
+    toks = synth.tokens(NP, hp["n_vocab"], seed=42)
+    m = g.FalconModel(w, n_ctx=NP + ND + 8, n_batch=NP)
+    lg_p, hid_p = m.eval(toks, 0, logits_all=True, want_hidden=True)         # [NP, V], [L + 1, NP, E]
+    cur, hid_d, lg_d, seq = int(lg_p[-1].argmax()), [], [], []
+    for i in range(ND):
+        lg, h = m.eval(np.array([cur], np.int32), NP + i, want_hidden=True)
+        hid_d.append(h[:, 0, :]); lg_d.append(lg[0]); seq.append(cur)
+        cur = int(lg[0].argmax())
+    assert m.sync_error() == 0
+    # the same 128 steps through the device-side greedy loop (hipGraph replay): the same tokens
+    m.eval(toks, 0)
+    dev = m.decode_greedy(seq[0], NP, ND, use_graph=True)
+    assert np.array_equal(dev, np.array(seq[1:] + [cur], np.int32))
+    m.free()
+    hid_d = np.stack(hid_d, axis=1)                                          # [L + 1, ND, E]
+    lg_d = np.stack(lg_d)
+    mo = oracle.model(w, 8)
+    sp, sd = [0, 63, 127], [0, 1, 64, 127]
+    modes = {gemm_split(M, NP) for M in ((hp["n_head"] + 2 * hp["n_head_kv"]) * 64, hp["n_embd"], hp["n_ff"])}
+    assert len(modes) == 1
+    gmode = modes.pop()
+    try:
+        for il in range(L):
+            oracle.lib.orc_set_sum_order(gmode)
+            out, ko, vo = mo.block_sampled(oracle.lib, il, hid_p[il], sp, n_threads=NT, want_kv=True)
+            assert np.array_equal(out, hid_p[il + 1][sp]), "prompt, block %d" % il
+            oracle.lib.orc_set_sum_order(1)
+            out = mo.block_sampled(oracle.lib, il, hid_d[il], sd, pos0=NP, k_prev=ko, v_prev=vo, n_threads=NT)
+            assert np.array_equal(out, hid_d[il + 1][sd]), "decode, block %d" % il
+        oracle.lib.orc_set_sum_order(gemm_split(hp["n_vocab"], NP))
+        assert np.array_equal(mo.head_rows(oracle.lib, hid_p[L][sp], n_threads=NT), lg_p[sp])
+        oracle.lib.orc_set_sum_order(1)
+        assert np.array_equal(mo.head_rows(oracle.lib, hid_d[L][sd], n_threads=NT), lg_d[sd])
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+
+
 def test_config4_falcon40b_q5_1_two_stages(oracle):
     """BASELINE config 4 (Falcon-40B Q5_1 layer-sharded) at Falcon-40B's width: 4 blocks cut into two pipeline stages that
     run in ONE process through the stage API (falcon_hip_stage_step: device-resident hand-off of the residual row, as the

@@ -117,6 +117,36 @@ def test_falcon_main_unchanged_on_the_fast_path(oracle, golden, tmp_path):
     assert r.stdout == bytes(golden["cli"]["main_stdout"])
 
 
+def test_falcon_main_rope_context_follows_n_max_real_ctx(oracle, golden, tmp_path):
+    """-c 4096 with a short prompt: falcon_main hands falcon_eval n_max_real_ctx = min(n_ctx, prompt + n_predict)
+    (falcon_main.cpp:836), the reference ropes with THAT (libfalcon.cpp:2229-2230: NTK factor 1, not the 4096-context's 3);
+    the wrap follows it per call (falcon_hip_context_set_rope_n_ctx) -- same bytes as the pure-CPU build"""
+    exe = _need("falcon_main_hip")
+    if "main_c4096_stdout" not in golden["cli"]:
+        pytest.skip("fixture predates the -c 4096 run (python oracle/gen_golden.py cli)")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    _cli_model(oracle, path)
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    r = subprocess.run([exe, "-m", path, "-p", "The quick brown fox didn't jump", "-n", "8", "--temp", "0", "-t", "2", "-c", "4096", "-b", "8", "--ignore-eos", "-s", "1"],
+                       capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout == bytes(golden["cli"]["main_c4096_stdout"])
+
+
+def test_session_files_fail_loudly_on_the_fast_path(oracle, tmp_path):
+    """--prompt-cache would restore / save the reference context's host KV cache, which the device path does not use: the wrap makes
+    llama_load_session_file fail with a message instead of generating from an empty cache (falcon_main.cpp:425 then exits 1)"""
+    exe = _need("falcon_main_hip")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    _cli_model(oracle, path)
+    sess = str(tmp_path / "s.bin")
+    open(sess, "wb").write(b"\0" * 64)                       # (any existing file: the wrap refuses before it is parsed)
+    r = subprocess.run([exe, "-m", path, "-p", "The quick", "-n", "2", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--prompt-cache", sess, "-s", "1"],
+                       capture_output=True, timeout=600)
+    assert r.returncode != 0
+    assert b"llama_load_session_file is not supported for a context evaluated on the device" in r.stderr
+
+
 def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path):
     """the reference's falcon_perplexity tool, unchanged, with falcon_eval on the device: the chunk perplexities it prints"""
     exe = _need("falcon_perplexity_hip")

@@ -42,7 +42,8 @@ CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0, "tiny_models"), ("gqa_q5_1", s
 #       1e-7 level -- re-associating an f32 block sum (which every vectorised build of the reference does as well) now and
 #       then flips one 8-bit activation rounding, and one flip moves logits by 1e-3..1e-2. The reference's own AVX2 and
 #       scalar builds differ by up to 2.8e-2 on these fixtures (both are in the golden files). For the legacy formats the
-#       default order is asserted within max(1e-3, 2 x that spread) of the reference; it is printed for all.
+#       default order is asserted within max(1e-3, 2 x that spread) of the reference, for the k-quants (whose two reference
+#       builds share one association) within 5.6e-2 = twice the largest legacy spread; it is printed for all.
 
 
 @pytest.mark.parametrize("name,hp,t,gfile", CASES)
@@ -80,6 +81,12 @@ def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t, gfile):
     print(name, "default order vs reference logits: prefill %.2e decode %.2e (reference AVX2-vs-scalar spread %.2e)" % (e_l, e_d, spread))
     if t in ob.LEGACY:
         assert max(e_l, e_d) <= max(LOGIT_TOL, 2 * spread)
+    else:
+        # k-quants: the reference's two builds keep the same eight float lanes, so THEIR spread is ~1e-6 and says nothing about the
+        # model's sensitivity; the default order's distance is the backend's own re-association (one term per lane-unit + butterfly for
+        # N <= 4, K-split partial sums in the GEMM), amplified by the same activation-rounding flips as on the legacy models, whose
+        # builds differ by up to 2.8e-2 on these fixtures: the stated bound is twice that
+        assert max(e_l, e_d) <= 5.6e-2, (name, e_l, e_d)
 
 
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),

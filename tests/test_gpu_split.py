@@ -1,6 +1,7 @@
 """GPU: row-split tensor parallelism (csrc/split_tp.hip, the reference's -ts / GGML_BACKEND_GPU_SPLIT): every rank's row range
 of a quantized matrix uploaded on its own (ggml_hip_weight_upload_rows, the bytes ggml_cuda_transform_tensor would send it),
-the parts multiplied one by one in this process -- the assembled result is the unsplit mat-mul bit for bit."""
+the parts multiplied one by one in this process -- the assembled result is the oracle's mat-mul (backend order) and the unsplit
+mat-mul, bit for bit."""
 import ctypes as C
 
 import numpy as np
@@ -53,5 +54,13 @@ def test_row_split_equals_unsplit(oracle, ts, t, N):
     for b in (xd, yd, y1):
         b.free()
     whole.free()
+    # against the oracle, not only against ourselves: the backend's association for this shape (wave order for N <= 4, the GEMM's K
+    # split above; a part has fewer rows than the matrix but the same split: 4 partial sums below 1024 tiles)
+    oracle.lib.orc_set_sum_order(2)
+    try:
+        exp = oracle.mul_mat(t, w, K, M, x, 8)
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    assert np.array_equal(got, exp)
     assert np.array_equal(got, want)
     assert np.array_equal(got1, want)
