@@ -50,6 +50,7 @@ struct falcon_hip_context {
     // ([layer][seq][n_ctx][HKV][D]) -- one pass over the stage's weights serves n_seq tokens
     int n_seq = 0;
     float * x = nullptr, * ln = nullptr, * ln2 = nullptr, * qkv = nullptr, * att = nullptr, * wo_out = nullptr, * up = nullptr;
+    fq_att_scratch att_scratch{nullptr, 0};
     float * logits_dev = nullptr;
     // quantized-activation images. Each buffer holds the LARGEST image of its length (Q8_1: 1.25 bytes per element) and is
     // typed per use from the weight that consumes it (ggml.c:1627-1718 vec_dot_type), so that a file which mixes weight
@@ -268,6 +269,9 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     c->ln2    = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
     c->qkv    = (float *) dev_alloc(c->allocs, (size_t) B * QKV * 4);
     c->att    = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
+    // score rows of the long-prompt attention forms, owned here and sized once (kernels.h): no launch of this context allocates
+    c->att_scratch.bytes = n_seq > 0 ? 0 : fq_attention_scratch_need(n_batch, hp.n_head, n_ctx);
+    c->att_scratch.p     = c->att_scratch.bytes ? (float *) dev_alloc(c->allocs, c->att_scratch.bytes) : nullptr;
     c->wo_out = (float *) dev_alloc(c->allocs, (size_t) B * E * 4);
     c->up     = (float *) dev_alloc(c->allocs, (size_t) B * FF * 4);
     if (m->last_stage()) c->logits_dev = (float *) dev_alloc(c->allocs, (size_t) B * hp.n_vocab * 4);
@@ -668,7 +672,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_launch_quantize_act(c->up, FF, a_ff, c->side);
             fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
             fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, 0);
-            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, 0);
+            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, 0, &c->att_scratch);
             fq_launch_quantize_act(c->att, E, a_att, st);
             fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
             HIP_CHECK(hipEventRecord(c->ev_attn[li], st));
@@ -688,7 +692,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             if (!att_q) fq_launch_quantize_act(c->att, E, a_att, st);
         } else {
             fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);
-            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride);
+            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride, &c->att_scratch);
             fq_launch_quantize_act(c->att, E, a_att, st);
         }
         if (!up_done) {

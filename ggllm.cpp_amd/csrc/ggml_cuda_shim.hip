@@ -183,7 +183,7 @@ extern "C" void * ggml_cuda_host_malloc(size_t size) {                          
 extern "C" void ggml_cuda_host_free(void * p) { if (p) HIP_CHECK(hipHostFree(p)); }
 
 // ---------------------------------------------------------------------------------------------- weights
-struct shim_extra : ggml_tensor_extra_gpu { bool is_weight; size_t bytes; bool split; int64_t row_low[GGML_CUDA_MAX_DEVICES], row_high[GGML_CUDA_MAX_DEVICES]; };
+struct shim_extra : ggml_tensor_extra_gpu { bool is_weight; size_t bytes; bool split; ggml_hip_split_comm * comm; int64_t row_low[GGML_CUDA_MAX_DEVICES], row_high[GGML_CUDA_MAX_DEVICES]; };
 
 // Row-split tensor parallelism over several PROCESSES (one per GPU, every process running the same reference graph): once
 // ggml_hip_split_configure has joined this process to a job, GGML_BACKEND_GPU_SPLIT tensors are uploaded as this rank's row
@@ -191,7 +191,11 @@ struct shim_extra : ggml_tensor_extra_gpu { bool is_weight; size_t bytes; bool s
 // (csrc/split_tp.hip). Not configured (the default): the whole matrix lives on this process's device.
 static ggml_hip_split_comm * g_split = nullptr;
 static int g_split_rank = 0, g_split_world = 1;
+static bool g_split_ts_checked = false;
+static int g_split_live = 0;            // split tensors uploaded under the current communicator and not yet freed
 extern "C" int ggml_hip_split_configure(int rank, int world, const void * unique_id) {
+    // a split tensor holds this rank's rows of the job it was uploaded under: the job cannot change below it
+    if (g_split_live) { fprintf(stderr, "ggml-hip: split: %d split tensors are alive -- free them (ggml_cuda_free_data) before reconfiguring\n", g_split_live); return 1; }
     if (g_split) { ggml_hip_split_comm_free(g_split); g_split = nullptr; }
     g_split_rank = 0; g_split_world = 1;
     if (world <= 1) return 0;
@@ -199,7 +203,7 @@ extern "C" int ggml_hip_split_configure(int rank, int world, const void * unique
     ggml_init_cublas(false);
     g_split = ggml_hip_split_comm_create(rank, world, unique_id);
     if (!g_split) return 1;
-    g_split_rank = rank; g_split_world = world;
+    g_split_rank = rank; g_split_world = world; g_split_ts_checked = false;
     return 0;
 }
 
@@ -208,14 +212,18 @@ extern "C" void ggml_cuda_transform_tensor(void * data, ggml_tensor * t) {      
     ggml_init_cublas(false);
     shim_extra * ex = new shim_extra();
     memset(ex->data_device, 0, sizeof(ex->data_device));
-    ex->split = false;
+    ex->split = false; ex->comm = nullptr;
     if (is_quantized(t->type)) {
         const int64_t nrows = t->ne[1] * t->ne[2] * t->ne[3];
         if (t->backend == GGML_BACKEND_GPU_SPLIT && g_split) {
             // this rank's rows of the -ts split (ggml-cuda.cu:3044-3066); an empty range holds nothing
+            if (!g_split_ts_checked) {      // once per job, collectively (every rank uploads the same tensors in the same order)
+                if (ggml_hip_split_comm_agree(g_split, g_tensor_split, sizeof(g_tensor_split)) != 0) { fprintf(stderr, "ggml-hip: split: rank %d: the ranks of this job were given different -ts proportions\n", g_split_rank); exit(1); }
+                g_split_ts_checked = true;
+            }
             ggml_hip_tensor_split_rows(g_tensor_split, g_split_world, nrows, ex->row_low, ex->row_high);
             ex->data_device[0] = ggml_hip_weight_upload_rows((int) t->type, data, t->ne[0], nrows, ex->row_low[g_split_rank], ex->row_high[g_split_rank]);
-            ex->split = true;
+            ex->split = true; ex->comm = g_split; ++g_split_live;
         } else {
             // the whole matrix on this process's device: the north star shards by LAYER (one process per GPU)
             ex->data_device[0] = ggml_hip_weight_upload((int) t->type, data, t->ne[0], nrows);
@@ -236,6 +244,7 @@ extern "C" void ggml_cuda_transform_tensor(void * data, ggml_tensor * t) {      
 extern "C" void ggml_cuda_free_data(ggml_tensor * t) {                              // ggml-cuda.cu:3075-3092
     if (!t || !on_device(t) || !t->extra) return;
     shim_extra * ex = (shim_extra *) t->extra;
+    if (ex->split && g_split_live > 0) --g_split_live;
     if (ex->is_weight) { if (ex->data_device[0]) ggml_hip_weight_free((ggml_hip_weight *) ex->data_device[0]); }
     else               ggml_hip_free(ex->data_device[0]);
     delete ex;
@@ -281,7 +290,8 @@ static void shim_mul_mat(const ggml_tensor * src0, const ggml_tensor * src1, ggm
     const ggml_hip_weight * w = (const ggml_hip_weight *) ex->data_device[0];
     float * x = (float *) pool_get((size_t) N * K * 4), * y = (float *) pool_get((size_t) N * M * 4);
     ggml_hip_memcpy_h2d(x, src1->data, (size_t) N * K * 4);                         // reference: H2D of src1 every op (ggml-cuda.cu:2717)
-    if (ex->split) { if (ggml_hip_mul_mat_q_split(g_split, w, x, K, N, y, M, ex->row_low, ex->row_high) != 0) exit(1); }   // rows exchanged by RCCL (reference: peer copies, :2779-2788)
+    if (ex->split) { if (!ex->comm || ex->comm != g_split) { fprintf(stderr, "ggml-hip: mul_mat '%s': split tensor without its communicator\n", dst->name); exit(1); }
+                     if (ggml_hip_mul_mat_q_split(ex->comm, w, x, K, N, y, M, ex->row_low, ex->row_high) != 0) exit(1); }   // rows exchanged by RCCL (reference: peer copies, :2779-2788)
     else ggml_hip_mul_mat_q(w, x, K, N, y, M);
     ggml_hip_memcpy_d2h(dst->data, y, (size_t) N * M * 4);                          // reference: D2H of dst every op (ggml-cuda.cu:2787-2791)
     pool_put(x); pool_put(y);

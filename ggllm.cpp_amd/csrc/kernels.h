@@ -55,8 +55,14 @@ void   fq_launch_add3(const float * a, const float * b, const float * c, float *
 void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs,
                          float * k_cache, float * v_cache, hipStream_t st, int64_t seq_stride = 0);
 // att[N][H*D] = softmax(mask(K.Q * scale)) V, one workgroup per (head, token)
+// own_scratch: the caller's score-row buffer for the long-prompt forms (a model context sizes it once with
+// fq_attention_scratch_need(n_batch, H, n_ctx); never grown inside a launch); nullptr: a process-wide buffer grown on demand
+// (op-level API only: it synchronizes and reallocates).
+struct fq_att_scratch { float * p; size_t bytes; };
+size_t fq_attention_scratch_need(int N, int H, int max_n_kv);          // 0: no launch of that size uses a scratch
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
-                           const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride = 0);
+                           const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride = 0,
+                           fq_att_scratch * own_scratch = nullptr);
 
 int    fq_selftest_reduce(hipStream_t st);
 int    fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st);   // number of non-NaN inputs where the formula != table   // 0 = DPP wave reductions agree with the __shfl_xor butterfly

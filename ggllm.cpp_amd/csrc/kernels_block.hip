@@ -427,12 +427,27 @@ static void launch_attention_rows(const float * qkv, int N, int H, int HKV, cons
     if (g_attn_f64) launch_attention_rows_t<R, true>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, p_scratch, st);
     else            launch_attention_rows_t<R, false>(qkv, N, H, HKV, n_past_dev, p_stride, lds, k_cache, v_cache, exp_table, att, p_scratch, st);
 }
-// score rows of long-context launches (one slice per workgroup), grown on demand up to 4 GiB
+// score rows of long-context launches (one slice per workgroup). A model context owns its own buffer, sized once for its
+// (n_batch, n_ctx) at context_create (fq_attention_scratch_need) and passed in; the process-wide one below serves only the
+// op-level API (ggml_hip_attention: synchronous, one stream) and is grown on demand up to FQ_ATTN_SCRATCH_GB (default 4) GiB.
+static size_t att_scratch_cap() {
+    static const size_t cap = (size_t)(getenv("FQ_ATTN_SCRATCH_GB") ? atoi(getenv("FQ_ATTN_SCRATCH_GB")) : 4) << 30;
+    return cap;
+}
+size_t fq_attention_scratch_need(int N, int H, int max_n_kv) {
+    if (N < 4) return 0;
+    const size_t ps = (size_t)((max_n_kv + 31) & ~31);
+    const size_t a = N >= 32 ? (size_t)((N + 31) / 32) * (size_t) H * 32 * ps * 4 : 0;                 // k_attention_mfma: 32 tokens per workgroup
+    const size_t row = (size_t)((max_n_kv + 3) & ~3) * 4;
+    const size_t b = (16 * 4 + 16 * 64 * 8) + 4 * row > 56 * 1024 ? (size_t)((N + 3) / 4) * (size_t) H * 4 * row : 0;   // 4 tokens per workgroup, once their rows leave LDS
+    const size_t need = a > b ? a : b;
+    return need > att_scratch_cap() ? 0 : need;
+}
 static float * g_att_scratch = nullptr;
 static size_t  g_att_scratch_bytes = 0;
-static float * att_scratch(size_t bytes, hipStream_t st) {
-    static const size_t cap = (size_t)(getenv("FQ_ATTN_SCRATCH_GB") ? atoi(getenv("FQ_ATTN_SCRATCH_GB")) : 4) << 30;
-    if (bytes > cap) return nullptr;
+static float * att_scratch(fq_att_scratch * own, size_t bytes, hipStream_t st) {
+    if (own) return bytes <= own->bytes ? own->p : nullptr;          // never grown here: launches of a context may be captured
+    if (bytes > att_scratch_cap()) return nullptr;
     if (bytes > g_att_scratch_bytes) {
         HIP_CHECK(hipStreamSynchronize(st));
         if (g_att_scratch) HIP_CHECK(hipFree(g_att_scratch));
@@ -444,7 +459,7 @@ static float * att_scratch(size_t bytes, hipStream_t st) {
 }
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
-                         const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride) {
+                         const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride, fq_att_scratch * own_scratch) {
     if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
     const int p_stride = (max_n_kv + 3) & ~3;
     const size_t fixed = 16 * 4 + 16 * 64 * 8, row = (size_t) p_stride * 4, budget = 150 * 1024;
@@ -475,7 +490,7 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
             return;
         }
         const int ps = (max_n_kv + 31) & ~31;
-        float * scr = att_scratch((size_t)((N + 31) / 32) * (size_t) H * 32 * (size_t) ps * 4, st);
+        float * scr = att_scratch(own_scratch, (size_t)((N + 31) / 32) * (size_t) H * 32 * (size_t) ps * 4, st);
         if (scr) {
             // (a 128-token-per-workgroup form with the key / value tiles shared through LDS was built and measured: 124 ms against
             // 112 ms for a 2048-token Falcon-7B prompt -- a barrier per tile and idle waves at the causal edge cost more than the
@@ -487,7 +502,7 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     static const int use_scratch = getenv("FQ_ATTN_SCRATCH") ? atoi(getenv("FQ_ATTN_SCRATCH")) : 1;
     if (use_scratch && force < 0 && R == 2 && N >= 4 && !seq_stride) {
         const size_t need = (size_t)((N + 3) / 4) * (size_t) H * 4 * row;
-        float * scr = att_scratch(need, st);
+        float * scr = att_scratch(own_scratch, need, st);
         if (scr) { launch_attention_rows<4>(qkv, N, H, HKV, n_past_dev, p_stride, fixed, k_cache, v_cache, exp_table, att, st, scr); return; }
     }
     if (R == 8)      launch_attention_rows<8>(qkv, N, H, HKV, n_past_dev, p_stride, fixed + 8 * row, k_cache, v_cache, exp_table, att, st);

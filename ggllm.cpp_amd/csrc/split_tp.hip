@@ -76,6 +76,23 @@ void ggml_hip_split_comm_free(ggml_hip_split_comm * c) {
     delete c;
 }
 
+// collective: 0 when every rank of the job passed the same `n` bytes (the shim checks the `-ts` proportions once per job: row
+// ranges computed from different proportions would exchange the wrong rows without any error), 1 otherwise
+int ggml_hip_split_comm_agree(ggml_hip_split_comm * c, const void * bytes, size_t n) {
+    if (!c || c->world == 1 || n == 0) return 0;
+    hipStream_t st = fq_ctx().stream;
+    uint8_t * dev = nullptr;
+    HIP_CHECK(hipMalloc((void **) &dev, n * (size_t)(c->world + 1)));
+    HIP_CHECK(hipMemcpyAsync(dev, bytes, n, hipMemcpyHostToDevice, st));
+    RCCL_CHECK(fq_rccl()->ncclAllGather(dev, dev + n, n, ncclUint8, c->comm, st));
+    std::vector<uint8_t> all(n * (size_t) c->world);
+    HIP_CHECK(hipMemcpyAsync(all.data(), dev + n, all.size(), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(dev));
+    for (int r = 0; r < c->world; ++r) if (memcmp(all.data() + n * (size_t) r, bytes, n) != 0) return 1;
+    return 0;
+}
+
 // dst[N][M] (row-major by token, ldd = M) = the unsplit mat-mul, on EVERY rank: this rank computes rows [row_low[rank],
 // row_high[rank]) with its part `w_rows` (nullptr for an empty range), then the ranks exchange their rows. row_low / row_high:
 // world entries (ggml_hip_tensor_split_rows). Returns 0. Synchronous like ggml_hip_mul_mat_q.

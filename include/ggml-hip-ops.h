@@ -50,12 +50,15 @@ int     ggml_hip_get_reference_order(void);
 typedef struct ggml_hip_split_comm ggml_hip_split_comm;
 /* joins this process to a row-split job at the ggml-cuda.h boundary: from now on ggml_cuda_transform_tensor uploads this
  * rank's rows of GGML_BACKEND_GPU_SPLIT tensors (proportions: ggml_cuda_set_tensor_split) and their mat-muls inside
- * ggml_cuda_compute_forward exchange rows by RCCL. world <= 1 leaves / restores the default (whole matrices). Returns 0. */
+ * ggml_cuda_compute_forward exchange rows by RCCL. world <= 1 leaves / restores the default (whole matrices). Returns 0; 1 (nothing changed)
+ * while split tensors uploaded under the current job are still alive. */
 int     ggml_hip_split_configure(int rank, int world, const void * unique_id);
 void    ggml_hip_tensor_split_rows(const float * tensor_split, int n_devices, int64_t nrows, int64_t * row_low, int64_t * row_high);
 ggml_hip_weight * ggml_hip_weight_upload_rows(int type, const void * host_blocks, int64_t K, int64_t nrows, int64_t row_low, int64_t row_high);
 ggml_hip_split_comm * ggml_hip_split_comm_create(int rank, int world, const void * unique_id);
 void    ggml_hip_split_comm_free(ggml_hip_split_comm * c);
+/* collective: 0 when every rank passed the same n bytes (the shim checks the -ts proportions with it once per job), 1 otherwise */
+int     ggml_hip_split_comm_agree(ggml_hip_split_comm * c, const void * bytes, size_t n);
 int     ggml_hip_mul_mat_q_split(ggml_hip_split_comm * c, const ggml_hip_weight * w_rows, const float * x_dev, int64_t K, int64_t N,
                                  float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
 int     ggml_hip_mul_mat_q_split_local(ggml_hip_weight * const * parts, int world, const float * x_dev, int64_t K, int64_t N,

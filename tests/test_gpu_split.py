@@ -47,6 +47,8 @@ def test_row_split_equals_unsplit(oracle, ts, t, N):
     y1 = g.DevBuf(N * M * 4)
     assert L.ggml_hip_mul_mat_q_split(comm, whole.h, xd.ptr, K, N, y1.ptr, M, one_lo, one_hi) == 0
     got1 = y1.to_host(np.float32, (N, M))
+    ts_bytes = (C.c_float * n)(*ts)
+    assert L.ggml_hip_split_comm_agree(comm, ts_bytes, 4 * n) == 0      # one rank agrees with itself
     L.ggml_hip_split_comm_free(comm)
     for r in range(n):
         if parts[r]:
