@@ -135,6 +135,7 @@ static float dot_f32(const float * a, const float * b, int64_t n, int64_t stride
  * eight partial sums are added as ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)). V.P: one chain per class j mod 16 over
  * increasing j, the 16 classes added in order. Selected by orc_set_sum_order(2) ("as the backend"). */
 int orc_attn_backend_order(void);
+int orc_backend_batch(void);      /* > 0: the rows at hand stand for a batch of this many tokens (oracle_quants.c) */
 static float dot_qk_backend(const float * k, const float * q) {
     float part[8];
     for (int s = 0; s < 8; ++s) {
@@ -283,7 +284,7 @@ static void * att_worker(void * arg) {
     const int group = (int)(H / HKV);
     const float kq_scale = 1.0f / sqrtf((float) D);
     const int backend_attn = orc_attn_backend_order() && D == 64;
-    const int mfma_attn = backend_attn && j->N >= ORC_ATTN_MFMA_MIN_N;
+    const int mfma_attn = backend_attn && (orc_backend_batch() > 0 ? orc_backend_batch() : j->N) >= ORC_ATTN_MFMA_MIN_N;
     float * p = (float *) malloc(sizeof(float) * (size_t)(j->pos0 + j->N));
     for (int64_t w = j->ith; w < (int64_t) j->ns * H; w += j->nth) {
         const int si = (int)(w / H), h = (int)(w % H), hk = h / group;

@@ -382,6 +382,11 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
  * columns, order 2 for GEMMs. mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
  * legacy formats' reference order; for the k-quants one d * isum - dmin * msum term per super-block, left to right). */
 static int g_split = 4;
+/* mode 2 only: > 0 = decide as if the mat-mul had this many columns (the sampled-token checks evaluate a few tokens OF a batch:
+ * the backend chose its order for the whole batch) */
+static int g_backend_batch = 0;
+void orc_set_backend_batch(int n) { g_backend_batch = n > 0 ? n : 0; }
+int  orc_backend_batch(void) { return g_backend_batch; }
 int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 = "as the backend" for the attention too */
 void orc_set_sum_order(int mode) {
     g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4 || mode == 5) ? 2 : 0);
@@ -624,7 +629,7 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
                    float * dst, int n_threads, int flavour) {
     const int at = orc_vec_dot_type(wtype);
     const size_t act_row = orc_row_bytes(at, K);
-    if (g_sum_mode == 2) { g_sum_order = (N <= 4) ? 1 : 2; g_split = (((M + 31) / 32) * ((N + 31) / 32) < 4 * 256) ? 4 : 2; }
+    if (g_sum_mode == 2) { const int64_t Nb = g_backend_batch > 0 ? g_backend_batch : N; g_sum_order = (Nb <= 4) ? 1 : 2; g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2; }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
     /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */
     for (int64_t n = 0; n < N; ++n) orc_quantize_act(at, x + n * K, act + (size_t) n * act_row, K, flavour);

@@ -113,15 +113,14 @@ def test_config2_falcon7b_q4_0_full_depth(oracle):
     lg_d = np.stack(lg_d)
     mo = oracle.model(w, 8)
     sp, sd = [0, 63, 127], [0, 1, 64, 127]
-    modes = {gemm_split(M, NP) for M in ((hp["n_head"] + 2 * hp["n_head_kv"]) * 64, hp["n_embd"], hp["n_ff"])}
-    assert len(modes) == 1
-    gmode = modes.pop()
+    # at 128 columns the mat-muls of a block do not share one K split (Wup's 568 x 4 tiles get two partial sums, the others
+    # four): mode 2 decides per mat-mul like the backend, told that the sampled rows stand for a batch of NP
     try:
         for il in range(L):
-            oracle.lib.orc_set_sum_order(gmode)
+            oracle.lib.orc_set_sum_order(2); oracle.lib.orc_set_backend_batch(NP)
             out, ko, vo = mo.block_sampled(oracle.lib, il, hid_p[il], sp, n_threads=NT, want_kv=True)
             assert np.array_equal(out, hid_p[il + 1][sp]), "prompt, block %d" % il
-            oracle.lib.orc_set_sum_order(1)
+            oracle.lib.orc_set_backend_batch(1)             # decode steps: one column each (wave order, the decode attention's chains)
             out = mo.block_sampled(oracle.lib, il, hid_d[il], sd, pos0=NP, k_prev=ko, v_prev=vo, n_threads=NT)
             assert np.array_equal(out, hid_d[il + 1][sd]), "decode, block %d" % il
         oracle.lib.orc_set_sum_order(gemm_split(hp["n_vocab"], NP))
@@ -129,7 +128,7 @@ def test_config2_falcon7b_q4_0_full_depth(oracle):
         oracle.lib.orc_set_sum_order(1)
         assert np.array_equal(mo.head_rows(oracle.lib, hid_d[L][sd], n_threads=NT), lg_d[sd])
     finally:
-        oracle.lib.orc_set_sum_order(0)
+        oracle.lib.orc_set_sum_order(0); oracle.lib.orc_set_backend_batch(0)
 
 
 def test_config4_falcon40b_q5_1_two_stages(oracle):
