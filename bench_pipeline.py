@@ -319,7 +319,7 @@ def main(a, rank, world, local):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side control only (id hand-out, barrier, max over ranks); the data path is RCCL inside libggml_hip.so
-    batch = max(1, min(int(getattr(a, "pipe_batch", 4)), 64))
+    batch = max(1, min(int(getattr(a, "pipe_batch", 4)), 256))
     groups = max(2 * world, 2) if world > 1 else max(1, getattr(a, "streams", 2))
     n_ctx = min(a.n_ctx, 512)
     if a.warmup + a.steps + 1 > n_ctx:

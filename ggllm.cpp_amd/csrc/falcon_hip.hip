@@ -316,7 +316,7 @@ extern "C" falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, 
     return context_create(m, n_ctx, n_batch, rope_n_ctx, 0);
 }
 extern "C" falcon_hip_context * falcon_hip_context_create_seqs(falcon_hip_model * m, int n_ctx, int n_seq, int rope_n_ctx) {
-    if (n_seq < 1 || n_seq > 64) { fprintf(stderr, "falcon-hip: a lock-step context holds 1..64 sequences, not %d\n", n_seq); return nullptr; }
+    if (n_seq < 1 || n_seq > 256) { fprintf(stderr, "falcon-hip: a lock-step context holds 1..256 sequences, not %d\n", n_seq); return nullptr; }
     return context_create(m, n_ctx, n_seq, rope_n_ctx, n_seq > 1 ? n_seq : 0);
 }
 extern "C" int falcon_hip_context_n_seq(const falcon_hip_context * c) { return c->n_seq > 0 ? c->n_seq : 1; }
@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
 
 // ------------------------------------------------------------------------------------------------ pipeline step
 __global__ void k_set_i32(int * p, int v) { *p = v; }
-__global__ void k_copy_i32(int32_t * dst, const int32_t * src, int n = 1) { if ((int) threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
+__global__ void k_copy_i32(int32_t * dst, const int32_t * src, int n = 1) { for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i]; }
 // greedy sample of every row of a lock-step step: token[row] = argmax(logits[row]), lowest index on ties (as k_argmax_advance)
 __global__ void __launch_bounds__(1024) k_argmax_rows(const float * __restrict__ logits, int n, int32_t * __restrict__ token) {
     __shared__ float bv[16];

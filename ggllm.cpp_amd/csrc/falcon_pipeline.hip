@@ -151,7 +151,7 @@ void exchange_rccl(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st)
 }
 
 falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx) {
-    if (!m || world < 1 || rank < 0 || rank >= world || n_groups < 1 || batch < 1 || batch > 64 || n_ctx < 1) {
+    if (!m || world < 1 || rank < 0 || rank >= world || n_groups < 1 || batch < 1 || batch > 256 || n_ctx < 1) {
         fprintf(stderr, "falcon-hip: pipeline: bad arguments (rank %d of %d, %d groups of %d sequences, n_ctx %d)\n", rank, world, n_groups, batch, n_ctx);
         return nullptr;
     }

@@ -613,7 +613,13 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
     const size_t lds_group = (attn_decode_lds(max_n_kv) + 15) & ~(size_t) 15;
     const size_t lds_mv = fq_act_col_bytes(act, g.w_down.K) + fq_act_col_bytes(act, g.w_wo.K) + (g.att_image ? 0 : (size_t) g.w_wo.K * 4) + 16;
     size_t lds = lds_group * hpw > lds_mv ? lds_group * hpw : lds_mv;
-    if (n_attn + n_mv > n_cu || lds > 160 * 1024) return false;
+    // more workgroups than CUs (Falcon-40B width: 64 + 342): only with FQ_ATTN_OUT_ROUNDS=2 -- the attention workgroups are the
+    // PREFIX of the grid, the dispatcher places workgroups in index order, so every producer is resident before any consumer
+    // spins on it and the second round of mat-vec workgroups follows as the first retires (measured against the three-launch
+    // form, DESIGN "Falcon-40B width")
+    static const int rounds = getenv("FQ_ATTN_OUT_ROUNDS") ? atoi(getenv("FQ_ATTN_OUT_ROUNDS")) : 1;
+    if (lds > 160 * 1024) return false;
+    if (n_attn + n_mv > n_cu && !(rounds >= 2 && !ln && n_attn <= n_cu / 2 && n_attn + n_mv <= 2 * n_cu)) return false;
     fq_attn_out_args a{};
     a.g = g;
     a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, const_cast<float *>(g.att_image ? nullptr : g.att),

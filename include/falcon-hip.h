@@ -75,7 +75,7 @@ void falcon_hip_model_get_hparams(const falcon_hip_model * m, falcon_hip_hparams
  * (n_max_real_ctx or n_ctx, libfalcon.cpp:2229-2230)                                                           */
 falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx);
 void                 falcon_hip_context_free(falcon_hip_context * c);
-/* A context of n_seq (1..64) independent sequences that advance in LOCK STEP: every falcon_hip_eval_stage / falcon_hip_stage_step
+/* A context of n_seq (1..256) independent sequences that advance in LOCK STEP: every falcon_hip_eval_stage / falcon_hip_stage_step
  * evaluates n_seq rows = one token of each sequence, all at position n_past, row t attending to its own KV cache. One pass
  * over the weights serves n_seq tokens (n_seq <= 4: the same mat-vec, the same bits per sequence as a context of its own).
  * token_dev / next_token_dev of falcon_hip_stage_step then hold n_seq ids, the hidden rows are [n_seq][n_embd].          */

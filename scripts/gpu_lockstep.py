@@ -8,9 +8,9 @@ from ggllm_cpp_amd import synth
 g.init(0); L = g.load()
 hp = dict(synth.HP_7B)
 w = synth.make_model_fast(hp, g.Q4_0, seed=1234)
-model = g.FalconModel(w, n_ctx=512, n_batch=64)
+model = g.FalconModel(w, n_ctx=512, n_batch=256)
 for B in [int(x) for x in sys.argv[1:]] or [4, 8, 16]:
-    G, R = 2, 48
+    G, R = 2, 32
     pipe = g.Pipeline(model, 0, 1, G, B, 512)
     pipe.set_tokens(synth.tokens(G * B, hp["n_vocab"], seed=42))
     pipe.run(8, 0)

@@ -1,6 +1,12 @@
 #!/bin/bash
 # One gpurun call of a round: every -m gpu test, smoke, the bench line the driver reads; optionally rocprofv3 kernel trace + PMC passes.
-# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|all ...]
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|all ...]
+#   prof         rocprofv3 kernel trace of the decode bench             -> <tag>/decode_7b_q4_0_kernel_stats.{csv,md}
+#   pmc          FETCH_SIZE / WRITE_SIZE passes (HBM traffic per launch)  -> <tag>/pmc_traffic.json
+#   mfma         SQ matrix-pipe / VALU counters (decode + 128- and 2048-token prefill in one run) -> <tag>/pmc_mfma.json
+#   prefill2048  kernel trace of a 2048-token prompt                     -> <tag>/prefill2048_7b_q4_0_kernel_stats.{csv,md}
+#   b40          Falcon-40B Q4_K, all 60 blocks, one GPU: bench line + kernel trace -> <tag>/bench_40b_q4_k.json, <tag>/decode_40b_q4_k_kernel_stats.{csv,md}
+#   lockstep     kernel trace of 16 lock-step streams per weight pass    -> <tag>/lockstep_b16_kernel_stats.{csv,md}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD
@@ -39,5 +45,36 @@ if has pmc; then
   fdb=$(find $OUT/pmc -name "fetch*results.db" | head -1); wdb=$(find $OUT/pmc -name "write*results.db" | head -1)
   python scripts/pmc_summary.py $fdb $wdb $OUT/pmc_traffic.json > $OUT/pmc_summary.log 2>&1; tail -5 $OUT/pmc_summary.log
   find $OUT/pmc -name "*.db" -delete
+fi
+trace() {   # trace <name> <command...>: kernel trace -> $OUT/<name>_kernel_stats.{csv,md}
+  local name=$1; shift
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$name -o trace -- "$@" > $R/$OUT/prof_$name.log 2>&1
+  echo "rocprof $name exit $?" | tee -a $R/$OUT/summary.txt
+  cd $R
+  local db=$(find $OUT/prof_$name -name "*results.db" | head -1)
+  [ -n "$db" ] && python scripts/prof_summary.py $db $OUT/$name > /dev/null 2>&1 && head -10 $OUT/${name}_kernel_stats.md | cut -c1-170
+  rm -rf $OUT/prof_$name
+}
+if has mfma; then
+  mkdir -p $OUT/pmc
+  cd /tmp
+  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc -o mfma -- python $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu --no-graph --no-north-star --no-lock-step --no-cli > $R/$OUT/pmc/mfma.log 2>&1
+  echo "mfma counters exit $?" | tee -a $R/$OUT/summary.txt
+  cd $R
+  mdb=$(find $OUT/pmc -name "mfma*results.db" | head -1)
+  python scripts/pmc_mfma_summary.py $mdb $OUT/pmc_mfma.json > $OUT/pmc_mfma_summary.log 2>&1; tail -6 $OUT/pmc_mfma_summary.log
+  find $OUT/pmc -name "*.db" -delete
+fi
+if has prefill2048; then
+  trace prefill2048_7b_q4_0 python $R/bench.py --prompt 2048 --n-ctx 4096 --steps 8 --warmup 2 --repeats 1 --no-cpu --no-north-star --no-lock-step --no-cli --prefill-long 0
+fi
+if has b40; then
+  timeout 900 python bench.py --model 40b --quant q4_k --no-cpu --no-cli --no-lock-step --no-north-star --prefill-long 0 --steps 32 --warmup 4 --repeats 1 > $OUT/bench_40b_q4_k.json 2> $OUT/bench_40b.err; echo "bench 40b exit $?" | tee -a $OUT/summary.txt
+  python scripts/bench_brief.py < $OUT/bench_40b_q4_k.json
+  trace decode_40b_q4_k python $R/bench.py --model 40b --quant q4_k --layers 12 --no-cpu --no-cli --no-graph --no-lock-step --no-north-star --prefill-long 0 --steps 16 --warmup 2 --repeats 1
+fi
+if has lockstep; then
+  FALCON_HIP_STAGE_GRAPH=0 trace lockstep_b16 python $R/bench.py --force-pipeline --streams 1 --pipe-batch 16 --steps 16 --warmup 4 --no-cpu --no-cli
 fi
 cat $OUT/summary.txt

@@ -7,8 +7,16 @@ import json, sqlite3, sys
 from collections import defaultdict
 c = sqlite3.connect(sys.argv[1]).cursor()
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-for name, counter, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
+try:        # per launch shape when the view carries the grid (the 128- and 2048-token prompts launch the same GEMM templates)
+    rows = list(c.execute("select kernel_name, counter_name, value, grid_size_x, grid_size_y from counters_collection"))
+except sqlite3.OperationalError:
+    try:
+        rows = [(a, b, v, gx, 0) for a, b, v, gx in c.execute("select kernel_name, counter_name, value, grid_size from counters_collection")]
+    except sqlite3.OperationalError:
+        rows = [(a, b, v, None, None) for a, b, v in c.execute("select kernel_name, counter_name, value from counters_collection")]
+for name, counter, val, gx, gy in rows:
     k = name.split("(")[0].replace("void ", "")
+    if gx is not None and k.startswith(("k_gemm", "k_attention")): k += " grid %sx%s" % (gx, gy)
     acc[k][counter][0] += 1; acc[k][counter][1] += val
 out = {}
 for k, d in acc.items():

@@ -101,6 +101,30 @@ def test_cpp_pipeline_reproduces_single_process_greedy_decode(oracle, hp, t, wor
     assert np.array_equal(got, want)
 
 
+def test_lock_step_groups_beyond_64_sequences(oracle):
+    """80 sequences per weight pass (the int8-MFMA tile GEMM's range): every sequence reads its own token id and KV cache -- 80
+    streams started from 5 distinct tokens fall into 5 classes of identical streams (a row of the mat-mul does not depend on the
+    other rows), each the stream of a 16-sequence pass started from the same token"""
+    hp, w = _model(oracle, synth.HP_TINY_GQA, ob.Q4_0, 2)
+    m = g.FalconModel(w, n_ctx=16, n_batch=128)
+    first5 = synth.tokens(5, hp["n_vocab"], seed=21)
+    B = 80
+    first = np.array([first5[b % 5] for b in range(B)], np.int32)
+    p = g.Pipeline(m, 0, 1, 1, B, 16)
+    p.set_tokens(first)
+    p.run(6, 0)
+    got = p.history(0, 6)                                    # [round][sequence]
+    p.free()
+    q = g.Pipeline(m, 0, 1, 1, 20, 16)                       # 20 > 16 columns: the same mat-mul kernel, the same per-row arithmetic
+    q.set_tokens(first[:20])
+    q.run(6, 0)
+    want = q.history(0, 6)
+    q.free()
+    m.free()
+    for b in range(B):
+        assert np.array_equal(got[:, b], want[:, b % 5]), b
+
+
 def test_cpp_pipeline_world_1_run_without_rccl(oracle):
     """falcon_hip_pipeline_create with world 1 needs no communicator: falcon_hip_pipeline_run advances groups x batch
     sequences on one GPU (what bench.py --force-pipeline times)"""
