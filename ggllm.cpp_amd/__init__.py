@@ -390,7 +390,7 @@ class FalconModel:
         return nll.value, n
 
     def set_fused(self, mode):
-        """0 = op list, 1 = three launches per block, 2 (True) = two (default), 3 = one launch per block, 4 = persistent engine"""
+        """0 = op list, 1 = three launches per block, 2 (True) = two (default), 3 = one launch per block, 4 = persistent engine, 5 = two launches, ring form"""
         load().falcon_hip_context_set_fused(self.ctx, 2 if mode is True else int(mode))
 
     def engine_active(self):

@@ -95,6 +95,7 @@ struct falcon_hip_context {
     const void * sg_in[2] = { nullptr, nullptr }; void * sg_out[2] = { nullptr, nullptr };
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
+    bool ring_ln = false;                      // FALCON_HIP_RING=1: k_gemv_ln's launches in the ring form (kernels_ring.hip)
     int  graph_base = -1;                      // n_past the captured graph was built for
     int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
     unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
@@ -307,6 +308,8 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     HIP_CHECK(hipMemset(c->x_gran, 0, (size_t) hp.n_embd * 8 + 64));
     if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
+    if (const char * e = getenv("FALCON_HIP_RING")) c->ring_ln = atoi(e) != 0;
+    if (c->ring_ln && nl > 0) c->ring_ln = fq_ring_prepare(m->layers[0].qkv.type, E, FF, m->layers[0].qkv.M, fq_ctx().n_cu);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
@@ -358,6 +361,9 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     c->merged_attn_out = mode >= 2;
     c->two_phase = mode == 3;
     c->engine = mode == 4;
+    // 5 = two launches per block, the LayerNorm mat-vec launch in the ring form (kernels_ring.hip; FALCON_HIP_RING=1 selects it at creation)
+    c->ring_ln = mode == 5 && !c->m->layers.empty() &&
+                 fq_ring_prepare(c->m->layers[0].qkv.type, c->m->hp.n_embd, c->m->hp.n_ff, c->m->layers[0].qkv.M, fq_ctx().n_cu);
 }
 // 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)
 extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c);
@@ -558,7 +564,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 fq_launch_gemv_ln(gq, hc.n_cu, st);
             } else if (!ln_done) {
                 if (prof) fq_prof_open(st);
-                fq_launch_gemv_ln(ga, hc.n_cu, st);
+                if (!(c->ring_ln && quant_epi && fq_launch_gemv_ln_ring(ga, c->sync_words + 1, hc.n_cu, st))) fq_launch_gemv_ln(ga, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
                 if (!quant_epi) fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st);
             }

@@ -117,6 +117,11 @@ void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, 
                                   float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
                                   int att_act_type, int64_t image_stride, hipStream_t st);
 
+// kernels_ring.hip -- the ring form of k_gemv_ln's launch (LDS-DMA loader wave + consumers out of an LDS ring, one workgroup per CU);
+// false = outside its scope, nothing launched. fq_ring_prepare: builds the shape's schedule (allocates: not inside a stream capture)
+bool   fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu);
+bool   fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st);
+
 // kernels_cols.hip -- the two mat-vec launches of a block for 2..4 lock-step sequences (one weight pass serves all columns)
 struct fq_gemv_cols_seg {
     fq_weight       w;

@@ -1,0 +1,31 @@
+"""tuning aid (GPU): phase timeline of the ring-form decode launch (k_gemv_ln_ring), medians over the workgroups"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ggllm_cpp_amd as g
+from ggllm_cpp_amd import synth
+g.init(0); L = g.load()
+hp = dict(synth.HP_7B); hp["n_layer"] = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+w = synth.make_model_fast(hp, g.Q4_0)
+m = g.FalconModel(w, n_ctx=512, n_batch=8)
+m.set_fused(5)
+toks = synth.tokens(8, hp["n_vocab"])
+m.eval(toks, 0)
+out = m.decode_greedy(1, 8, 150)
+L.ggml_hip_debug_stamps(1, None)
+m.decode_greedy(int(out[-1]), 158, 4)
+st = np.zeros(2 * 4096 * 8, np.int64)
+L.ggml_hip_debug_stamps(1, st.ctypes.data)
+st = st.reshape(2, 4096, 8)[0].astype(np.float64)
+t0 = st[:256, 0].min()
+names = {(0, 0): "workgroup starts", (0, 1): "loader starts", (0, 2): "last piece issued", (0, 3): "all landed",
+         (1, 1): "epilogue wave: mean known", (1, 2): "epilogue wave: image done", (1, 3): "epilogue wave: epilogues done",
+         (2, 1): "consumer 0: mean known", (2, 2): "consumer 0: image done", (2, 3): "consumer 0: qkv rows done", (2, 4): "consumer 0: up rows done",
+         (3, 3): "consumer 9: qkv rows done", (3, 4): "consumer 9: up rows done"}
+for (role, slot), nm in names.items():
+    v = st[role * 256:(role + 1) * 256, slot]
+    v = (v[v > 0] - t0) / 100.0
+    if len(v):
+        print("%-34s med %6.2f us   p10 %6.2f  p90 %6.2f  max %6.2f   (%d workgroups)" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), v.max(), len(v)))
+m.free()
