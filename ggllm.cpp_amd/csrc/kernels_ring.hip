@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
     auto rows_e = [&](unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, auto && sink) {
-        if ((unsigned)(2 * ENG_NC) * rsE * 2u <= (unsigned) RING) rows(R2, seg_pos, padded, nrows, col, sink);
+        if (!(a.debug_mode & 16) && (unsigned)(2 * ENG_NC) * rsE * 2u <= (unsigned) RING) rows(R2, seg_pos, padded, nrows, col, sink);
         else                                                       rows(R1, seg_pos, padded, nrows, col, sink);
     };
     rows_e(0u, pA1, nA1, a.two_norms ? col_e2 : col_e, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
