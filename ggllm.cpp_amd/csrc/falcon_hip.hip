@@ -77,7 +77,7 @@ struct falcon_hip_context {
     bool dual_stream = false;
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join, ev_attn;  // per local layer (dual-stream decode; two-branch prefill: fork, MLP branch done, attention branch done)
-    int  par2_max_n = 1 << 30;                  // batches of 5 .. par2_max_n tokens run a block's attention and MLP branches on two streams (FALCON_HIP_PAR2_MAX_N; 0: never)
+    int  par2_max_n = 1 << 30;                  // batches of 33 .. par2_max_n tokens run a block's attention and MLP branches on two streams (FALCON_HIP_PAR2_MAX_N; 0: never). Up to 32 columns the streaming mat-mul fills every CU by itself (16 tokens: 4.14 ms in stream order against 4.63 forked)
     bool fused_decode = true;                  // N == 1: k_gemv_ln / k_attn_decode / k_gemv_out instead of the op-by-op list
     bool merged_attn_out = true;               // ... with attention and the output mat-vec in one launch (k_attn_out) when the grid fits the chip
     // ... and the next block's k_gemv_ln as a second phase of that launch (k_attn_out_ln): one launch per block. Measured on
@@ -669,7 +669,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // epilogue adds Wo's result and the residual) after the attention branch. Same kernels, same bits. Measured in one
         // process on the same resident Falcon-7B Q4_0 (scripts/gpu_par2_ab.py), one stream -> two branches: 16 tokens 8.66 -> 7.83
         // ms, 32: 9.17 -> 8.13, 128: 9.41 -> 8.82, 512: 26.75 -> 24.59, 1024: 49.3 -> 47.3, 2048: 104.9 -> 101.7.
-        const bool par2 = !cols_path && !seq_stride && N > 4 && N <= c->par2_max_n && !fq_prof_active() && !fq_ctx().dbg_stamps;
+        const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
             HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));

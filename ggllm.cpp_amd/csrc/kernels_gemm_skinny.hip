@@ -20,6 +20,7 @@
 // Scope: the legacy formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0); k-quants keep kernels_gemm.hip.
 #include "fq_block_dev.h"
 #include "kernels.h"
+#include "hip_context.h"
 
 typedef int  sk_v4i __attribute__((ext_vector_type(4)));
 typedef int  sk_v2i __attribute__((ext_vector_type(2)));
@@ -321,10 +322,284 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny(fq_weight w, f
     }
 }
 
+// =============================================================================================== resident columns, persistent workgroups
+// The same arithmetic with the N activation columns RESIDENT in LDS for the whole launch (K <= ~4.6 k: the quants of 16 columns are 73 KiB,
+// their scales transposed once) and one workgroup per CU that walks its 32-row pairs with the weight pipeline running across pair
+// boundaries: no per-stage column DMA (the largest single cost of the form above, and it ADDS to the rest), no per-stage transposition,
+// one barrier per stage, no pipeline fill per 32 rows. The S partial sums of a pair meet through LDS at the next stage's barrier.
+template <int TYPE> struct sk_res {
+    typedef sk_fmt<TYPE> F;
+    static constexpr int NBW = 3;
+    static __host__ __device__ int tqs(int nblk) { const int q = nblk * 32; return q + ((16 - (q & 255)) & 255); }      // column stride: = 16 mod 256 -> the 16 columns' operand reads fall into distinct banks
+    static __host__ __device__ size_t lds(int nblk, int S) {
+        return (size_t) NBW * SK_TM * F::ROWB + (size_t) SK_TN * tqs(nblk) + 2 * (size_t) nblk * SK_TN * 4 + (S > 1 ? 2 * (size_t)(S - 1) * 2 * 64 * 16 : 0);
+    }
+};
+
+template <int TYPE, int S>
+__global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight w, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef sk_fmt<TYPE> F;
+    constexpr int ACT = fq_act_of(TYPE);
+    constexpr int NCW = 2 * S, NBW = sk_res<TYPE>::NBW, NLW = 2;
+    constexpr int WSTAGE = SK_TM * F::ROWB;
+    constexpr int WOPS = (F::NL + 63) / 64;
+    constexpr int LOPS = 16 * WOPS;
+    static_assert(LOPS <= 63, "vmcnt range");
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nblk = (int) w.nblk;
+    const int nstages = (nblk + SK_GS - 1) / SK_GS;
+    const int npairs = (int)((M + SK_TM - 1) / SK_TM);
+    const int mine = ((int) blockIdx.x < npairs) ? (npairs - 1 - (int) blockIdx.x) / (int) gridDim.x + 1 : 0;      // pairs blockIdx.x, + gridDim.x, ..
+    const int nq = mine * nstages;                                         // stages this workgroup runs
+    const size_t img = fq_act_col_bytes(ACT, K);
+    const int TQS = sk_res<TYPE>::tqs(nblk);
+    uint8_t * tqb0 = smem + (size_t) NBW * WSTAGE;                         // [16 columns][TQS]: the quants
+    uint8_t * dxT  = tqb0 + (size_t) SK_TN * TQS;                          // [nblk][16] f32: the columns' d
+    uint8_t * ciT  = dxT + (size_t) nblk * SK_TN * 4;                      // [nblk][16]: C start values (int) or the columns' s (f32)
+    float   * xch  = (float *)(ciT + (size_t) nblk * SK_TN * 4);           // [2][S - 1][tile][lane][4]: partial sums of a finished pair
+    auto wbuf = [&](int q) { return smem + (size_t)(q % NBW) * WSTAGE; };
+
+    auto issue_weights = [&](int q, int lw) {                                // stage q = (pair q / nstages, blocks [32 s, 32 s + 32)); loader wave lw: rows 16 lw ..
+        const int s = q % nstages;
+        const int64_t m0 = (int64_t)(blockIdx.x + (q / nstages) * gridDim.x) * SK_TM;
+        const int c = s / F::SPC, hf = s % F::SPC;
+        const int rem = nblk - F::CB * c, nbc = rem < F::CB ? rem : F::CB;
+        const unsigned colb = (unsigned) c * (unsigned)(F::CB * F::D.tsize);
+        auto src_of = [&](int l) {
+            const int p = 16 * l;
+            unsigned o;
+            if (p < SK_GS * F::QB)                   o = colb + (unsigned)(SK_GS * hf * F::QB + p);
+            else if (p < SK_GS * (F::QB + F::PB1))   o = colb + (unsigned)(nbc * F::QB + SK_GS * hf * F::PB1 + (p - SK_GS * F::QB));
+            else                                     o = colb + (unsigned)(((nbc * (F::QB + F::PB1)) & ~15) + SK_GS * hf * F::PB2 + (p - SK_GS * (F::QB + F::PB1)));
+            return o;
+        };
+        const unsigned v0 = src_of(lane), v1 = src_of(lane + 64 < F::NL ? lane + 64 : F::NL - 1);
+        const unsigned wb = __builtin_amdgcn_readfirstlane(sk_lds(wbuf(q)));
+        if (m0 + SK_TM <= M) {
+            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) m0 * w.row_stride);
+            const unsigned rs = (unsigned) w.row_stride;
+            sk_voff16 o;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o.v[i] = v0 + (unsigned)(16 * lw + i) * rs;
+            unsigned ml = wb + (unsigned)(16 * lw * F::ROWB);
+            if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma16(base, o, ml, (unsigned) F::ROWB);
+            if constexpr (WOPS > 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o.v[i] = v1 + (unsigned)(16 * lw + i) * rs;
+                unsigned ml2 = wb + (unsigned)(16 * lw * F::ROWB + 1024);
+                if (lane + 64 < F::NL) sk_dma16(base, o, ml2, (unsigned) F::ROWB);
+            }
+            return;
+        }
+        for (int r = 16 * lw; r < 16 * lw + 16; ++r) {                     // the matrix's last, partial pair: rows beyond M re-read row M - 1
+            const int64_t row = m0 + r < M ? m0 + r : M - 1;
+            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) row * w.row_stride);
+            if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma(base, v0, wb + (unsigned)(r * F::ROWB));
+            if constexpr (WOPS > 1) { if (lane + 64 < F::NL) sk_dma(base, v1, wb + (unsigned)(r * F::ROWB + 1024)); }
+        }
+    };
+
+    const bool loader = wid < NLW;
+    const int cw = wid - NLW, tile = cw & 1, sw = cw >> 1;
+    const int l16 = lane & 15, kq = lane >> 4;
+    if (nq == 0) return;
+
+    // ---- prologue: the loaders start the weight pipeline; the consumers bring in the columns (quants by DMA, 1 KiB per instruction) and
+    // write the transposed scales
+    if (loader) { for (int q = 0; q < NBW - 1 && q < nq; ++q) if (!(dbg & 8)) issue_weights(q, wid); }
+    else {
+        const unsigned last = (unsigned)(img - 16);
+        const int kbytes = nblk * 32;
+        for (int t = cw; t < SK_TN; t += NCW) {
+            const uint8_t * base = act.base + (size_t)(t < N ? t : N - 1) * img;
+            const unsigned tb = sk_lds(tqb0) + (unsigned)(t * TQS);
+            for (int o = 0; o < kbytes; o += 1024) {
+                unsigned vq = (unsigned)(o + 16 * lane);
+                vq = vq < last ? vq : last;
+                if (o + 16 * lane < kbytes && !(dbg & 4)) sk_dma(base, vq, tb + (unsigned) o);
+            }
+        }
+        const size_t nd4 = fq_act_d_elems(ACT, K) * 4;
+        for (int e = cw * 64 + lane; e < nblk * SK_TN; e += NCW * 64) {
+            const int gi = e >> 4, tok = e & 15;
+            const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img + (size_t) K;
+            const float d = ((const float *) tp)[gi];
+            const uint32_t aux = ((const uint32_t *)(tp + nd4))[gi];
+            ((float *) dxT)[e] = d;
+            uint32_t cv;
+            if constexpr (TYPE == FQ_Q4_0)      cv = (uint32_t)(-8 * (int32_t) aux);         // sum (nib - 8) x = sum nib x - 8 sum x
+            else if constexpr (TYPE == FQ_Q5_0) cv = (uint32_t)(-16 * (int32_t) aux);
+            else if constexpr (F::HAS_MIN)      cv = aux;                                       // y.s (f32)
+            else                                cv = 0u;
+            ((uint32_t *) ciT)[e] = cv;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's column DMA has landed (the first barrier publishes it)
+    }
+
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, fin[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    // the pair whose last stage ran before the barrier just passed: its partial sums are in xch (and fin): sum, epilogue, store
+    auto finish_pair = [&](int i) {
+        if (sw != 0) return;
+        if constexpr (S > 1) {
+            const float * xb = xch + (size_t)(i & 1) * (S - 1) * 2 * 64 * 4;
+#pragma unroll
+            for (int r = 1; r < S; ++r) {                                   // ((P0 + P1) + P2) + P3
+                const float4 p = *(const float4 *)(xb + ((size_t)((r - 1) * 2 + tile) * 64 + lane) * 4);
+                fin[0] = fin[0] + p.x; fin[1] = fin[1] + p.y; fin[2] = fin[2] + p.z; fin[3] = fin[3] + p.w;
+            }
+        }
+        const int64_t m = (int64_t)(blockIdx.x + i * gridDim.x) * SK_TM + 16 * tile + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 4 * kq + r;
+            if (n < N && m < M) {
+                float v = fin[r];
+                if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+                else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+                dst[n * ldd + m] = v;
+            }
+        }
+    };
+
+    for (int q = 0; q < nq; ++q) {
+        const int s = q % nstages, i = q / nstages;
+        if (loader) {
+            const int ahead = nq - 1 - q < NBW - 2 ? nq - 1 - q : NBW - 2;  // later stages already issued
+            if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOPS) : "memory");
+            else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                                   // stage q has landed; nobody reads stage q - 1 any more; the previous pair's partial sums are written
+        if (loader) { if (q + NBW - 1 < nq && !(dbg & 8)) issue_weights(q + NBW - 1, wid); continue; }
+        if (s == 0 && i > 0) finish_pair(i - 1);
+        const uint8_t * W = wbuf(q);
+        const int ng = nblk - SK_GS * s < SK_GS ? nblk - SK_GS * s : SK_GS;
+        const int cst = s / F::SPC, remc = nblk - F::CB * cst, nbcs = remc < F::CB ? remc : F::CB;
+        const int p2d = (nbcs * (F::QB + F::PB1)) & 15;
+        const uint8_t * wr = W + (16 * tile + l16) * F::ROWB;
+        struct sk_ops { sk_v2i xa, raw; uint32_t s1, s2; float4 dx4, sx4; sk_v4i ci4; };
+        const int g0 = SK_GS * s;                                          // the stage's first block: offsets into the resident columns
+        const uint8_t * tqb = tqb0 + (size_t) l16 * TQS + 32 * g0 + 8 * kq + 32 * sw;
+        const uint8_t * wrq = wr + (TYPE == FQ_Q8_0 ? 8 * kq + 32 * sw : 8 * (kq & 1) + 16 * sw);
+        const uint8_t * dxb = dxT + (size_t) g0 * SK_TN * 4 + 16 * kq + sw * SK_TN * 4, * cib = ciT + (size_t) g0 * SK_TN * 4 + 16 * kq + sw * SK_TN * 4;
+        const uint8_t * wr2 = wr + 2 * sw, * wr4 = wr + 4 * sw;
+        auto load_ops = [&](int gi) __attribute__((always_inline)) {
+            sk_ops o;
+            o.xa = *(const sk_v2i *)(tqb + 32 * gi);
+            o.s2 = 0u;
+            if constexpr (TYPE == FQ_Q8_0) { o.raw = *(const sk_v2i *)(wrq + 32 * gi); o.s1 = *(const uint16_t *)(wr2 + SK_GS * 32 + 2 * gi); }
+            else {
+                o.raw = *(const sk_v2i *)(wrq + 16 * gi);
+                if constexpr (TYPE == FQ_Q4_0)      o.s1 = *(const uint16_t *)(wr2 + SK_GS * 16 + 2 * gi);
+                else if constexpr (TYPE == FQ_Q4_1) o.s1 = *(const uint32_t *)(wr4 + SK_GS * 16 + 4 * gi);
+                else {
+                    o.s1 = *(const uint32_t *)(wr4 + SK_GS * 16 + 4 * gi);
+                    if constexpr (TYPE == FQ_Q5_0) o.s2 = *(const uint16_t *)(wr2 + SK_GS * 20 + p2d + 2 * gi);
+                    else                           o.s2 = *(const uint32_t *)(wr4 + SK_GS * 20 + p2d + 4 * gi);
+                }
+            }
+            o.dx4 = *(const float4 *)(dxb + gi * SK_TN * 4);
+            if constexpr (F::HAS_MIN) { o.sx4 = *(const float4 *)(cib + gi * SK_TN * 4); o.ci4 = sk_v4i{ 0, 0, 0, 0 }; }
+            else { o.ci4 = *(const sk_v4i *)(cib + gi * SK_TN * 4); o.sx4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            return o;
+        };
+        auto run_mfma = [&](const sk_ops & o, float & dw, float & mw) __attribute__((always_inline)) {
+            sk_v2i wb2;
+            mw = 0.0f;
+            if constexpr (TYPE == FQ_Q8_0) { wb2 = o.raw; dw = fq_h2f((uint16_t) o.s1); }
+            else {
+                const int sh = 4 * (kq >> 1);
+                wb2 = sk_v2i{ (int)(((uint32_t) o.raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw.y >> sh) & 0x0F0F0F0Fu) };
+                if constexpr (TYPE == FQ_Q4_0) dw = fq_h2f((uint16_t) o.s1);
+                else if constexpr (TYPE == FQ_Q4_1) { dw = fq_h2f((uint16_t) o.s1); mw = fq_h2f((uint16_t)(o.s1 >> 16)); }
+                else {
+                    const uint32_t hb = o.s1 >> (8 * kq);
+                    wb2.x |= (int)(spread4(hb) << 4); wb2.y |= (int)(spread4(hb >> 4) << 4);
+                    dw = fq_h2f((uint16_t) o.s2);
+                    if constexpr (TYPE == FQ_Q5_1) mw = fq_h2f((uint16_t)(o.s2 >> 16));
+                }
+            }
+            sk_v4i c = o.ci4;
+            return __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa), __builtin_bit_cast(long, wb2), c, 0, 0, 0);
+        };
+        auto scale = [&](const sk_v4i & c, const sk_ops & o, float dw, float mw) __attribute__((always_inline)) {
+            const float dxv[4] = { o.dx4.x, o.dx4.y, o.dx4.z, o.dx4.w };
+            const float sxv[4] = { o.sx4.x, o.sx4.y, o.sx4.z, o.sx4.w };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ci = (float) c[r];
+                float t;
+                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                acc[r] = acc[r] + t;
+            }
+        };
+        if (!(dbg & 16)) {
+            if (ng == SK_GS) {
+                constexpr int NG = SK_GS / S;
+                sk_ops o[NG]; sk_v4i c[NG]; float dwv[NG], mwv[NG];
+                o[0] = load_ops(0);
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    if (k + 1 < NG) o[k + 1] = load_ops((k + 1) * S);
+                    c[k] = run_mfma(o[k], dwv[k], mwv[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k > 0) scale(c[k - 1], o[k - 1], dwv[k - 1], mwv[k - 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                scale(c[NG - 1], o[NG - 1], dwv[NG - 1], mwv[NG - 1]);
+            } else {
+                for (int gi = sw; gi < ng; gi += S) {
+                    const sk_ops o = load_ops(gi - sw);
+                    float dw, mw;
+                    const sk_v4i c = run_mfma(o, dw, mw);
+                    scale(c, o, dw, mw);
+                }
+            }
+        }
+        if (s == nstages - 1) {                                            // the pair is complete: hand the partial sums over (read after the next barrier)
+            if (sw == 0) { fin[0] = acc[0]; fin[1] = acc[1]; fin[2] = acc[2]; fin[3] = acc[3]; }
+            else if constexpr (S > 1)
+                *(float4 *)(xch + (size_t)(i & 1) * (S - 1) * 2 * 64 * 4 + ((size_t)((sw - 1) * 2 + tile) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+        }
+    }
+    __syncthreads();
+    if (!loader) finish_pair(mine - 1);
+}
+
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
+    // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
+    static const bool use_res = !(getenv("FQ_SKINNY_RES") && atoi(getenv("FQ_SKINNY_RES")) == 0);
+    if (use_res) {
+        size_t need = 0;
+        switch (w.type) {
+            case FQ_Q4_0: need = sk_res<FQ_Q4_0>::lds((int) w.nblk, S); break; case FQ_Q4_1: need = sk_res<FQ_Q4_1>::lds((int) w.nblk, S); break;
+            case FQ_Q5_0: need = sk_res<FQ_Q5_0>::lds((int) w.nblk, S); break; case FQ_Q5_1: need = sk_res<FQ_Q5_1>::lds((int) w.nblk, S); break;
+            default:      need = sk_res<FQ_Q8_0>::lds((int) w.nblk, S); break;
+        }
+        if (need <= 160 * 1024) {
+            const int npairs = (int)((w.M + SK_TM - 1) / SK_TM);
+            const unsigned g = (unsigned)(npairs < fq_ctx().n_cu ? npairs : fq_ctx().n_cu);
+#define FQ_SKR_LAUNCH(T, SS) { \
+                static bool set = false; \
+                if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_res<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+                hipLaunchKernelGGL((k_gemm_skinny_res<T, SS>), dim3(g), dim3(64 * (2 + 2 * SS)), need, st, w, act, (int) N, dst, ldd, ep, fq_gemm_debug_get()); }
+#define FQ_SKR_CASE(T) case T: if (S == 1) FQ_SKR_LAUNCH(T, 1) else if (S == 2) FQ_SKR_LAUNCH(T, 2) else FQ_SKR_LAUNCH(T, 4) break;
+            switch (w.type) {
+                FQ_SKR_CASE(FQ_Q4_0) FQ_SKR_CASE(FQ_Q4_1) FQ_SKR_CASE(FQ_Q5_0) FQ_SKR_CASE(FQ_Q5_1) FQ_SKR_CASE(FQ_Q8_0)
+                default: return false;
+            }
+#undef FQ_SKR_CASE
+#undef FQ_SKR_LAUNCH
+            return true;
+        }
+    }
     const unsigned grid = (unsigned)((w.M + SK_TM - 1) / SK_TM);
 #define FQ_SK_LAUNCH(T, SS) { \
         typedef sk_fmt<T> F; \
