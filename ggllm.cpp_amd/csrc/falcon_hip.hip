@@ -689,7 +689,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
             continue;
         }
-        if (!up_done) fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
+        // Wqkv and Wup behind the same LayerNorm image (one-norm blocks): one launch of the small-batch mat-mul for both (5..16 columns)
+        bool pair_done = false;
+        if (!up_done && a_qkv.base == a_up.base && a_qkv.type == a_up.type) {
+            const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
+            pair_done = fq_mul_mat_q_acts_pair(L.qkv, L.up, a_up, N, c->qkv, QKV, store, c->up, FF, gelu, st);
+        }
+        if (!up_done && !pair_done) fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
         if (seq_stride && !fq_reference_order() && !fq_attn_f64()) {
             // lock-step sequences: RoPE, KV append, attention and (Q8_0 / Q8_1 consumers) the activation image of all N tokens in
             // one launch of the decode attention (k_attn_decode's code: the same bits as the three launches below)
@@ -701,7 +707,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride, &c->att_scratch);
             fq_launch_quantize_act(c->att, E, a_att, st);
         }
-        if (!up_done) {
+        if (!up_done && !pair_done) {
             const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
             fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
         }

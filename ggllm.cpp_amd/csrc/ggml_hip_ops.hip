@@ -34,6 +34,7 @@ static void build_tables(hip_context & c) {
     HIP_CHECK(hipMalloc((void **) &c.exp_table, 1 << 17));
     HIP_CHECK(hipMemcpy(c.gelu_table, gelu.data(), 1 << 17, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(c.exp_table, ex.data(), 1 << 17, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc((void **) &c.ks_scratch, (size_t) 4 * 16 * FQ_KS_MAX_M * 4));
 }
 
 extern "C" int ggml_hip_device_count(void) {
@@ -305,6 +306,19 @@ void fq_prof_events(hipEvent_t * start, hipEvent_t * stop) { *start = g_prof_pen
 void fq_prof_close(hipStream_t, double bytes) {
     g_prof_pending[0] = g_prof_pending[1] = nullptr;
     g_prof_bytes += bytes;
+}
+
+// two mat-muls behind the same activation columns (Wqkv and Wup of a one-norm block) as ONE launch of the small-batch form, where that
+// applies (5..16 columns, default order, same format / K / K split); false: nothing launched, the caller runs them one by one
+bool fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & a, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
+                            float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st) {
+    static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG") && !(getenv("FQ_SKINNY_PAIR") && atoi(getenv("FQ_SKINNY_PAIR")) == 0);
+    if (!skinny || g_reference_order || g_force_gemv || N <= FQ_GEMV_MAX_COLS || N > 16) return false;
+    if (fq_desc(w0.type).act_type != a.type || a.K != w0.K || w1.K != w0.K || w1.type != w0.type) return false;
+    const int n_cu = fq_ctx().n_cu;
+    const int S0 = fq_gemm_split_for(w0.M, N, n_cu), S1 = fq_gemm_split_for(w1.M, N, n_cu);
+    if (S0 != S1) return false;
+    return fq_launch_gemm_skinny_pair(w0, w1, a, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S0, st);
 }
 
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {

@@ -19,13 +19,17 @@ struct hip_context {
     const uint16_t * exp_table_attn = nullptr;   // what the attention kernels get: nullptr once exp_f16_formula is verified == exp_table
     int *       scalar_i32 = nullptr;     // device scratch scalar for the op-level API
     long long * dbg_stamps = nullptr;     // optional phase-stamp buffer (ggml_hip_debug_stamps), 2 x 4096 x 8 entries
+    float *     ks_scratch = nullptr;     // partial sums of the K-share small-batch mat-mul: 4 x 16 columns x FQ_KS_MAX_M rows (allocated at init: launches may be captured)
 };
 
+#define FQ_KS_MAX_M 32768
 hip_context & fq_ctx();
 fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out);
 fq_act    fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_out);
 void      fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd,
                             const fq_gemv_epi & ep, hipStream_t st);
+bool      fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & a, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
+                                 float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st);
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_reference_order();
 bool      fq_prof_active();

@@ -43,6 +43,10 @@ void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float 
 // kernels_gemm_skinny.hip -- N <= 16 columns of a legacy format at weight-stream speed; S = K split (1, 2, 4: k_gemm_q's association);
 // false = outside its scope, nothing launched
 bool   fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st);
+// two matrices of one format and K behind the same columns in ONE launch of the resident form (Wqkv and Wup of a one-norm block); false: nothing launched
+bool   fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & act, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
+                                  float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st);
+int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1, 2, 4) fq_launch_gemm gives an M x N result
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);

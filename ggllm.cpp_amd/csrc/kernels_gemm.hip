@@ -684,6 +684,12 @@ static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, fl
     hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT, RB>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
 }
 
+int fq_gemm_split_for(int64_t M, int64_t N, int n_cu) {
+    if (g_gemm_sequential) return 1;
+    const int64_t tiles = ((M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
+    return tiles < 4 * (int64_t) n_cu ? 4 : 2;
+}
+
 // dst[n*ldd + m], n < N; act holds N quantized columns
 void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int n_cu, hipStream_t st) {
     // The unit of parallelism is a 32-token x 32-row tile (568 of them for a 4544-row matrix and 128 tokens), split S ways

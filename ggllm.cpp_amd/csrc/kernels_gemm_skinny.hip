@@ -37,8 +37,11 @@ template <int TYPE> struct sk_fmt {
     static constexpr int QB = D.plane[0].bytes, PB1 = D.plane[1].bytes, PB2 = D.nplanes > 2 ? D.plane[2].bytes : 0;
     static constexpr int CB = 1024 / QB, SPC = CB / SK_GS;      // blocks per column of the device layout (64; Q8_0: 32), stages per column
     static constexpr int P2PAD = PB2 ? 16 : 0;                  // plane 2 of a partial column starts on a 4-byte boundary only: read from the 16-byte boundary below
-    static constexpr int ROWB = SK_GS * (QB + PB1 + PB2) + P2PAD;      // LDS bytes of a row's stage: [quants | plane 1 | plane 2 (+ 16)]
-    static constexpr int NL = ROWB / 16;                        // 16-byte lanes of the row's gather
+    static constexpr int ROWD = SK_GS * (QB + PB1 + PB2) + P2PAD;      // bytes of a row's stage: [quants | plane 1 | plane 2 (+ 16)]
+    static constexpr int NL = ROWD / 16;                        // 16-byte lanes of the row's gather
+    // LDS pitch of a row: an ODD number of 16-byte slots, so that the 16 rows of a tile fall into distinct banks (an operand read of
+    // Q4_0's 576-byte rows was a 4-way bank conflict: 576 = 64 mod 256)
+    static constexpr int ROWB = (NL % 2 == 0) ? ROWD + 16 : ROWD;
     static constexpr bool HAS_MIN = (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1);
     // stage buffers: the weights (HBM: long latency) run NBW - 1 stages ahead, the columns (L2 hits) NBT - 1
     static constexpr int NBW = ROWB > 800 ? 2 : 4, NBT = 2;
@@ -66,6 +69,15 @@ __device__ __forceinline__ void sk_dma16(const void * base, const sk_voff16 & o,
                  : "memory", "scc");
 }
 __device__ __forceinline__ unsigned sk_lds(const void * p) { return (unsigned)(uintptr_t) p; }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 15 (the immediate must be a constant)
+__device__ __forceinline__ void sk_wait_vm_upto(int n) {
+    switch (n) {
+#define SK_WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        SK_WV(1) SK_WV(2) SK_WV(3) SK_WV(4) SK_WV(5) SK_WV(6) SK_WV(7) SK_WV(8) SK_WV(9) SK_WV(10) SK_WV(11) SK_WV(12) SK_WV(13) SK_WV(14) SK_WV(15)
+#undef SK_WV
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 __device__ __forceinline__ const uint8_t * sk_uniform(const uint8_t * p) {
     const unsigned long long v = (unsigned long long)(uintptr_t) p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -337,7 +349,8 @@ template <int TYPE> struct sk_res {
 };
 
 template <int TYPE, int S>
-__global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight w, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep, int dbg) {
+__global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight w, fq_weight w1, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep, float * dst1, int64_t ldd1, fq_gemv_epi ep1, int dbg) {
+    // two matrices of the same K and format in one launch (w1.M == 0: one): the 32-row pairs of w, then those of w1, share the resident columns
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef sk_fmt<TYPE> F;
     constexpr int ACT = fq_act_of(TYPE);
@@ -347,10 +360,11 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
     constexpr int LOPS = 16 * WOPS;
     static_assert(LOPS <= 63, "vmcnt range");
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t K = w.K, M = w.M;
+    const int64_t K = w.K;
     const int nblk = (int) w.nblk;
     const int nstages = (nblk + SK_GS - 1) / SK_GS;
-    const int npairs = (int)((M + SK_TM - 1) / SK_TM);
+    const int pairs0 = (int)((w.M + SK_TM - 1) / SK_TM);
+    const int npairs = pairs0 + (int)((w1.M + SK_TM - 1) / SK_TM);
     const int mine = ((int) blockIdx.x < npairs) ? (npairs - 1 - (int) blockIdx.x) / (int) gridDim.x + 1 : 0;      // pairs blockIdx.x, + gridDim.x, ..
     const int nq = mine * nstages;                                         // stages this workgroup runs
     const size_t img = fq_act_col_bytes(ACT, K);
@@ -363,7 +377,11 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
 
     auto issue_weights = [&](int q, int lw) {                                // stage q = (pair q / nstages, blocks [32 s, 32 s + 32)); loader wave lw: rows 16 lw ..
         const int s = q % nstages;
-        const int64_t m0 = (int64_t)(blockIdx.x + (q / nstages) * gridDim.x) * SK_TM;
+        const int P = (int) blockIdx.x + (q / nstages) * (int) gridDim.x;    // pair index over both matrices
+        const bool second = P >= pairs0;
+        const int64_t m0 = (int64_t)(second ? P - pairs0 : P) * SK_TM, M = second ? w1.M : w.M;
+        const uint8_t * plane0 = second ? w1.plane[0] : w.plane[0];
+        const int64_t rstride = second ? w1.row_stride : w.row_stride;
         const int c = s / F::SPC, hf = s % F::SPC;
         const int rem = nblk - F::CB * c, nbc = rem < F::CB ? rem : F::CB;
         const unsigned colb = (unsigned) c * (unsigned)(F::CB * F::D.tsize);
@@ -378,8 +396,8 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
         const unsigned v0 = src_of(lane), v1 = src_of(lane + 64 < F::NL ? lane + 64 : F::NL - 1);
         const unsigned wb = __builtin_amdgcn_readfirstlane(sk_lds(wbuf(q)));
         if (m0 + SK_TM <= M) {
-            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) m0 * w.row_stride);
-            const unsigned rs = (unsigned) w.row_stride;
+            const uint8_t * base = sk_uniform(plane0 + (size_t) m0 * rstride);
+            const unsigned rs = (unsigned) rstride;
             sk_voff16 o;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o.v[i] = v0 + (unsigned)(16 * lw + i) * rs;
@@ -395,7 +413,7 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
         }
         for (int r = 16 * lw; r < 16 * lw + 16; ++r) {                     // the matrix's last, partial pair: rows beyond M re-read row M - 1
             const int64_t row = m0 + r < M ? m0 + r : M - 1;
-            const uint8_t * base = sk_uniform(w.plane[0] + (size_t) row * w.row_stride);
+            const uint8_t * base = sk_uniform(plane0 + (size_t) row * rstride);
             if (lane < (F::NL < 64 ? F::NL : 64)) sk_dma(base, v0, wb + (unsigned)(r * F::ROWB));
             if constexpr (WOPS > 1) { if (lane + 64 < F::NL) sk_dma(base, v1, wb + (unsigned)(r * F::ROWB + 1024)); }
         }
@@ -450,15 +468,20 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
                 fin[0] = fin[0] + p.x; fin[1] = fin[1] + p.y; fin[2] = fin[2] + p.z; fin[3] = fin[3] + p.w;
             }
         }
-        const int64_t m = (int64_t)(blockIdx.x + i * gridDim.x) * SK_TM + 16 * tile + l16;
+        const int P = (int) blockIdx.x + i * (int) gridDim.x;
+        const bool second = P >= pairs0;
+        const int64_t m = (int64_t)(second ? P - pairs0 : P) * SK_TM + 16 * tile + l16, M = second ? w1.M : w.M;
+        const fq_gemv_epi & e = second ? ep1 : ep;
+        float * d = second ? dst1 : dst;
+        const int64_t ld = second ? ldd1 : ldd;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = 4 * kq + r;
             if (n < N && m < M) {
                 float v = fin[r];
-                if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
-                else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
-                dst[n * ldd + m] = v;
+                if (e.mode == FQ_EPI_GELU)      v = h2f_bits(e.gelu_table[f2h_bits(v)]);
+                else if (e.mode == FQ_EPI_ADD2) v = (v + e.add1[n * e.ld_add + m]) + e.add2[n * e.ld_add + m];
+                d[n * ld + m] = v;
             }
         }
     };
@@ -570,33 +593,237 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
     if (!loader) finish_pair(mine - 1);
 }
 
+// =============================================================================================== one K share per workgroup (long rows)
+// Matrices with long rows and few of them (Falcon's down projection: 4544 x 18176) cannot keep 16 columns of the whole K in LDS, and a
+// workgroup per 32 rows reaches only 142 CUs. Here a workgroup owns ONE of the four interleaved K shares (groups g = s, s + 4, ..: the
+// association of k_gemm_q<S = 4>) of T 16-row tiles: it needs a quarter of the columns' bytes -- resident for the whole launch -- and every
+// consumer wave runs one (tile, share) accumulator chain over all of its groups. The four shares of a row block run on the same XCD
+// (workgroup index mod 8), so the 64-byte segments their 16-byte pieces sit in are fetched from HBM once. Partial sums go to a scratch
+// ([share][column][row], f32); k_skinny_sum4 adds them as ((P0 + P1) + P2) + P3 and applies the epilogue: bit-identical to k_gemm_q.
+// Q4_0 only; stage = a span of 32 blocks = 8 own groups per row: 8 quant pieces (stride 64 B) + the 64 B of scales of the span.
+constexpr int KS_TMAX = 8;                 // tiles (consumer waves) per workgroup
+constexpr int KS_ROWB = 208;               // LDS bytes per row and stage: 8 x 16 quants | 64 scales | 16 pad (13 slots: the 16 rows of a tile in distinct banks)
+constexpr int KS_NBW = 3;
+struct sk_ks {
+    static __host__ __device__ int nj(int nblk, int s) { return (nblk - s + 3) / 4; }                  // own groups of share s
+    static __host__ __device__ int tqs(int nblk) { const int q = ((nblk + 3) / 4) * 32; return q + ((16 - (q & 255)) & 255); }
+    static __host__ __device__ size_t lds(int nblk, int T) {
+        return (size_t) KS_NBW * 16 * T * KS_ROWB + (size_t) SK_TN * tqs(nblk) + 2 * (size_t)((nblk + 3) / 4) * SK_TN * 4;
+    }
+};
+
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int ACT = FQ_Q8_0;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nblk = (int) w.nblk;
+    const int nsp = (nblk + 31) / 32;                                      // stages: spans of 32 blocks
+    // workgroup -> (row block, share): the four shares of a row block on one XCD
+    const int xcd = (int) blockIdx.x & 7, kk = (int) blockIdx.x >> 3;
+    const int rb = (kk >> 2) * 8 + xcd, s = kk & 3;
+    if (rb >= nrb) return;
+    const int64_t m0 = (int64_t) rb * 16 * T;
+    const size_t img = fq_act_col_bytes(ACT, K);
+    const int NJ = sk_ks::nj(nblk, s), NJMAX = (nblk + 3) / 4;
+    const int TQS = sk_ks::tqs(nblk);
+    constexpr int WSTAGE = 16 * KS_ROWB;                                   // one tile's stage: 3.25 KiB = four DMA instructions (the last: 16 lanes)
+    constexpr int KOPS = 4;
+    uint8_t * tqb0 = smem + (size_t) KS_NBW * WSTAGE * T;                  // [16 columns][TQS]: the quants of the share's groups
+    uint8_t * dxT  = tqb0 + (size_t) SK_TN * TQS;                          // [own group][16] f32: the columns' d
+    uint8_t * ciT  = dxT + (size_t) NJMAX * SK_TN * 4;                     // [own group][16]: -8 isum
+    const int NW = (int)(blockDim.x >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    constexpr int COLB = 64 * 18;                                          // bytes of a full column of the device layout (Q4_0)
+
+    // ---- prologue, every wave: the columns' own groups (32 bytes each = two lanes; 32 groups per DMA instruction), the transposed scales
+    {
+        const unsigned last = (unsigned)(img - 16);
+        for (int t = wid; t < SK_TN; t += NW) {
+            const uint8_t * base = act.base + (size_t)(t < N ? t : N - 1) * img;
+            const unsigned tb = sk_lds(tqb0) + (unsigned)(t * TQS);
+            for (int j0 = 0; j0 < NJ; j0 += 32) {
+                const int j = j0 + (lane >> 1);
+                unsigned vq = (unsigned)((s + 4 * j) * 32 + 16 * (lane & 1));
+                vq = vq < last ? vq : last;
+                if (j < NJ && !(dbg & 4)) sk_dma(base, vq, tb + (unsigned)(j0 * 32));
+            }
+        }
+        const size_t nd4 = fq_act_d_elems(ACT, K) * 4;
+        for (int e = tid; e < NJ * SK_TN; e += (int) blockDim.x) {
+            const int j = e >> 4, tok = e & 15;
+            const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img + (size_t) K;
+            const int g = s + 4 * j;
+            ((float *) dxT)[e] = ((const float *) tp)[g];
+            ((uint32_t *) ciT)[e] = (uint32_t)(-8 * ((const int32_t *)(tp + nd4))[g]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                       // the only barrier: the columns are in LDS
+    if (wid >= T) return;
+    const int64_t mt = m0 + 16 * wid;                                      // the wave's tile: it stages its own weights and runs its own chain
+    if (mt >= M) return;
+
+    // ---- the wave's weight pipeline: per stage (span sp) 16 rows x 13 slots = 4 DMA instructions into its private ring, two stages ahead,
+    // paced by vmcnt alone. Lane L = 64 k + lane of instruction k is (row L / 13, slot L % 13): 8 quant pieces (stride 64 B), 4 of scales, 1 pad
+    uint8_t * myring = smem + (size_t) wid * KS_NBW * WSTAGE;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(sk_lds(myring));
+    const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
+    unsigned rowoff[KOPS]; int piece[KOPS];
+#pragma unroll
+    for (int k = 0; k < KOPS; ++k) {
+        const int L = 64 * k + lane, row = (L / 13) & 15;                   // (lanes beyond the 208 of the last instruction are masked off below)
+        piece[k] = L % 13 < 12 ? L % 13 : 11;                              // slot 12 = padding: re-reads piece 11
+        const int64_t r = mt + row < M ? row : M - 1 - mt;                  // rows beyond M re-read row M - 1
+        rowoff[k] = (unsigned)(r * (int64_t) w.row_stride);
+    }
+    const unsigned rs16 = (unsigned) w.row_stride - 16u;
+    auto issue = [&](int sp) {
+        const int c = sp >> 1, half = sp & 1;
+        const int rem = nblk - 64 * c, nbc = rem < 64 ? rem : 64;
+        const unsigned bq = (unsigned)(c * COLB + (32 * half + s) * 16), bd = (unsigned)(c * COLB + nbc * 16 + 64 * half);
+        const unsigned dst = ring_lds + (unsigned)((sp % KS_NBW) * WSTAGE);
+#pragma unroll
+        for (int k = 0; k < KOPS; ++k) {
+            unsigned o = piece[k] < 8 ? bq + 64u * (unsigned) piece[k] : bd + 16u * (unsigned)(piece[k] - 8);
+            o = o < rs16 ? o : rs16;                                       // (a partial last column: pieces beyond its blocks are never used)
+            if (64 * k + lane < 16 * 13) sk_dma(wbase, rowoff[k] + o, dst + (unsigned)(k * 1024));
+        }
+    };
+    if (!(dbg & 8)) { issue(0); if (nsp > 1) issue(1); }
+
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const int sh = 4 * (kq >> 1);
+    struct ks_ops { sk_v2i xa, raw; uint32_t s1; float4 dx4; sk_v4i ci4; };
+    for (int sp = 0; sp < nsp; ++sp) {
+        if (sp + 2 < nsp && !(dbg & 8)) issue(sp + 2);
+        // stage sp has landed: at most the stages issued after it (3 instructions each) are still in flight
+        if (dbg & 8)            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (sp + 2 < nsp)  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (sp + 1 < nsp)  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg & 16) continue;
+        const uint8_t * wr = myring + (size_t)(sp % KS_NBW) * WSTAGE + l16 * KS_ROWB;
+        const int jbase = 8 * sp;                                          // own-group index of the span's first own group
+        const int njs = NJ - jbase < 8 ? NJ - jbase : 8;                   // own groups in this span
+        const uint8_t * tqp = tqb0 + (size_t) l16 * TQS + 32 * jbase + 8 * kq;
+        const uint8_t * dxp = dxT + (size_t) jbase * SK_TN * 4 + 16 * kq, * cip = ciT + (size_t) jbase * SK_TN * 4 + 16 * kq;
+        const uint8_t * wq = wr + 8 * (kq & 1), * wd = wr + 128 + 2 * s;
+        auto load_ops = [&](int jj) __attribute__((always_inline)) {
+            ks_ops o;
+            o.xa = *(const sk_v2i *)(tqp + 32 * jj);
+            o.raw = *(const sk_v2i *)(wq + 16 * jj);
+            o.s1 = *(const uint16_t *)(wd + 8 * jj);
+            o.dx4 = *(const float4 *)(dxp + jj * SK_TN * 4);
+            o.ci4 = *(const sk_v4i *)(cip + jj * SK_TN * 4);
+            return o;
+        };
+        auto run_mfma = [&](const ks_ops & o) __attribute__((always_inline)) {
+            const sk_v2i wb2 = sk_v2i{ (int)(((uint32_t) o.raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw.y >> sh) & 0x0F0F0F0Fu) };
+            return __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa), __builtin_bit_cast(long, wb2), o.ci4, 0, 0, 0);
+        };
+        auto scale = [&](const sk_v4i & c, const ks_ops & o) __attribute__((always_inline)) {
+            const float dw = fq_h2f((uint16_t) o.s1);
+            const float dxv[4] = { o.dx4.x, o.dx4.y, o.dx4.z, o.dx4.w };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float t = ((float) c[r] * dw) * dxv[r]; acc[r] = acc[r] + t; }      // ggml.c:2606
+        };
+        if (njs == 8) {
+            ks_ops o[8]; sk_v4i c[8];
+            o[0] = load_ops(0); o[1] = load_ops(1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                                   // reads two groups ahead, the matrix instruction one ahead of its scaling
+                if (k + 2 < 8) o[k + 2] = load_ops(k + 2);
+                c[k] = run_mfma(o[k]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k > 0) scale(c[k - 1], o[k - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            scale(c[7], o[7]);
+        } else {
+            for (int jj = 0; jj < njs; ++jj) { const ks_ops o = load_ops(jj); const sk_v4i c = run_mfma(o); scale(c, o); }
+        }
+    }
+    const int64_t m = mt + l16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 4 * kq + r;
+        if (n < N && m < M) part[((size_t) s * SK_TN + n) * FQ_KS_MAX_M + m] = acc[r];
+    }
+}
+
+__global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep) {
+    const int64_t m = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (m >= M || n >= N) return;
+    const float p0 = part[((size_t) 0 * SK_TN + n) * FQ_KS_MAX_M + m], p1 = part[((size_t) 1 * SK_TN + n) * FQ_KS_MAX_M + m];
+    const float p2 = part[((size_t) 2 * SK_TN + n) * FQ_KS_MAX_M + m], p3 = part[((size_t) 3 * SK_TN + n) * FQ_KS_MAX_M + m];
+    float v = ((p0 + p1) + p2) + p3;
+    if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+    else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+    dst[n * ldd + m] = v;
+}
+
+// the resident form for one matrix (w1.M == 0) or two of the same K and format sharing their columns (e.g. Wqkv and Wup behind one LayerNorm)
+static bool fq_launch_gemm_skinny_res(const fq_weight & w, const fq_weight & w1, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep,
+                                      float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st) {
+    static const bool use_res = !(getenv("FQ_SKINNY_RES") && atoi(getenv("FQ_SKINNY_RES")) == 0);
+    if (!use_res) return false;
+    size_t need = 0;
+    switch (w.type) {
+        case FQ_Q4_0: need = sk_res<FQ_Q4_0>::lds((int) w.nblk, S); break; case FQ_Q4_1: need = sk_res<FQ_Q4_1>::lds((int) w.nblk, S); break;
+        case FQ_Q5_0: need = sk_res<FQ_Q5_0>::lds((int) w.nblk, S); break; case FQ_Q5_1: need = sk_res<FQ_Q5_1>::lds((int) w.nblk, S); break;
+        case FQ_Q8_0: need = sk_res<FQ_Q8_0>::lds((int) w.nblk, S); break;
+        default: return false;
+    }
+    if (need > 160 * 1024) return false;
+    const int npairs = (int)((w.M + SK_TM - 1) / SK_TM) + (int)((w1.M + SK_TM - 1) / SK_TM);
+    const unsigned g = (unsigned)(npairs < fq_ctx().n_cu ? npairs : fq_ctx().n_cu);
+#define FQ_SKR_LAUNCH(T, SS) { \
+        static bool set = false; \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_res<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_res<T, SS>), dim3(g), dim3(64 * (2 + 2 * SS)), need, st, w, w1, act, (int) N, dst, ldd, ep, dst1, ldd1, ep1, fq_gemm_debug_get()); }
+#define FQ_SKR_CASE(T) case T: if (S == 1) FQ_SKR_LAUNCH(T, 1) else if (S == 2) FQ_SKR_LAUNCH(T, 2) else FQ_SKR_LAUNCH(T, 4) break;
+    switch (w.type) {
+        FQ_SKR_CASE(FQ_Q4_0) FQ_SKR_CASE(FQ_Q4_1) FQ_SKR_CASE(FQ_Q5_0) FQ_SKR_CASE(FQ_Q5_1) FQ_SKR_CASE(FQ_Q8_0)
+        default: return false;
+    }
+#undef FQ_SKR_CASE
+#undef FQ_SKR_LAUNCH
+    return true;
+}
+
+// two matrices behind the same N <= 16 activation columns in one launch (same format, same K, the same K split S); false: nothing launched
+bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & act, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
+                                float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st) {
+    if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4) || w0.type != w1.type || w0.K != w1.K || w0.nblk != w1.nblk) return false;
+    return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
+}
+
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
-    static const bool use_res = !(getenv("FQ_SKINNY_RES") && atoi(getenv("FQ_SKINNY_RES")) == 0);
-    if (use_res) {
-        size_t need = 0;
-        switch (w.type) {
-            case FQ_Q4_0: need = sk_res<FQ_Q4_0>::lds((int) w.nblk, S); break; case FQ_Q4_1: need = sk_res<FQ_Q4_1>::lds((int) w.nblk, S); break;
-            case FQ_Q5_0: need = sk_res<FQ_Q5_0>::lds((int) w.nblk, S); break; case FQ_Q5_1: need = sk_res<FQ_Q5_1>::lds((int) w.nblk, S); break;
-            default:      need = sk_res<FQ_Q8_0>::lds((int) w.nblk, S); break;
-        }
-        if (need <= 160 * 1024) {
-            const int npairs = (int)((w.M + SK_TM - 1) / SK_TM);
-            const unsigned g = (unsigned)(npairs < fq_ctx().n_cu ? npairs : fq_ctx().n_cu);
-#define FQ_SKR_LAUNCH(T, SS) { \
-                static bool set = false; \
-                if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_res<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-                hipLaunchKernelGGL((k_gemm_skinny_res<T, SS>), dim3(g), dim3(64 * (2 + 2 * SS)), need, st, w, act, (int) N, dst, ldd, ep, fq_gemm_debug_get()); }
-#define FQ_SKR_CASE(T) case T: if (S == 1) FQ_SKR_LAUNCH(T, 1) else if (S == 2) FQ_SKR_LAUNCH(T, 2) else FQ_SKR_LAUNCH(T, 4) break;
-            switch (w.type) {
-                FQ_SKR_CASE(FQ_Q4_0) FQ_SKR_CASE(FQ_Q4_1) FQ_SKR_CASE(FQ_Q5_0) FQ_SKR_CASE(FQ_Q5_1) FQ_SKR_CASE(FQ_Q8_0)
-                default: return false;
-            }
-#undef FQ_SKR_CASE
-#undef FQ_SKR_LAUNCH
+    {
+        fq_weight none = w; none.M = 0;
+        if (fq_launch_gemm_skinny_res(w, none, act, N, dst, ldd, ep, nullptr, 0, ep, S, st)) return true;
+    }
+    // long rows (the columns do not fit): one K share per workgroup (Q4_0, four partial sums; FQ_SKINNY_KS=0: never)
+    static const bool use_ks = !(getenv("FQ_SKINNY_KS") && atoi(getenv("FQ_SKINNY_KS")) == 0);
+    if (use_ks && w.type == FQ_Q4_0 && S == 4 && w.M <= FQ_KS_MAX_M && w.nblk >= 256) {
+        const int n_cu = fq_ctx().n_cu;
+        const int ntiles = (int)((w.M + 15) / 16);
+        int T = (ntiles * 4 + n_cu - 1) / n_cu;                            // tiles per workgroup: all workgroups resident in one round
+        if (T < 1) T = 1;
+        const size_t need = sk_ks::lds((int) w.nblk, T);
+        if (T <= KS_TMAX && need <= 160 * 1024) {
+            const int nrb = (ntiles + T - 1) / T;
+            const unsigned g = (unsigned)(32 * ((nrb + 7) / 8));
+            static bool set = false;
+            if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_ks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+            hipLaunchKernelGGL(k_gemm_skinny_ks, dim3(g), dim3(64 * KS_TMAX), need, st, w, act, (int) N, fq_ctx().ks_scratch, T, nrb, fq_gemm_debug_get());
+            hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep);
             return true;
         }
     }
