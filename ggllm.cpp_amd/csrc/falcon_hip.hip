@@ -483,9 +483,15 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // ------------------------------------------------------------------------------------------------ one eval
 // Launches every kernel of this stage for N tokens. Inputs already in place: tokens_dev (first stage) or x, and
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
-// lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides)
-static int fq_cols_max_n() { static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 8; return v; }
-#define FQ_COLS_MAX_N fq_cols_max_n()
+// lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides): 4 for the
+// legacy formats, whose streaming small-batch mat-mul serves 5..16 columns in less time than two chunks (Falcon-7B Q4_0: 2.9 ms per pass
+// against 3.6 at 8 sequences), 12 for the k-quants, which have only the tile GEMM beyond (8-9 ms per pass whatever the width)
+static int fq_cols_max_n(int wtype) {
+    static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 0;
+    if (v > 0) return v;
+    return (wtype == FQ_Q4_0 || wtype == FQ_Q4_1 || wtype == FQ_Q5_0 || wtype == FQ_Q5_1 || wtype == FQ_Q8_0) ? 4 : 12;
+}
+#define FQ_COLS_MAX_N fq_cols_max_n(m->layers.empty() ? FQ_Q4_0 : m->layers[0].qkv.type)
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
     const falcon_hip_hparams & hp = m->hp;
