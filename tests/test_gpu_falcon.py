@@ -247,6 +247,15 @@ def test_falcon7b_shaped_layer_vs_oracle(oracle):
     print("7B-shaped block: association spread %.2e" % _both_orders(oracle, w, synth.tokens(4, 1024, seed=2), 3, 16))
 
 
+@pytest.mark.parametrize("n_pre", [9, 16, 23])
+def test_falcon7b_shaped_layer_small_batch_vs_oracle(oracle, n_pre):
+    """the same block with prompts of 9, 16 and 23 tokens: Wqkv and Wup in ONE launch of the small-batch mat-mul with the columns resident
+    in LDS, Wdown as one K share per workgroup (kernels_gemm_skinny.hip; 23 = two passes) -- bit-exact in both orders"""
+    hp = dict(n_vocab=1024, n_embd=4544, n_head=71, n_head_kv=1, n_layer=1, n_ff=18176, two_norms=False)
+    w = synth.make_model(oracle, hp, ob.Q4_0, seed=9)
+    _both_orders(oracle, w, synth.tokens(n_pre + 1, 1024, seed=3), n_pre, 32)
+
+
 def test_falcon40b_shaped_layer_vs_oracle(oracle):
     """one block with the 40B geometry (n_embd 8192, 128 heads, 8 kv heads, two norms), Q4_K weights: bit-exact in both orders"""
     hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
