@@ -612,7 +612,7 @@ struct sk_ks {
     }
 };
 
-__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int dbg) {
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int nslots, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = FQ_Q8_0;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -621,9 +621,8 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     const int nsp = (nblk + 31) / 32;                                      // stages: spans of 32 blocks
     // workgroup -> (row block, share): the four shares of a row block on one XCD
     const int xcd = (int) blockIdx.x & 7, kk = (int) blockIdx.x >> 3;
-    const int rb = (kk >> 2) * 8 + xcd, s = kk & 3;
-    if (rb >= nrb) return;
-    const int64_t m0 = (int64_t) rb * 16 * T;
+    const int slot = (kk >> 2) * 8 + xcd, s = kk & 3;                     // row blocks slot, slot + nslots, .. (one round when they all fit the chip)
+    if (slot >= nrb) return;
     const size_t img = fq_act_col_bytes(ACT, K);
     const int NJ = sk_ks::nj(nblk, s), NJMAX = (nblk + 3) / 4;
     const int TQS = sk_ks::tqs(nblk);
@@ -661,8 +660,9 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     }
     __syncthreads();                                                       // the only barrier: the columns are in LDS
     if (wid >= T) return;
-    const int64_t mt = m0 + 16 * wid;                                      // the wave's tile: it stages its own weights and runs its own chain
-    if (mt >= M) return;
+  for (int rb = slot; rb < nrb; rb += nslots) {
+    const int64_t mt = ((int64_t) rb * T + wid) * 16;                      // the wave's tile: it stages its own weights and runs its own chain
+    if (mt >= M) break;
 
     // ---- the wave's weight pipeline: per stage (span sp) 16 rows x 13 slots = 4 DMA instructions into its private ring, two stages ahead,
     // paced by vmcnt alone. Lane L = 64 k + lane of instruction k is (row L / 13, slot L % 13): 8 quant pieces (stride 64 B), 4 of scales, 1 pad
@@ -750,6 +750,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
         const int n = 4 * kq + r;
         if (n < N && m < M) part[((size_t) s * SK_TN + n) * FQ_KS_MAX_M + m] = acc[r];
     }
+  }
 }
 
 __global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep) {
@@ -814,15 +815,18 @@ bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, f
     if (use_ks && w.type == FQ_Q4_0 && S == 4 && w.M <= FQ_KS_MAX_M && w.nblk >= 256) {
         const int n_cu = fq_ctx().n_cu;
         const int ntiles = (int)((w.M + 15) / 16);
-        int T = (ntiles * 4 + n_cu - 1) / n_cu;                            // tiles per workgroup: all workgroups resident in one round
+        int T = (ntiles * 4 + n_cu - 1) / n_cu;                            // tiles per workgroup: all workgroups resident in one round ..
         if (T < 1) T = 1;
+        if (T > KS_TMAX) T = KS_TMAX;                                      // .. or full workgroups that walk their row blocks (the columns stay resident)
         const size_t need = sk_ks::lds((int) w.nblk, T);
-        if (T <= KS_TMAX && need <= 160 * 1024) {
+        if (need <= 160 * 1024) {
             const int nrb = (ntiles + T - 1) / T;
-            const unsigned g = (unsigned)(32 * ((nrb + 7) / 8));
+            int nslots = 8 * ((nrb + 7) / 8);
+            if (4 * nslots > n_cu) nslots = (n_cu / 32) * 8;
+            const unsigned g = (unsigned)(4 * nslots);
             static bool set = false;
             if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_ks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-            hipLaunchKernelGGL(k_gemm_skinny_ks, dim3(g), dim3(64 * KS_TMAX), need, st, w, act, (int) N, fq_ctx().ks_scratch, T, nrb, fq_gemm_debug_get());
+            hipLaunchKernelGGL(k_gemm_skinny_ks, dim3(g), dim3(64 * KS_TMAX), need, st, w, act, (int) N, fq_ctx().ks_scratch, T, nrb, nslots, fq_gemm_debug_get());
             hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep);
             return true;
         }
