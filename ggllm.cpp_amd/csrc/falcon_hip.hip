@@ -96,6 +96,12 @@ struct falcon_hip_context {
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
     bool ring_ln = false;                      // FALCON_HIP_RING=1: k_gemv_ln's launches in the ring form (kernels_ring.hip)
+    // batched evaluation replayed from hipGraphs (FALCON_HIP_PREFILL_GRAPH=0: plain launches): the ~320 launches and 96 cross-stream joins of a
+    // prompt batch are then scheduled by the graph instead of the host (the joins cost ~12 us of idle device each as stream events: 11 % of a
+    // 128-token Falcon-7B prompt). Keyed by (tokens, keys, mode signature, keep_hidden); the position and the token ids are read from device memory.
+    struct batch_graph { int N, max_kv, sig; hipGraphExec_t exec; };
+    std::vector<batch_graph> batch_graphs;
+    bool prefill_graph = true;
     int  graph_base = -1;                      // n_past the captured graph was built for
     int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
     unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
@@ -309,6 +315,7 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_RING")) c->ring_ln = atoi(e) != 0;
+    if (const char * e = getenv("FALCON_HIP_PREFILL_GRAPH")) c->prefill_graph = atoi(e) != 0;
     if (c->ring_ln && nl > 0) c->ring_ln = fq_ring_prepare(m->layers[0].qkv.type, E, FF, m->layers[0].qkv.M, fq_ctx().n_cu);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
@@ -329,6 +336,7 @@ extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
     if (c->step_graph) HIP_CHECK(hipGraphExecDestroy(c->step_graph));
     if (c->token_graph) HIP_CHECK(hipGraphExecDestroy(c->token_graph));
+    for (auto & bg : c->batch_graphs) HIP_CHECK(hipGraphExecDestroy(bg.exec));
     for (hipEvent_t e : c->ev_fork) HIP_CHECK(hipEventDestroy(e));
     for (hipEvent_t e : c->ev_join) HIP_CHECK(hipEventDestroy(e));
     for (hipEvent_t e : c->ev_attn) HIP_CHECK(hipEventDestroy(e));
@@ -357,6 +365,8 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
     if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
     if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
+    for (auto & bg : c->batch_graphs) HIP_CHECK(hipGraphExecDestroy(bg.exec));
+    c->batch_graphs.clear();
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
     c->two_phase = mode == 3;
@@ -775,7 +785,26 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     if (m->first_stage()) HIP_CHECK(hipMemcpyAsync(c->tokens_dev, tokens, (size_t) N * 4, hipMemcpyHostToDevice, st));
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));        // n_past / tokens may live on the caller's stack
-    launch_stage(c, N, n_past + adv, st);
+    // batches: one hipGraph replay per (size, keys) instead of ~10 launches and 3 cross-stream joins per block from the host
+    if (c->prefill_graph && N > 4 && c->n_seq == 0 && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
+        const int sig = (graph_signature(c) | (c->keep_hidden ? 128 : 0)) + 256 * fq_config_epoch();
+        hipGraphExec_t exec = nullptr;
+        for (const auto & bg : c->batch_graphs) if (bg.N == N && bg.max_kv == n_past + adv && bg.sig == sig) { exec = bg.exec; break; }
+        if (!exec) {
+            hipGraph_t gr;
+            HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            launch_stage(c, N, n_past + adv, st);
+            HIP_CHECK(hipStreamEndCapture(st, &gr));
+            HIP_CHECK(hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(gr));
+            if (c->batch_graphs.size() >= 8) { HIP_CHECK(hipGraphExecDestroy(c->batch_graphs.front().exec)); c->batch_graphs.erase(c->batch_graphs.begin()); }
+            c->batch_graphs.push_back({ N, n_past + adv, sig, exec });
+        }
+        HIP_CHECK(hipGraphLaunch(exec, st));
+        if (c->keep_hidden) c->hidden_tokens = N;                  // (host-side state that launch_stage sets when it runs)
+    } else {
+        launch_stage(c, N, n_past + adv, st);
+    }
     if (m->last_stage()) {
         const int64_t V = m->hp.n_vocab;
         if (logits_all) {

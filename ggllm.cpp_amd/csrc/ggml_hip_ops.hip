@@ -84,7 +84,10 @@ extern "C" void ggml_hip_debug_stamps(int enable, long long * out_host) {
     if (!enable && c.dbg_stamps) { HIP_CHECK(hipFree(c.dbg_stamps)); c.dbg_stamps = nullptr; }
 }
 
-extern "C" void ggml_hip_debug_gemm_mode(int m) { fq_gemm_debug_mode(m); }
+// every switch that changes which kernels a launch list contains bumps this: captured launch lists (hipGraphs) are keyed by it
+static int g_config_epoch = 0;
+int fq_config_epoch() { return g_config_epoch; }
+extern "C" void ggml_hip_debug_gemm_mode(int m) { ++g_config_epoch; fq_gemm_debug_mode(m); }
 extern "C" int ggml_hip_selftest(void) { return fq_selftest_reduce(fq_ctx().stream); }
 // 0 = the fp16 EXP table is recomputed in-kernel (verified identical at init), else the number of mismatching inputs / -1 forced gather
 extern "C" int ggml_hip_exp_formula_mismatches(void) {
@@ -241,13 +244,13 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
 }
 
 static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
-extern "C" void ggml_hip_debug_force_gemv(int on) { g_force_gemv = on != 0; }
-extern "C" void ggml_hip_gemm_sequential(int on) { fq_gemm_set_sequential(on); }
+extern "C" void ggml_hip_debug_force_gemv(int on) { ++g_config_epoch; g_force_gemv = on != 0; }
+extern "C" void ggml_hip_gemm_sequential(int on) { ++g_config_epoch; fq_gemm_set_sequential(on); }
 // reference order: every mat-mul through the per-thread scalar restatement (kernels_ref.hip: the reference's own block /
 // lane order for all ten formats and any N), attention with f64 accumulation (the portable ggml_vec_dot_f32)
 static bool g_reference_order = false;
 bool fq_reference_order() { return g_reference_order; }
-extern "C" void ggml_hip_reference_order(int on) { g_reference_order = on != 0; fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
+extern "C" void ggml_hip_reference_order(int on) { ++g_config_epoch; g_reference_order = on != 0; fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
 extern "C" int  ggml_hip_get_reference_order(void) { return g_reference_order ? 1 : 0; }
 
 // ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream

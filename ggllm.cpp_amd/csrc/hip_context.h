@@ -32,6 +32,7 @@ bool      fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, con
                                  float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st);
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_reference_order();
+int       fq_config_epoch();        // bumped by every global switch that changes a launch list (reference order, forced mat-vec, sequential GEMM, debug modes)
 bool      fq_prof_active();
 void      fq_prof_open(hipStream_t st);
 void      fq_prof_close(hipStream_t st, double bytes);

@@ -429,3 +429,23 @@ def test_text_perplexity_example(oracle, tmp_path):
     nll, n2 = m.perplexity(ids, 32, 8)
     m.free()
     assert n2 == n and ppl == math.exp(nll / n) and 1.0 < ppl < 10.0 * len(vocab)
+
+
+def test_batched_eval_graph_replay_equals_plain_launches(oracle, monkeypatch):
+    """batches (N > 4) are replayed from a hipGraph cached per (size, keys): the same logits as plain launches, on first use (capture),
+    on replays, at other positions, and after a global switch changed the launch list"""
+    hp = synth.HP_TINY_GQA
+    w = synth.make_model(oracle, hp, ob.Q5_1, seed=31)
+    toks = synth.tokens(40, hp["n_vocab"], seed=4)
+    monkeypatch.setenv("FALCON_HIP_PREFILL_GRAPH", "0")
+    plain = g.FalconModel(w, n_ctx=64, n_batch=16)
+    monkeypatch.setenv("FALCON_HIP_PREFILL_GRAPH", "1")
+    graph = g.FalconModel(w, n_ctx=64, n_batch=16)
+    for rep in range(3):
+        for n_past, n in ((0, 12), (12, 9), (21, 12), (0, 6)):
+            a = plain.eval(toks[n_past:n_past + n], n_past, logits_all=True)
+            b = graph.eval(toks[n_past:n_past + n], n_past, logits_all=True)
+            assert np.array_equal(a, b), (rep, n_past, n)
+        g.load().ggml_hip_debug_force_gemv(rep == 0)           # second round: the mat-muls through the mat-vec kernel
+    g.load().ggml_hip_debug_force_gemv(0)
+    plain.free(); graph.free()
