@@ -341,20 +341,19 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny(fq_weight w, f
 // one barrier per stage, no pipeline fill per 32 rows. The S partial sums of a pair meet through LDS at the next stage's barrier.
 template <int TYPE> struct sk_res {
     typedef sk_fmt<TYPE> F;
-    static constexpr int NBW = 3;
     static __host__ __device__ int tqs(int nblk) { const int q = nblk * 32; return q + ((16 - (q & 255)) & 255); }      // column stride: = 16 mod 256 -> the 16 columns' operand reads fall into distinct banks
-    static __host__ __device__ size_t lds(int nblk, int S) {
+    static __host__ __device__ size_t lds(int nblk, int S, int NBW) {       // NBW weight stages: 3, or 2 for the formats with wider rows
         return (size_t) NBW * SK_TM * F::ROWB + (size_t) SK_TN * tqs(nblk) + 2 * (size_t) nblk * SK_TN * 4 + (S > 1 ? 2 * (size_t)(S - 1) * 2 * 64 * 16 : 0);
     }
 };
 
-template <int TYPE, int S>
+template <int TYPE, int S, int NBW>
 __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight w, fq_weight w1, fq_act act, int N, float * dst, int64_t ldd, fq_gemv_epi ep, float * dst1, int64_t ldd1, fq_gemv_epi ep1, int dbg) {
     // two matrices of the same K and format in one launch (w1.M == 0: one): the 32-row pairs of w, then those of w1, share the resident columns
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef sk_fmt<TYPE> F;
     constexpr int ACT = fq_act_of(TYPE);
-    constexpr int NCW = 2 * S, NBW = sk_res<TYPE>::NBW, NLW = 2;
+    constexpr int NCW = 2 * S, NLW = 2;
     constexpr int WSTAGE = SK_TM * F::ROWB;
     constexpr int WOPS = (F::NL + 63) / 64;
     constexpr int LOPS = 16 * WOPS;
@@ -770,26 +769,31 @@ static bool fq_launch_gemm_skinny_res(const fq_weight & w, const fq_weight & w1,
                                       float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st) {
     static const bool use_res = !(getenv("FQ_SKINNY_RES") && atoi(getenv("FQ_SKINNY_RES")) == 0);
     if (!use_res) return false;
-    size_t need = 0;
-    switch (w.type) {
-        case FQ_Q4_0: need = sk_res<FQ_Q4_0>::lds((int) w.nblk, S); break; case FQ_Q4_1: need = sk_res<FQ_Q4_1>::lds((int) w.nblk, S); break;
-        case FQ_Q5_0: need = sk_res<FQ_Q5_0>::lds((int) w.nblk, S); break; case FQ_Q5_1: need = sk_res<FQ_Q5_1>::lds((int) w.nblk, S); break;
-        case FQ_Q8_0: need = sk_res<FQ_Q8_0>::lds((int) w.nblk, S); break;
-        default: return false;
+    size_t need = 0; int nbw = 0;
+    for (int n : { 3, 2 }) {
+        switch (w.type) {
+            case FQ_Q4_0: need = sk_res<FQ_Q4_0>::lds((int) w.nblk, S, n); break; case FQ_Q4_1: need = sk_res<FQ_Q4_1>::lds((int) w.nblk, S, n); break;
+            case FQ_Q5_0: need = sk_res<FQ_Q5_0>::lds((int) w.nblk, S, n); break; case FQ_Q5_1: need = sk_res<FQ_Q5_1>::lds((int) w.nblk, S, n); break;
+            case FQ_Q8_0: need = sk_res<FQ_Q8_0>::lds((int) w.nblk, S, n); break;
+            default: return false;
+        }
+        if (need <= 160 * 1024) { nbw = n; break; }
     }
-    if (need > 160 * 1024) return false;
+    if (!nbw) return false;
     const int npairs = (int)((w.M + SK_TM - 1) / SK_TM) + (int)((w1.M + SK_TM - 1) / SK_TM);
     const unsigned g = (unsigned)(npairs < fq_ctx().n_cu ? npairs : fq_ctx().n_cu);
-#define FQ_SKR_LAUNCH(T, SS) { \
+#define FQ_SKR_LAUNCH(T, SS, NB) { \
         static bool set = false; \
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_res<T, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((k_gemm_skinny_res<T, SS>), dim3(g), dim3(64 * (2 + 2 * SS)), need, st, w, w1, act, (int) N, dst, ldd, ep, dst1, ldd1, ep1, fq_gemm_debug_get()); }
-#define FQ_SKR_CASE(T) case T: if (S == 1) FQ_SKR_LAUNCH(T, 1) else if (S == 2) FQ_SKR_LAUNCH(T, 2) else FQ_SKR_LAUNCH(T, 4) break;
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_res<T, SS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_res<T, SS, NB>), dim3(g), dim3(64 * (2 + 2 * SS)), need, st, w, w1, act, (int) N, dst, ldd, ep, dst1, ldd1, ep1, fq_gemm_debug_get()); }
+#define FQ_SKR_S(T, NB) if (S == 1) FQ_SKR_LAUNCH(T, 1, NB) else if (S == 2) FQ_SKR_LAUNCH(T, 2, NB) else FQ_SKR_LAUNCH(T, 4, NB)
+#define FQ_SKR_CASE(T) case T: if (nbw == 3) { FQ_SKR_S(T, 3) } else { FQ_SKR_S(T, 2) } break;
     switch (w.type) {
         FQ_SKR_CASE(FQ_Q4_0) FQ_SKR_CASE(FQ_Q4_1) FQ_SKR_CASE(FQ_Q5_0) FQ_SKR_CASE(FQ_Q5_1) FQ_SKR_CASE(FQ_Q8_0)
         default: return false;
     }
 #undef FQ_SKR_CASE
+#undef FQ_SKR_S
 #undef FQ_SKR_LAUNCH
     return true;
 }
