@@ -601,19 +601,31 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
 // ([share][column][row], f32); k_skinny_sum4 adds them as ((P0 + P1) + P2) + P3 and applies the epilogue: bit-identical to k_gemm_q.
 // Q4_0 only; stage = a span of 32 blocks = 8 own groups per row: 8 quant pieces (stride 64 B) + the 64 B of scales of the span.
 constexpr int KS_TMAX = 8;                 // tiles (consumer waves) per workgroup
-constexpr int KS_ROWB = 208;               // LDS bytes per row and stage: 8 x 16 quants | 64 scales | 16 pad (13 slots: the 16 rows of a tile in distinct banks)
-constexpr int KS_NBW = 3;
-struct sk_ks {
+// per row and stage (a span of 32 blocks, 8 of them the share's): NQ quant pieces (16 B each; Q8_0: two per group), the span's plane 1 (P1 pieces)
+// and plane 2 (P2 pieces, one more than its bytes: a partial column's plane 2 is only 4-byte aligned and is read from the boundary below),
+// padded to an ODD number of 16-byte slots (the 16 rows of a tile in distinct LDS banks)
+template <int TYPE> struct ks_fmt {
+    static constexpr fq_type_desc D = fq_desc(TYPE);
+    static constexpr int QB = D.plane[0].bytes, PB1 = D.plane[1].bytes, PB2 = D.nplanes > 2 ? D.plane[2].bytes : 0;
+    static constexpr int CB = 1024 / QB;                                   // blocks per column: 64 (Q8_0: 32 = one span)
+    static constexpr int NQ = 8 * (QB / 16), P1 = 32 * PB1 / 16, P2 = PB2 ? 32 * PB2 / 16 + 1 : 0;
+    static constexpr int NP = NQ + P1 + P2, NPP = (NP % 2) ? NP : NP + 1;
+    static constexpr int ROWB = 16 * NPP, WSTAGE = 16 * ROWB, KOPS = (16 * NPP + 63) / 64;
+    static constexpr int OFF1 = 16 * NQ, OFF2 = 16 * (NQ + P1);            // byte offsets of the planes inside a row's stage
+    static constexpr bool HAS_MIN = (TYPE == FQ_Q4_1 || TYPE == FQ_Q5_1);
     static __host__ __device__ int nj(int nblk, int s) { return (nblk - s + 3) / 4; }                  // own groups of share s
     static __host__ __device__ int tqs(int nblk) { const int q = ((nblk + 3) / 4) * 32; return q + ((16 - (q & 255)) & 255); }
-    static __host__ __device__ size_t lds(int nblk, int T) {
-        return (size_t) KS_NBW * 16 * T * KS_ROWB + (size_t) SK_TN * tqs(nblk) + 2 * (size_t)((nblk + 3) / 4) * SK_TN * 4;
+    static __host__ __device__ size_t lds(int nblk, int T, int nbw) {
+        return (size_t) nbw * T * WSTAGE + (size_t) SK_TN * tqs(nblk) + 2 * (size_t)((nblk + 3) / 4) * SK_TN * 4;
     }
 };
 
+template <int TYPE, int NBW>
 __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int nslots, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int ACT = FQ_Q8_0;
+    typedef ks_fmt<TYPE> F;
+    constexpr int ACT = fq_act_of(TYPE);
+    constexpr int WSTAGE = F::WSTAGE, KOPS = F::KOPS;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t K = w.K, M = w.M;
     const int nblk = (int) w.nblk;
@@ -623,16 +635,14 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     const int slot = (kk >> 2) * 8 + xcd, s = kk & 3;                     // row blocks slot, slot + nslots, .. (one round when they all fit the chip)
     if (slot >= nrb) return;
     const size_t img = fq_act_col_bytes(ACT, K);
-    const int NJ = sk_ks::nj(nblk, s), NJMAX = (nblk + 3) / 4;
-    const int TQS = sk_ks::tqs(nblk);
-    constexpr int WSTAGE = 16 * KS_ROWB;                                   // one tile's stage: 3.25 KiB = four DMA instructions (the last: 16 lanes)
-    constexpr int KOPS = 4;
-    uint8_t * tqb0 = smem + (size_t) KS_NBW * WSTAGE * T;                  // [16 columns][TQS]: the quants of the share's groups
+    const int NJ = F::nj(nblk, s), NJMAX = (nblk + 3) / 4;
+    const int TQS = F::tqs(nblk);
+    uint8_t * tqb0 = smem + (size_t) NBW * WSTAGE * T;                     // [16 columns][TQS]: the quants of the share's groups
     uint8_t * dxT  = tqb0 + (size_t) SK_TN * TQS;                          // [own group][16] f32: the columns' d
-    uint8_t * ciT  = dxT + (size_t) NJMAX * SK_TN * 4;                     // [own group][16]: -8 isum
+    uint8_t * ciT  = dxT + (size_t) NJMAX * SK_TN * 4;                     // [own group][16]: C start values (int) or the columns' s (f32)
     const int NW = (int)(blockDim.x >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
-    constexpr int COLB = 64 * 18;                                          // bytes of a full column of the device layout (Q4_0)
+    constexpr int COLB = F::CB * F::D.tsize;                               // bytes of a full column of the device layout
 
     // ---- prologue, every wave: the columns' own groups (32 bytes each = two lanes; 32 groups per DMA instruction), the transposed scales
     {
@@ -653,7 +663,13 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
             const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img + (size_t) K;
             const int g = s + 4 * j;
             ((float *) dxT)[e] = ((const float *) tp)[g];
-            ((uint32_t *) ciT)[e] = (uint32_t)(-8 * ((const int32_t *)(tp + nd4))[g]);
+            const uint32_t aux = ((const uint32_t *)(tp + nd4))[g];
+            uint32_t cv;
+            if constexpr (TYPE == FQ_Q4_0)      cv = (uint32_t)(-8 * (int32_t) aux);         // sum (nib - 8) x = sum nib x - 8 sum x
+            else if constexpr (TYPE == FQ_Q5_0) cv = (uint32_t)(-16 * (int32_t) aux);
+            else if constexpr (F::HAS_MIN)      cv = aux;                                       // y.s (f32)
+            else                                cv = 0u;
+            ((uint32_t *) ciT)[e] = cv;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -663,84 +679,119 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     const int64_t mt = ((int64_t) rb * T + wid) * 16;                      // the wave's tile: it stages its own weights and runs its own chain
     if (mt >= M) break;
 
-    // ---- the wave's weight pipeline: per stage (span sp) 16 rows x 13 slots = 4 DMA instructions into its private ring, two stages ahead,
-    // paced by vmcnt alone. Lane L = 64 k + lane of instruction k is (row L / 13, slot L % 13): 8 quant pieces (stride 64 B), 4 of scales, 1 pad
-    uint8_t * myring = smem + (size_t) wid * KS_NBW * WSTAGE;
+    // ---- the wave's weight pipeline: per stage (span sp) 16 rows x NPP slots = KOPS DMA instructions into its private ring, NBW - 1 stages
+    // ahead, paced by vmcnt alone. Lane L = 64 k + lane of instruction k is (row L / NPP, slot L % NPP)
+    uint8_t * myring = smem + (size_t) wid * NBW * WSTAGE;
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(sk_lds(myring));
     const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
     unsigned rowoff[KOPS]; int piece[KOPS];
 #pragma unroll
     for (int k = 0; k < KOPS; ++k) {
-        const int L = 64 * k + lane, row = (L / 13) & 15;                   // (lanes beyond the 208 of the last instruction are masked off below)
-        piece[k] = L % 13 < 12 ? L % 13 : 11;                              // slot 12 = padding: re-reads piece 11
+        const int L = 64 * k + lane, row = (L / F::NPP) & 15;                // (lanes beyond 16 NPP of the last instruction are masked off below)
+        piece[k] = L % F::NPP < F::NP ? L % F::NPP : F::NP - 1;            // the padding slot re-reads the last piece
         const int64_t r = mt + row < M ? row : M - 1 - mt;                  // rows beyond M re-read row M - 1
         rowoff[k] = (unsigned)(r * (int64_t) w.row_stride);
     }
     const unsigned rs16 = (unsigned) w.row_stride - 16u;
     auto issue = [&](int sp) {
-        const int c = sp >> 1, half = sp & 1;
-        const int rem = nblk - 64 * c, nbc = rem < 64 ? rem : 64;
-        const unsigned bq = (unsigned)(c * COLB + (32 * half + s) * 16), bd = (unsigned)(c * COLB + nbc * 16 + 64 * half);
-        const unsigned dst = ring_lds + (unsigned)((sp % KS_NBW) * WSTAGE);
+        const int c = sp / (F::CB / 32), half = sp % (F::CB / 32);
+        const int rem = nblk - F::CB * c, nbc = rem < F::CB ? rem : F::CB;
+        // first byte of the share's first group, of the span's plane 1 and (from the 16-byte boundary below it) of its plane 2
+        const unsigned bq = (unsigned)(c * COLB + (32 * half + s) * F::QB);
+        const unsigned b1 = (unsigned)(c * COLB + nbc * F::QB + 32 * half * F::PB1);
+        const unsigned b2 = (unsigned)(c * COLB + ((nbc * (F::QB + F::PB1)) & ~15) + 32 * half * F::PB2);
+        const unsigned dst = ring_lds + (unsigned)((sp % NBW) * WSTAGE);
 #pragma unroll
         for (int k = 0; k < KOPS; ++k) {
-            unsigned o = piece[k] < 8 ? bq + 64u * (unsigned) piece[k] : bd + 16u * (unsigned)(piece[k] - 8);
+            const int p = piece[k];
+            unsigned o;
+            if (p < F::NQ)              o = F::QB == 16 ? bq + 64u * (unsigned) p : bq + 128u * (unsigned)(p >> 1) + 16u * (unsigned)(p & 1);
+            else if (p < F::NQ + F::P1) o = b1 + 16u * (unsigned)(p - F::NQ);
+            else                        o = b2 + 16u * (unsigned)(p - F::NQ - F::P1);
             o = o < rs16 ? o : rs16;                                       // (a partial last column: pieces beyond its blocks are never used)
-            if (64 * k + lane < 16 * 13) sk_dma(wbase, rowoff[k] + o, dst + (unsigned)(k * 1024));
+            if (64 * k + lane < 16 * F::NPP) sk_dma(wbase, rowoff[k] + o, dst + (unsigned)(k * 1024));
         }
     };
-    if (!(dbg & 8)) { issue(0); if (nsp > 1) issue(1); }
+    if (!(dbg & 8)) { for (int q = 0; q < NBW - 1 && q < nsp; ++q) issue(q); }
 
     float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     const int sh = 4 * (kq >> 1);
-    struct ks_ops { sk_v2i xa, raw; uint32_t s1; float4 dx4; sk_v4i ci4; };
+    struct ks_ops { sk_v2i xa, raw; uint32_t s1, s2; float4 dx4, sx4; sk_v4i ci4; };
     for (int sp = 0; sp < nsp; ++sp) {
-        if (sp + 2 < nsp && !(dbg & 8)) issue(sp + 2);
-        // stage sp has landed: at most the stages issued after it (3 instructions each) are still in flight
-        if (dbg & 8)            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (sp + 2 < nsp)  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (sp + 1 < nsp)  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (sp + NBW - 1 < nsp && !(dbg & 8)) issue(sp + NBW - 1);
+        // stage sp has landed: at most the stages issued after it (KOPS instructions each) are still in flight
+        {
+            const int later = (dbg & 8) ? 0 : (nsp - 1 - sp < NBW - 1 ? nsp - 1 - sp : NBW - 1);
+            if (later >= 2)      sk_wait_vm_upto(2 * KOPS);
+            else if (later == 1) sk_wait_vm_upto(KOPS);
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (dbg & 16) continue;
-        const uint8_t * wr = myring + (size_t)(sp % KS_NBW) * WSTAGE + l16 * KS_ROWB;
+        const uint8_t * wr = myring + (size_t)(sp % NBW) * WSTAGE + l16 * F::ROWB;
         const int jbase = 8 * sp;                                          // own-group index of the span's first own group
         const int njs = NJ - jbase < 8 ? NJ - jbase : 8;                   // own groups in this span
+        const int cst = sp / (F::CB / 32), remc = nblk - F::CB * cst, nbcs = remc < F::CB ? remc : F::CB;
+        const int p2d = (nbcs * (F::QB + F::PB1)) & 15;                    // plane 2's offset from the boundary its DMA started at
         const uint8_t * tqp = tqb0 + (size_t) l16 * TQS + 32 * jbase + 8 * kq;
         const uint8_t * dxp = dxT + (size_t) jbase * SK_TN * 4 + 16 * kq, * cip = ciT + (size_t) jbase * SK_TN * 4 + 16 * kq;
-        const uint8_t * wq = wr + 8 * (kq & 1), * wd = wr + 128 + 2 * s;
+        const uint8_t * wq = wr + (TYPE == FQ_Q8_0 ? 8 * kq : 8 * (kq & 1));
+        const uint8_t * w1 = wr + F::OFF1 + s * F::PB1, * w2 = wr + F::OFF2 + p2d + s * F::PB2;
         auto load_ops = [&](int jj) __attribute__((always_inline)) {
             ks_ops o;
             o.xa = *(const sk_v2i *)(tqp + 32 * jj);
-            o.raw = *(const sk_v2i *)(wq + 16 * jj);
-            o.s1 = *(const uint16_t *)(wd + 8 * jj);
+            o.raw = *(const sk_v2i *)(wq + F::QB * jj);
+            o.s2 = 0u;
+            if constexpr (F::PB1 == 2) o.s1 = *(const uint16_t *)(w1 + 4 * F::PB1 * jj); else o.s1 = *(const uint32_t *)(w1 + 4 * F::PB1 * jj);
+            if constexpr (F::PB2 == 2) o.s2 = *(const uint16_t *)(w2 + 4 * F::PB2 * jj); else if constexpr (F::PB2 == 4) o.s2 = *(const uint32_t *)(w2 + 4 * F::PB2 * jj);
             o.dx4 = *(const float4 *)(dxp + jj * SK_TN * 4);
-            o.ci4 = *(const sk_v4i *)(cip + jj * SK_TN * 4);
+            if constexpr (F::HAS_MIN) { o.sx4 = *(const float4 *)(cip + jj * SK_TN * 4); o.ci4 = sk_v4i{ 0, 0, 0, 0 }; }     // (two typed loads: see k_gemm_skinny)
+            else { o.ci4 = *(const sk_v4i *)(cip + jj * SK_TN * 4); o.sx4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
             return o;
         };
-        auto run_mfma = [&](const ks_ops & o) __attribute__((always_inline)) {
-            const sk_v2i wb2 = sk_v2i{ (int)(((uint32_t) o.raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw.y >> sh) & 0x0F0F0F0Fu) };
+        auto run_mfma = [&](const ks_ops & o, float & dw, float & mw) __attribute__((always_inline)) {
+            sk_v2i wb2;
+            mw = 0.0f;
+            if constexpr (TYPE == FQ_Q8_0) { wb2 = o.raw; dw = fq_h2f((uint16_t) o.s1); }
+            else {
+                wb2 = sk_v2i{ (int)(((uint32_t) o.raw.x >> sh) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw.y >> sh) & 0x0F0F0F0Fu) };
+                if constexpr (TYPE == FQ_Q4_0) dw = fq_h2f((uint16_t) o.s1);
+                else if constexpr (TYPE == FQ_Q4_1) { dw = fq_h2f((uint16_t) o.s1); mw = fq_h2f((uint16_t)(o.s1 >> 16)); }
+                else {
+                    const uint32_t hb = o.s1 >> (8 * kq);                  // bit e of qh = 5th bit of element e
+                    wb2.x |= (int)(spread4(hb) << 4); wb2.y |= (int)(spread4(hb >> 4) << 4);
+                    dw = fq_h2f((uint16_t) o.s2);
+                    if constexpr (TYPE == FQ_Q5_1) mw = fq_h2f((uint16_t)(o.s2 >> 16));
+                }
+            }
             return __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa), __builtin_bit_cast(long, wb2), o.ci4, 0, 0, 0);
         };
-        auto scale = [&](const sk_v4i & c, const ks_ops & o) __attribute__((always_inline)) {
-            const float dw = fq_h2f((uint16_t) o.s1);
+        auto scale = [&](const sk_v4i & c, const ks_ops & o, float dw, float mw) __attribute__((always_inline)) {
             const float dxv[4] = { o.dx4.x, o.dx4.y, o.dx4.z, o.dx4.w };
+            const float sxv[4] = { o.sx4.x, o.sx4.y, o.sx4.z, o.sx4.w };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = ((float) c[r] * dw) * dxv[r]; acc[r] = acc[r] + t; }      // ggml.c:2606
+            for (int r = 0; r < 4; ++r) {
+                const float ci = (float) c[r];
+                float t;
+                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                acc[r] = acc[r] + t;
+            }
         };
         if (njs == 8) {
-            ks_ops o[8]; sk_v4i c[8];
+            ks_ops o[8]; sk_v4i c[8]; float dwv[8], mwv[8];
             o[0] = load_ops(0); o[1] = load_ops(1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {                                   // reads two groups ahead, the matrix instruction one ahead of its scaling
                 if (k + 2 < 8) o[k + 2] = load_ops(k + 2);
-                c[k] = run_mfma(o[k]);
+                c[k] = run_mfma(o[k], dwv[k], mwv[k]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (k > 0) scale(c[k - 1], o[k - 1]);
+                if (k > 0) scale(c[k - 1], o[k - 1], dwv[k - 1], mwv[k - 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            scale(c[7], o[7]);
+            scale(c[7], o[7], dwv[7], mwv[7]);
         } else {
-            for (int jj = 0; jj < njs; ++jj) { const ks_ops o = load_ops(jj); const sk_v4i c = run_mfma(o); scale(c, o); }
+            for (int jj = 0; jj < njs; ++jj) { const ks_ops o = load_ops(jj); float dw, mw; const sk_v4i c = run_mfma(o, dw, mw); scale(c, o, dw, mw); }
         }
     }
     const int64_t m = mt + l16;
@@ -816,21 +867,37 @@ bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, f
     }
     // long rows (the columns do not fit): one K share per workgroup (Q4_0, four partial sums; FQ_SKINNY_KS=0: never)
     static const bool use_ks = !(getenv("FQ_SKINNY_KS") && atoi(getenv("FQ_SKINNY_KS")) == 0);
-    if (use_ks && w.type == FQ_Q4_0 && S == 4 && w.M <= FQ_KS_MAX_M && w.nblk >= 256) {
+    if (use_ks && S == 4 && w.M <= FQ_KS_MAX_M && w.nblk >= 256) {
         const int n_cu = fq_ctx().n_cu;
         const int ntiles = (int)((w.M + 15) / 16);
         int T = (ntiles * 4 + n_cu - 1) / n_cu;                            // tiles per workgroup: all workgroups resident in one round ..
         if (T < 1) T = 1;
         if (T > KS_TMAX) T = KS_TMAX;                                      // .. or full workgroups that walk their row blocks (the columns stay resident)
-        const size_t need = sk_ks::lds((int) w.nblk, T);
-        if (need <= 160 * 1024) {
+        size_t need = 0; int nbw = 0;
+        for (int n : { 3, 2 }) {
+            switch (w.type) {
+                case FQ_Q4_0: need = ks_fmt<FQ_Q4_0>::lds((int) w.nblk, T, n); break; case FQ_Q4_1: need = ks_fmt<FQ_Q4_1>::lds((int) w.nblk, T, n); break;
+                case FQ_Q5_0: need = ks_fmt<FQ_Q5_0>::lds((int) w.nblk, T, n); break; case FQ_Q5_1: need = ks_fmt<FQ_Q5_1>::lds((int) w.nblk, T, n); break;
+                default:      need = ks_fmt<FQ_Q8_0>::lds((int) w.nblk, T, n); break;
+            }
+            if (need <= 160 * 1024) { nbw = n; break; }
+        }
+        if (nbw) {
             const int nrb = (ntiles + T - 1) / T;
             int nslots = 8 * ((nrb + 7) / 8);
             if (4 * nslots > n_cu) nslots = (n_cu / 32) * 8;
             const unsigned g = (unsigned)(4 * nslots);
-            static bool set = false;
-            if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_ks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-            hipLaunchKernelGGL(k_gemm_skinny_ks, dim3(g), dim3(64 * KS_TMAX), need, st, w, act, (int) N, fq_ctx().ks_scratch, T, nrb, nslots, fq_gemm_debug_get());
+#define FQ_KS_LAUNCH(TT, NB) { \
+                static bool set = false; \
+                if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_ks<TT, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+                hipLaunchKernelGGL((k_gemm_skinny_ks<TT, NB>), dim3(g), dim3(64 * KS_TMAX), need, st, w, act, (int) N, fq_ctx().ks_scratch, T, nrb, nslots, fq_gemm_debug_get()); }
+#define FQ_KS_CASE(TT) case TT: if (nbw == 3) FQ_KS_LAUNCH(TT, 3) else FQ_KS_LAUNCH(TT, 2) break;
+            switch (w.type) {
+                FQ_KS_CASE(FQ_Q4_0) FQ_KS_CASE(FQ_Q4_1) FQ_KS_CASE(FQ_Q5_0) FQ_KS_CASE(FQ_Q5_1) FQ_KS_CASE(FQ_Q8_0)
+                default: return false;
+            }
+#undef FQ_KS_CASE
+#undef FQ_KS_LAUNCH
             hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep);
             return true;
         }
