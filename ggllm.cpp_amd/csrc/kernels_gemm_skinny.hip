@@ -18,6 +18,11 @@
 //               ((P0 + P1) + P2) + P3; S chosen by the same rule): results are bit-identical to kernels_gemm.hip's, and the
 //               oracle's split orders (orc_set_sum_order 2 / 3 / 4 / 5) apply unchanged.
 // Scope: the legacy formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0); k-quants keep kernels_gemm.hip.
+//
+// Three forms, picked by fq_launch_gemm_skinny (all bit-identical to each other and to k_gemm_q):
+//   k_gemm_skinny_res   the columns RESIDENT in LDS, one persistent workgroup per CU, optionally two matrices per launch -- rows up to ~4.6 k long
+//   k_gemm_skinny_ks    one K share per workgroup for longer rows (+ k_skinny_sum4): a quarter of the columns resident, self-paced waves
+//   k_gemm_skinny       the per-stage form described above: the fallback when neither fits LDS
 #include "fq_block_dev.h"
 #include "kernels.h"
 #include "hip_context.h"
@@ -599,7 +604,7 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
 // consumer wave runs one (tile, share) accumulator chain over all of its groups. The four shares of a row block run on the same XCD
 // (workgroup index mod 8), so the 64-byte segments their 16-byte pieces sit in are fetched from HBM once. Partial sums go to a scratch
 // ([share][column][row], f32); k_skinny_sum4 adds them as ((P0 + P1) + P2) + P3 and applies the epilogue: bit-identical to k_gemm_q.
-// Q4_0 only; stage = a span of 32 blocks = 8 own groups per row: 8 quant pieces (stride 64 B) + the 64 B of scales of the span.
+// All five legacy formats; stage = a span of 32 blocks = 8 own groups per row: their quant pieces (stride 64 B; Q8_0: 128 B) + the span's scale planes.
 constexpr int KS_TMAX = 8;                 // tiles (consumer waves) per workgroup
 // per row and stage (a span of 32 blocks, 8 of them the share's): NQ quant pieces (16 B each; Q8_0: two per group), the span's plane 1 (P1 pieces)
 // and plane 2 (P2 pieces, one more than its bytes: a partial column's plane 2 is only 4-byte aligned and is read from the boundary below),
