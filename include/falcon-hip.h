@@ -119,7 +119,8 @@ void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* cap
  * when the grid fits the chip), 3 = one launch per block (the next block's LayerNorm mat-vec as a second phase of the same
  * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests), 4 = the persistent decode
  * engine: ONE launch per token for all blocks of the stage + lm_head (csrc/kernels_engine.hip; legacy formats, one format
- * per stage -- other models keep mode 2). All produce the same bits. */
+ * per stage -- other models keep mode 2), 5 = mode 2 with the LayerNorm mat-vec launch in the ring form (csrc/kernels_ring.hip: an LDS-DMA
+ * loader wave + consumers out of an LDS ring; legacy formats). All produce the same bits; 3, 4 and 5 are measured no faster than 2. */
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
 /* 1 when N == 1 evals of this context run through the persistent engine (mode 4 and a model inside its scope) */
 int   falcon_hip_context_engine_active(falcon_hip_context * c);
