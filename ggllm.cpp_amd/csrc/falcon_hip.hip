@@ -95,13 +95,13 @@ struct falcon_hip_context {
     const void * sg_in[2] = { nullptr, nullptr }; void * sg_out[2] = { nullptr, nullptr };
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
-    bool ring_ln = false;                      // FALCON_HIP_RING=1: k_gemv_ln's launches in the ring form (kernels_ring.hip)
-    // batched evaluation replayed from hipGraphs (FALCON_HIP_PREFILL_GRAPH=0: plain launches): the ~320 launches and 96 cross-stream joins of a
+    bool ring_ln = false;                      // k_gemv_ln's launches in the ring form (kernels_ring.hip); FALCON_HIP_RING=0: never
+    // batched evaluation replayed from hipGraphs (FALCON_HIP_PREFILL_GRAPH=1; default: plain launches): the ~320 launches and 96 cross-stream joins of a
     // prompt batch are then scheduled by the graph instead of the host (the joins cost ~12 us of idle device each as stream events: 11 % of a
     // 128-token Falcon-7B prompt). Keyed by (tokens, keys, mode signature, keep_hidden); the position and the token ids are read from device memory.
     struct batch_graph { int N, max_kv, sig; hipGraphExec_t exec; };
     std::vector<batch_graph> batch_graphs;
-    bool prefill_graph = true;
+    bool prefill_graph = false;                // (off by default: a replay saves 1-2 % of a batch, capturing a new (tokens, keys) shape costs ~5 ms once)
     int  graph_base = -1;                      // n_past the captured graph was built for
     int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
     unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
@@ -314,7 +314,7 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     HIP_CHECK(hipMemset(c->x_gran, 0, (size_t) hp.n_embd * 8 + 64));
     if (const char * e = getenv("FALCON_HIP_TWO_PHASE")) c->two_phase = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
-    if (const char * e = getenv("FALCON_HIP_RING")) c->ring_ln = atoi(e) != 0;
+    c->ring_ln = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);      // (default on: a context starts in mode 2)
     if (const char * e = getenv("FALCON_HIP_PREFILL_GRAPH")) c->prefill_graph = atoi(e) != 0;
     if (c->ring_ln && nl > 0) c->ring_ln = fq_ring_prepare(m->layers[0].qkv.type, E, FF, m->layers[0].qkv.M, fq_ctx().n_cu);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
@@ -371,8 +371,10 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     c->merged_attn_out = mode >= 2;
     c->two_phase = mode == 3;
     c->engine = mode == 4;
-    // 5 = two launches per block, the LayerNorm mat-vec launch in the ring form (kernels_ring.hip; FALCON_HIP_RING=1 selects it at creation)
-    c->ring_ln = mode == 5 && !c->m->layers.empty() &&
+    // the LayerNorm mat-vec launch in the ring form (kernels_ring.hip): mode 5 always, mode 2 unless FALCON_HIP_RING=0 (measured +1.6 % on
+    // Falcon-7B Q4_0; legacy formats only, other models keep k_gemv_ln)
+    static const bool ring_default = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);
+    c->ring_ln = (mode == 5 || (mode == 2 && ring_default)) && !c->m->layers.empty() &&
                  fq_ring_prepare(c->m->layers[0].qkv.type, c->m->hp.n_embd, c->m->hp.n_ff, c->m->layers[0].qkv.M, fq_ctx().n_cu);
 }
 // 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)

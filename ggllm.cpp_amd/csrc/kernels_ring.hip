@@ -154,8 +154,9 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         // the residual row's loads go first: every helper wave has issued its share
         if (!(a.debug_mode & 1)) w.until(ctl + RING_XISSUED, (unsigned) ENG_NH, ENG_W_XG);
         RING_T(0, 1);
-        if (nA1 > 0) seg(src(0), pA1);
-        if (nA2 > 0 && !w.dead) seg(src(1), pA2);
+        // Wup first: its rows end in the epilogue wave's GELU + Q8 work, which then overlaps the Wqkv rows instead of trailing the launch
+        if (nA2 > 0) seg(src(1), pA2);
+        if (nA1 > 0 && !w.dead) seg(src(0), pA1);
         RING_T(0, 2);
         // the end of the stream is reported as it lands, not in one piece: the consumers' last runs start while the final pieces are in flight
 #define RING_END_STEP(N) if (pos - reported > (N + MIRP) * 1024u) { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); report_keep(N); }
@@ -307,8 +308,9 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
     }
 
     // ---- consumers: rows out of the ring, runs of R consecutive rows round-robin (kernels_engine.hip `rows`)
-    auto rows = [&](auto rtag, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, auto && sink) {
+    auto rows = [&](auto rtag, auto ptag, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink) {
         constexpr int R = decltype(rtag)::value;
+        constexpr bool PRE = decltype(ptag)::value;                        // (compile-time: a run-time choice between the arrays would put them into scratch memory)
         const unsigned row_bytes = (unsigned)(nblkE * TS);
         if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, R * c < nrows ? seg_pos + (unsigned)(R * c) * rsE : seg_pos + padded);
         const int npass = (nblkE + 63) >> 6;
@@ -325,7 +327,12 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
                 const unsigned need = rowl + (upto < row_bytes ? upto : row_bytes);
                 for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) < 0;) { if (!w.spin(spins, ENG_W_LAND, need, 0)) break; __builtin_amdgcn_s_sleep(1); }
                 if (!nodots) {
-                    if (np == 3)      eng_pass_group<TYPE, RING, R, 3>(ring, pr, nblkE, 64 * ps, col, lane, acc);
+                    if (PRE) {                                  // rows of <= 3 passes: the lane's activation slices were loaded once, before the row loop
+                        if (np == 3)      eng_pass_group_pre<TYPE, RING, R, 3>(ring, pr, nblkE, 0, pre, lane, acc);
+                        else if (np == 2) eng_pass_group_pre<TYPE, RING, R, 2>(ring, pr, nblkE, 0, pre, lane, acc);
+                        else              eng_pass_group_pre<TYPE, RING, R, 1>(ring, pr, nblkE, 0, pre, lane, acc);
+                    }
+                    else if (np == 3) eng_pass_group<TYPE, RING, R, 3>(ring, pr, nblkE, 64 * ps, col, lane, acc);
                     else if (np == 2) eng_pass_group<TYPE, RING, R, 2>(ring, pr, nblkE, 64 * ps, col, lane, acc);
                     else              eng_pass_group<TYPE, RING, R, 1>(ring, pr, nblkE, 64 * ps, col, lane, acc);
                 }
@@ -340,13 +347,26 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         }
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
-    auto rows_e = [&](unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, auto && sink) {
-        if (!(a.debug_mode & 16) && (unsigned)(2 * ENG_NC) * rsE * 2u <= (unsigned) RING) rows(R2, seg_pos, padded, nrows, col, sink);
-        else                                                       rows(R1, seg_pos, padded, nrows, col, sink);
+    std::integral_constant<bool, true> PT; std::integral_constant<bool, false> PF;
+    auto rows_e = [&](bool prefit_, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink) {
+        const bool r2 = !(a.debug_mode & 16) && (unsigned)(2 * ENG_NC) * rsE * 2u <= (unsigned) RING;
+        if (prefit_) { if (r2) rows(R2, PT, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PT, seg_pos, padded, nrows, col, pre, sink); }
+        else         { if (r2) rows(R2, PF, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PF, seg_pos, padded, nrows, col, pre, sink); }
     };
-    rows_e(0u, pA1, nA1, a.two_norms ? col_e2 : col_e, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
+    // a lane's units are lane, lane + 64, lane + 128 of EVERY row: their activation slices stay in registers when a row is <= 3 passes long
+    const bool prefit = ((nblkE + 63) >> 6) <= 3 && !(a.debug_mode & 32);
+    fq_act32 preA[3], preB[3];
+    if (prefit) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int u = 64 * p + lane, uc = u < nblkE ? u : nblkE - 1;
+            preA[p] = fq_act32_load(col_e, uc);
+            preB[p] = a.two_norms ? fq_act32_load(col_e2, uc) : preA[p];
+        }
+    }
+    rows_e(prefit, 0u, pA2, nA2, col_e, preA, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 3);
-    rows_e(pA1, pA2, nA2, col_e, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
+    rows_e(prefit, pA2, pA1, nA1, a.two_norms ? col_e2 : col_e, preB, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 4);
 }
 

@@ -21,8 +21,8 @@ st = st.reshape(2, 4096, 8)[0].astype(np.float64)
 t0 = st[:256, 0].min()
 names = {(0, 0): "workgroup starts", (0, 1): "loader starts", (0, 2): "last piece issued", (0, 3): "all landed",
          (1, 1): "epilogue wave: mean known", (1, 2): "epilogue wave: image done", (1, 3): "epilogue wave: epilogues done",
-         (2, 1): "consumer 0: mean known", (2, 2): "consumer 0: image done", (2, 3): "consumer 0: qkv rows done", (2, 4): "consumer 0: up rows done",
-         (3, 3): "consumer 9: qkv rows done", (3, 4): "consumer 9: up rows done"}
+         (2, 1): "consumer 0: mean known", (2, 2): "consumer 0: image done", (2, 3): "consumer 0: up rows done", (2, 4): "consumer 0: qkv rows done",
+         (3, 3): "consumer 9: up rows done", (3, 4): "consumer 9: qkv rows done"}
 for (role, slot), nm in names.items():
     v = st[role * 256:(role + 1) * 256, slot]
     v = (v[v > 0] - t0) / 100.0
