@@ -23,6 +23,9 @@ namespace {
 // control words of this kernel beyond eng_ctl's (which it shares: PSUM, STAT, OUT, CNT, LANDED, LOW, XG_DONE, LN_STAT, IMG_DONE, LN_MEAN, S2_DONE, PSQ)
 constexpr unsigned RING_XISSUED = eng_ctl::A_DONE;    // helper waves that have issued their loads of the residual row
 constexpr unsigned RING_CTL_BYTES = eng_ctl::PTRS + 64;
+// waves of a workgroup: the loader, the epilogue wave, RNC consumers. (12 consumers instead of 10 were measured SLOWER, 959 against 988 tok/s: their
+// working set leaves the loader less of the ring and the stream ends 1.2 us later -- the consumers' time is latency, not issue slots.)
+constexpr int RNH = 11, RNC = RNH - 1, RNT = 64 * (RNH + 1), RHT = 64 * RNH;
 // phase stamps (ggml_hip_debug_stamps): rows [role * 256 + workgroup][slot], role 0 = loader, 1 = epilogue wave, 2 = consumer 0, 3 = consumer 9
 #define RING_T(role, slot) do { if (a.dbg && lane == 0) a.dbg[((size_t)(role) * 256 + blockIdx.x) * 8 + (slot)] = (long long) wall_clock64(); } while (0)
 
@@ -40,8 +43,8 @@ struct fq_ring_ln_args {
     unsigned * err; int debug_mode; long long * dbg;
 };
 
-template <int TYPE, int NSLOT>
-__global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
+template <int TYPE, int NSLOT, bool TWO>
+__global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = eng_act<TYPE>::value;
     constexpr int RING = NSLOT * ENG_SLOT;
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
     if (a.rope_cur && blockIdx.x == gridDim.x - 1 && tid >= 64 && tid < 128) a.rope_cur[tid - 64] = a.rope_cs[(int64_t)(*a.n_past_ptr) * 64 + (tid - 64)];
     if (tid < 2) lds_st64(ctl + eng_ctl::PTRS + 8 * tid, (unsigned long long)(uintptr_t)(tid == 0 ? a.qkv + (size_t) sc.qg0 * rsE : a.up + (size_t) sc.ug0 * 32 * rsE));
     if (tid < 32) lds_st(ctl + eng_ctl::CNT + 4 * tid, 0u);
-    if (tid < 16) lds_st(ctl + eng_ctl::LOW + 4 * tid, tid < ENG_NC ? 0u : 0xFFFFFFFFu);
+    if (tid < 16) lds_st(ctl + eng_ctl::LOW + 4 * tid, tid < RNC ? 0u : 0xFFFFFFFFu);
     if (tid < 16) lds_st(ctl + eng_ctl::XG_DONE + 4 * tid, 0u);
     if (tid == 0) lds_st(ctl + eng_ctl::LANDED, 0u);
     if (a.dbg && tid == 0) a.dbg[(size_t) blockIdx.x * 8] = (long long) wall_clock64();
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
             return (const uint8_t *)(uintptr_t)(((unsigned long long) hi << 32) | lo);
         };
         // the residual row's loads go first: every helper wave has issued its share
-        if (!(a.debug_mode & 1)) w.until(ctl + RING_XISSUED, (unsigned) ENG_NH, ENG_W_XG);
+        if (!(a.debug_mode & 1)) w.until(ctl + RING_XISSUED, (unsigned) RNH, ENG_W_XG);
         RING_T(0, 1);
         // Wup first: its rows end in the epilogue wave's GELU + Q8 work, which then overlaps the Wqkv rows instead of trailing the launch
         if (nA2 > 0) seg(src(1), pA2);
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
     // ---- the residual row -> LDS (chunks of 1024 values, one per helper wave, each with its f64 partial sum) -> statistics -> Q8 image(s)
     // (the engine's one-pass LayerNorm, kernels_engine.hip: ggml.c:10577-10591 with the sums in f64)
     ln_row_regs<NLN> wr, br;
-    ln_regs_issue_wb(a.ln_w, a.ln_b, E, ENG_HT, wr, br, ht);
+    ln_regs_issue_wb(a.ln_w, a.ln_b, E, RHT, wr, br, ht);
     {
         unsigned own = 0;
         float v[16]; int kown = -1;
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         double s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < NLN; ++k) {
-            const int q4 = k * ENG_HT + ht;
+            const int q4 = k * RHT + ht;
             float4 t = ((const float4 *) xrow)[q4 < nv ? q4 : nv - 1];
             t.x -= mean; t.y -= mean; t.z -= mean; t.w -= mean;
             xv[k] = t;
@@ -235,11 +238,11 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         unsigned old2 = 0;
         if (lane == 0) old2 = lds_add_rtn(ctl + eng_ctl::S2_DONE, 1u);
         old2 = __builtin_amdgcn_readfirstlane(old2);
-        if (old2 + 1u == (unsigned) ENG_NH) {                              // the last wave: partial sums in wave order -> scale
-            const unsigned long long pk = lds_ld64(ctl + eng_ctl::PSQ + 8u * (unsigned)(lane < ENG_NH ? lane : 0));
+        if (old2 + 1u == (unsigned) RNH) {                              // the last wave: partial sums in wave order -> scale
+            const unsigned long long pk = lds_ld64(ctl + eng_ctl::PSQ + 8u * (unsigned)(lane < RNH ? lane : 0));
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < ENG_NH; ++k) t += lane_get(__builtin_bit_cast(double, (long long) pk), k);
+            for (int k = 0; k < RNH; ++k) t += lane_get(__builtin_bit_cast(double, (long long) pk), k);
             const float variance = (float)(t / (double) E);
             const float scale = 1.0f / sqrtf(variance + 1e-5f);
             if (lane == 0) ldsf_st(eng_ctl::STAT + 4, scale);
@@ -252,7 +255,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
             const act_image_ptr o = act_image_at(img, ACT, E);
 #pragma unroll
             for (int k = 0; k < NLN; ++k) {
-                const int q4 = k * ENG_HT + ht;
+                const int q4 = k * RHT + ht;
                 if ((q4 & ~63) < nv) {                                     // wave-uniform
                     const bool lv = q4 < nv; const int j = lv ? q4 : nv - 1;
                     float4 t = xv[k];
@@ -266,12 +269,12 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         norm_quant(wr, br, img_e);
         if (a.two_norms) {
             ln_row_regs<NLN> w2r, b2r;
-            ln_regs_issue_wb(a.ln2_w, a.ln2_b, E, ENG_HT, w2r, b2r, ht);
+            ln_regs_issue_wb(a.ln2_w, a.ln2_b, E, RHT, w2r, b2r, ht);
             norm_quant(w2r, b2r, img_e2);
         }
         lds_drain();
         if (lane == 0) lds_add(ctl + eng_ctl::IMG_DONE, 1u);
-        w.until(ctl + eng_ctl::IMG_DONE, (unsigned) ENG_NH, ENG_W_IMG);
+        w.until(ctl + eng_ctl::IMG_DONE, (unsigned) RNH, ENG_W_IMG);
         if (h <= 1) RING_T(1 + h, 2);
     }
 
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
         const unsigned row_bytes = (unsigned)(nblkE * TS);
         if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, R * c < nrows ? seg_pos + (unsigned)(R * c) * rsE : seg_pos + padded);
         const int npass = (nblkE + 63) >> 6;
-        for (int i = R * c; i < nrows; i += R * ENG_NC) {
+        for (int i = R * c; i < nrows; i += R * RNC) {
             const int last = i + R - 1 < nrows ? i + R - 1 : nrows - 1;
             const unsigned row0 = seg_pos + (unsigned) i * rsE, rowl = seg_pos + (unsigned) last * rsE;
             unsigned pr[R]; float v[R], acc[R];
@@ -342,31 +345,32 @@ __global__ void __launch_bounds__(ENG_NT) k_gemv_ln_ring(fq_ring_ln_args a) {
             for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[r]);
 #pragma unroll
             for (int r = 0; r < R; ++r) if (i + r <= last) sink(i + r, v[r]);
-            const int nx_ = i + R * ENG_NC;
+            const int nx_ = i + R * RNC;
             if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rsE : seg_pos + padded);
         }
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
     std::integral_constant<bool, true> PT; std::integral_constant<bool, false> PF;
     auto rows_e = [&](bool prefit_, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink) {
-        const bool r2 = !(a.debug_mode & 16) && (unsigned)(2 * ENG_NC) * rsE * 2u <= (unsigned) RING;
+        const bool r2 = !(a.debug_mode & 16) && (unsigned)(2 * RNC) * rsE * 2u <= (unsigned) RING;
         if (prefit_) { if (r2) rows(R2, PT, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PT, seg_pos, padded, nrows, col, pre, sink); }
         else         { if (r2) rows(R2, PF, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PF, seg_pos, padded, nrows, col, pre, sink); }
     };
     // a lane's units are lane, lane + 64, lane + 128 of EVERY row: their activation slices stay in registers when a row is <= 3 passes long
     const bool prefit = ((nblkE + 63) >> 6) <= 3 && !(a.debug_mode & 32);
-    fq_act32 preA[3], preB[3];
+    fq_act32 preA[3], preB[TWO ? 3 : 1];                                 // (one norm: Wqkv reads the same image)
     if (prefit) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int u = 64 * p + lane, uc = u < nblkE ? u : nblkE - 1;
             preA[p] = fq_act32_load(col_e, uc);
-            preB[p] = a.two_norms ? fq_act32_load(col_e2, uc) : preA[p];
+            if constexpr (TWO) preB[p] = fq_act32_load(col_e2, uc);
         }
     }
     rows_e(prefit, 0u, pA2, nA2, col_e, preA, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 3);
-    rows_e(prefit, pA2, pA1, nA1, a.two_norms ? col_e2 : col_e, preB, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
+    if constexpr (TWO) rows_e(prefit, pA2, pA1, nA1, col_e2, preB, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
+    else rows_e(prefit, pA2, pA1, nA1, col_e, preA, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 4);
 }
 
@@ -439,12 +443,13 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
     // a row (<= 3 passes of it) must fit the ring next to the loader's restart slot
     if ((size_t) 2 * 2 * a.rsE + ENG_SLOT > (size_t) nslot * ENG_SLOT) return false;
     const size_t lds = (size_t) nslot * ENG_SLOT + fixed;
-#define FQ_RING_LAUNCH(T, NS) { \
+#define FQ_RING_LAUNCH2(T, NS, TW) { \
         static bool set = false; \
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ring<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ring<T, NS, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_);      /* (the open profile bracket's events, if any, go to the dispatch) */ \
-        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS>), dim3((unsigned) n_cu), dim3(ENG_NT), lds, st, e0_, e1_, 0, a); \
-        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS>), dim3((unsigned) n_cu), dim3(ENG_NT), lds, st, a); }
+        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW>), dim3((unsigned) n_cu), dim3(RNT), lds, st, e0_, e1_, 0, a); \
+        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW>), dim3((unsigned) n_cu), dim3(RNT), lds, st, a); }
+#define FQ_RING_LAUNCH(T, NS) { if (two_norms) FQ_RING_LAUNCH2(T, NS, true) else FQ_RING_LAUNCH2(T, NS, false) }
 #define FQ_RING_CASE(T) case T: if (nslot == 7) FQ_RING_LAUNCH(T, 7) else if (nslot == 6) FQ_RING_LAUNCH(T, 6) else FQ_RING_LAUNCH(T, 4) break;
     switch (type) {
         FQ_RING_CASE(FQ_Q4_0) FQ_RING_CASE(FQ_Q4_1) FQ_RING_CASE(FQ_Q5_0) FQ_RING_CASE(FQ_Q5_1) FQ_RING_CASE(FQ_Q8_0)
@@ -452,5 +457,6 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
     }
 #undef FQ_RING_CASE
 #undef FQ_RING_LAUNCH
+#undef FQ_RING_LAUNCH2
     return true;
 }
