@@ -355,7 +355,7 @@ def main():
             ovh = L.ggml_hip_profile_bracket_overhead_us()
             avg_us = us.value / nl.value
             ach = (by.value / nl.value) / (avg_us * 1e-6) / 1e9
-            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln + k_attn_out (fused quantized mat-vec launches; lm_head included)",
+            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln_ring (lm_head: k_gemv_ln) + k_attn_out (fused quantized mat-vec launches; lm_head included)",
                         launches=nl.value, avg_launch_us=avg_us, empty_event_pair_us=ovh, bytes_per_launch=by.value / nl.value)
     # HBM traffic per launch from the PMC counters: collected off-line (scripts/gpu_pmc.sh: one rocprofv3 --pmc pass per
     # counter over this same command, corrected by scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes) and committed
