@@ -717,8 +717,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         if (seq_stride && !fq_reference_order() && !fq_attn_f64()) {
             // lock-step sequences: RoPE, KV append, attention and (Q8_0 / Q8_1 consumers) the activation image of all N tokens in
             // one launch of the decode attention (k_attn_decode's code: the same bits as the three launches below)
+            // (Wup's GELU output exists already when both mat-muls went in one launch: its quantizer rides on this launch)
+            static const bool ride_on = !(getenv("FALCON_HIP_QUANT_RIDER") && atoi(getenv("FALCON_HIP_QUANT_RIDER")) == 0);
+            const bool ride = ride_on && pair_done && !ff_quantized && (a_ff.type == FQ_Q8_0 || a_ff.type == FQ_Q8_1);
             fq_launch_attn_decode_seqs(c->qkv, N, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, seq_stride, hc.exp_table_attn,
-                                       att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, a_att.type, (int64_t) fq_act_col_bytes(a_att.type, E), st);
+                                       att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, a_att.type, (int64_t) fq_act_col_bytes(a_att.type, E), st,
+                                       ride ? c->up : nullptr, FF, ride ? &a_ff : nullptr);
+            if (ride) ff_quantized = true;
             if (!att_q) fq_launch_quantize_act(c->att, E, a_att, st);
         } else {
             fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);

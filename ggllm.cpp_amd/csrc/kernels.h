@@ -119,7 +119,8 @@ void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_pa
 // B lock-step sequences: row t of qkv / att, KV cache t (seq_stride floats apart), image column t (image_stride bytes apart)
 void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                                   float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
-                                  int att_act_type, int64_t image_stride, hipStream_t st);
+                                  int att_act_type, int64_t image_stride, hipStream_t st, const float * qx = nullptr, int64_t q_ldx = 0, const fq_act * qa = nullptr);
+// (qx / qa: optional rider -- the f32 matrix qx [n_seq][q_ldx] is quantized into the image qa by extra workgroups of the same launch)
 
 // kernels_ring.hip -- the ring form of k_gemv_ln's launch (LDS-DMA loader wave + consumers out of an LDS ring, one workgroup per CU);
 // false = outside its scope, nothing launched. fq_ring_prepare: builds the shape's schedule (allocates: not inside a stream capture)

@@ -432,9 +432,24 @@ void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past
 
 // the same for B lock-step sequences (falcon_hip_context_create_seqs): blockIdx.y = sequence, with its own qkv row, KV cache
 // and output column -- RoPE, KV append, attention and the Q8 image of B tokens in one launch
-__global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a, int64_t qkv_stride, int64_t seq_stride, int64_t att_stride, int64_t image_stride) {
+// Optional rider (qx != nullptr): workgroups blockIdx.x >= H quantize column blockIdx.y of the f32 matrix qx into the image qa (k_quantize_q8's
+// code) -- the GELU output of the block's other branch, which is ready at the same time as q / k / v and otherwise costs a launch of its own.
+__global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a, int64_t qkv_stride, int64_t seq_stride, int64_t att_stride, int64_t image_stride,
+                                                          int H, const float * __restrict__ qx, int64_t q_ldx, fq_act qa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int64_t t = blockIdx.y;
+    if ((int) blockIdx.x >= H) {
+        const int64_t quads = qa.K >> 2;                                   // (a multiple of 8: whole 32-blocks)
+        const int nb = (int) gridDim.x - H;
+        const act_image_ptr o = act_image_at(qa.base + (size_t) t * fq_act_col_bytes(qa.type, qa.K), qa.type, qa.K);
+        for (int64_t q4 = (int64_t)((int) blockIdx.x - H) * 256 + threadIdx.x; q4 < ((quads + 63) & ~(int64_t) 63); q4 += (int64_t) nb * 256) {
+            const bool live = q4 < quads;
+            const int64_t qq = live ? q4 : quads - 1;
+            const float4 v = *(const float4 *)(qx + t * q_ldx + 4 * qq);
+            if (qa.type == FQ_Q8_0) quant_q8_quad<FQ_Q8_0>(v, qq, o, live); else quant_q8_quad<FQ_Q8_1>(v, qq, o, live);
+        }
+        return;
+    }
     a.qkv += t * qkv_stride; a.kc += t * seq_stride; a.vc += t * seq_stride;
     if (a.att) a.att += t * att_stride;
     if (a.att_image) a.att_image += t * image_stride;
@@ -442,12 +457,15 @@ __global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a,
 }
 void fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                                 float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
-                                int att_act_type, int64_t image_stride, hipStream_t st) {
+                                int att_act_type, int64_t image_stride, hipStream_t st, const float * qx, int64_t q_ldx, const fq_act * qa) {
     const size_t lds = attn_decode_lds(max_n_kv);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode_seqs, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     const fq_attn_decode_args a{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type, max_n_kv, nullptr, nullptr, nullptr, nullptr };
-    hipLaunchKernelGGL(k_attn_decode_seqs, dim3((unsigned) H, (unsigned) n_seq), dim3(256), lds, st, a, (int64_t)(H + 2 * HKV) * 64, seq_stride, (int64_t) H * 64, image_stride);
+    const bool ride = qx && qa && (qa->type == FQ_Q8_0 || qa->type == FQ_Q8_1) && qa->ncols >= n_seq;
+    const int extra = ride ? (int)(((qa->K >> 2) + 255) / 256) : 0;        // quantizer workgroups per column
+    hipLaunchKernelGGL(k_attn_decode_seqs, dim3((unsigned)(H + extra), (unsigned) n_seq), dim3(256), lds, st, a, (int64_t)(H + 2 * HKV) * 64, seq_stride, (int64_t) H * 64,
+                       image_stride, H, ride ? qx : nullptr, q_ldx, ride ? *qa : fq_act{});
 }
 
 // =============================================================================================== k_attn_out
