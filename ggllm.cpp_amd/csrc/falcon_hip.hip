@@ -497,13 +497,14 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
 // lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides): 4 for the
 // legacy formats, whose streaming small-batch mat-mul serves 5..16 columns in less time than two chunks (Falcon-7B Q4_0: 2.9 ms per pass
-// against 3.6 at 8 sequences), 12 for the k-quants, which have only the tile GEMM beyond (8-9 ms per pass whatever the width)
+// against 3.6 at 8 sequences), 12 for the k-quants, which have only the tile GEMM beyond (8-9 ms per pass whatever the width) -- except Q4_K, below
 static int fq_cols_max_n(int wtype) {
     static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 0;
     if (v > 0) return v;
     return (wtype == FQ_Q4_0 || wtype == FQ_Q4_1 || wtype == FQ_Q5_0 || wtype == FQ_Q5_1 || wtype == FQ_Q8_0) ? 4 : 12;
 }
-#define FQ_COLS_MAX_N fq_cols_max_n(m->layers.empty() ? FQ_Q4_0 : m->layers[0].qkv.type)
+// (Q4_K at model widths has its own streaming form for 5..16 columns: kernels_gemm_skinny.hip, k_gemm_skinny_q4k)
+#define FQ_COLS_MAX_N (m->layers.empty() ? 4 : (fq_skinny_q4k_shape(m->layers[0].qkv) && !getenv("FALCON_HIP_COLS_MAX_N") ? 4 : fq_cols_max_n(m->layers[0].qkv.type)))
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
     const falcon_hip_hparams & hp = m->hp;
@@ -646,11 +647,15 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         const layer_weights & L = m->layers[li];
         if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
         const fq_act a_up = act_for(c->buf_e, L.up, N);
-        fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);      // (the f32 row is not needed)
         fq_act a_qkv = a_up;
-        if (hp.two_norms) {
+        if (hp.two_norms) {                                                              // ln_mlp and ln_attn: one launch when both images are of one type
             a_qkv = act_for(c->buf_e2, L.qkv, N);
-            fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, a_qkv, st);
+            if (!fq_launch_layer_norm_quant2(c->x, E, N, L.ln_w, L.ln_b, a_up, L.ln2_w, L.ln2_b, a_qkv, st)) {
+                fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);
+                fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, a_qkv, st);
+            }
+        } else fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);      // (the f32 row is not needed)
+        if (hp.two_norms) {
         } else if (fq_desc(L.qkv.type).act_type != a_up.type) {                          // same norm, the other activation family
             a_qkv = act_for(c->buf_e2, L.qkv, N);
             fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_qkv, st);

@@ -34,7 +34,7 @@ static void build_tables(hip_context & c) {
     HIP_CHECK(hipMalloc((void **) &c.exp_table, 1 << 17));
     HIP_CHECK(hipMemcpy(c.gelu_table, gelu.data(), 1 << 17, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(c.exp_table, ex.data(), 1 << 17, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMalloc((void **) &c.ks_scratch, (size_t) 4 * 16 * FQ_KS_MAX_M * 4));
+    HIP_CHECK(hipMalloc((void **) &c.ks_scratch, FQ_KS_FLOATS * 4));
 }
 
 extern "C" int ggml_hip_device_count(void) {

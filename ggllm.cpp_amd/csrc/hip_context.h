@@ -23,6 +23,7 @@ struct hip_context {
 };
 
 #define FQ_KS_MAX_M 32768
+#define FQ_KS_FLOATS ((size_t) 16 << 20)      // the scratch: 64 MiB = [segment][share][16 columns][rows] of the Q4_K form (4 x 16 x FQ_KS_MAX_M of the legacy K-share form)
 hip_context & fq_ctx();
 fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out);
 fq_act    fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_out);

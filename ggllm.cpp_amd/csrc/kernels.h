@@ -46,11 +46,14 @@ bool   fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N,
 // two matrices of one format and K behind the same columns in ONE launch of the resident form (Wqkv and Wup of a one-norm block); false: nothing launched
 bool   fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & act, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                                   float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st);
+bool   fq_skinny_q4k_shape(const fq_weight & w);          // Q4_K shapes the small-batch form takes (N <= 16: always four partial sums)
 int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1, 2, 4) fq_launch_gemm gives an M x N result
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
 void   fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st);
+bool   fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const float * w0, const float * b0, const fq_act & a0,
+                                   const float * w1, const float * b1, const fq_act & a1, hipStream_t st);      // two norms of the same rows, one launch (same image type; else false)
 void   fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st);
 void   fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st);
 // qkv: [N][(H+2HKV)*D] fused rows; rotates Q (in place) and K, appends K/V at positions n_past.. of the layer's cache.

@@ -50,6 +50,30 @@ void fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const 
     else                        hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_K>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
 }
 
+// two norms of the same rows in one launch (Falcon-40B's ln_mlp and ln_attn: blockIdx.y picks the weights and the image)
+template <int ACT>
+__global__ void __launch_bounds__(256) k_layer_norm_quant2(const float * __restrict__ x, int64_t n, const float * __restrict__ w0, const float * __restrict__ b0, fq_act a0,
+                                                           const float * __restrict__ w1, const float * __restrict__ b1, fq_act a1) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float  * row = (float *) smem;
+    double * red = (double *)(smem + ((n * 4 + 15) & ~(int64_t) 15));
+    const bool second = blockIdx.y != 0;
+    layer_norm_row_block(x + (int64_t) blockIdx.x * n, n, second ? w1 : w0, second ? b1 : b0, row, red);
+    __syncthreads();
+    uint8_t * col = (second ? a1.base : a0.base) + (size_t) blockIdx.x * fq_act_col_bytes(ACT, n);
+    quantize_row_block<ACT>(row, n, act_image_at(col, ACT, n));
+}
+bool fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const float * w0, const float * b0, const fq_act & a0,
+                                 const float * w1, const float * b1, const fq_act & a1, hipStream_t st) {
+    if (a0.type != a1.type) return false;
+    const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
+    const dim3 grid((unsigned) rows, 2);
+    if (a0.type == FQ_Q8_0)      hipLaunchKernelGGL(k_layer_norm_quant2<FQ_Q8_0>, grid, dim3(256), lds, st, x, n, w0, b0, a0, w1, b1, a1);
+    else if (a0.type == FQ_Q8_1) hipLaunchKernelGGL(k_layer_norm_quant2<FQ_Q8_1>, grid, dim3(256), lds, st, x, n, w0, b0, a0, w1, b1, a1);
+    else                         hipLaunchKernelGGL(k_layer_norm_quant2<FQ_Q8_K>, grid, dim3(256), lds, st, x, n, w0, b0, a0, w1, b1, a1);
+    return true;
+}
+
 void fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st) {
     const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
     hipLaunchKernelGGL(k_layer_norm, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y);

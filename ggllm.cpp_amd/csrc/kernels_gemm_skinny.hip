@@ -808,13 +808,236 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
   }
 }
 
-__global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep) {
+// =============================================================================================== Q4_K: a pair of K shares per workgroup
+// The k-quants' mat-mul for 5..16 columns (ggml_vec_dot_q4_K_q8_K, k_quants.c:1751-2055, once per row and column). Association: K is cut into SEGMENTS
+// of 32 super-blocks; inside a segment k_gemm_q<S = 4>'s order -- the super-block's eight 32-element groups are dealt to four partial sums (group g ->
+// g mod 4), each adds (d dy) * (its two groups' integer sum) per super-block, the last one (d dy) isum - (dmin dy) msum, segment value ((P0 + P1) + P2) + P3
+// -- and the segment values are added left to right (k_skinny_sum4). The oracle restates it (orc_set_sum_order: split 4 with segments); rows of up to
+// 32 super-blocks (Falcon-40B's K = 8192) are exactly the tile GEMM's four-sum order.
+// Q4_K packs groups 2c (low nibbles) and 2c + 1 (high nibbles) into the 32 bytes of chunk c, so shares {0, 1} live in chunks {0, 2} and shares
+// {2, 3} in chunks {1, 3}: a workgroup owns one PAIR q of shares of one segment = half of the rows' quant bytes there and half of the columns' bytes,
+// which stay resident in LDS. Every wave runs the two accumulator chains of one 16-row tile per row block and stages its own weights by LDS-DMA into a
+// private ring, paced by vmcnt alone, the pipeline running on across the workgroup's row blocks. Both pairs of a (row block, segment) sit on one XCD (the
+// 64-byte segments their 32-byte chunks share come from HBM once). Per stage (4 super-blocks) and row: 16 quant pieces | 3 of packed scales | 2 of d, dmin.
+constexpr int KQ_SEG = 32;                 // super-blocks per segment
+constexpr int KQ_ROWP = 21, KQ_ROWB = 16 * KQ_ROWP, KQ_WSTAGE = 16 * KQ_ROWB, KQ_KOPS = (16 * KQ_ROWP + 63) / 64;
+struct kq_plan { int tqs; size_t rings, cols, dy, gs, total; };
+static __host__ __device__ inline kq_plan kq_lds(int seg_sb, int T, int nbw) {
+    kq_plan p;
+    const int qb = seg_sb * 128;
+    p.tqs = qb + ((16 - (qb & 255)) & 255);                                 // column pitch = 16 mod 256 bytes: the 16 tokens of an operand read in distinct banks
+    p.rings = (size_t) nbw * T * KQ_WSTAGE; p.cols = (size_t) SK_TN * p.tqs; p.dy = (size_t) seg_sb * SK_TN * 4; p.gs = (size_t) seg_sb * SK_TN * 16;
+    p.total = p.rings + p.cols + p.dy + p.gs + 16;                          // (+ 16 zero bytes: the mins' matrix operands of the lanes that carry none)
+    return p;
+}
+
+// part: [segment][share][16 columns][mstride rows]
+template <int NBW>
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, fq_act act, int N, float * part, int64_t mstride, int T, int nrb, int nslots, int seg_sb, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nsb = (int) w.nblk;
+    const int xcd = (int) blockIdx.x & 7, kk = (int) blockIdx.x >> 3;
+    const int slot = (kk >> 1) * 8 + xcd, q = kk & 1;                      // row blocks slot, slot + nslots, ..; pair q = shares 2 q, 2 q + 1
+    if (slot >= nrb) return;
+    const int seg = (int) blockIdx.y;
+    const int sb0 = seg * seg_sb, nsbs = nsb - sb0 < seg_sb ? nsb - sb0 : seg_sb;
+    const size_t img = fq_act_col_bytes(FQ_Q8_K, K);
+    const kq_plan P = kq_lds(seg_sb, T, NBW);
+    const int TQS = P.tqs;
+    uint8_t * cols = smem + P.rings;                                       // [16 columns][TQS]: per super-block 4 groups x 32 B: 2 q, 2 q + 1, 2 q + 4, 2 q + 5
+    float   * dyT  = (float *)(cols + P.cols);                             // [super-block][16]: the columns' d
+    uint8_t * gsT  = (uint8_t *) dyT + P.dy;                               // [super-block][16][16 B]: sub-block sums gs_j = 64 hi_j + lo_j as bytes hi_0..7 | lo_0..7
+    const int l16 = lane & 15, kq = lane >> 4;
+    int nmine = 0;                                                         // the wave's tiles: one per row block of the workgroup
+    for (int rb = slot; rb < nrb; rb += nslots) if (((int64_t) rb * T + wid) * 16 < M) ++nmine;
+    // lane L = 64 k + lane of a stage's DMA instruction k is (row L / 21, piece L % 21) -- LDS rows are exactly 21 slots
+    unsigned poff[KQ_KOPS], rowb[KQ_KOPS]; int pkind[KQ_KOPS];
+#pragma unroll
+    for (int k = 0; k < KQ_KOPS; ++k) {
+        const int L = 64 * k + lane, row = (L / KQ_ROWP) & 15, p = L % KQ_ROWP;
+        if (p < 16)      { poff[k] = (unsigned)((p >> 2) * 128 + ((p >> 1) & 1) * 64 + (p & 1) * 16); pkind[k] = 0; }
+        else if (p < 19) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 1; }
+        else             { poff[k] = (unsigned)(16 * (p - 19)); pkind[k] = 2; }
+        rowb[k] = (unsigned) row * (unsigned) w.row_stride;
+    }
+    const unsigned rs16 = (unsigned) w.row_stride - 16u;
+    uint8_t * myring = smem + (size_t) wid * NBW * KQ_WSTAGE;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(sk_lds(myring));
+    const int nst = (nsbs + 3) / 4;                                        // stages per row block
+    const int total = nmine * nst;
+    auto issue = [&](int u) {
+        const int rbi = u / nst, sp = u - rbi * nst;
+        const int64_t mt = ((int64_t)(slot + rbi * nslots) * T + wid) * 16;
+        const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
+        const int gsb = sb0 + 4 * sp, c = gsb >> 3, in = gsb & 7;
+        const int nbc = nsb - 8 * c < 8 ? nsb - 8 * c : 8;
+        const unsigned b0 = (unsigned)(c * 1152 + in * 128 + q * 32);
+        const unsigned b1 = (unsigned)(c * 1152 + nbc * 128 + in * 12);
+        const unsigned b2 = (unsigned)(c * 1152 + ((nbc * 140) & ~15) + in * 4);
+        const unsigned dst = ring_lds + (unsigned)((u % NBW) * KQ_WSTAGE);
+#pragma unroll
+        for (int k = 0; k < KQ_KOPS; ++k) {
+            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : b2));
+            o = o < rs16 ? o : rs16;                                       // (a partial last column: pieces beyond its blocks are never used)
+            if (64 * k + lane < 16 * KQ_ROWP) sk_dma(wbase, rowb[k] + o, dst + (unsigned)(k * 1024));
+        }
+    };
+    // ---- the weights' first stages are on their way while the columns are staged
+    if (!(dbg & 8)) { for (int u = 0; u < NBW - 1 && u < total; ++u) issue(u); }
+    // ---- the segment's columns: the pair's groups (8 pieces per super-block and column, 8 super-blocks per DMA instruction), d, sub-block sums
+    {
+        const unsigned last = (unsigned)(K - 16);
+        for (int t = wid; t < SK_TN; t += T) {
+            const uint8_t * base = sk_uniform(act.base + (size_t)(t < N ? t : N - 1) * img);
+            const unsigned tb = sk_lds(cols) + (unsigned)(t * TQS);
+            for (int j0 = 0; j0 < nsbs; j0 += 8) {
+                const int sb = j0 + (lane >> 3), p = lane & 7;
+                unsigned vq = (unsigned)((sb0 + sb) * 256 + 64 * q + 128 * (p >> 2) + 16 * (p & 3));
+                vq = vq < last ? vq : last;
+                if (sb < nsbs && !(dbg & 4)) sk_dma(base, vq, tb + (unsigned)(j0 * 128));
+            }
+        }
+        const size_t aux = fq_act_aux_off(FQ_Q8_K, K);
+        if (tid < 4) ((uint32_t *)(gsT + P.gs))[tid] = 0u;
+        for (int e = tid; e < nsbs * SK_TN; e += (int) blockDim.x) {
+            const int sbl = e >> 4, tok = e & 15;
+            const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img;
+            dyT[e] = ((const float *)(tp + K))[sb0 + sbl];
+            const uint32_t * bs = (const uint32_t *)(tp + aux) + (size_t)(sb0 + sbl) * 8;      // 16 x int16 bsums: gs_j = bsums[2 j] + bsums[2 j + 1]
+            uint32_t hi[2] = { 0u, 0u }, lo[2] = { 0u, 0u };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t v = bs[j];
+                const int gs = (int)(int16_t)(v & 0xFFFFu) + (int)(int16_t)(v >> 16);
+                hi[j >> 2] |= ((uint32_t)(gs >> 6) & 0xFFu) << (8 * (j & 3));
+                lo[j >> 2] |= ((uint32_t) gs & 63u) << (8 * (j & 3));
+            }
+            *(uint4 *)(gsT + (size_t) e * 16) = make_uint4(hi[0], hi[1], lo[0], lo[1]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                       // the only barrier: the columns are in LDS
+
+    auto run = [&](auto pair_tag) __attribute__((always_inline)) {
+        constexpr int Q = decltype(pair_tag)::value;
+        float * part0 = part + ((size_t)(4 * seg + 2 * Q) * SK_TN) * (size_t) mstride, * part1 = part0 + (size_t) SK_TN * (size_t) mstride;
+        int u = 0;
+        for (int rbi = 0; rbi < nmine; ++rbi) {
+            const int64_t m = ((int64_t)(slot + rbi * nslots) * T + wid) * 16 + l16;
+            float acc0[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, acc1[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int sp = 0; sp < nst; ++sp, ++u) {
+                if (u + NBW - 1 < total && !(dbg & 8)) issue(u + NBW - 1);
+                {
+                    const int later = (dbg & 8) ? 0 : (total - 1 - u < NBW - 1 ? total - 1 - u : NBW - 1);
+                    if (later >= 2)      sk_wait_vm_upto(2 * KQ_KOPS);
+                    else if (later == 1) sk_wait_vm_upto(KQ_KOPS);
+                    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (dbg & 16) continue;
+                const uint8_t * wr = myring + (size_t)(u % NBW) * KQ_WSTAGE + l16 * KQ_ROWB;
+                const int gsb = sb0 + 4 * sp, c = gsb >> 3;
+                const int nbc = nsb - 8 * c < 8 ? nsb - 8 * c : 8;
+                const int p2d = (nbc * 140) & 15;                          // d, dmin: offset from the boundary the DMA started at
+                const int ns = nsbs - 4 * sp < 4 ? nsbs - 4 * sp : 4;      // super-blocks in this stage
+                const uint8_t * tqp = cols + (size_t) l16 * TQS + (size_t)(4 * sp) * 128 + 8 * kq;
+                const uint8_t * dyp = (const uint8_t *) dyT + (size_t)(4 * sp) * 64 + 16 * kq;
+                // the mins' sum_j m_j gs_j as two more matrix instructions (hi and lo bytes of gs): k slots 0..7 = j, carried by the lanes kq = 0 -- token
+                // l16's bytes as the A operand, row l16's mins as B; the other lanes read zeros
+                const uint8_t * gsp = kq == 0 ? gsT + (size_t)(4 * sp) * 256 + 16 * l16 : gsT + P.gs;
+                const int gstep = kq == 0 ? 256 : 0;
+                const uint32_t kq0 = kq == 0 ? 0xFFFFFFFFu : 0u;
+                struct kq_ops { sk_v2i xa[4], raw0, raw1; uint32_t u0, u1, u2, dm; float4 dy; uint4 gs; };
+                auto load_ops = [&](int i) __attribute__((always_inline)) {
+                    kq_ops o;
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) o.xa[gi] = *(const sk_v2i *)(tqp + 128 * i + 32 * gi);
+                    o.raw0 = *(const sk_v2i *)(wr + 64 * i + 8 * kq);
+                    o.raw1 = *(const sk_v2i *)(wr + 64 * i + 32 + 8 * kq);
+                    o.u0 = *(const uint32_t *)(wr + 256 + 12 * i); o.u1 = *(const uint32_t *)(wr + 260 + 12 * i); o.u2 = *(const uint32_t *)(wr + 264 + 12 * i);
+                    o.dm = *(const uint32_t *)(wr + 304 + p2d + 4 * i);
+                    o.dy = *(const float4 *)(dyp + 64 * i);
+                    if constexpr (Q == 1) o.gs = *(const uint4 *)(gsp + gstep * i);
+                    return o;
+                };
+                struct kq_c { sk_v4i c[6]; };
+                auto run_mfma = [&](const kq_ops & o) __attribute__((always_inline)) {
+                    kq_c r;
+                    const sk_v4i z = { 0, 0, 0, 0 };
+                    const sk_v2i l0 = { (int)((uint32_t) o.raw0.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw0.y & 0x0F0F0F0Fu) };
+                    const sk_v2i h0 = { (int)(((uint32_t) o.raw0.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw0.y >> 4) & 0x0F0F0F0Fu) };
+                    const sk_v2i l1 = { (int)((uint32_t) o.raw1.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw1.y & 0x0F0F0F0Fu) };
+                    const sk_v2i h1 = { (int)(((uint32_t) o.raw1.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw1.y >> 4) & 0x0F0F0F0Fu) };
+                    r.c[0] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[0]), __builtin_bit_cast(long, l0), z, 0, 0, 0);     // group 2 Q
+                    r.c[1] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[1]), __builtin_bit_cast(long, h0), z, 0, 0, 0);     // 2 Q + 1
+                    r.c[2] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[2]), __builtin_bit_cast(long, l1), z, 0, 0, 0);     // 2 Q + 4
+                    r.c[3] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[3]), __builtin_bit_cast(long, h1), z, 0, 0, 0);     // 2 Q + 5
+                    if constexpr (Q == 1) {                                 // get_scale_min_k4's mins, four to a register
+                        const sk_v2i mn = { (int)((o.u1 & 0x3F3F3F3Fu) & kq0), (int)((((o.u2 >> 4) & 0x0F0F0F0Fu) | ((o.u1 >> 2) & 0x30303030u)) & kq0) };
+                        r.c[4] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, sk_v2i{ (int) o.gs.x, (int) o.gs.y }), __builtin_bit_cast(long, mn), z, 0, 0, 0);
+                        r.c[5] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, sk_v2i{ (int) o.gs.z, (int) o.gs.w }), __builtin_bit_cast(long, mn), z, 0, 0, 0);
+                    }
+                    return r;
+                };
+                auto scale = [&](const kq_c & cc, const kq_ops & o) __attribute__((always_inline)) {
+                    // the 6-bit scales / mins of the row's super-block, four to a register (get_scale_min_k4, k_quants.c:264-272)
+                    const uint32_t scLo = o.u0 & 0x3F3F3F3Fu, scHi = (o.u2 & 0x0F0F0F0Fu) | ((o.u0 >> 2) & 0x30303030u);
+                    const int sc0 = (int)((scLo >> (16 * Q)) & 0xFFu), sc1 = (int)((scLo >> (16 * Q + 8)) & 0xFFu);
+                    const int sc2 = (int)((scHi >> (16 * Q)) & 0xFFu), sc3 = (int)((scHi >> (16 * Q + 8)) & 0xFFu);
+                    const float d = fq_h2f((uint16_t) o.dm);
+                    const float dyv[4] = { o.dy.x, o.dy.y, o.dy.z, o.dy.w };
+                    float dmin = 0.0f;
+                    if constexpr (Q == 1) dmin = fq_h2f((uint16_t)(o.dm >> 16));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int is0 = __mul24(cc.c[0][r], sc0) + __mul24(cc.c[2][r], sc2);      // share 2 Q: groups 2 Q, 2 Q + 4 (|c| < 2^16, sc < 64)
+                        const int is1 = __mul24(cc.c[1][r], sc1) + __mul24(cc.c[3][r], sc3);      // share 2 Q + 1
+                        const float dd = d * dyv[r];                                        // k_quants.c:2027 (d = y.d * fp16(x.d))
+                        acc0[r] = acc0[r] + dd * (float) is0;
+                        float t1 = dd * (float) is1;
+                        if constexpr (Q == 1) t1 = t1 - (dmin * dyv[r]) * (float)((cc.c[4][r] << 6) + cc.c[5][r]);      // the mins with the last share: - (dmin dy) sum_j m_j gs_j
+                        acc1[r] = acc1[r] + t1;
+                    }
+                };
+                if (ns == 4) {
+                    kq_ops o[4]; kq_c c4[4];
+                    o[0] = load_ops(0); o[1] = load_ops(1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                           // reads two super-blocks ahead, the matrix instructions one ahead of their scaling
+                        if (k + 2 < 4) o[k + 2] = load_ops(k + 2);
+                        c4[k] = run_mfma(o[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k > 0) scale(c4[k - 1], o[k - 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    scale(c4[3], o[3]);
+                } else {
+                    for (int i = 0; i < ns; ++i) { const kq_ops o = load_ops(i); const kq_c c1 = run_mfma(o); scale(c1, o); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 4 * kq + r;
+                if (n < N) { part0[(size_t) n * mstride + m] = acc0[r]; part1[(size_t) n * mstride + m] = acc1[r]; }
+            }
+        }
+    };
+    if (q) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+}
+
+// part: [segment][share][16][mstride]; dst = the segments' ((P0 + P1) + P2) + P3 added left to right, then the epilogue
+__global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep, int64_t mstride, int nseg) {
     const int64_t m = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.y;
     if (m >= M || n >= N) return;
-    const float p0 = part[((size_t) 0 * SK_TN + n) * FQ_KS_MAX_M + m], p1 = part[((size_t) 1 * SK_TN + n) * FQ_KS_MAX_M + m];
-    const float p2 = part[((size_t) 2 * SK_TN + n) * FQ_KS_MAX_M + m], p3 = part[((size_t) 3 * SK_TN + n) * FQ_KS_MAX_M + m];
-    float v = ((p0 + p1) + p2) + p3;
+    float v = 0.0f;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const float * p = part + ((size_t)(4 * sg) * SK_TN + n) * (size_t) mstride + m;
+        const size_t st = (size_t) SK_TN * (size_t) mstride;
+        const float one = ((p[0] + p[st]) + p[2 * st]) + p[3 * st];
+        v = sg ? v + one : one;
+    }
     if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
     else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
     dst[n * ldd + m] = v;
@@ -861,9 +1084,51 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
     return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
 }
 
+// Q4_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
+bool fq_skinny_q4k_shape(const fq_weight & w) {
+    static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
+    const int64_t nseg = (w.nblk + KQ_SEG - 1) / KQ_SEG, mstride = (w.M + 63) & ~(int64_t) 63;
+    return on && w.type == FQ_Q4_K && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
+           w.row_stride * 16 < ((size_t) 1 << 31);
+}
+static bool fq_launch_gemm_skinny_q4k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
+    if (S == 1 || !fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K) return false;
+    const int n_cu = fq_ctx().n_cu;
+    const int ntiles = (int)(w.M / 16);
+    const int nsb = (int) w.nblk;
+    static const int env_t = getenv("FQ_KQ_T") ? atoi(getenv("FQ_KQ_T")) : 0, env_nbw = getenv("FQ_KQ_NBW") ? atoi(getenv("FQ_KQ_NBW")) : 0;
+    const int nseg = (nsb + KQ_SEG - 1) / KQ_SEG;
+    const int seg_sb = nseg > 1 ? KQ_SEG : ((nsb + 7) & ~7);               // (LDS is sized by it; stages of 4 super-blocks never straddle a column of the device layout)
+    int T = env_t > 0 ? env_t : (ntiles * 2 * nseg + n_cu - 1) / n_cu;     // tiles per workgroup: all workgroups resident in one round when they fit
+    if (T < 1) T = 1;
+    if (T > KS_TMAX) T = KS_TMAX;
+    int nbw = 0;
+    for (;;) {
+        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (kq_lds(seg_sb, T, n).total <= 160 * 1024) { nbw = n; break; } }
+        if (nbw || T == 1) break;
+        --T;
+    }
+    if (!nbw) return false;
+    const size_t need = kq_lds(seg_sb, T, nbw).total;
+    const int nrb = (ntiles + T - 1) / T;
+    int nslots = 8 * ((nrb + 7) / 8);
+    const int cap = ((n_cu / (2 * nseg)) / 8) * 8;                         // row-block slots per segment when the launch is larger than the chip
+    if (2 * nslots * nseg > n_cu) nslots = cap < 8 ? 8 : (nslots < cap ? nslots : cap);
+    const int64_t mstride = (w.M + 63) & ~(int64_t) 63;
+#define FQ_KQ_LAUNCH(NB) { \
+        static bool set = false; \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q4k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_q4k<NB>), dim3((unsigned)(2 * nslots), (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, fq_ctx().ks_scratch, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
+    if (nbw == 3) FQ_KQ_LAUNCH(3) else FQ_KQ_LAUNCH(2)
+#undef FQ_KQ_LAUNCH
+    hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep, mstride, nseg);
+    return true;
+}
+
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
+    if (w.type == FQ_Q4_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
     {
@@ -903,7 +1168,7 @@ bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, f
             }
 #undef FQ_KS_CASE
 #undef FQ_KS_LAUNCH
-            hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep);
+            hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep, (int64_t) FQ_KS_MAX_M, 1);
             return true;
         }
     }

@@ -379,9 +379,12 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
 /* order 2 = what the backend's prefill GEMM does (ggllm.cpp_amd/csrc/kernels_gemm.hip): g_split interleaved partial sums,
  * P_s = blocks s, s + g_split, ... left to right, result ((P0 + P1) + P2) + P3; 4 of them on matrices with fewer than
  * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
- * columns, order 2 for GEMMs. mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
+ * columns, order 2 for GEMMs (Q4_K with 5..32 columns: always four partial sums, the small-batch form). mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
  * legacy formats' reference order; for the k-quants one d * isum - dmin * msum term per super-block, left to right). */
 static int g_split = 4;
+/* order 2 only, > 0: the partial sums restart every g_kseg super-blocks and the segments' values ((P0 + P1) + P2) + P3 are added left to right
+ * (the backend's small-batch form for Q4_K, k_gemm_skinny_q4k: segments of 32 super-blocks; set per mat-mul by mode 2) */
+static int g_kseg = 0;
 /* mode 2 only: > 0 = decide as if the mat-mul had this many columns (the sampled-token checks evaluate a few tokens OF a batch:
  * the backend chose its order for the whole batch) */
 static int g_backend_batch = 0;
@@ -391,6 +394,7 @@ int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 
 void orc_set_sum_order(int mode) {
     g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4 || mode == 5) ? 2 : 0);
     g_split = (mode == 4) ? 2 : ((mode == 5) ? 1 : 4);
+    g_kseg = 0;
 }
 
 /* ------------------------------------------------------------------ k-quant dots against Q8_K
@@ -461,6 +465,7 @@ static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t
     float lane[64] = {0};
     float lanes8[8] = {0};
     int   eight = 0;
+    float seg_tot = 0.0f; int have_seg = 0;
     const int split = (g_sum_order == 2 && nsb > 0) ? g_split : 0;
     const int wave  = (g_sum_order == 1 && nsb > 0);
     int64_t unit = 0;
@@ -505,6 +510,11 @@ static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t
                 const float A = dd * (float) is;
                 part[sp] = part[sp] + ((has_min && sp == split - 1) ? (A - dmn * (float) msum) : A);
             }
+            if (g_kseg > 0 && (i + 1) % g_kseg == 0 && i + 1 < nsb) {         /* a segment ends here and another follows */
+                const float one = ((part[0] + part[1]) + part[2]) + part[3];
+                seg_tot = have_seg ? seg_tot + one : one; have_seg = 1;
+                part[0] = part[1] = part[2] = part[3] = 0.0f;
+            }
         } else if (wtype == ORC_Q2_K) {                                       /* k_quants.c:1303 */
             int is = 0;
             for (int b = 0; b < 16; ++b) is += sc16[b] * i16[b];
@@ -524,7 +534,8 @@ static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t
         for (int o = 1; o < 64; o <<= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ o]; memcpy(lane, t, sizeof(t)); }
         return lane[0];
     }
-    return split ? ((part[0] + part[1]) + part[2]) + part[3] : sumf;
+    if (split) { const float one = ((part[0] + part[1]) + part[2]) + part[3]; return have_seg ? seg_tot + one : one; }
+    return sumf;
 }
 
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
@@ -629,7 +640,15 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
                    float * dst, int n_threads, int flavour) {
     const int at = orc_vec_dot_type(wtype);
     const size_t act_row = orc_row_bytes(at, K);
-    if (g_sum_mode == 2) { const int64_t Nb = g_backend_batch > 0 ? g_backend_batch : N; g_sum_order = (Nb <= 4) ? 1 : 2; g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2; }
+    if (g_sum_mode == 2) {
+        const int64_t Nb = g_backend_batch > 0 ? g_backend_batch : N;
+        g_sum_order = (Nb <= 4) ? 1 : 2;
+        g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2;
+        /* Q4_K with 5..32 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
+        g_kseg = 0;
+        if (wtype == ORC_Q4_K && Nb > 4 && Nb <= 32 && M % 16 == 0 && K / 256 >= 8 &&
+            ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; }
+    }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
     /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */
     for (int64_t n = 0; n < N; ++n) orc_quantize_act(at, x + n * K, act + (size_t) n * act_row, K, flavour);
