@@ -466,10 +466,10 @@ def north_star_1gpu(g, synth, L, tname, a):
     model.decode_greedy(int(out_w[-1]), 132, K, use_graph=not a.no_graph)
     L.ggml_hip_synchronize()
     dt = time.perf_counter() - t0
-    # lock-step decode streams on the same resident model: one weight pass serves B tokens (B <= 12: the k-quant column mat-vec kernels in
-    # chunks of 4; beyond: the int8-MFMA tile GEMM)
+    # lock-step decode streams on the same resident model: one weight pass serves B tokens (B <= 4: the k-quant column mat-vec kernels;
+    # 5..80: passes of the Q4_K small-batch form, 16 columns each; beyond: the int8-MFMA tile GEMM)
     ls = {}
-    for B in (8, 128):
+    for B in (8, 16, 32, 64, 128):
         pipe = g.Pipeline(model, 0, 1, 1, B, 64)
         pipe.set_tokens(synth.tokens(B, hp["n_vocab"], seed=42))
         pipe.run(2, 0)

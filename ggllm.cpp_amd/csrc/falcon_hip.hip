@@ -692,7 +692,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // epilogue adds Wo's result and the residual) after the attention branch. Same kernels, same bits. Measured in one
         // process on the same resident Falcon-7B Q4_0 (scripts/gpu_par2_ab.py), one stream -> two branches: 16 tokens 8.66 -> 7.83
         // ms, 32: 9.17 -> 8.13, 128: 9.41 -> 8.82, 512: 26.75 -> 24.59, 1024: 49.3 -> 47.3, 2048: 104.9 -> 101.7.
-        const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !fq_prof_active() && !fq_ctx().dbg_stamps;
+        // (not where the mat-muls are passes of the Q4_K small-batch form: they fill the chip and share one partial-sum scratch)
+        const bool q4k_passes = N <= FQ_SKINNY_Q4K_MAX_COLS && (fq_skinny_q4k_shape(L.qkv) || fq_skinny_q4k_shape(L.up) || fq_skinny_q4k_shape(L.wo) || fq_skinny_q4k_shape(L.down));
+        const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
             HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
@@ -736,8 +738,12 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_launch_quantize_act(c->att, E, a_att, st);
         }
         if (!up_done && !pair_done) {
-            const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
-            fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
+            // (Q4_K, 5..16 columns: GELU and Wdown's Q8_K image come out of the small-batch form's sum launch)
+            if (fq_mul_mat_q_acts_gelu_q8k(L.up, a_up, N, c->up, FF, a_ff, st)) ff_quantized = true;
+            else {
+                const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
+                fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
+            }
         }
         if (!ff_quantized) fq_launch_quantize_act(c->up, FF, a_ff, st);
         bool out_done = false;
@@ -749,6 +755,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
             }
         }
+        if (!out_done && fq_mul_mat_q_acts_out2(L.wo, a_att, L.down, a_ff, N, c->x, E, st)) out_done = true;      // (Q4_K, 5..16 columns: one sum launch for both)
         if (!out_done) {
             fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
             const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place

@@ -46,6 +46,9 @@ bool   fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N,
 // two matrices of one format and K behind the same columns in ONE launch of the resident form (Wqkv and Wup of a one-norm block); false: nothing launched
 bool   fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & act, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                                   float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st);
+bool   fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const uint16_t * gelu_table, const fq_act & out, hipStream_t st);
+bool   fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st);
+#define FQ_SKINNY_Q4K_MAX_COLS 80                         // .. in passes of 16 (beyond: the tile GEMM)
 bool   fq_skinny_q4k_shape(const fq_weight & w);          // Q4_K shapes the small-batch form takes (N <= 16: always four partial sums)
 int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1, 2, 4) fq_launch_gemm gives an M x N result
 

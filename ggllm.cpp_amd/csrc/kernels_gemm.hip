@@ -704,18 +704,23 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0);
     if (skinny && N <= 16 && !getenv("FQ_GEMM_CFG") && fq_launch_gemm_skinny(w, act, N, dst, ldd, ep, cfg == 0 ? 1 : (cfg == 2 ? 4 : 2), st)) return;
     // 17..32 columns: two passes of the streaming form (same K split as this shape's tile GEMM, so the same bits; 7.5 against 9.1 ms
-    // per Falcon-7B pass of 32 lock-step sequences) -- beyond that the tiles below win
+    // per Falcon-7B pass of 32 lock-step sequences) -- beyond that the tiles below win. Q4_K at model widths: up to five passes (Falcon-40B, 12 blocks:
+    // 48 columns 6.0 against 10.4 ms, 64: 7.9 against 10.7, 80: 9.8 against ~11; 96: 11.7 against 11.3)
     static const bool skinny2 = !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0);
-    if (skinny && skinny2 && N > 16 && N <= 32 && !getenv("FQ_GEMM_CFG")) {
+    const int64_t max_cols = fq_skinny_q4k_shape(w) ? FQ_SKINNY_Q4K_MAX_COLS : 32;
+    if (skinny && skinny2 && N > 16 && N <= max_cols && !getenv("FQ_GEMM_CFG")) {
         const int S = cfg == 0 ? 1 : (cfg == 2 ? 4 : 2);
-        fq_act a1 = act; a1.ncols = 16;
-        if (fq_launch_gemm_skinny(w, a1, 16, dst, ldd, ep, S, st)) {
-            fq_act a2 = act; a2.ncols = N - 16; a2.base = act.base + 16 * fq_act_col_bytes(act.type, act.K);
-            fq_gemv_epi e2 = ep;
-            if (e2.add1) e2.add1 += 16 * e2.ld_add;
-            if (e2.add2) e2.add2 += 16 * e2.ld_add;
-            if (!fq_launch_gemm_skinny(w, a2, N - 16, dst + 16 * ldd, ldd, e2, S, st)) { fprintf(stderr, "ggml-hip: gemm: second small-batch pass refused\n"); exit(1); }
-            return;
+        for (int64_t n0 = 0; n0 < N; n0 += 16) {
+            const int64_t nc = N - n0 < 16 ? N - n0 : 16;
+            fq_act a1 = act; a1.ncols = nc; a1.base = act.base + n0 * fq_act_col_bytes(act.type, act.K);
+            fq_gemv_epi e1 = ep;
+            if (e1.add1) e1.add1 += n0 * e1.ld_add;
+            if (e1.add2) e1.add2 += n0 * e1.ld_add;
+            if (!fq_launch_gemm_skinny(w, a1, nc, dst + n0 * ldd, ldd, e1, S, st)) {
+                if (n0 == 0) break;                                         // not this form's shape: the tiles below
+                fprintf(stderr, "ggml-hip: gemm: a later small-batch pass refused\n"); exit(1);
+            }
+            if (n0 + 16 >= N) return;
         }
     }
     // 64-row workgroups (RB = 2) where there are tiles enough to fill the chip with them: two partial sums as <2,4> above,

@@ -1043,6 +1043,47 @@ __global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M,
     dst[n * ldd + m] = v;
 }
 
+// a segment list's value at (column n, row m): the segments' ((P0 + P1) + P2) + P3 left to right
+__device__ __forceinline__ float sk_sum_segments(const float * __restrict__ part, int64_t mstride, int nseg, int n, int64_t m) {
+    const size_t st = (size_t) SK_TN * (size_t) mstride;
+    float v = 0.0f;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const float * p = part + ((size_t)(4 * sg) * SK_TN + n) * (size_t) mstride + m;
+        const float one = ((p[0] + p[st]) + p[2 * st]) + p[3 * st];
+        v = sg ? v + one : one;
+    }
+    return v;
+}
+// x = (down + wo) + x: FQ_EPI_ADD2 with Wo's result summed here instead of read from a matrix
+__global__ void k_skinny_sum4_out2(const float * __restrict__ part_d, int nseg_d, const float * __restrict__ part_w, int nseg_w, int64_t mstride, int N, int64_t M,
+                                   float * __restrict__ x, int64_t ldx) {
+    const int64_t m = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (m >= M || n >= N) return;
+    const float v = sk_sum_segments(part_d, mstride, nseg_d, n, m), wv = sk_sum_segments(part_w, mstride, nseg_w, n, m);
+    x[n * ldx + m] = (v + wv) + x[n * ldx + m];
+}
+// GELU + the next mat-mul's Q8_K image: one wave per (column, 256 rows), a lane = 4 consecutive rows (quant_q8K_wave: k_quantize_q8K's arithmetic)
+__global__ void __launch_bounds__(256) k_skinny_sum4_gelu_q8k(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd,
+                                                              const uint16_t * __restrict__ gelu_table, fq_act out, int64_t mstride, int nseg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6), per_col = M >> 8;
+    if (wv >= (int64_t) N * per_col) return;                               // (wave-uniform)
+    const int n = (int)(wv / per_col);
+    const int64_t sb = wv - (int64_t) n * per_col, m = 256 * sb + 4 * lane;
+    const size_t st = (size_t) SK_TN * (size_t) mstride;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int sg = 0; sg < nseg; ++sg) {
+        const float * p = part + ((size_t)(4 * sg) * SK_TN + n) * (size_t) mstride + m;
+        const float4 p0 = *(const float4 *) p, p1 = *(const float4 *)(p + st), p2 = *(const float4 *)(p + 2 * st), p3 = *(const float4 *)(p + 3 * st);
+        const float4 one = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        v = sg ? make_float4(v.x + one.x, v.y + one.y, v.z + one.z, v.w + one.w) : one;
+    }
+    v.x = h2f_bits(gelu_table[f2h_bits(v.x)]); v.y = h2f_bits(gelu_table[f2h_bits(v.y)]); v.z = h2f_bits(gelu_table[f2h_bits(v.z)]); v.w = h2f_bits(gelu_table[f2h_bits(v.w)]);
+    if (dst) *(float4 *)(dst + n * ldd + m) = v;
+    quant_q8K_wave(v, lane, sb, act_image_at(out.base + (size_t) n * fq_act_col_bytes(FQ_Q8_K, out.K), FQ_Q8_K, out.K));
+}
+
 // the resident form for one matrix (w1.M == 0) or two of the same K and format sharing their columns (e.g. Wqkv and Wup behind one LayerNorm)
 static bool fq_launch_gemm_skinny_res(const fq_weight & w, const fq_weight & w1, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep,
                                       float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st) {
@@ -1091,13 +1132,14 @@ bool fq_skinny_q4k_shape(const fq_weight & w) {
     return on && w.type == FQ_Q4_K && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
            w.row_stride * 16 < ((size_t) 1 << 31);
 }
-static bool fq_launch_gemm_skinny_q4k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
-    if (S == 1 || !fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K) return false;
+// the main launch: partial sums of w x act into scratch region `part` ([segment][share][16][mstride]); false: not this form's shape
+static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
+    if (!fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int n_cu = fq_ctx().n_cu;
     const int ntiles = (int)(w.M / 16);
     const int nsb = (int) w.nblk;
     static const int env_t = getenv("FQ_KQ_T") ? atoi(getenv("FQ_KQ_T")) : 0, env_nbw = getenv("FQ_KQ_NBW") ? atoi(getenv("FQ_KQ_NBW")) : 0;
-    const int nseg = (nsb + KQ_SEG - 1) / KQ_SEG;
+    nseg = (nsb + KQ_SEG - 1) / KQ_SEG;
     const int seg_sb = nseg > 1 ? KQ_SEG : ((nsb + 7) & ~7);               // (LDS is sized by it; stages of 4 super-blocks never straddle a column of the device layout)
     int T = env_t > 0 ? env_t : (ntiles * 2 * nseg + n_cu - 1) / n_cu;     // tiles per workgroup: all workgroups resident in one round when they fit
     if (T < 1) T = 1;
@@ -1114,14 +1156,42 @@ static bool fq_launch_gemm_skinny_q4k(const fq_weight & w, const fq_act & act, i
     int nslots = 8 * ((nrb + 7) / 8);
     const int cap = ((n_cu / (2 * nseg)) / 8) * 8;                         // row-block slots per segment when the launch is larger than the chip
     if (2 * nslots * nseg > n_cu) nslots = cap < 8 ? 8 : (nslots < cap ? nslots : cap);
-    const int64_t mstride = (w.M + 63) & ~(int64_t) 63;
+    mstride = (w.M + 63) & ~(int64_t) 63;
 #define FQ_KQ_LAUNCH(NB) { \
         static bool set = false; \
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q4k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((k_gemm_skinny_q4k<NB>), dim3((unsigned)(2 * nslots), (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, fq_ctx().ks_scratch, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
+        hipLaunchKernelGGL((k_gemm_skinny_q4k<NB>), dim3((unsigned)(2 * nslots), (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
     if (nbw == 3) FQ_KQ_LAUNCH(3) else FQ_KQ_LAUNCH(2)
 #undef FQ_KQ_LAUNCH
+    return true;
+}
+static bool fq_launch_gemm_skinny_q4k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
+    int64_t mstride; int nseg;
+    if (S == 1 || !q4k_main(w, act, N, fq_ctx().ks_scratch, mstride, nseg, st)) return false;
     hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep, mstride, nseg);
+    return true;
+}
+// Wup of a block whose Wdown takes Q8_K columns: the sum launch applies GELU and writes the Q8_K image of the result (k_quantize_q8K's code) next to
+// the f32 matrix. false: nothing launched (not this form's shape)
+bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const uint16_t * gelu_table, const fq_act & out, hipStream_t st) {
+    if (out.type != FQ_Q8_K || out.K != w.M || w.M % 256 || out.ncols < N) return false;
+    int64_t mstride; int nseg;
+    if (!q4k_main(w, act, N, fq_ctx().ks_scratch, mstride, nseg, st)) return false;
+    const int64_t waves = N * (w.M / 256);
+    hipLaunchKernelGGL(k_skinny_sum4_gelu_q8k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, gelu_table, out, mstride, nseg);
+    return true;
+}
+// x = (Wdown a_ff + Wo a_att) + x for both matrices in this form: two main launches, ONE sum launch (Wo's result never exists as a matrix)
+bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
+    if (wo.M != down.M || !fq_skinny_q4k_shape(wo) || !fq_skinny_q4k_shape(down) || a_att.type != FQ_Q8_K || a_ff.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
+    const int64_t ms = (down.M + 63) & ~(int64_t) 63;
+    const int64_t nsd = (down.nblk + KQ_SEG - 1) / KQ_SEG, nsw = (wo.nblk + KQ_SEG - 1) / KQ_SEG;
+    if ((nsd + nsw) * 4 * SK_TN * ms > (int64_t) FQ_KS_FLOATS) return false;
+    float * part_d = fq_ctx().ks_scratch, * part_w = part_d + (size_t) nsd * 4 * SK_TN * ms;
+    int64_t m1, m2; int s1, s2;
+    if (!q4k_main(wo, a_att, N, part_w, m2, s2, st)) return false;
+    if (!q4k_main(down, a_ff, N, part_d, m1, s1, st)) { fprintf(stderr, "ggml-hip: gemm: the output pair's second launch refused\n"); exit(1); }
+    hipLaunchKernelGGL(k_skinny_sum4_out2, dim3((unsigned)((down.M + 255) / 256), (unsigned) N), dim3(256), 0, st, part_d, s1, part_w, s2, m1, (int) N, down.M, x, ldx);
     return true;
 }
 

@@ -379,7 +379,7 @@ static int g_sum_mode  = 0;       /* 0 scalar, 1 wave, 2 = as the HIP backend (b
 /* order 2 = what the backend's prefill GEMM does (ggllm.cpp_amd/csrc/kernels_gemm.hip): g_split interleaved partial sums,
  * P_s = blocks s, s + g_split, ... left to right, result ((P0 + P1) + P2) + P3; 4 of them on matrices with fewer than
  * 4 x 256 (CUs of an MI355X) 32 x 32 tiles, 2 above. mode 2 picks per mat-mul like the backend: wave order for N <= 4
- * columns, order 2 for GEMMs (Q4_K with 5..32 columns: always four partial sums, the small-batch form). mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
+ * columns, order 2 for GEMMs (Q4_K with 5..80 columns at model widths: four partial sums per segment of 32 super-blocks, the small-batch form). mode 3 / 4 / 5: order 2 with 4 / 2 / 1 partial sums for every mat-mul (5 = ggml_hip_gemm_sequential: the
  * legacy formats' reference order; for the k-quants one d * isum - dmin * msum term per super-block, left to right). */
 static int g_split = 4;
 /* order 2 only, > 0: the partial sums restart every g_kseg super-blocks and the segments' values ((P0 + P1) + P2) + P3 are added left to right
@@ -644,9 +644,9 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
         const int64_t Nb = g_backend_batch > 0 ? g_backend_batch : N;
         g_sum_order = (Nb <= 4) ? 1 : 2;
         g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2;
-        /* Q4_K with 5..32 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
+        /* Q4_K with 5..80 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
         g_kseg = 0;
-        if (wtype == ORC_Q4_K && Nb > 4 && Nb <= 32 && M % 16 == 0 && K / 256 >= 8 &&
+        if (wtype == ORC_Q4_K && Nb > 4 && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
             ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; }
     }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
