@@ -1,12 +1,13 @@
 #!/bin/bash
 # One gpurun call of a round: every -m gpu test, smoke, the bench line the driver reads; optionally rocprofv3 kernel trace + PMC passes.
-# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|all ...]
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|lockstep40|all ...]
 #   prof         rocprofv3 kernel trace of the decode bench             -> <tag>/decode_7b_q4_0_kernel_stats.{csv,md}
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (HBM traffic per launch)  -> <tag>/pmc_traffic.json
 #   mfma         SQ matrix-pipe / VALU counters (decode + 128- and 2048-token prefill in one run) -> <tag>/pmc_mfma.json
 #   prefill2048  kernel trace of a 2048-token prompt                     -> <tag>/prefill2048_7b_q4_0_kernel_stats.{csv,md}
 #   b40          Falcon-40B Q4_K, all 60 blocks, one GPU: bench line + kernel trace -> <tag>/bench_40b_q4_k.json, <tag>/decode_40b_q4_k_kernel_stats.{csv,md}
 #   lockstep     kernel trace of 16 lock-step streams per weight pass    -> <tag>/lockstep_b16_kernel_stats.{csv,md}
+#   lockstep40   Falcon-40B Q4_K, 60 blocks: lock-step streams 4..128 per pass + kernel trace of 16 per pass (12 blocks) -> <tag>/lockstep_40b_q4_k.txt, <tag>/lockstep40_b16_kernel_stats.{csv,md}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD
@@ -76,5 +77,9 @@ if has b40; then
 fi
 if has lockstep; then
   FALCON_HIP_STAGE_GRAPH=0 trace lockstep_b16 python $R/bench.py --force-pipeline --streams 1 --pipe-batch 16 --steps 16 --warmup 4 --no-cpu --no-cli
+fi
+if has lockstep40; then
+  LOCKSTEP_MODEL=40b_q4_k timeout 600 python scripts/gpu_lockstep.py 1 2 4 8 12 16 32 48 64 80 128 2>&1 | grep "streams per pass" | tee $OUT/lockstep_40b_q4_k.txt
+  LOCKSTEP_MODEL=40b_q4_k LOCKSTEP_LAYERS=12 trace lockstep40_b16 python $R/scripts/gpu_lockstep.py 16
 fi
 cat $OUT/summary.txt
