@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
     ap.add_argument("--streams", type=int, default=2, help="groups of decode streams in flight for --force-pipeline at one GPU")
-    ap.add_argument("--pipe-batch", type=int, default=8, help="pipeline: lock-step streams per group (one weight pass serves them; 1..256; 5..16 through the small-batch mat-mul, beyond through the int8-MFMA tile GEMM)")
+    ap.add_argument("--pipe-batch", type=int, default=16, help="pipeline: lock-step streams per group (one weight pass serves them; 1..256; 5..16 through the small-batch mat-muls -- 16 is their best operating point --, beyond in passes of them or through the int8-MFMA tile GEMM)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra keys of the north-star configuration (Falcon-40B Q4_K, all 60 blocks, on the same GPUs)")
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     ap.add_argument("--no-cli", action="store_true", help="skip the reference_cli key (the reference's own falcon_main, linked against libggml_hip.so, on a written GGCC file)")
