@@ -820,9 +820,19 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
 // private ring, paced by vmcnt alone, the pipeline running on across the workgroup's row blocks. Both pairs of a (row block, segment) sit on one XCD (the
 // 64-byte segments their 32-byte chunks share come from HBM once). Per stage (4 super-blocks) and row: 16 quant pieces | 3 of packed scales | 2 of d, dmin.
 constexpr int KQ_SEG = 32;                 // super-blocks per segment
-constexpr int KQ_ROWP = 21, KQ_ROWB = 16 * KQ_ROWP, KQ_WSTAGE = 16 * KQ_ROWB, KQ_KOPS = (16 * KQ_ROWP + 63) / 64;
+// Q5_K is the same kernel plus the plane of fifth bits (32 bytes per super-block: bit g of byte l belongs to element l of group g; both pairs need all
+// of it): 8 more pieces per row and stage, the bit of the lane's 8 elements or-ed into the nibbles on the way to the matrix instruction.
+template <int TYPE> struct kq_fmt {
+    static constexpr bool Q5 = TYPE == FQ_Q5_K;
+    static constexpr int ROWP = Q5 ? 29 : 21;                              // 16-byte slots per row and stage (odd: the 16 rows of a tile in distinct banks)
+    static constexpr int ROWB = 16 * ROWP, WSTAGE = 16 * ROWB, KOPS = (16 * ROWP + 63) / 64;
+    static constexpr int QHOFF = 256, SOFF = Q5 ? 384 : 256, DOFF = SOFF + 48;      // LDS offsets inside a row's stage: quants | (fifth bits) | scales | d, dmin
+    static constexpr int COLB = Q5 ? 1408 : 1152;                          // bytes of a full column (8 super-blocks) of the device layout
+    static constexpr int PRE_QH = 128, PRE_SC = Q5 ? 160 : 128, PRE_DM = PRE_SC + 12;   // bytes per super-block in front of each plane
+};
 struct kq_plan { int tqs; size_t rings, cols, dy, gs, total; };
-static __host__ __device__ inline kq_plan kq_lds(int seg_sb, int T, int nbw) {
+template <int TYPE> static __host__ __device__ inline kq_plan kq_lds(int seg_sb, int T, int nbw) {
+    constexpr int KQ_WSTAGE = kq_fmt<TYPE>::WSTAGE;
     kq_plan p;
     const int qb = seg_sb * 128;
     p.tqs = qb + ((16 - (qb & 255)) & 255);                                 // column pitch = 16 mod 256 bytes: the 16 tokens of an operand read in distinct banks
@@ -832,9 +842,11 @@ static __host__ __device__ inline kq_plan kq_lds(int seg_sb, int T, int nbw) {
 }
 
 // part: [segment][share][16 columns][mstride rows]
-template <int NBW>
+template <int TYPE, int NBW>
 __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, fq_act act, int N, float * part, int64_t mstride, int T, int nrb, int nslots, int seg_sb, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef kq_fmt<TYPE> F;
+    constexpr int KQ_ROWP = F::ROWP, KQ_ROWB = F::ROWB, KQ_WSTAGE = F::WSTAGE, KQ_KOPS = F::KOPS;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t K = w.K, M = w.M;
     const int nsb = (int) w.nblk;
@@ -844,7 +856,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
     const int seg = (int) blockIdx.y;
     const int sb0 = seg * seg_sb, nsbs = nsb - sb0 < seg_sb ? nsb - sb0 : seg_sb;
     const size_t img = fq_act_col_bytes(FQ_Q8_K, K);
-    const kq_plan P = kq_lds(seg_sb, T, NBW);
+    const kq_plan P = kq_lds<TYPE>(seg_sb, T, NBW);
     const int TQS = P.tqs;
     uint8_t * cols = smem + P.rings;                                       // [16 columns][TQS]: per super-block 4 groups x 32 B: 2 q, 2 q + 1, 2 q + 4, 2 q + 5
     float   * dyT  = (float *)(cols + P.cols);                             // [super-block][16]: the columns' d
@@ -857,9 +869,11 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
 #pragma unroll
     for (int k = 0; k < KQ_KOPS; ++k) {
         const int L = 64 * k + lane, row = (L / KQ_ROWP) & 15, p = L % KQ_ROWP;
-        if (p < 16)      { poff[k] = (unsigned)((p >> 2) * 128 + ((p >> 1) & 1) * 64 + (p & 1) * 16); pkind[k] = 0; }
-        else if (p < 19) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 1; }
-        else             { poff[k] = (unsigned)(16 * (p - 19)); pkind[k] = 2; }
+        constexpr int NQH = F::Q5 ? 8 : 0;                                  // pieces of fifth bits (4 super-blocks x 32 B)
+        if (p < 16)            { poff[k] = (unsigned)((p >> 2) * 128 + ((p >> 1) & 1) * 64 + (p & 1) * 16); pkind[k] = 0; }
+        else if (p < 16 + NQH) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 3; }
+        else if (p < 19 + NQH) { poff[k] = (unsigned)(16 * (p - 16 - NQH)); pkind[k] = 1; }
+        else                   { poff[k] = (unsigned)(16 * (p - 19 - NQH)); pkind[k] = 2; }
         rowb[k] = (unsigned) row * (unsigned) w.row_stride;
     }
     const unsigned rs16 = (unsigned) w.row_stride - 16u;
@@ -873,13 +887,14 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
         const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
         const int gsb = sb0 + 4 * sp, c = gsb >> 3, in = gsb & 7;
         const int nbc = nsb - 8 * c < 8 ? nsb - 8 * c : 8;
-        const unsigned b0 = (unsigned)(c * 1152 + in * 128 + q * 32);
-        const unsigned b1 = (unsigned)(c * 1152 + nbc * 128 + in * 12);
-        const unsigned b2 = (unsigned)(c * 1152 + ((nbc * 140) & ~15) + in * 4);
+        const unsigned b0 = (unsigned)(c * F::COLB + in * 128 + q * 32);
+        const unsigned bh = (unsigned)(c * F::COLB + nbc * F::PRE_QH + in * 32);
+        const unsigned b1 = (unsigned)(c * F::COLB + nbc * F::PRE_SC + in * 12);
+        const unsigned b2 = (unsigned)(c * F::COLB + ((nbc * F::PRE_DM) & ~15) + in * 4);
         const unsigned dst = ring_lds + (unsigned)((u % NBW) * KQ_WSTAGE);
 #pragma unroll
         for (int k = 0; k < KQ_KOPS; ++k) {
-            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : b2));
+            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : (pkind[k] == 2 ? b2 : bh)));
             o = o < rs16 ? o : rs16;                                       // (a partial last column: pieces beyond its blocks are never used)
             if (64 * k + lane < 16 * KQ_ROWP) sk_dma(wbase, rowb[k] + o, dst + (unsigned)(k * 1024));
         }
@@ -939,7 +954,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
                 const uint8_t * wr = myring + (size_t)(u % NBW) * KQ_WSTAGE + l16 * KQ_ROWB;
                 const int gsb = sb0 + 4 * sp, c = gsb >> 3;
                 const int nbc = nsb - 8 * c < 8 ? nsb - 8 * c : 8;
-                const int p2d = (nbc * 140) & 15;                          // d, dmin: offset from the boundary the DMA started at
+                const int p2d = (nbc * F::PRE_DM) & 15;                    // d, dmin: offset from the boundary the DMA started at
                 const int ns = nsbs - 4 * sp < 4 ? nsbs - 4 * sp : 4;      // super-blocks in this stage
                 const uint8_t * tqp = cols + (size_t) l16 * TQS + (size_t)(4 * sp) * 128 + 8 * kq;
                 const uint8_t * dyp = (const uint8_t *) dyT + (size_t)(4 * sp) * 64 + 16 * kq;
@@ -948,15 +963,16 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
                 const uint8_t * gsp = kq == 0 ? gsT + (size_t)(4 * sp) * 256 + 16 * l16 : gsT + P.gs;
                 const int gstep = kq == 0 ? 256 : 0;
                 const uint32_t kq0 = kq == 0 ? 0xFFFFFFFFu : 0u;
-                struct kq_ops { sk_v2i xa[4], raw0, raw1; uint32_t u0, u1, u2, dm; float4 dy; uint4 gs; };
+                struct kq_ops { sk_v2i xa[4], raw0, raw1, qh; uint32_t u0, u1, u2, dm; float4 dy; uint4 gs; };
                 auto load_ops = [&](int i) __attribute__((always_inline)) {
                     kq_ops o;
 #pragma unroll
                     for (int gi = 0; gi < 4; ++gi) o.xa[gi] = *(const sk_v2i *)(tqp + 128 * i + 32 * gi);
                     o.raw0 = *(const sk_v2i *)(wr + 64 * i + 8 * kq);
                     o.raw1 = *(const sk_v2i *)(wr + 64 * i + 32 + 8 * kq);
-                    o.u0 = *(const uint32_t *)(wr + 256 + 12 * i); o.u1 = *(const uint32_t *)(wr + 260 + 12 * i); o.u2 = *(const uint32_t *)(wr + 264 + 12 * i);
-                    o.dm = *(const uint32_t *)(wr + 304 + p2d + 4 * i);
+                    if constexpr (F::Q5) o.qh = *(const sk_v2i *)(wr + F::QHOFF + 32 * i + 8 * kq); else o.qh = sk_v2i{ 0, 0 };
+                    o.u0 = *(const uint32_t *)(wr + F::SOFF + 12 * i); o.u1 = *(const uint32_t *)(wr + F::SOFF + 4 + 12 * i); o.u2 = *(const uint32_t *)(wr + F::SOFF + 8 + 12 * i);
+                    o.dm = *(const uint32_t *)(wr + F::DOFF + p2d + 4 * i);
                     o.dy = *(const float4 *)(dyp + 64 * i);
                     if constexpr (Q == 1) o.gs = *(const uint4 *)(gsp + gstep * i);
                     return o;
@@ -965,10 +981,17 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
                 auto run_mfma = [&](const kq_ops & o) __attribute__((always_inline)) {
                     kq_c r;
                     const sk_v4i z = { 0, 0, 0, 0 };
-                    const sk_v2i l0 = { (int)((uint32_t) o.raw0.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw0.y & 0x0F0F0F0Fu) };
-                    const sk_v2i h0 = { (int)(((uint32_t) o.raw0.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw0.y >> 4) & 0x0F0F0F0Fu) };
-                    const sk_v2i l1 = { (int)((uint32_t) o.raw1.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw1.y & 0x0F0F0F0Fu) };
-                    const sk_v2i h1 = { (int)(((uint32_t) o.raw1.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw1.y >> 4) & 0x0F0F0F0Fu) };
+                    sk_v2i l0 = { (int)((uint32_t) o.raw0.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw0.y & 0x0F0F0F0Fu) };
+                    sk_v2i h0 = { (int)(((uint32_t) o.raw0.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw0.y >> 4) & 0x0F0F0F0Fu) };
+                    sk_v2i l1 = { (int)((uint32_t) o.raw1.x & 0x0F0F0F0Fu), (int)((uint32_t) o.raw1.y & 0x0F0F0F0Fu) };
+                    sk_v2i h1 = { (int)(((uint32_t) o.raw1.x >> 4) & 0x0F0F0F0Fu), (int)(((uint32_t) o.raw1.y >> 4) & 0x0F0F0F0Fu) };
+                    if constexpr (F::Q5) {                                  // k_quants.c:2358-2364: bit g of qh[l] adds 16 to element l of group g
+                        const uint32_t qx = (uint32_t) o.qh.x, qy = (uint32_t) o.qh.y;
+                        auto fifth = [&](sk_v2i & v, int g) __attribute__((always_inline)) {
+                            v.x |= (int)(((qx >> g) & 0x01010101u) << 4); v.y |= (int)(((qy >> g) & 0x01010101u) << 4);
+                        };
+                        fifth(l0, 2 * Q); fifth(h0, 2 * Q + 1); fifth(l1, 2 * Q + 4); fifth(h1, 2 * Q + 5);
+                    }
                     r.c[0] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[0]), __builtin_bit_cast(long, l0), z, 0, 0, 0);     // group 2 Q
                     r.c[1] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[1]), __builtin_bit_cast(long, h0), z, 0, 0, 0);     // 2 Q + 1
                     r.c[2] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[2]), __builtin_bit_cast(long, l1), z, 0, 0, 0);     // 2 Q + 4
@@ -1125,11 +1148,11 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
     return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
 }
 
-// Q4_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
+// Q4_K / Q5_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
 bool fq_skinny_q4k_shape(const fq_weight & w) {
     static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
     const int64_t nseg = (w.nblk + KQ_SEG - 1) / KQ_SEG, mstride = (w.M + 63) & ~(int64_t) 63;
-    return on && w.type == FQ_Q4_K && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
+    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
            w.row_stride * 16 < ((size_t) 1 << 31);
 }
 // the main launch: partial sums of w x act into scratch region `part` ([segment][share][16][mstride]); false: not this form's shape
@@ -1144,24 +1167,26 @@ static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float *
     int T = env_t > 0 ? env_t : (ntiles * 2 * nseg + n_cu - 1) / n_cu;     // tiles per workgroup: all workgroups resident in one round when they fit
     if (T < 1) T = 1;
     if (T > KS_TMAX) T = KS_TMAX;
+    const bool q5 = w.type == FQ_Q5_K;
+    auto lds_of = [&](int t, int n) { return q5 ? kq_lds<FQ_Q5_K>(seg_sb, t, n).total : kq_lds<FQ_Q4_K>(seg_sb, t, n).total; };
     int nbw = 0;
     for (;;) {
-        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (kq_lds(seg_sb, T, n).total <= 160 * 1024) { nbw = n; break; } }
+        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (q5 && n == 3) continue; if (lds_of(T, n) <= 160 * 1024) { nbw = n; break; } }   // (Q5_K: 8 DMA instructions per stage: two stages ahead would pass vmcnt's 15)
         if (nbw || T == 1) break;
         --T;
     }
     if (!nbw) return false;
-    const size_t need = kq_lds(seg_sb, T, nbw).total;
+    const size_t need = lds_of(T, nbw);
     const int nrb = (ntiles + T - 1) / T;
     int nslots = 8 * ((nrb + 7) / 8);
     const int cap = ((n_cu / (2 * nseg)) / 8) * 8;                         // row-block slots per segment when the launch is larger than the chip
     if (2 * nslots * nseg > n_cu) nslots = cap < 8 ? 8 : (nslots < cap ? nslots : cap);
     mstride = (w.M + 63) & ~(int64_t) 63;
-#define FQ_KQ_LAUNCH(NB) { \
+#define FQ_KQ_LAUNCH(TT, NB) { \
         static bool set = false; \
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q4k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((k_gemm_skinny_q4k<NB>), dim3((unsigned)(2 * nslots), (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
-    if (nbw == 3) FQ_KQ_LAUNCH(3) else FQ_KQ_LAUNCH(2)
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q4k<TT, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_q4k<TT, NB>), dim3((unsigned)(2 * nslots), (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
+    if (q5) FQ_KQ_LAUNCH(FQ_Q5_K, 2) else if (nbw == 3) FQ_KQ_LAUNCH(FQ_Q4_K, 3) else FQ_KQ_LAUNCH(FQ_Q4_K, 2)
 #undef FQ_KQ_LAUNCH
     return true;
 }
@@ -1198,7 +1223,7 @@ bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
-    if (w.type == FQ_Q4_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
+    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
     {

@@ -644,9 +644,9 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
         const int64_t Nb = g_backend_batch > 0 ? g_backend_batch : N;
         g_sum_order = (Nb <= 4) ? 1 : 2;
         g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2;
-        /* Q4_K with 5..80 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
+        /* Q4_K / Q5_K with 5..80 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
         g_kseg = 0;
-        if (wtype == ORC_Q4_K && Nb > 4 && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
+        if ((wtype == ORC_Q4_K || wtype == ORC_Q5_K) && Nb > 4 && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
             ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; }
     }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);

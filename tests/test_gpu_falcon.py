@@ -263,13 +263,13 @@ def test_falcon40b_shaped_layer_vs_oracle(oracle):
     print("40B-shaped block: association spread %.2e" % _both_orders(oracle, w, synth.tokens(3, 512, seed=4), 2, 16))
 
 
-@pytest.mark.parametrize("n_pre", [6, 16, 21])
-def test_falcon40b_shaped_layer_small_batch_vs_oracle(oracle, n_pre):
+@pytest.mark.parametrize("t,n_pre", [(ob.Q4_K, 6), (ob.Q4_K, 16), (ob.Q4_K, 21), (ob.Q5_K, 9)])
+def test_falcon40b_shaped_layer_small_batch_vs_oracle(oracle, t, n_pre):
     """the 40B-shaped Q4_K block with prompts of 6, 16 and 21 tokens: every mat-mul through the share-pair small-batch form (k_gemm_skinny_q4k;
     21 = two passes), Wup's sum launch applying GELU and writing Wdown's Q8_K image, Wo and Wdown (four K segments) sharing one sum launch with
     the residual -- bit-exact in both orders (the oracle's mode 2 restates the segmented four-sum order)"""
     hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
-    w = synth.make_model_fast(hp, ob.Q4_K, seed=11)
+    w = synth.make_model_fast(hp, t, seed=11)
     _both_orders(oracle, w, synth.tokens(n_pre + 1, 512, seed=5), n_pre, 32)
 
 

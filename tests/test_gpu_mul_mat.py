@@ -148,13 +148,13 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
 
 @pytest.mark.parametrize("K,M,N", [(2048, 64, 7), (2560, 48, 16), (8192, 144, 5), (10240, 32, 13), (16384, 16, 16), (8192, 144, 29), (4096, 64, 77), (2048, 20480, 6),
                                    (10240, 20480, 5)])
-def test_q4k_small_batch_vs_oracle(oracle, K, M, N):
-    """Q4_K, 5..16 columns (17..32: two passes) at model widths: the share-pair streaming form (k_gemm_skinny_q4k + k_skinny_sum4) -- four
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K])
+def test_q4k_small_batch_vs_oracle(oracle, t, K, M, N):
+    """Q4_K and Q5_K (the same kernel plus the plane of fifth bits), 5..16 columns (17..80: passes) at model widths: the share-pair streaming form (k_gemm_skinny_q4k + k_skinny_sum4) -- four
     interleaved partial sums per segment of 32 super-blocks whatever the shape, the segments added left to right == orc_set_sum_order(2), which
     follows the same rule (== order 3 for rows of one segment). Shapes: one device column, a partial last column (10 super-blocks), one full segment,
     two segments (40 super-blocks), two full segments on one tile, two passes, more row blocks than workgroup slots, and the latter with two segments."""
-    t = ob.Q4_K
-    rng = np.random.default_rng(K + M + N)
+    rng = np.random.default_rng(K + M + N + t)
     w = synth.random_blocks(t, M, K, rng) if M > 1024 else synth.quantized_matrix(oracle, t, M, K, rng)
     x = rng.standard_normal((N, K)).astype(np.float32)
     dw = g.Weight(t, w, K, M)
