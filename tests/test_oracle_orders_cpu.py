@@ -58,3 +58,34 @@ def test_orders_exact_on_integer_terms(oracle, t):
         finally:
             oracle.lib.orc_set_sum_order(0)
         assert np.array_equal(got, ref), order
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K])
+def test_backend_mode_segments_for_q4k_small_batches(oracle, t):
+    """mode 2 for Q4_K / Q5_K at model widths and 5..80 columns = the backend's small-batch form (k_gemm_skinny_q4k): four interleaved partial
+    sums per segment of 32 super-blocks, the segments' values added left to right -- i.e. the order-3 results of the two K halves of a 64-super-block
+    row, added; one segment (K = 8192) is order 3 itself; 4 columns and 81 columns keep the other rules (unit order / the tile GEMM's split)"""
+    rng = np.random.default_rng(7 + t)
+    K, M = 16384, 32
+    w = synth.random_blocks(t, M, K, rng)
+    x = rng.standard_normal((81, K)).astype(np.float32)
+    half, rb = K // 2, w.shape[1] // 2
+    try:
+        oracle.lib.orc_set_sum_order(2)
+        seg = oracle.mul_mat(t, w, K, M, x[:5], 2)
+        four_cols = oracle.mul_mat(t, w, K, M, x[:4], 2)
+        many = oracle.mul_mat(t, w, K, M, x, 2)
+        one_seg = oracle.mul_mat(t, np.ascontiguousarray(w[:, :rb]), half, M, np.ascontiguousarray(x[:5, :half]), 2)
+        oracle.lib.orc_set_sum_order(3)
+        a = oracle.mul_mat(t, np.ascontiguousarray(w[:, :rb]), half, M, np.ascontiguousarray(x[:5, :half]), 2)
+        b = oracle.mul_mat(t, np.ascontiguousarray(w[:, rb:]), half, M, np.ascontiguousarray(x[:5, half:]), 2)
+        whole3 = oracle.mul_mat(t, w, K, M, x, 2)
+        oracle.lib.orc_set_sum_order(1)
+        unit = oracle.mul_mat(t, w, K, M, x[:4], 2)
+    finally:
+        oracle.lib.orc_set_sum_order(0)
+    assert np.array_equal(seg, (a + b).astype(np.float32))
+    assert np.array_equal(one_seg, a)
+    assert np.array_equal(four_cols, unit)
+    assert np.array_equal(many, whole3)              # 81 columns: the tile GEMM's four sums over the whole row (M = 32: few tiles)
+    assert not np.array_equal(seg, whole3[:5])
