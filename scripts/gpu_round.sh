@@ -1,12 +1,13 @@
 #!/bin/bash
 # One gpurun call of a round: every -m gpu test, smoke, the bench line the driver reads; optionally rocprofv3 kernel trace + PMC passes.
-# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|lockstep40|all ...]
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|lockstep40|q4kpmc|all ...]
 #   prof         rocprofv3 kernel trace of the decode bench             -> <tag>/decode_7b_q4_0_kernel_stats.{csv,md}
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (HBM traffic per launch)  -> <tag>/pmc_traffic.json
 #   mfma         SQ matrix-pipe / VALU counters (decode + 128- and 2048-token prefill in one run) -> <tag>/pmc_mfma.json
 #   prefill2048  kernel trace of a 2048-token prompt                     -> <tag>/prefill2048_7b_q4_0_kernel_stats.{csv,md}
 #   b40          Falcon-40B Q4_K, all 60 blocks, one GPU: bench line + kernel trace -> <tag>/bench_40b_q4_k.json, <tag>/decode_40b_q4_k_kernel_stats.{csv,md}
 #   lockstep     kernel trace of 16 lock-step streams per weight pass    -> <tag>/lockstep_b16_kernel_stats.{csv,md}
+#   q4kpmc       counters of the Q4_K small-batch launches on Falcon-40B shapes (16 columns): VALU / matrix pipe, HBM fetch / write -> <tag>/q4k_pmc_mfma.json, <tag>/q4k_pmc_traffic.json
 #   lockstep40   Falcon-40B Q4_K, 60 blocks: lock-step streams 4..128 per pass + kernel trace of 16 per pass (12 blocks) -> <tag>/lockstep_40b_q4_k.txt, <tag>/lockstep40_b16_kernel_stats.{csv,md}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -81,5 +82,18 @@ fi
 if has lockstep40; then
   LOCKSTEP_MODEL=40b_q4_k timeout 600 python scripts/gpu_lockstep.py 1 2 4 8 12 16 32 48 64 80 128 2>&1 | grep "streams per pass" | tee $OUT/lockstep_40b_q4_k.txt
   LOCKSTEP_MODEL=40b_q4_k LOCKSTEP_LAYERS=12 trace lockstep40_b16 python $R/scripts/gpu_lockstep.py 16
+fi
+if has q4kpmc; then
+  mkdir -p $OUT/pmc
+  cd /tmp
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc -o q4kmfma -- python $R/scripts/gpu_q4k_skinny.py 16 > $R/$OUT/pmc/q4kmfma.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    n=q4k$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+    timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc -o $n -- python $R/scripts/gpu_q4k_skinny.py 16 > $R/$OUT/pmc/$n.log 2>&1
+  done
+  cd $R
+  python scripts/pmc_mfma_summary.py $(find $OUT/pmc -name "q4kmfma*results.db" | head -1) $OUT/q4k_pmc_mfma.json | cut -c1-170
+  python scripts/pmc_summary.py $(find $OUT/pmc -name "q4kfetch*results.db" | head -1) $(find $OUT/pmc -name "q4kwrite*results.db" | head -1) $OUT/q4k_pmc_traffic.json 2>&1 | tail -8
+  find $OUT/pmc -name "*.db" -delete
 fi
 cat $OUT/summary.txt

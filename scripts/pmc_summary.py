@@ -9,8 +9,13 @@ from collections import defaultdict
 def per_kernel(db, counter):
     c = sqlite3.connect(db).cursor()
     acc = defaultdict(lambda: [0, 0.0])
-    for name, val in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+    try:        # per launch shape for the mat-mul templates (one template serves several matrices)
+        rows = list(c.execute("select kernel_name, value, grid_size_x, grid_size_y from counters_collection where counter_name = ?", (counter,)))
+    except sqlite3.OperationalError:
+        rows = [(a, v, None, None) for a, v in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,))]
+    for name, val, gx, gy in rows:
         k = name.split("(")[0].replace("void ", "")
+        if gx is not None and k.startswith("k_gemm_skinny_q4k"): k += " grid %sx%s" % (gx, gy)
         acc[k][0] += 1; acc[k][1] += val
     return {k: (n, s / n) for k, (n, s) in acc.items()}
 
