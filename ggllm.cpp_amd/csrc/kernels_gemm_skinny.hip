@@ -1049,6 +1049,218 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
     if (q) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
 }
 
+// =============================================================================================== Q2_K: all four K shares per wave
+// ggml_vec_dot_q2_K_q8_K (k_quants.c:1005-1306) for 5..16 columns. Q2_K keeps the four 32-element groups of a 128-element half in the SAME 32 bytes
+// (bits 2t of byte l = element l of group t): every K share g mod 4 = t reads all of a row's quant bytes, so a wave owns a whole 16-row tile -- four
+// accumulator chains -- and a workgroup keeps the full 16 columns of one SEGMENT of 16 super-blocks resident (64 KiB). Association: the segmented four-sum
+// order of k_gemm_skinny_q4k with 16-super-block segments (the oracle restates it). The 16-element sub-blocks carry 4-bit scales: a lane's 8 elements of a
+// group sit in ONE sub-block (lanes kq < 2: the first, kq >= 2: the second), so the scale goes INTO the matrix operand -- v_perm_b32 looks the 2-bit
+// quants up in the lane's table {0, sc, 2 sc, 3 sc} (<= 45: int8) -- and ONE v_mfma_i32_16x16x32_i8 per group returns sum_b sc_b I_b; the two groups of
+// a share chain through the accumulator operand: no integer multiply-adds at all. The mins: sum_b m_b bsum_b (16 sub-blocks) as two more matrix
+// instructions on the hi / lo bytes of the Q8_K block sums (bsum = 64 hi + lo), k slots 0..15 carried by the lanes kq < 2.
+// Per stage (4 super-blocks) and row: 16 quant pieces | 4 of scales | 1 of d, dmin = 21 slots, as in the Q4_K form.
+constexpr int K2_SEG = 16;
+constexpr int K2_ROWP = 21, K2_ROWB = 16 * K2_ROWP, K2_WSTAGE = 16 * K2_ROWB, K2_KOPS = (16 * K2_ROWP + 63) / 64;
+struct k2_plan { int tqs; size_t rings, cols, dy, bs, total; };
+static __host__ __device__ inline k2_plan k2_lds(int seg_sb, int T, int nbw) {
+    k2_plan p;
+    const int qb = seg_sb * 256;
+    p.tqs = qb + ((16 - (qb & 255)) & 255);
+    p.rings = (size_t) nbw * T * K2_WSTAGE; p.cols = (size_t) SK_TN * p.tqs; p.dy = (size_t) seg_sb * SK_TN * 4; p.bs = (size_t) seg_sb * SK_TN * 32;
+    p.total = p.rings + p.cols + p.dy + p.bs + 32;                          // (+ 32 zero bytes: the mins' operands of the lanes that carry none)
+    return p;
+}
+
+template <int NBW>
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, fq_act act, int N, float * part, int64_t mstride, int T, int nrb, int nslots, int seg_sb, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nsb = (int) w.nblk;
+    const int slot = (int) blockIdx.x, seg = (int) blockIdx.y;
+    if (slot >= nrb) return;
+    const int sb0 = seg * seg_sb, nsbs = nsb - sb0 < seg_sb ? nsb - sb0 : seg_sb;
+    const size_t img = fq_act_col_bytes(FQ_Q8_K, K);
+    const k2_plan P = k2_lds(seg_sb, T, NBW);
+    const int TQS = P.tqs;
+    uint8_t * cols = smem + P.rings;                                       // [16 columns][TQS]: the segment's quants as they are
+    float   * dyT  = (float *)(cols + P.cols);                             // [super-block][16]: the columns' d
+    uint8_t * bsT  = (uint8_t *) dyT + P.dy;                               // [super-block][16][32 B]: block sums bsum_b = 64 hi_b + lo_b as bytes hi_0..15 | lo_0..15
+    const int l16 = lane & 15, kq = lane >> 4;
+    int nmine = 0;
+    for (int rb = slot; rb < nrb; rb += nslots) if (((int64_t) rb * T + wid) * 16 < M) ++nmine;
+    unsigned poff[K2_KOPS], rowb[K2_KOPS]; int pkind[K2_KOPS];
+#pragma unroll
+    for (int k = 0; k < K2_KOPS; ++k) {
+        const int L = 64 * k + lane, row = (L / K2_ROWP) & 15, p = L % K2_ROWP;
+        if (p < 16)      { poff[k] = (unsigned)(16 * p); pkind[k] = 0; }
+        else if (p < 20) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 1; }
+        else             { poff[k] = 0u; pkind[k] = 2; }
+        rowb[k] = (unsigned) row * (unsigned) w.row_stride;
+    }
+    const unsigned rs16 = (unsigned) w.row_stride - 16u;
+    uint8_t * myring = smem + (size_t) wid * NBW * K2_WSTAGE;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(sk_lds(myring));
+    const int nst = (nsbs + 3) / 4;
+    const int total = nmine * nst;
+    auto issue = [&](int u) {
+        const int rbi = u / nst, sp = u - rbi * nst;
+        const int64_t mt = ((int64_t)(slot + rbi * nslots) * T + wid) * 16;
+        const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
+        const int gsb = sb0 + 4 * sp, c = gsb >> 4, in = gsb & 15;
+        const int nbc = nsb - 16 * c < 16 ? nsb - 16 * c : 16;
+        const unsigned b0 = (unsigned)(c * 1344 + in * 64);
+        const unsigned b1 = (unsigned)(c * 1344 + nbc * 64 + in * 16);
+        const unsigned b2 = (unsigned)(c * 1344 + nbc * 80 + in * 4);      // (in is a multiple of 4: 16-byte aligned)
+        const unsigned dst = ring_lds + (unsigned)((u % NBW) * K2_WSTAGE);
+#pragma unroll
+        for (int k = 0; k < K2_KOPS; ++k) {
+            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : b2));
+            o = o < rs16 ? o : rs16;
+            if (64 * k + lane < 16 * K2_ROWP) sk_dma(wbase, rowb[k] + o, dst + (unsigned)(k * 1024));
+        }
+    };
+    if (!(dbg & 8)) { for (int u = 0; u < NBW - 1 && u < total; ++u) issue(u); }
+    {
+        const unsigned last = (unsigned)(K - 16);
+        const int NW = (int)(blockDim.x >> 6);
+        for (int t = wid; t < SK_TN; t += NW) {
+            const uint8_t * base = sk_uniform(act.base + (size_t)(t < N ? t : N - 1) * img);
+            const unsigned tb = sk_lds(cols) + (unsigned)(t * TQS);
+            for (int j0 = 0; j0 < nsbs; j0 += 4) {
+                unsigned vq = (unsigned)((sb0 + j0) * 256 + 16 * lane);
+                vq = vq < last ? vq : last;
+                if (j0 + (lane >> 4) < nsbs && !(dbg & 4)) sk_dma(base, vq, tb + (unsigned)(j0 * 256));
+            }
+        }
+        const size_t aux = fq_act_aux_off(FQ_Q8_K, K);
+        if (tid < 8) ((uint32_t *)(bsT + P.bs))[tid] = 0u;
+        for (int e = tid; e < nsbs * SK_TN; e += (int) blockDim.x) {
+            const int sbl = e >> 4, tok = e & 15;
+            const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img;
+            dyT[e] = ((const float *)(tp + K))[sb0 + sbl];
+            const uint32_t * bs = (const uint32_t *)(tp + aux) + (size_t)(sb0 + sbl) * 8;
+            uint32_t hi[4] = { 0u, 0u, 0u, 0u }, lo[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t v = bs[j];
+                const int b0 = (int)(int16_t)(v & 0xFFFFu), b1 = (int)(int16_t)(v >> 16);
+                hi[j >> 1] |= (((uint32_t)(b0 >> 6) & 0xFFu) << (16 * (j & 1))) | (((uint32_t)(b1 >> 6) & 0xFFu) << (16 * (j & 1) + 8));
+                lo[j >> 1] |= (((uint32_t) b0 & 63u) << (16 * (j & 1))) | (((uint32_t) b1 & 63u) << (16 * (j & 1) + 8));
+            }
+            *(uint4 *)(bsT + (size_t) e * 32)      = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *(uint4 *)(bsT + (size_t) e * 32 + 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                       // the only barrier: the columns are in LDS
+
+    float * pbase = part + ((size_t)(4 * seg) * SK_TN) * (size_t) mstride;
+    const size_t sstride = (size_t) SK_TN * (size_t) mstride;
+    const int s01 = kq >> 1;                                               // which 16-element sub-block of a group the lane's elements sit in
+    const bool mlane = kq < 2;                                             // lanes that carry the mins' k slots (sub-blocks 8 kq .. 8 kq + 7)
+    int u = 0;
+    for (int rbi = 0; rbi < nmine; ++rbi) {
+        const int64_t m = ((int64_t)(slot + rbi * nslots) * T + wid) * 16 + l16;
+        float acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t][0] = 0.0f; acc[t][1] = 0.0f; acc[t][2] = 0.0f; acc[t][3] = 0.0f; }
+        for (int sp = 0; sp < nst; ++sp, ++u) {
+            if (u + NBW - 1 < total && !(dbg & 8)) issue(u + NBW - 1);
+            {
+                const int later = (dbg & 8) ? 0 : (total - 1 - u < NBW - 1 ? total - 1 - u : NBW - 1);
+                if (later >= 2)      sk_wait_vm_upto(2 * K2_KOPS);
+                else if (later == 1) sk_wait_vm_upto(K2_KOPS);
+                else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (dbg & 16) continue;
+            const uint8_t * wr = myring + (size_t)(u % NBW) * K2_WSTAGE + l16 * K2_ROWB;
+            const int ns = nsbs - 4 * sp < 4 ? nsbs - 4 * sp : 4;
+            const uint8_t * tqp = cols + (size_t) l16 * TQS + (size_t)(4 * sp) * 256 + 8 * kq;
+            const uint8_t * dyp = (const uint8_t *) dyT + (size_t)(4 * sp) * 64 + 16 * kq;
+            const uint8_t * bsp = mlane ? bsT + (size_t)(4 * sp) * 512 + 32 * l16 + 8 * kq : bsT + P.bs;
+            const int bstep = mlane ? 512 : 0;
+            struct k2_ops { sk_v2i xa[8], raw[2], bh, bl; uint4 sc; uint32_t dm; float4 dy; };
+            auto load_ops = [&](int i) __attribute__((always_inline)) {
+                k2_ops o;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) o.xa[g] = *(const sk_v2i *)(tqp + 256 * i + 32 * g);
+                o.raw[0] = *(const sk_v2i *)(wr + 64 * i + 8 * kq);
+                o.raw[1] = *(const sk_v2i *)(wr + 64 * i + 32 + 8 * kq);
+                o.sc = *(const uint4 *)(wr + 256 + 16 * i);
+                o.dm = *(const uint32_t *)(wr + 320 + 4 * i);
+                o.dy = *(const float4 *)(dyp + 64 * i);
+                o.bh = *(const sk_v2i *)(bsp + bstep * i);
+                o.bl = *(const sk_v2i *)(bsp + bstep * i + 16);
+                return o;
+            };
+            struct k2_c { sk_v4i c[6]; };
+            auto run_mfma = [&](const k2_ops & o) __attribute__((always_inline)) {
+                k2_c r;
+                const sk_v4i z = { 0, 0, 0, 0 };
+                // the lane's sub-block scale of group (h, t): byte 8 h + 2 t + s01 of the 16 -> after the shift by s01 bytes: dword 2 h + (t >> 1), bits 16 (t & 1)
+                const uint32_t S[4] = { o.sc.x >> (8 * s01), o.sc.y >> (8 * s01), o.sc.z >> (8 * s01), o.sc.w >> (8 * s01) };
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    sk_v4i c = z;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t sc = (S[2 * h + (t >> 1)] >> (16 * (t & 1))) & 15u;
+                        const uint32_t lut = __umul24(sc, 0x030201u) << 8;                 // bytes {0, sc, 2 sc, 3 sc}
+                        const uint32_t qx = ((uint32_t) o.raw[h].x >> (2 * t)) & 0x03030303u, qy = ((uint32_t) o.raw[h].y >> (2 * t)) & 0x03030303u;
+                        const sk_v2i b = { (int) __builtin_amdgcn_perm(0u, lut, qx), (int) __builtin_amdgcn_perm(0u, lut, qy) };
+                        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[4 * h + t]), __builtin_bit_cast(long, b), c, 0, 0, 0);
+                    }
+                    r.c[t] = c;
+                }
+                // the mins (high nibbles of the 16 scale bytes), sub-blocks 8 kq .. 8 kq + 7 in the lanes kq < 2
+                const uint32_t m0 = kq == 0 ? o.sc.x : o.sc.z, m1 = kq == 0 ? o.sc.y : o.sc.w;
+                const sk_v2i mn = { mlane ? (int)((m0 >> 4) & 0x0F0F0F0Fu) : 0, mlane ? (int)((m1 >> 4) & 0x0F0F0F0Fu) : 0 };
+                r.c[4] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.bh), __builtin_bit_cast(long, mn), z, 0, 0, 0);
+                r.c[5] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.bl), __builtin_bit_cast(long, mn), z, 0, 0, 0);
+                return r;
+            };
+            auto scale = [&](const k2_c & cc, const k2_ops & o) __attribute__((always_inline)) {
+                const float d = fq_h2f((uint16_t) o.dm), dmin = fq_h2f((uint16_t)(o.dm >> 16));
+                const float dyv[4] = { o.dy.x, o.dy.y, o.dy.z, o.dy.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dd = dyv[r] * d, dmn = dyv[r] * dmin;              // k_quants.c:1282-1283: dall = y.d * d, dmin = y.d * dmin
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float a = dd * (float) cc.c[t][r];
+                        if (t == 3) a = a - dmn * (float)((cc.c[4][r] << 6) + cc.c[5][r]);
+                        acc[t][r] = acc[t][r] + a;
+                    }
+                }
+            };
+            if (ns == 4) {
+                k2_ops o[4]; k2_c c4[4];
+                o[0] = load_ops(0); o[1] = load_ops(1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                               // reads two super-blocks ahead, the matrix instructions one ahead of their scaling
+                    if (k + 2 < 4) o[k + 2] = load_ops(k + 2);
+                    c4[k] = run_mfma(o[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k > 0) scale(c4[k - 1], o[k - 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                scale(c4[3], o[3]);
+            } else {
+                for (int i = 0; i < ns; ++i) { const k2_ops o = load_ops(i); const k2_c c1 = run_mfma(o); scale(c1, o); }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 4 * kq + r;
+            if (n < N) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pbase[(size_t) t * sstride + (size_t) n * mstride + m] = acc[t][r];
+            }
+        }
+    }
+}
+
 // part: [segment][share][16][mstride]; dst = the segments' ((P0 + P1) + P2) + P3 added left to right, then the epilogue
 __global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep, int64_t mstride, int nseg) {
     const int64_t m = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1148,15 +1360,49 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
     return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
 }
 
-// Q4_K / Q5_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
+// Q4_K / Q5_K / Q2_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
 bool fq_skinny_q4k_shape(const fq_weight & w) {
     static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
-    const int64_t nseg = (w.nblk + KQ_SEG - 1) / KQ_SEG, mstride = (w.M + 63) & ~(int64_t) 63;
-    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
+    const int seg = w.type == FQ_Q2_K ? K2_SEG : KQ_SEG;
+    const int64_t nseg = (w.nblk + seg - 1) / seg, mstride = (w.M + 63) & ~(int64_t) 63;
+    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
            w.row_stride * 16 < ((size_t) 1 << 31);
+}
+static bool q2k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
+    if (!fq_skinny_q4k_shape(w) || w.type != FQ_Q2_K || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
+    const int n_cu = fq_ctx().n_cu;
+    const int ntiles = (int)(w.M / 16);
+    const int nsb = (int) w.nblk;
+    static const int env_t = getenv("FQ_KQ_T") ? atoi(getenv("FQ_KQ_T")) : 0, env_nbw = getenv("FQ_KQ_NBW") ? atoi(getenv("FQ_KQ_NBW")) : 0;
+    nseg = (nsb + K2_SEG - 1) / K2_SEG;
+    const int seg_sb = nseg > 1 ? K2_SEG : ((nsb + 3) & ~3);
+    int T = env_t > 0 ? env_t : (ntiles * nseg + n_cu - 1) / n_cu;         // tiles (waves) per workgroup: one round when they fit
+    if (T < 1) T = 1;
+    if (T > KS_TMAX) T = KS_TMAX;
+    int nbw = 0;
+    for (;;) {
+        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (k2_lds(seg_sb, T, n).total <= 160 * 1024) { nbw = n; break; } }
+        if (nbw || T == 1) break;
+        --T;
+    }
+    if (!nbw) return false;
+    const size_t need = k2_lds(seg_sb, T, nbw).total;
+    const int nrb = (ntiles + T - 1) / T;
+    // more (row block, segment) pairs than CUs: persistent workgroups in full rounds, unless the last round would be nearly empty
+    int nslots = nrb;
+    if (nrb * nseg > n_cu) { const int cap = n_cu / nseg > 0 ? n_cu / nseg : 1; if (nrb % cap == 0 || nrb > 2 * cap) nslots = cap; }
+    mstride = (w.M + 63) & ~(int64_t) 63;
+#define FQ_K2_LAUNCH(NB) { \
+        static bool set = false; \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q2k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_q2k<NB>), dim3((unsigned) nslots, (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
+    if (nbw == 3) FQ_K2_LAUNCH(3) else FQ_K2_LAUNCH(2)
+#undef FQ_K2_LAUNCH
+    return true;
 }
 // the main launch: partial sums of w x act into scratch region `part` ([segment][share][16][mstride]); false: not this form's shape
 static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
+    if (w.type == FQ_Q2_K) return q2k_main(w, act, N, part, mstride, nseg, st);
     if (!fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int n_cu = fq_ctx().n_cu;
     const int ntiles = (int)(w.M / 16);
@@ -1210,7 +1456,8 @@ bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act,
 bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
     if (wo.M != down.M || !fq_skinny_q4k_shape(wo) || !fq_skinny_q4k_shape(down) || a_att.type != FQ_Q8_K || a_ff.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int64_t ms = (down.M + 63) & ~(int64_t) 63;
-    const int64_t nsd = (down.nblk + KQ_SEG - 1) / KQ_SEG, nsw = (wo.nblk + KQ_SEG - 1) / KQ_SEG;
+    const int sgd = down.type == FQ_Q2_K ? K2_SEG : KQ_SEG, sgw = wo.type == FQ_Q2_K ? K2_SEG : KQ_SEG;
+    const int64_t nsd = (down.nblk + sgd - 1) / sgd, nsw = (wo.nblk + sgw - 1) / sgw;
     if ((nsd + nsw) * 4 * SK_TN * ms > (int64_t) FQ_KS_FLOATS) return false;
     float * part_d = fq_ctx().ks_scratch, * part_w = part_d + (size_t) nsd * 4 * SK_TN * ms;
     int64_t m1, m2; int s1, s2;
@@ -1223,7 +1470,7 @@ bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
-    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
+    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
     {
