@@ -693,7 +693,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // process on the same resident Falcon-7B Q4_0 (scripts/gpu_par2_ab.py), one stream -> two branches: 16 tokens 8.66 -> 7.83
         // ms, 32: 9.17 -> 8.13, 128: 9.41 -> 8.82, 512: 26.75 -> 24.59, 1024: 49.3 -> 47.3, 2048: 104.9 -> 101.7.
         // (not where the mat-muls are passes of the Q4_K small-batch form: they fill the chip and share one partial-sum scratch)
-        const bool q4k_passes = N <= FQ_SKINNY_Q4K_MAX_COLS && (fq_skinny_q4k_shape(L.qkv) || fq_skinny_q4k_shape(L.up) || fq_skinny_q4k_shape(L.wo) || fq_skinny_q4k_shape(L.down));
+        const bool q4k_passes = N <= fq_skinny_kq_max_cols(L.qkv.type) && (fq_skinny_q4k_shape(L.qkv) || fq_skinny_q4k_shape(L.up) || fq_skinny_q4k_shape(L.wo) || fq_skinny_q4k_shape(L.down));
         const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));

@@ -707,7 +707,7 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // per Falcon-7B pass of 32 lock-step sequences) -- beyond that the tiles below win. Q4_K at model widths: up to five passes (Falcon-40B, 12 blocks:
     // 48 columns 6.0 against 10.4 ms, 64: 7.9 against 10.7, 80: 9.8 against ~11; 96: 11.7 against 11.3)
     static const bool skinny2 = !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0);
-    const int64_t max_cols = fq_skinny_q4k_shape(w) ? FQ_SKINNY_Q4K_MAX_COLS : 32;
+    const int64_t max_cols = fq_skinny_q4k_shape(w) ? fq_skinny_kq_max_cols(w.type) : 32;      // (Q2_K, 12 blocks of Falcon-40B: 80 columns 7.6 against ~11.6 ms, 128: 12.2 against 11.8)
     if (skinny && skinny2 && N > 16 && N <= max_cols && !getenv("FQ_GEMM_CFG")) {
         const int S = cfg == 0 ? 1 : (cfg == 2 ? 4 : 2);
         for (int64_t n0 = 0; n0 < N; n0 += 16) {

@@ -146,7 +146,7 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
     assert relrms(got, via_gemv) <= TOL
 
 
-@pytest.mark.parametrize("K,M,N", [(2048, 64, 7), (2560, 48, 16), (8192, 144, 5), (10240, 32, 13), (16384, 16, 16), (8192, 144, 29), (4096, 64, 77), (2048, 20480, 6),
+@pytest.mark.parametrize("K,M,N", [(2048, 64, 7), (2560, 48, 16), (8192, 144, 5), (10240, 32, 13), (16384, 16, 16), (8192, 144, 29), (4096, 64, 77), (4096, 32, 100), (2048, 20480, 6),
                                    (10240, 20480, 5)])
 @pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K, ob.Q2_K])
 def test_q4k_small_batch_vs_oracle(oracle, t, K, M, N):
