@@ -504,7 +504,8 @@ static int fq_cols_max_n(int wtype) {
     return (wtype == FQ_Q4_0 || wtype == FQ_Q4_1 || wtype == FQ_Q5_0 || wtype == FQ_Q5_1 || wtype == FQ_Q8_0) ? 4 : 12;
 }
 // (Q4_K at model widths has its own streaming form for 5..16 columns: kernels_gemm_skinny.hip, k_gemm_skinny_q4k)
-#define FQ_COLS_MAX_N (m->layers.empty() ? 4 : (fq_skinny_q4k_shape(m->layers[0].qkv) && !getenv("FALCON_HIP_COLS_MAX_N") ? 4 : fq_cols_max_n(m->layers[0].qkv.type)))
+// -- from 3 sequences up: a pass of 16 columns costs less there than the column kernels' pass of 4; contexts of 2 keep them and their bit-identity with a single stream
+#define FQ_COLS_MAX_N (m->layers.empty() ? 4 : (fq_skinny_q4k_shape(m->layers[0].qkv) && !getenv("FALCON_HIP_COLS_MAX_N") ? 2 : fq_cols_max_n(m->layers[0].qkv.type)))
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
     const falcon_hip_hparams & hp = m->hp;
@@ -720,7 +721,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
             pair_done = fq_mul_mat_q_acts_pair(L.qkv, L.up, a_up, N, c->qkv, QKV, store, c->up, FF, gelu, st);
         }
-        if (!up_done && !pair_done) fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
+        const int min_cols = seq_stride ? 3 : 5;                             // (lock-step contexts: the k-quant small-batch forms from 3 sequences up)
+        if (!up_done && !pair_done) { if (seq_stride) fq_mul_mat_q_acts_from3(L.qkv, a_qkv, N, c->qkv, QKV, store, st); else fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st); }
         if (seq_stride && !fq_reference_order() && !fq_attn_f64()) {
             // lock-step sequences: RoPE, KV append, attention and (Q8_0 / Q8_1 consumers) the activation image of all N tokens in
             // one launch of the decode attention (k_attn_decode's code: the same bits as the three launches below)
@@ -739,10 +741,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         }
         if (!up_done && !pair_done) {
             // (Q4_K, 5..16 columns: GELU and Wdown's Q8_K image come out of the small-batch form's sum launch)
-            if (fq_mul_mat_q_acts_gelu_q8k(L.up, a_up, N, c->up, FF, a_ff, st)) ff_quantized = true;
+            if (fq_mul_mat_q_acts_gelu_q8k(L.up, a_up, N, c->up, FF, a_ff, st, min_cols)) ff_quantized = true;
             else {
                 const fq_gemv_epi gelu{ FQ_EPI_GELU, hc.gelu_table, nullptr, nullptr, 0 };
-                fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
+                if (seq_stride) fq_mul_mat_q_acts_from3(L.up, a_up, N, c->up, FF, gelu, st); else fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, st);
             }
         }
         if (!ff_quantized) fq_launch_quantize_act(c->up, FF, a_ff, st);
@@ -755,11 +757,11 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 out_done = fq_launch_gemv_out_cols(go, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
             }
         }
-        if (!out_done && fq_mul_mat_q_acts_out2(L.wo, a_att, L.down, a_ff, N, c->x, E, st)) out_done = true;      // (Q4_K, 5..16 columns: one sum launch for both)
+        if (!out_done && fq_mul_mat_q_acts_out2(L.wo, a_att, L.down, a_ff, N, c->x, E, st, min_cols)) out_done = true;      // (Q4_K, 5..16 columns: one sum launch for both)
         if (!out_done) {
-            fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
             const fq_gemv_epi resid{ FQ_EPI_ADD2, hc.gelu_table, c->wo_out, c->x, E };          // x = (down + wo) + x, in place
-            fq_mul_mat_q_acts(L.down, a_ff, N, c->x, E, resid, st);
+            if (seq_stride) { fq_mul_mat_q_acts_from3(L.wo, a_att, N, c->wo_out, E, store, st); fq_mul_mat_q_acts_from3(L.down, a_ff, N, c->x, E, resid, st); }
+            else            { fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st); fq_mul_mat_q_acts(L.down, a_ff, N, c->x, E, resid, st); }
         }
     }
     if (c->keep_hidden) {
@@ -779,7 +781,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 head_done = fq_launch_gemv_cols(ga, hc.n_cu, st) || (c0 > 0 && (fprintf(stderr, "falcon-hip: column mat-vec refused a later chunk\n"), exit(1), false));
             }
         }
-        if (!head_done) fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st);   // all N rows, libfalcon.cpp:2440
+        if (!head_done) { if (seq_stride) fq_mul_mat_q_acts_from3(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st); else fq_mul_mat_q_acts(m->lm_head, a_head, N, c->logits_dev, hp.n_vocab, store, st); }   // all N rows, libfalcon.cpp:2440
     }
 }
 

@@ -325,17 +325,27 @@ bool fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq
 }
 
 // Q4_K blocks at 5..16 columns, default order: the fused sum launches of the small-batch form. false: nothing launched, the caller runs the generic calls
-static bool q4k_fused_ok(int64_t N) {
+static bool q4k_fused_ok(int64_t N, int64_t min_cols = FQ_GEMV_MAX_COLS + 1) {
     static const bool on = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG") && !(getenv("FQ_SKINNY_Q4K_FUSED") && atoi(getenv("FQ_SKINNY_Q4K_FUSED")) == 0);
-    return on && !g_reference_order && !g_force_gemv && fq_gemm_split_for(16, N, fq_ctx().n_cu) != 1 && N > FQ_GEMV_MAX_COLS && N <= 16;
+    return on && !g_reference_order && !g_force_gemv && fq_gemm_split_for(16, N, fq_ctx().n_cu) != 1 && N >= min_cols && N <= 16;
 }
-bool fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_act & out, hipStream_t st) {
-    if (!q4k_fused_ok(N) || fq_desc(w.type).act_type != a.type || a.K != w.K) return false;
+bool fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_act & out, hipStream_t st, int min_cols) {
+    if (!q4k_fused_ok(N, min_cols) || fq_desc(w.type).act_type != a.type || a.K != w.K) return false;
     return fq_launch_gemm_skinny_q4k_gelu_q8k(w, a, N, dst, ldd, fq_ctx().gelu_table, out, st);
 }
-bool fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
-    if (!q4k_fused_ok(N) || a_att.K != wo.K || a_ff.K != down.K) return false;
+bool fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st, int min_cols) {
+    if (!q4k_fused_ok(N, min_cols) || a_att.K != wo.K || a_ff.K != down.K) return false;
     return fq_launch_gemm_skinny_q4k_out2(wo, a_att, down, a_ff, N, x, ldx, st);
+}
+
+// lock-step contexts of 3 and 4 sequences on the k-quant formats with a small-batch form at this shape: that form (a pass of 16 columns costs less than
+// the column mat-vec kernels' pass of 4 there: Falcon-40B Q2_K 8.2 against 18.5 ms, Q4_K 9.9 against 15.2); everything else: fq_mul_mat_q_acts
+void fq_mul_mat_q_acts_from3(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
+    if (N >= 3 && N <= FQ_GEMV_MAX_COLS && q4k_fused_ok(N, 3) && fq_skinny_q4k_shape(w) && fq_desc(w.type).act_type == a.type && a.K == w.K) {
+        fq_launch_gemm(w, a, N, dst, ldd, ep, fq_ctx().n_cu, st);
+        return;
+    }
+    fq_mul_mat_q_acts(w, a, N, dst, ldd, ep, st);
 }
 
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {

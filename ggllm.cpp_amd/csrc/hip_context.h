@@ -30,8 +30,10 @@ fq_act    fq_act_alloc(int act_type, int64_t K, int64_t max_cols, void ** slab_o
 void      fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd,
                             const fq_gemv_epi & ep, hipStream_t st);
 // Q4_K blocks at 5..16 columns (the small-batch form's fused sum launches); false: nothing launched, run the generic calls
-bool      fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_act & out, hipStream_t st);      // dst = gelu(w a) + its Q8_K image
-bool      fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st);   // x = (down + wo) + x
+// (min_cols: 5 = the mat-mul's own threshold; 3 for lock-step contexts, see fq_mul_mat_q_acts_from3)
+bool      fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_act & out, hipStream_t st, int min_cols = 5);      // dst = gelu(w a) + its Q8_K image
+bool      fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st, int min_cols = 5);   // x = (down + wo) + x
+void      fq_mul_mat_q_acts_from3(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st);
 bool      fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & a, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                                  float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st);
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);

@@ -50,22 +50,33 @@ def test_lock_step_sequences_equal_contexts_of_their_own(oracle, hp, t, B):
     m.free()
 
 
-def test_lock_step_at_falcon40b_width(oracle):
-    """one 40B-shaped block (n_embd 8192, n_ff 32768, GQA 128/8, two norms, Q4_K): the output launch takes two columns at a time
-    (four would not fit its LDS) -- still one context's bits per sequence"""
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q2_K])
+def test_lock_step_at_falcon40b_width(oracle, t):
+    """one 40B-shaped block (n_embd 8192, n_ff 32768, GQA 128/8, two norms; Q4_K, Q2_K): a context of 2 sequences runs the column mat-vec kernels
+    (the output launch two columns at a time: four would not fit its LDS) -- one context's bits per sequence; contexts of 3 and more run the k-quant
+    small-batch forms (a pass of 16 columns costs less than the column kernels' pass of 4 at this width): a row of those mat-muls does not depend
+    on the other rows, so a 4-sequence context gives the bits of the first 4 sequences of an 8-sequence one, within the association spread of the
+    single contexts"""
     hp = dict(n_vocab=512, n_embd=8192, n_head=128, n_head_kv=8, n_layer=1, n_ff=32768, two_norms=True)
-    w = synth.make_model(oracle, hp, ob.Q4_K, seed=10)
-    m = g.FalconModel(w, n_ctx=16, n_batch=4)
-    B = 4
+    w = synth.make_model_fast(hp, t, seed=10)
+    m = g.FalconModel(w, n_ctx=16, n_batch=8)
+    B = 8
     streams = [synth.tokens(5, hp["n_vocab"], seed=70 + b) for b in range(B)]
     singles = [np.stack([m.eval(streams[b][i:i + 1], i)[0] for i in range(5)]) for b in range(B)]
-    sc = g.SeqContext(m, 16, B)
-    for i in range(5):
-        lg = sc.eval([int(streams[b][i]) for b in range(B)], i)
-        for b in range(B):
-            assert np.array_equal(lg[b], singles[b][i]), (b, i)
-    sc.free()
+    out = {}
+    for nb in (2, 4, 8):
+        sc = g.SeqContext(m, 16, nb)
+        out[nb] = [sc.eval([int(streams[b][i]) for b in range(nb)], i) for i in range(5)]
+        sc.free()
     m.free()
+    for i in range(5):
+        for b in range(2):
+            assert np.array_equal(out[2][i][b], singles[b][i]), (b, i)
+        for b in range(4):
+            assert np.array_equal(out[4][i][b], out[8][i][b]), (b, i)
+        for b in range(8):
+            ref = singles[b][i].astype(np.float64)
+            assert float(np.abs(out[8][i][b] - ref).max() / (np.sqrt((ref ** 2).mean()) + 1e-30)) <= 5e-2, (b, i)
 
 
 def _greedy_reference(w, hp, first, rounds):
