@@ -1060,20 +1060,33 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q4k(fq_weight w, f
 // instructions on the hi / lo bytes of the Q8_K block sums (bsum = 64 hi + lo), k slots 0..15 carried by the lanes kq < 2.
 // Per stage (4 super-blocks) and row: 16 quant pieces | 4 of scales | 1 of d, dmin = 21 slots, as in the Q4_K form.
 constexpr int K2_SEG = 16;
-constexpr int K2_ROWP = 21, K2_ROWB = 16 * K2_ROWP, K2_WSTAGE = 16 * K2_ROWB, K2_KOPS = (16 * K2_ROWP + 63) / 64;
+// Q3_K (ggml_vec_dot_q3_K_q8_K, k_quants.c:1310-1746) is the same kernel with the plane of high bits (32 bytes per super-block, bit g of byte l = element
+// l of group g; clear = subtract 4) and sixteen 6-bit scales - 32: the quant q_lo - 4 hbar times the scale s in [-32, 31] reaches 128, one past int8, so
+// a group is TWO matrix instructions -- the table look-up of q_lo s in [-96, 93] and hbar (4 s) in [-128, 124], whose result is subtracted -- and no mins.
+template <int TYPE> struct k2_fmt {
+    static constexpr bool Q3 = TYPE == FQ_Q3_K;
+    static constexpr int ROWP = Q3 ? 29 : 21, ROWB = 16 * ROWP, WSTAGE = 16 * ROWB, KOPS = (16 * ROWP + 63) / 64;
+    static constexpr int HMOFF = 256, SOFF = Q3 ? 384 : 256, DOFF = Q3 ? 432 : 320;      // LDS offsets inside a row's stage: quants | (high bits) | scales | d (, dmin)
+    static constexpr int COLB = Q3 ? 1760 : 1344;                          // bytes of a full column (16 super-blocks) of the device layout
+    static constexpr int PRE_HM = 64, PRE_SC = Q3 ? 96 : 64, PRE_D = Q3 ? 108 : 80, SCB = Q3 ? 12 : 16, DB = Q3 ? 2 : 4;
+};
 struct k2_plan { int tqs; size_t rings, cols, dy, bs, total; };
-static __host__ __device__ inline k2_plan k2_lds(int seg_sb, int T, int nbw) {
+template <int TYPE> static __host__ __device__ inline k2_plan k2_lds(int seg_sb, int T, int nbw) {
+    constexpr int K2_WSTAGE = k2_fmt<TYPE>::WSTAGE;
     k2_plan p;
     const int qb = seg_sb * 256;
     p.tqs = qb + ((16 - (qb & 255)) & 255);
-    p.rings = (size_t) nbw * T * K2_WSTAGE; p.cols = (size_t) SK_TN * p.tqs; p.dy = (size_t) seg_sb * SK_TN * 4; p.bs = (size_t) seg_sb * SK_TN * 32;
+    p.rings = (size_t) nbw * T * K2_WSTAGE; p.cols = (size_t) SK_TN * p.tqs; p.dy = (size_t) seg_sb * SK_TN * 4; p.bs = k2_fmt<TYPE>::Q3 ? 0 : (size_t) seg_sb * SK_TN * 32;
     p.total = p.rings + p.cols + p.dy + p.bs + 32;                          // (+ 32 zero bytes: the mins' operands of the lanes that carry none)
     return p;
 }
 
-template <int NBW>
+template <int TYPE, int NBW>
 __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, fq_act act, int N, float * part, int64_t mstride, int T, int nrb, int nslots, int seg_sb, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef k2_fmt<TYPE> F;
+    constexpr bool Q3 = F::Q3;
+    constexpr int K2_ROWP = F::ROWP, K2_ROWB = F::ROWB, K2_WSTAGE = F::WSTAGE, K2_KOPS = F::KOPS;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t K = w.K, M = w.M;
     const int nsb = (int) w.nblk;
@@ -1081,7 +1094,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
     if (slot >= nrb) return;
     const int sb0 = seg * seg_sb, nsbs = nsb - sb0 < seg_sb ? nsb - sb0 : seg_sb;
     const size_t img = fq_act_col_bytes(FQ_Q8_K, K);
-    const k2_plan P = k2_lds(seg_sb, T, NBW);
+    const k2_plan P = k2_lds<TYPE>(seg_sb, T, NBW);
     const int TQS = P.tqs;
     uint8_t * cols = smem + P.rings;                                       // [16 columns][TQS]: the segment's quants as they are
     float   * dyT  = (float *)(cols + P.cols);                             // [super-block][16]: the columns' d
@@ -1093,9 +1106,11 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
 #pragma unroll
     for (int k = 0; k < K2_KOPS; ++k) {
         const int L = 64 * k + lane, row = (L / K2_ROWP) & 15, p = L % K2_ROWP;
-        if (p < 16)      { poff[k] = (unsigned)(16 * p); pkind[k] = 0; }
-        else if (p < 20) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 1; }
-        else             { poff[k] = 0u; pkind[k] = 2; }
+        constexpr int NHM = Q3 ? 8 : 0, NSC = Q3 ? 3 : 4;                   // pieces of high bits (4 x 32 B), of scales (4 x 12 / 16 B)
+        if (p < 16)                  { poff[k] = (unsigned)(16 * p); pkind[k] = 0; }
+        else if (p < 16 + NHM)       { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 3; }
+        else if (p < 16 + NHM + NSC) { poff[k] = (unsigned)(16 * (p - 16 - NHM)); pkind[k] = 1; }
+        else                         { poff[k] = (unsigned)(16 * (p - 16 - NHM - NSC)); pkind[k] = 2; }
         rowb[k] = (unsigned) row * (unsigned) w.row_stride;
     }
     const unsigned rs16 = (unsigned) w.row_stride - 16u;
@@ -1109,13 +1124,14 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
         const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
         const int gsb = sb0 + 4 * sp, c = gsb >> 4, in = gsb & 15;
         const int nbc = nsb - 16 * c < 16 ? nsb - 16 * c : 16;
-        const unsigned b0 = (unsigned)(c * 1344 + in * 64);
-        const unsigned b1 = (unsigned)(c * 1344 + nbc * 64 + in * 16);
-        const unsigned b2 = (unsigned)(c * 1344 + nbc * 80 + in * 4);      // (in is a multiple of 4: 16-byte aligned)
+        const unsigned b0 = (unsigned)(c * F::COLB + in * 64);
+        const unsigned bh = (unsigned)(c * F::COLB + nbc * F::PRE_HM + in * 32);
+        const unsigned b1 = (unsigned)(c * F::COLB + nbc * F::PRE_SC + in * F::SCB);
+        const unsigned b2 = (unsigned)(c * F::COLB + ((nbc * F::PRE_D + in * F::DB) & ~15));      // (Q2_K: aligned as it is; Q3_K: read from the boundary below)
         const unsigned dst = ring_lds + (unsigned)((u % NBW) * K2_WSTAGE);
 #pragma unroll
         for (int k = 0; k < K2_KOPS; ++k) {
-            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : b2));
+            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : (pkind[k] == 2 ? b2 : bh)));
             o = o < rs16 ? o : rs16;
             if (64 * k + lane < 16 * K2_ROWP) sk_dma(wbase, rowb[k] + o, dst + (unsigned)(k * 1024));
         }
@@ -1139,6 +1155,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
             const int sbl = e >> 4, tok = e & 15;
             const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img;
             dyT[e] = ((const float *)(tp + K))[sb0 + sbl];
+            if constexpr (Q3) continue;
             const uint32_t * bs = (const uint32_t *)(tp + aux) + (size_t)(sb0 + sbl) * 8;
             uint32_t hi[4] = { 0u, 0u, 0u, 0u }, lo[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
@@ -1176,22 +1193,35 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
             if (dbg & 16) continue;
             const uint8_t * wr = myring + (size_t)(u % NBW) * K2_WSTAGE + l16 * K2_ROWB;
             const int ns = nsbs - 4 * sp < 4 ? nsbs - 4 * sp : 4;
+            const int gsb_ = sb0 + 4 * sp, cc_ = gsb_ >> 4, nbc_ = nsb - 16 * cc_ < 16 ? nsb - 16 * cc_ : 16;
+            const int p3d = (nbc_ * F::PRE_D + (gsb_ & 15) * F::DB) & 15;      // d (, dmin): offset from the boundary the DMA started at (Q2_K: 0)
             const uint8_t * tqp = cols + (size_t) l16 * TQS + (size_t)(4 * sp) * 256 + 8 * kq;
             const uint8_t * dyp = (const uint8_t *) dyT + (size_t)(4 * sp) * 64 + 16 * kq;
             const uint8_t * bsp = mlane ? bsT + (size_t)(4 * sp) * 512 + 32 * l16 + 8 * kq : bsT + P.bs;
             const int bstep = mlane ? 512 : 0;
-            struct k2_ops { sk_v2i xa[8], raw[2], bh, bl; uint4 sc; uint32_t dm; float4 dy; };
+            struct k2_ops { sk_v2i xa[8], raw[2], bh, bl, hm; uint4 sc; uint32_t dm; float4 dy; };
             auto load_ops = [&](int i) __attribute__((always_inline)) {
                 k2_ops o;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) o.xa[g] = *(const sk_v2i *)(tqp + 256 * i + 32 * g);
                 o.raw[0] = *(const sk_v2i *)(wr + 64 * i + 8 * kq);
                 o.raw[1] = *(const sk_v2i *)(wr + 64 * i + 32 + 8 * kq);
-                o.sc = *(const uint4 *)(wr + 256 + 16 * i);
-                o.dm = *(const uint32_t *)(wr + 320 + 4 * i);
+                if constexpr (Q3) {
+                    const uint32_t s0 = *(const uint32_t *)(wr + F::SOFF + 12 * i), s1 = *(const uint32_t *)(wr + F::SOFF + 4 + 12 * i), s2 = *(const uint32_t *)(wr + F::SOFF + 8 + 12 * i);
+                    // the sixteen 6-bit scales (still + 32) as bytes of four words (k_quants.c:491-496)
+                    o.sc = make_uint4((s0 & 0x0F0F0F0Fu) | ((s2 & 0x03030303u) << 4), (s1 & 0x0F0F0F0Fu) | (((s2 >> 2) & 0x03030303u) << 4),
+                                      ((s0 >> 4) & 0x0F0F0F0Fu) | (((s2 >> 4) & 0x03030303u) << 4), ((s1 >> 4) & 0x0F0F0F0Fu) | (((s2 >> 6) & 0x03030303u) << 4));
+                    o.dm = *(const uint16_t *)(wr + F::DOFF + p3d + 2 * i);
+                    o.hm = *(const sk_v2i *)(wr + F::HMOFF + 32 * i + 8 * kq);
+                    o.bh = sk_v2i{ 0, 0 }; o.bl = sk_v2i{ 0, 0 };
+                } else {
+                    o.sc = *(const uint4 *)(wr + F::SOFF + 16 * i);
+                    o.dm = *(const uint32_t *)(wr + F::DOFF + 4 * i);
+                    o.bh = *(const sk_v2i *)(bsp + bstep * i);
+                    o.bl = *(const sk_v2i *)(bsp + bstep * i + 16);
+                    o.hm = sk_v2i{ 0, 0 };
+                }
                 o.dy = *(const float4 *)(dyp + 64 * i);
-                o.bh = *(const sk_v2i *)(bsp + bstep * i);
-                o.bl = *(const sk_v2i *)(bsp + bstep * i + 16);
                 return o;
             };
             struct k2_c { sk_v4i c[6]; };
@@ -1202,17 +1232,29 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
                 const uint32_t S[4] = { o.sc.x >> (8 * s01), o.sc.y >> (8 * s01), o.sc.z >> (8 * s01), o.sc.w >> (8 * s01) };
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    sk_v4i c = z;
+                    sk_v4i c = z, c2 = z;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const uint32_t sc = (S[2 * h + (t >> 1)] >> (16 * (t & 1))) & 15u;
-                        const uint32_t lut = __umul24(sc, 0x030201u) << 8;                 // bytes {0, sc, 2 sc, 3 sc}
                         const uint32_t qx = ((uint32_t) o.raw[h].x >> (2 * t)) & 0x03030303u, qy = ((uint32_t) o.raw[h].y >> (2 * t)) & 0x03030303u;
+                        uint32_t lut;
+                        if constexpr (Q3) {
+                            const int sv = (int)((S[2 * h + (t >> 1)] >> (16 * (t & 1))) & 63u) - 32;            // the lane's sub-block scale
+                            lut = (((uint32_t) sv & 0xFFu) << 8) | (((uint32_t)(2 * sv) & 0xFFu) << 16) | (((uint32_t)(3 * sv) & 0xFFu) << 24);   // bytes {0, s, 2 s, 3 s} (int8)
+                            // elements whose high bit is clear: - 4 s each = minus the product with the byte 4 s in [-128, 124]
+                            const uint32_t nx = (~(uint32_t) o.hm.x >> (4 * h + t)) & 0x01010101u, ny = (~(uint32_t) o.hm.y >> (4 * h + t)) & 0x01010101u;
+                            const uint32_t s4 = __builtin_amdgcn_perm(0u, (uint32_t)(4 * sv) & 0xFFu, 0u);                  // the byte 4 s in every byte
+                            const sk_v2i b2 = { (int)(((nx << 8) - nx) & s4), (int)(((ny << 8) - ny) & s4) };
+                            c2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[4 * h + t]), __builtin_bit_cast(long, b2), c2, 0, 0, 0);
+                        } else {
+                            const uint32_t sc = (S[2 * h + (t >> 1)] >> (16 * (t & 1))) & 15u;
+                            lut = __umul24(sc, 0x030201u) << 8;                            // bytes {0, sc, 2 sc, 3 sc}
+                        }
                         const sk_v2i b = { (int) __builtin_amdgcn_perm(0u, lut, qx), (int) __builtin_amdgcn_perm(0u, lut, qy) };
                         c = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[4 * h + t]), __builtin_bit_cast(long, b), c, 0, 0, 0);
                     }
-                    r.c[t] = c;
+                    if constexpr (Q3) r.c[t] = sk_v4i{ c[0] - c2[0], c[1] - c2[1], c[2] - c2[2], c[3] - c2[3] }; else r.c[t] = c;
                 }
+                if constexpr (Q3) { r.c[4] = z; r.c[5] = z; return r; }
                 // the mins (high nibbles of the 16 scale bytes), sub-blocks 8 kq .. 8 kq + 7 in the lanes kq < 2
                 const uint32_t m0 = kq == 0 ? o.sc.x : o.sc.z, m1 = kq == 0 ? o.sc.y : o.sc.w;
                 const sk_v2i mn = { mlane ? (int)((m0 >> 4) & 0x0F0F0F0Fu) : 0, mlane ? (int)((m1 >> 4) & 0x0F0F0F0Fu) : 0 };
@@ -1221,15 +1263,15 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
                 return r;
             };
             auto scale = [&](const k2_c & cc, const k2_ops & o) __attribute__((always_inline)) {
-                const float d = fq_h2f((uint16_t) o.dm), dmin = fq_h2f((uint16_t)(o.dm >> 16));
+                const float d = fq_h2f((uint16_t) o.dm), dmin = Q3 ? 0.0f : fq_h2f((uint16_t)(o.dm >> 16));
                 const float dyv[4] = { o.dy.x, o.dy.y, o.dy.z, o.dy.w };
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dd = dyv[r] * d, dmn = dyv[r] * dmin;              // k_quants.c:1282-1283: dall = y.d * d, dmin = y.d * dmin
+                    const float dd = Q3 ? d * dyv[r] : dyv[r] * d, dmn = dyv[r] * dmin;    // k_quants.c:1282-1283: dall = y.d * d, dmin = y.d * dmin (Q3_K: d = y.d * fp16(x.d), k_quants.c:1737)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         float a = dd * (float) cc.c[t][r];
-                        if (t == 3) a = a - dmn * (float)((cc.c[4][r] << 6) + cc.c[5][r]);
+                        if (!Q3 && t == 3) a = a - dmn * (float)((cc.c[4][r] << 6) + cc.c[5][r]);
                         acc[t][r] = acc[t][r] + a;
                     }
                 }
@@ -1363,13 +1405,15 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
 // Q4_K / Q5_K / Q2_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
 bool fq_skinny_q4k_shape(const fq_weight & w) {
     static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
-    const int seg = w.type == FQ_Q2_K ? K2_SEG : KQ_SEG;
+    const int seg = (w.type == FQ_Q2_K || w.type == FQ_Q3_K) ? K2_SEG : KQ_SEG;
     const int64_t nseg = (w.nblk + seg - 1) / seg, mstride = (w.M + 63) & ~(int64_t) 63;
-    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
+    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
            w.row_stride * 16 < ((size_t) 1 << 31);
 }
 static bool q2k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
-    if (!fq_skinny_q4k_shape(w) || w.type != FQ_Q2_K || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
+    if (!fq_skinny_q4k_shape(w) || (w.type != FQ_Q2_K && w.type != FQ_Q3_K) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
+    const bool q3 = w.type == FQ_Q3_K;
+    auto lds_of = [&](int sg, int t, int n) { return q3 ? k2_lds<FQ_Q3_K>(sg, t, n).total : k2_lds<FQ_Q2_K>(sg, t, n).total; };
     const int n_cu = fq_ctx().n_cu;
     const int ntiles = (int)(w.M / 16);
     const int nsb = (int) w.nblk;
@@ -1381,28 +1425,28 @@ static bool q2k_main(const fq_weight & w, const fq_act & act, int64_t N, float *
     if (T > KS_TMAX) T = KS_TMAX;
     int nbw = 0;
     for (;;) {
-        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (k2_lds(seg_sb, T, n).total <= 160 * 1024) { nbw = n; break; } }
+        for (int n : { 3, 2 }) { if (env_nbw && n != env_nbw) continue; if (q3 && n == 3) continue; if (lds_of(seg_sb, T, n) <= 160 * 1024) { nbw = n; break; } }   // (Q3_K: 8 DMA instructions per stage)
         if (nbw || T == 1) break;
         --T;
     }
     if (!nbw) return false;
-    const size_t need = k2_lds(seg_sb, T, nbw).total;
+    const size_t need = lds_of(seg_sb, T, nbw);
     const int nrb = (ntiles + T - 1) / T;
     // more (row block, segment) pairs than CUs: persistent workgroups in full rounds, unless the last round would be nearly empty
     int nslots = nrb;
     if (nrb * nseg > n_cu) { const int cap = n_cu / nseg > 0 ? n_cu / nseg : 1; if (nrb % cap == 0 || nrb > 2 * cap) nslots = cap; }
     mstride = (w.M + 63) & ~(int64_t) 63;
-#define FQ_K2_LAUNCH(NB) { \
+#define FQ_K2_LAUNCH(TT, NB) { \
         static bool set = false; \
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q2k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((k_gemm_skinny_q2k<NB>), dim3((unsigned) nslots, (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
-    if (nbw == 3) FQ_K2_LAUNCH(3) else FQ_K2_LAUNCH(2)
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q2k<TT, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_q2k<TT, NB>), dim3((unsigned) nslots, (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get()); }
+    if (q3) FQ_K2_LAUNCH(FQ_Q3_K, 2) else if (nbw == 3) FQ_K2_LAUNCH(FQ_Q2_K, 3) else FQ_K2_LAUNCH(FQ_Q2_K, 2)
 #undef FQ_K2_LAUNCH
     return true;
 }
 // the main launch: partial sums of w x act into scratch region `part` ([segment][share][16][mstride]); false: not this form's shape
 static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
-    if (w.type == FQ_Q2_K) return q2k_main(w, act, N, part, mstride, nseg, st);
+    if (w.type == FQ_Q2_K || w.type == FQ_Q3_K) return q2k_main(w, act, N, part, mstride, nseg, st);
     if (!fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int n_cu = fq_ctx().n_cu;
     const int ntiles = (int)(w.M / 16);
@@ -1456,7 +1500,7 @@ bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act,
 bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
     if (wo.M != down.M || !fq_skinny_q4k_shape(wo) || !fq_skinny_q4k_shape(down) || a_att.type != FQ_Q8_K || a_ff.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int64_t ms = (down.M + 63) & ~(int64_t) 63;
-    const int sgd = down.type == FQ_Q2_K ? K2_SEG : KQ_SEG, sgw = wo.type == FQ_Q2_K ? K2_SEG : KQ_SEG;
+    const int sgd = (down.type == FQ_Q2_K || down.type == FQ_Q3_K) ? K2_SEG : KQ_SEG, sgw = (wo.type == FQ_Q2_K || wo.type == FQ_Q3_K) ? K2_SEG : KQ_SEG;
     const int64_t nsd = (down.nblk + sgd - 1) / sgd, nsw = (wo.nblk + sgw - 1) / sgw;
     if ((nsd + nsw) * 4 * SK_TN * ms > (int64_t) FQ_KS_FLOATS) return false;
     float * part_d = fq_ctx().ks_scratch, * part_w = part_d + (size_t) nsd * 4 * SK_TN * ms;
@@ -1470,7 +1514,7 @@ bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
-    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
+    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
     {
