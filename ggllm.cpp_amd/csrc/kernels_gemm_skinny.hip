@@ -17,7 +17,8 @@
 //   association the S waves of a tile split K exactly like k_gemm_q (group g -> partial sum g mod S, partial sums added as
 //               ((P0 + P1) + P2) + P3; S chosen by the same rule): results are bit-identical to kernels_gemm.hip's, and the
 //               oracle's split orders (orc_set_sum_order 2 / 3 / 4 / 5) apply unchanged.
-// Scope: the legacy formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0); k-quants keep kernels_gemm.hip.
+// Scope of these three: the legacy formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0). The k-quants have their own forms further down (k_gemm_skinny_q4k: Q4_K / Q5_K;
+// k_gemm_skinny_q2k: Q2_K / Q3_K; k_gemm_skinny_q6k), for matrices at model widths (fq_skinny_q4k_shape).
 //
 // Three forms, picked by fq_launch_gemm_skinny (all bit-identical to each other and to k_gemm_q):
 //   k_gemm_skinny_res   the columns RESIDENT in LDS, one persistent workgroup per CU, optionally two matrices per launch -- rows up to ~4.6 k long
@@ -1303,6 +1304,197 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q2k(fq_weight w, f
     }
 }
 
+// =============================================================================================== Q6_K: all four K shares per wave, two half operands per group
+// ggml_vec_dot_q6_K_q8_K (k_quants.c:2406-2789) in the frame of k_gemm_skinny_q2k (a wave = a 16-row tile with four accumulator chains, the full 16
+// columns of a 16-super-block segment resident, the same segmented four-sum order). Q6_K's 6-bit quants - 32 are int8 operands as they are, but its
+// sub-block scales are int8 too and cannot go into the operand: a group is two matrix instructions -- the lanes kq < 2 carry the group's first 16
+// elements, kq >= 2 the second, each launch with the other half zeroed -- and the scales are applied by v_mad_i32_i24 per result. 210 bytes per
+// super-block: a stage is TWO super-blocks (16 pieces of low nibbles | 8 of high bits | 2 of scales | 3 of d, read from the boundary below = 29 slots).
+constexpr int K6_ROWP = 29, K6_ROWB = 16 * K6_ROWP, K6_WSTAGE = 16 * K6_ROWB, K6_KOPS = (16 * K6_ROWP + 63) / 64;
+static __host__ __device__ inline k2_plan k6_lds(int seg_sb, int T, int nbw) {
+    k2_plan p;
+    const int qb = seg_sb * 256;
+    p.tqs = qb + ((16 - (qb & 255)) & 255);
+    p.rings = (size_t) nbw * T * K6_WSTAGE; p.cols = (size_t) SK_TN * p.tqs; p.dy = (size_t) seg_sb * SK_TN * 4; p.bs = 0;
+    p.total = p.rings + p.cols + p.dy;
+    return p;
+}
+
+template <int NBW>
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_q6k(fq_weight w, fq_act act, int N, float * part, int64_t mstride, int T, int nrb, int nslots, int seg_sb, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t K = w.K, M = w.M;
+    const int nsb = (int) w.nblk;
+    const int slot = (int) blockIdx.x, seg = (int) blockIdx.y;
+    if (slot >= nrb) return;
+    const int sb0 = seg * seg_sb, nsbs = nsb - sb0 < seg_sb ? nsb - sb0 : seg_sb;
+    const size_t img = fq_act_col_bytes(FQ_Q8_K, K);
+    const k2_plan P = k6_lds(seg_sb, T, NBW);
+    const int TQS = P.tqs;
+    uint8_t * cols = smem + P.rings;
+    float   * dyT  = (float *)(cols + P.cols);
+    const int l16 = lane & 15, kq = lane >> 4;
+    int nmine = 0;
+    for (int rb = slot; rb < nrb; rb += nslots) if (((int64_t) rb * T + wid) * 16 < M) ++nmine;
+    unsigned poff[K6_KOPS], rowb[K6_KOPS]; int pkind[K6_KOPS];
+#pragma unroll
+    for (int k = 0; k < K6_KOPS; ++k) {
+        const int L = 64 * k + lane, row = (L / K6_ROWP) & 15, p = L % K6_ROWP;
+        if (p < 16)      { poff[k] = (unsigned)(16 * p); pkind[k] = 0; }
+        else if (p < 24) { poff[k] = (unsigned)(16 * (p - 16)); pkind[k] = 3; }
+        else if (p < 26) { poff[k] = (unsigned)(16 * (p - 24)); pkind[k] = 1; }
+        else             { poff[k] = (unsigned)(16 * (p - 26)); pkind[k] = 2; }
+        rowb[k] = (unsigned) row * (unsigned) w.row_stride;
+    }
+    const unsigned rs16 = (unsigned) w.row_stride - 16u;
+    uint8_t * myring = smem + (size_t) wid * NBW * K6_WSTAGE;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(sk_lds(myring));
+    const int nst = (nsbs + 1) / 2;                                        // stages of two super-blocks
+    const int total = nmine * nst;
+    auto issue = [&](int u) {
+        const int rbi = u / nst, sp = u - rbi * nst;
+        const int64_t mt = ((int64_t)(slot + rbi * nslots) * T + wid) * 16;
+        const uint8_t * wbase = sk_uniform(w.plane[0] + (size_t) mt * w.row_stride);
+        const int gsb = sb0 + 2 * sp, c = gsb >> 3, in = gsb & 7;             // a column of the device layout = 8 super-blocks
+        const int nbc = nsb - 8 * c < 8 ? nsb - 8 * c : 8;
+        const unsigned b0 = (unsigned)(c * 1680 + in * 128);
+        const unsigned bh = (unsigned)(c * 1680 + nbc * 128 + in * 64);
+        const unsigned b1 = (unsigned)(c * 1680 + nbc * 192 + in * 16);
+        const unsigned b2 = (unsigned)(c * 1680 + ((nbc * 208 + in * 2) & ~15));
+        const unsigned dst = ring_lds + (unsigned)((u % NBW) * K6_WSTAGE);
+#pragma unroll
+        for (int k = 0; k < K6_KOPS; ++k) {
+            unsigned o = poff[k] + (pkind[k] == 0 ? b0 : (pkind[k] == 1 ? b1 : (pkind[k] == 2 ? b2 : bh)));
+            o = o < rs16 ? o : rs16;
+            if (64 * k + lane < 16 * K6_ROWP) sk_dma(wbase, rowb[k] + o, dst + (unsigned)(k * 1024));
+        }
+    };
+    if (!(dbg & 8)) { for (int u = 0; u < NBW - 1 && u < total; ++u) issue(u); }
+    {
+        const unsigned last = (unsigned)(K - 16);
+        const int NW = (int)(blockDim.x >> 6);
+        for (int t = wid; t < SK_TN; t += NW) {
+            const uint8_t * base = sk_uniform(act.base + (size_t)(t < N ? t : N - 1) * img);
+            const unsigned tb = sk_lds(cols) + (unsigned)(t * TQS);
+            for (int j0 = 0; j0 < nsbs; j0 += 4) {
+                unsigned vq = (unsigned)((sb0 + j0) * 256 + 16 * lane);
+                vq = vq < last ? vq : last;
+                if (j0 + (lane >> 4) < nsbs && !(dbg & 4)) sk_dma(base, vq, tb + (unsigned)(j0 * 256));
+            }
+        }
+        for (int e = tid; e < nsbs * SK_TN; e += (int) blockDim.x) {
+            const int sbl = e >> 4, tok = e & 15;
+            const uint8_t * tp = act.base + (size_t)(tok < N ? tok : N - 1) * img;
+            dyT[e] = ((const float *)(tp + K))[sb0 + sbl];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                                       // the only barrier: the columns are in LDS
+
+    float * pbase = part + ((size_t)(4 * seg) * SK_TN) * (size_t) mstride;
+    const size_t sstride = (size_t) SK_TN * (size_t) mstride;
+    const uint32_t ma = kq < 2 ? 0xFFFFFFFFu : 0u;                         // the lane's elements are the group's first / second 16
+    int u = 0;
+    for (int rbi = 0; rbi < nmine; ++rbi) {
+        const int64_t m = ((int64_t)(slot + rbi * nslots) * T + wid) * 16 + l16;
+        float acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t][0] = 0.0f; acc[t][1] = 0.0f; acc[t][2] = 0.0f; acc[t][3] = 0.0f; }
+        for (int sp = 0; sp < nst; ++sp, ++u) {
+            if (u + NBW - 1 < total && !(dbg & 8)) issue(u + NBW - 1);
+            {
+                const int later = (dbg & 8) ? 0 : (total - 1 - u < NBW - 1 ? total - 1 - u : NBW - 1);
+                if (later >= 1) sk_wait_vm_upto(K6_KOPS); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (NBW = 2: one stage ahead)
+            }
+            if (dbg & 16) continue;
+            const uint8_t * wr = myring + (size_t)(u % NBW) * K6_WSTAGE + l16 * K6_ROWB;
+            const int ns = nsbs - 2 * sp < 2 ? nsbs - 2 * sp : 2;
+            const int gsb_ = sb0 + 2 * sp, cc_ = gsb_ >> 3, nbc_ = nsb - 8 * cc_ < 8 ? nsb - 8 * cc_ : 8;
+            const int p3d = (nbc_ * 208 + (gsb_ & 7) * 2) & 15;
+            const uint8_t * tqp = cols + (size_t) l16 * TQS + (size_t)(2 * sp) * 256 + 8 * kq;
+            const uint8_t * dyp = (const uint8_t *) dyT + (size_t)(2 * sp) * 64 + 16 * kq;
+            struct k6_ops { sk_v2i xa[8], ql[4], qh[2]; uint4 sc; uint32_t dm; float4 dy; };
+            auto load_ops = [&](int i) __attribute__((always_inline)) {
+                k6_ops o;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) o.xa[g] = *(const sk_v2i *)(tqp + 256 * i + 32 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.ql[j] = *(const sk_v2i *)(wr + 128 * i + 32 * j + 8 * kq);      // j = 2 h + (t & 1): bytes 64 h + 32 (t & 1) + l
+                o.qh[0] = *(const sk_v2i *)(wr + 256 + 64 * i + 8 * kq);
+                o.qh[1] = *(const sk_v2i *)(wr + 256 + 64 * i + 32 + 8 * kq);
+                o.sc = *(const uint4 *)(wr + 384 + 16 * i);
+                o.dm = *(const uint16_t *)(wr + 416 + p3d + 2 * i);
+                o.dy = *(const float4 *)(dyp + 64 * i);
+                return o;
+            };
+            struct k6_c { sk_v4i c[4]; };
+            auto run_mfma = [&](const k6_ops & o) __attribute__((always_inline)) {
+                k6_c r;
+                const sk_v4i z = { 0, 0, 0, 0 };
+                const uint32_t S[4] = { o.sc.x, o.sc.y, o.sc.z, o.sc.w };
+                sk_v4i ia[8], ib[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const sk_v2i lo = o.ql[2 * h + (t & 1)], hi = o.qh[h];
+                        // (low nibble | 2 high bits << 4) - 32 per byte (k_quants.c:2759-2766): int8 as it is
+                        uint32_t vx = (((uint32_t) lo.x >> (4 * (t >> 1))) & 0x0F0F0F0Fu) | ((((uint32_t) hi.x >> (2 * t)) & 0x03030303u) << 4);
+                        uint32_t vy = (((uint32_t) lo.y >> (4 * (t >> 1))) & 0x0F0F0F0Fu) | ((((uint32_t) hi.y >> (2 * t)) & 0x03030303u) << 4);
+                        vx = ((vx | 0x80808080u) - 0x20202020u) ^ 0x80808080u; vy = ((vy | 0x80808080u) - 0x20202020u) ^ 0x80808080u;
+                        const sk_v2i ba = { (int)(vx & ma), (int)(vy & ma) }, bb = { (int)(vx & ~ma), (int)(vy & ~ma) };
+                        ia[4 * h + t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[4 * h + t]), __builtin_bit_cast(long, ba), z, 0, 0, 0);
+                        ib[4 * h + t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, o.xa[4 * h + t]), __builtin_bit_cast(long, bb), z, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    sk_v4i c = z;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t sw = S[2 * h + (t >> 1)] >> (16 * (t & 1));            // int8 scales of sub-blocks 8 h + 2 t, + 1
+                        const int sa = (int)(int8_t)(sw & 0xFFu), sb = (int)(int8_t)((sw >> 8) & 0xFFu);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c[q] = __mul24(ib[4 * h + t][q], sb) + (__mul24(ia[4 * h + t][q], sa) + c[q]);
+                    }
+                    r.c[t] = c;
+                }
+                return r;
+            };
+            auto scale = [&](const k6_c & cc, const k6_ops & o) __attribute__((always_inline)) {
+                const float d = fq_h2f((uint16_t) o.dm);
+                const float dyv[4] = { o.dy.x, o.dy.y, o.dy.z, o.dy.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dd = d * dyv[r];                                    // k_quants.c:2779 (d = x.d * y.d)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][r] = acc[t][r] + dd * (float) cc.c[t][r];
+                }
+            };
+            if (ns == 2) {
+                const k6_ops o0 = load_ops(0), o1 = load_ops(1);
+                const k6_c c0 = run_mfma(o0);
+                __builtin_amdgcn_sched_barrier(0);
+                const k6_c c1 = run_mfma(o1);
+                __builtin_amdgcn_sched_barrier(0);
+                scale(c0, o0);
+                scale(c1, o1);
+            } else {
+                for (int i = 0; i < ns; ++i) { const k6_ops o = load_ops(i); const k6_c c1 = run_mfma(o); scale(c1, o); }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 4 * kq + r;
+            if (n < N) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pbase[(size_t) t * sstride + (size_t) n * mstride + m] = acc[t][r];
+            }
+        }
+    }
+}
+
 // part: [segment][share][16][mstride]; dst = the segments' ((P0 + P1) + P2) + P3 added left to right, then the epilogue
 __global__ void k_skinny_sum4(const float * __restrict__ part, int N, int64_t M, float * __restrict__ dst, int64_t ldd, fq_gemv_epi ep, int64_t mstride, int nseg) {
     const int64_t m = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1405,10 +1597,33 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
 // Q4_K / Q5_K / Q2_K, 5..16 columns (fq_skinny_q4k_shape: the shapes it takes; the oracle's mode 2 follows the same rule)
 bool fq_skinny_q4k_shape(const fq_weight & w) {
     static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
-    const int seg = (w.type == FQ_Q2_K || w.type == FQ_Q3_K) ? K2_SEG : KQ_SEG;
+    const int seg = (w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) ? K2_SEG : KQ_SEG;
     const int64_t nseg = (w.nblk + seg - 1) / seg, mstride = (w.M + 63) & ~(int64_t) 63;
-    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
+    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
            w.row_stride * 16 < ((size_t) 1 << 31);
+}
+static bool q6k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
+    if (!fq_skinny_q4k_shape(w) || w.type != FQ_Q6_K || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
+    const int n_cu = fq_ctx().n_cu;
+    const int ntiles = (int)(w.M / 16);
+    const int nsb = (int) w.nblk;
+    static const int env_t = getenv("FQ_KQ_T") ? atoi(getenv("FQ_KQ_T")) : 0;
+    nseg = (nsb + K2_SEG - 1) / K2_SEG;
+    const int seg_sb = nseg > 1 ? K2_SEG : ((nsb + 3) & ~3);
+    int T = env_t > 0 ? env_t : (ntiles * nseg + n_cu - 1) / n_cu;
+    if (T < 1) T = 1;
+    if (T > KS_TMAX) T = KS_TMAX;
+    while (T > 1 && k6_lds(seg_sb, T, 2).total > 160 * 1024) --T;
+    if (k6_lds(seg_sb, T, 2).total > 160 * 1024) return false;
+    const size_t need = k6_lds(seg_sb, T, 2).total;
+    const int nrb = (ntiles + T - 1) / T;
+    int nslots = nrb;
+    if (nrb * nseg > n_cu) { const int cap = n_cu / nseg > 0 ? n_cu / nseg : 1; if (nrb % cap == 0 || nrb > 2 * cap) nslots = cap; }
+    mstride = (w.M + 63) & ~(int64_t) 63;
+    static bool set = false;
+    if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_q6k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL((k_gemm_skinny_q6k<2>), dim3((unsigned) nslots, (unsigned) nseg), dim3(64 * T), need, st, w, act, (int) N, part, mstride, T, nrb, nslots, seg_sb, fq_gemm_debug_get());
+    return true;
 }
 static bool q2k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
     if (!fq_skinny_q4k_shape(w) || (w.type != FQ_Q2_K && w.type != FQ_Q3_K) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
@@ -1447,6 +1662,7 @@ static bool q2k_main(const fq_weight & w, const fq_act & act, int64_t N, float *
 // the main launch: partial sums of w x act into scratch region `part` ([segment][share][16][mstride]); false: not this form's shape
 static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
     if (w.type == FQ_Q2_K || w.type == FQ_Q3_K) return q2k_main(w, act, N, part, mstride, nseg, st);
+    if (w.type == FQ_Q6_K) return q6k_main(w, act, N, part, mstride, nseg, st);
     if (!fq_skinny_q4k_shape(w) || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int n_cu = fq_ctx().n_cu;
     const int ntiles = (int)(w.M / 16);
@@ -1500,7 +1716,7 @@ bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act,
 bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
     if (wo.M != down.M || !fq_skinny_q4k_shape(wo) || !fq_skinny_q4k_shape(down) || a_att.type != FQ_Q8_K || a_ff.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int64_t ms = (down.M + 63) & ~(int64_t) 63;
-    const int sgd = (down.type == FQ_Q2_K || down.type == FQ_Q3_K) ? K2_SEG : KQ_SEG, sgw = (wo.type == FQ_Q2_K || wo.type == FQ_Q3_K) ? K2_SEG : KQ_SEG;
+    const int sgd = (down.type == FQ_Q4_K || down.type == FQ_Q5_K) ? KQ_SEG : K2_SEG, sgw = (wo.type == FQ_Q4_K || wo.type == FQ_Q5_K) ? KQ_SEG : K2_SEG;
     const int64_t nsd = (down.nblk + sgd - 1) / sgd, nsw = (wo.nblk + sgw - 1) / sgw;
     if ((nsd + nsw) * 4 * SK_TN * ms > (int64_t) FQ_KS_FLOATS) return false;
     float * part_d = fq_ctx().ks_scratch, * part_w = part_d + (size_t) nsd * 4 * SK_TN * ms;
@@ -1514,7 +1730,7 @@ bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
-    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
+    if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) return fq_launch_gemm_skinny_q4k(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;
     // the columns resident in LDS, one persistent workgroup per CU, when they fit (K up to ~4.6 k for Q4_0; FQ_SKINNY_RES=0: never)
     {

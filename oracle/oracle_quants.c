@@ -648,8 +648,8 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
         g_kseg = 0;
         if ((wtype == ORC_Q4_K || wtype == ORC_Q5_K) && Nb > 4 && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
             ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; }
-        /* Q2_K and Q3_K likewise (k_gemm_skinny_q2k): segments of 16 super-blocks */
-        if ((wtype == ORC_Q2_K || wtype == ORC_Q3_K) && Nb > 4 && Nb <= 112 && M % 16 == 0 && K / 256 >= 8 &&
+        /* Q2_K, Q3_K (k_gemm_skinny_q2k) and Q6_K (k_gemm_skinny_q6k, up to 80 columns) likewise: segments of 16 super-blocks */
+        if ((wtype == ORC_Q2_K || wtype == ORC_Q3_K || (wtype == ORC_Q6_K && Nb <= 80)) && Nb > 4 && Nb <= 112 && M % 16 == 0 && K / 256 >= 8 &&
             ((K / 256 + 15) / 16) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 16; }
     }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);

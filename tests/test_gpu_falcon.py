@@ -263,7 +263,7 @@ def test_falcon40b_shaped_layer_vs_oracle(oracle):
     print("40B-shaped block: association spread %.2e" % _both_orders(oracle, w, synth.tokens(3, 512, seed=4), 2, 16))
 
 
-@pytest.mark.parametrize("t,n_pre", [(ob.Q4_K, 6), (ob.Q4_K, 16), (ob.Q4_K, 21), (ob.Q5_K, 9), (ob.Q2_K, 11), (ob.Q3_K, 7)])
+@pytest.mark.parametrize("t,n_pre", [(ob.Q4_K, 6), (ob.Q4_K, 16), (ob.Q4_K, 21), (ob.Q5_K, 9), (ob.Q2_K, 11), (ob.Q3_K, 7), (ob.Q6_K, 13)])
 def test_falcon40b_shaped_layer_small_batch_vs_oracle(oracle, t, n_pre):
     """the 40B-shaped Q4_K block with prompts of 6, 16 and 21 tokens: every mat-mul through the share-pair small-batch form (k_gemm_skinny_q4k;
     21 = two passes), Wup's sum launch applying GELU and writing Wdown's Q8_K image, Wo and Wdown (four K segments) sharing one sum launch with

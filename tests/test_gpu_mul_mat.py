@@ -148,10 +148,10 @@ def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
 
 @pytest.mark.parametrize("K,M,N", [(2048, 64, 7), (2560, 48, 16), (8192, 144, 5), (10240, 32, 13), (16384, 16, 16), (8192, 144, 29), (4096, 64, 77), (4096, 32, 100), (2048, 20480, 6),
                                    (10240, 20480, 5)])
-@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K, ob.Q2_K, ob.Q3_K])
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K, ob.Q2_K, ob.Q3_K, ob.Q6_K])
 def test_q4k_small_batch_vs_oracle(oracle, t, K, M, N):
-    """Q4_K and Q5_K (the same kernel plus the plane of fifth bits) and Q2_K / Q3_K (k_gemm_skinny_q2k: all four shares per wave, the sub-block scales
-    folded into the matrix operand, segments of 16 super-blocks), 5..16 columns (17..80: passes) at model widths: the share-pair streaming form (k_gemm_skinny_q4k + k_skinny_sum4) -- four
+    """Q4_K and Q5_K (the same kernel plus the plane of fifth bits) Q2_K / Q3_K (k_gemm_skinny_q2k: all four shares per wave, the sub-block scales
+    folded into the matrix operand, segments of 16 super-blocks) and Q6_K (k_gemm_skinny_q6k: the same frame, two half operands per group), 5..16 columns (17..80: passes) at model widths: the share-pair streaming form (k_gemm_skinny_q4k + k_skinny_sum4) -- four
     interleaved partial sums per segment of 32 super-blocks whatever the shape, the segments added left to right == orc_set_sum_order(2), which
     follows the same rule (== order 3 for rows of one segment). Shapes: one device column, a partial last column (10 super-blocks), one full segment,
     two segments (40 super-blocks), two full segments on one tile, two passes, more row blocks than workgroup slots, and the latter with two segments."""
@@ -175,7 +175,7 @@ def test_q4k_small_batch_vs_oracle(oracle, t, K, M, N):
         exp_seq = oracle.mul_mat(t, w, K, M, x, 8)
     finally:
         oracle.lib.orc_set_sum_order(0)
-    if K <= (4096 if t in (ob.Q2_K, ob.Q3_K) else 8192):
+    if K <= (8192 if t in (ob.Q4_K, ob.Q5_K) else 4096):
         assert np.array_equal(exp_split, exp4)      # one segment: exactly the tile GEMM's four-sum order
     assert np.array_equal(got, exp_split)
     assert np.array_equal(seq, exp_seq)

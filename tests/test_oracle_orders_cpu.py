@@ -60,14 +60,14 @@ def test_orders_exact_on_integer_terms(oracle, t):
         assert np.array_equal(got, ref), order
 
 
-@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K, ob.Q2_K, ob.Q3_K])
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q5_K, ob.Q2_K, ob.Q3_K, ob.Q6_K])
 def test_backend_mode_segments_for_q4k_small_batches(oracle, t):
     """mode 2 for Q4_K / Q5_K at model widths and 5..80 columns = the backend's small-batch form (k_gemm_skinny_q4k): four interleaved partial
     sums per segment of 32 super-blocks, the segments' values added left to right -- i.e. the order-3 results of the two K halves of a 64-super-block
     row, added; one segment (K = 8192) is order 3 itself (Q2_K / Q3_K: segments of 16, K = 4096); 4 columns and 113 columns keep the other rules (unit
     order / the tile GEMM's split)"""
     rng = np.random.default_rng(7 + t)
-    K, M = (8192, 32) if t in (ob.Q2_K, ob.Q3_K) else (16384, 32)        # two segments: 32 super-blocks each (Q2_K: 16)
+    K, M = (16384, 32) if t in (ob.Q4_K, ob.Q5_K) else (8192, 32)        # two segments: 32 super-blocks each (Q2_K: 16)
     w = synth.random_blocks(t, M, K, rng)
     x = rng.standard_normal((113, K)).astype(np.float32)
     half, rb = K // 2, w.shape[1] // 2
