@@ -77,7 +77,10 @@ falcon_hip_context * falcon_hip_context_create(falcon_hip_model * m, int n_ctx, 
 void                 falcon_hip_context_free(falcon_hip_context * c);
 /* A context of n_seq (1..256) independent sequences that advance in LOCK STEP: every falcon_hip_eval_stage / falcon_hip_stage_step
  * evaluates n_seq rows = one token of each sequence, all at position n_past, row t attending to its own KV cache. One pass
- * over the weights serves n_seq tokens (n_seq <= 4: the same mat-vec, the same bits per sequence as a context of its own).
+ * over the weights serves n_seq tokens. n_seq <= 4 (k-quant models at model widths: <= 2): the column mat-vec kernels, the same
+ * bits per sequence as a context of its own; more: the small-batch mat-muls (5..16 columns per pass, larger contexts in
+ * passes of 16 or through the tile GEMM) -- a sequence's logits then equal a context of its own within the association
+ * spread of the f32 sums (a row of those mat-muls does not depend on the other rows).
  * token_dev / next_token_dev of falcon_hip_stage_step then hold n_seq ids, the hidden rows are [n_seq][n_embd].          */
 falcon_hip_context * falcon_hip_context_create_seqs(falcon_hip_model * m, int n_ctx, int n_seq, int rope_n_ctx);
 int                  falcon_hip_context_n_seq(const falcon_hip_context * c);
