@@ -497,14 +497,14 @@ extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long
 // n_past_dev. max_n_kv bounds n_past + N for LDS sizing.
 // lock-step contexts of up to this many sequences run the column mat-vec kernels in chunks of 4 (FALCON_HIP_COLS_MAX_N overrides): 4 for the
 // legacy formats, whose streaming small-batch mat-mul serves 5..16 columns in less time than two chunks (Falcon-7B Q4_0: 2.9 ms per pass
-// against 3.6 at 8 sequences), 12 for the k-quants, which have only the tile GEMM beyond (8-9 ms per pass whatever the width) -- except Q4_K, below
+// against 3.6 at 8 sequences), 12 for k-quant models whose matrices are not at model widths (they have only the tile GEMM beyond)
 static int fq_cols_max_n(int wtype) {
     static const int v = getenv("FALCON_HIP_COLS_MAX_N") ? atoi(getenv("FALCON_HIP_COLS_MAX_N")) : 0;
     if (v > 0) return v;
     return (wtype == FQ_Q4_0 || wtype == FQ_Q4_1 || wtype == FQ_Q5_0 || wtype == FQ_Q5_1 || wtype == FQ_Q8_0) ? 4 : 12;
 }
-// (Q4_K at model widths has its own streaming form for 5..16 columns: kernels_gemm_skinny.hip, k_gemm_skinny_q4k)
-// -- from 3 sequences up: a pass of 16 columns costs less there than the column kernels' pass of 4; contexts of 2 keep them and their bit-identity with a single stream
+// k-quant models at model widths (fq_skinny_q4k_shape) have their own streaming forms (kernels_gemm_skinny_k.hip) and use them from 3 sequences up: a
+// pass of 16 columns costs less there than the column kernels' pass of 4; contexts of 2 keep the column kernels and their bit-identity with a single stream
 #define FQ_COLS_MAX_N (m->layers.empty() ? 4 : (fq_skinny_q4k_shape(m->layers[0].qkv) && !getenv("FALCON_HIP_COLS_MAX_N") ? 2 : fq_cols_max_n(m->layers[0].qkv.type)))
 static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_t st) {
     falcon_hip_model * m = c->m;
