@@ -90,3 +90,21 @@ def test_backend_mode_segments_for_q4k_small_batches(oracle, t):
     assert np.array_equal(four_cols, unit)
     assert np.array_equal(many, whole3)              # 113 columns: the tile GEMM's four sums over the whole row (M = 32: few tiles)
     assert not np.array_equal(seg, whole3[:5])
+
+
+def test_backend_mode_pass_limits_per_format(oracle):
+    """the small-batch forms take up to 80 columns (Q4_K / Q5_K / Q6_K) or 112 (Q2_K / Q3_K: kernels.h fq_skinny_kq_max_cols); beyond, mode 2 is the
+    tile GEMM's split over the whole row again"""
+    K, M, N = 8192, 32, 100
+    for t, segmented in ((ob.Q2_K, True), (ob.Q3_K, True), (ob.Q6_K, False), (ob.Q4_K, False)):
+        rng = np.random.default_rng(11 + t)
+        w = synth.random_blocks(t, M, K, rng)
+        x = rng.standard_normal((N, K)).astype(np.float32)
+        try:
+            oracle.lib.orc_set_sum_order(2)
+            got = oracle.mul_mat(t, w, K, M, x, 2)
+            oracle.lib.orc_set_sum_order(3)
+            whole = oracle.mul_mat(t, w, K, M, x, 2)
+        finally:
+            oracle.lib.orc_set_sum_order(0)
+        assert np.array_equal(got, whole) != segmented, ob.TYPE_NAME[t]
