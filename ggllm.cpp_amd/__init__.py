@@ -25,21 +25,21 @@ TYPE_NAME = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0
              Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
 VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}
 
-EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
+EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_split_comm_create_loopback ggml_hip_split_comm_rccl_ranks ggml_hip_mul_mat_q_split_loopback ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
 ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
 ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_quantize_rows ggml_hip_weight_quantize ggml_hip_fp16_to_fp32_row ggml_hip_acts_alloc ggml_hip_acts_free
 ggml_hip_quantize_acts ggml_hip_acts_export ggml_hip_mul_mat_q ggml_hip_mul_mat_q_acts ggml_hip_layer_norm ggml_hip_gelu
 ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attention""".split()
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
-falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_set_rope_n_ctx
+falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_last_error falcon_hip_context_set_rope_n_ctx
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
 falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
 falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_rccl_ranks falcon_hip_pipeline_set_tokens
-falcon_hip_pipeline_run falcon_hip_pipeline_run_local falcon_hip_pipeline_get_history falcon_hip_pipeline_schedule""".split()
+falcon_hip_pipeline_run falcon_hip_pipeline_run_local falcon_hip_pipeline_local_attach_rccl falcon_hip_pipeline_get_history falcon_hip_pipeline_schedule""".split()
 
 
 def build(verbose=False):
@@ -82,6 +82,8 @@ def load():
         "ggml_hip_split_comm_create": (vp, [C.c_int, C.c_int, vp]), "ggml_hip_split_configure": (C.c_int, [C.c_int, C.c_int, vp]), "ggml_hip_split_comm_free": (None, [vp]), "ggml_hip_split_comm_agree": (C.c_int, [vp, vp, C.c_size_t]),
         "ggml_hip_mul_mat_q_split": (C.c_int, [vp, vp, vp, i64, i64, vp, i64, vp, vp]),
         "ggml_hip_mul_mat_q_split_local": (C.c_int, [vp, C.c_int, vp, i64, i64, vp, i64, vp, vp]),
+        "ggml_hip_split_comm_create_loopback": (vp, [C.c_int]), "ggml_hip_split_comm_rccl_ranks": (C.c_int, [vp]),
+        "ggml_hip_mul_mat_q_split_loopback": (C.c_int, [vp, vp, vp, i64, i64, vp, i64, vp, vp]),
         "ggml_hip_quantize_rows": (C.c_int, [C.c_int, vp, i64, i64, vp, vp]), "ggml_hip_weight_quantize": (vp, [C.c_int, vp, i64, i64]),
         "ggml_hip_fp16_to_fp32_row": (None, [vp, vp, i64]),
         "ggml_hip_acts_alloc": (vp, [C.c_int, i64, i64]), "ggml_hip_acts_free": (None, [vp]),
@@ -100,14 +102,14 @@ def load():
         "falcon_hip_pipeline_unique_id": (C.c_int, [vp]), "falcon_hip_pipeline_create": (vp, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]), "falcon_hip_pipeline_rccl_ranks": (C.c_int, [vp]),
         "falcon_hip_pipeline_set_tokens": (C.c_int, [vp, vp]), "falcon_hip_pipeline_run": (C.c_int, [vp, C.c_int, C.c_int]),
-        "falcon_hip_pipeline_run_local": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "falcon_hip_pipeline_run_local": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_local_attach_rccl": (C.c_int, [vp, C.c_int]),
         "falcon_hip_pipeline_get_history": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "falcon_hip_pipeline_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_context_create": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_free": (None, [vp]),
         "falcon_hip_eval": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "falcon_hip_eval_stage": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_decode_greedy": (C.c_int, [vp, i32, C.c_int, C.c_int, vp]),
-        "falcon_hip_eval_token": (C.c_int, [vp, i32, C.c_int]), "falcon_hip_context_set_rope_n_ctx": (None, [vp, C.c_int]),
+        "falcon_hip_eval_token": (C.c_int, [vp, i32, C.c_int]), "falcon_hip_context_last_error": (C.c_int, [vp]), "falcon_hip_context_set_rope_n_ctx": (None, [vp, C.c_int]),
         "falcon_hip_stage_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
         "falcon_hip_get_logits": (C.POINTER(C.c_float), [vp]),
         "falcon_hip_context_keep_hidden": (None, [vp, C.c_int]), "falcon_hip_get_hidden": (None, [vp, vp]),
@@ -483,6 +485,16 @@ class Pipeline:
         arr = (C.c_void_p * len(ranks))(*[r.p for r in ranks])
         if load().falcon_hip_pipeline_run_local(arr, len(ranks), rounds, n_past0) != 0:
             raise RuntimeError("falcon_hip_pipeline_run_local failed")
+
+    @staticmethod
+    def attach_rccl(ranks):
+        """the local job's hand-offs through a one-rank RCCL communicator (self send / recv) instead of device copies"""
+        arr = (C.c_void_p * len(ranks))(*[r.p for r in ranks])
+        if load().falcon_hip_pipeline_local_attach_rccl(arr, len(ranks)) != 0:
+            raise RuntimeError("falcon_hip_pipeline_local_attach_rccl failed (RCCL missing or refused)")
+
+    def rccl_ranks(self):
+        return load().falcon_hip_pipeline_rccl_ranks(self.p)
 
     def history(self, first_round, n_rounds):
         """[n_rounds][n_groups * batch] sampled tokens (last rank; waits for the device); None on other ranks"""

@@ -66,7 +66,10 @@ struct falcon_hip_context {
     bool keep_hidden = false;
     int  hidden_tokens = 0;
     std::vector<float> logits_host;
-    bool logits_pending = false;               // falcon_hip_eval_token: the row is still on the device (copied by falcon_hip_get_logits)
+    float * logits_pinned = nullptr;           // one row of page-locked host memory: falcon_hip_eval_token's copy is enqueued behind the graph replay
+    const float * logits_last = nullptr;       // what falcon_hip_get_logits returns: logits_host.data() or logits_pinned
+    bool logits_pending = false;               // falcon_hip_eval_token: the row's copy is in flight (falcon_hip_get_logits waits for it)
+    bool sync_err_sticky = false;              // an in-launch hand-off timed out in an asynchronous step: every later eval of this context fails (3)
     hipGraphExec_t token_graph = nullptr;      // falcon_hip_eval_token's captured step
     int token_sig = -1;
     std::vector<void *> allocs;
@@ -119,8 +122,9 @@ struct falcon_hip_context {
 static void fetch_sync_error(falcon_hip_context * c, hipStream_t st) {
     HIP_CHECK(hipMemcpyAsync(&c->sync_err_host, c->sync_words + 1, 4, hipMemcpyDeviceToHost, st));
 }
-static int report_sync_error(const falcon_hip_context * c, const char * where) {
+static int report_sync_error(falcon_hip_context * c, const char * where) {
     if (!c->sync_err_host) return 0;
+    c->sync_err_sticky = true;
     fprintf(stderr, "falcon-hip: %s: an in-launch hand-off timed out (sync word %u) -- the results of this call are invalid\n", where, c->sync_err_host);
     return 3;
 }
@@ -342,6 +346,7 @@ extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     for (hipEvent_t e : c->ev_attn) HIP_CHECK(hipEventDestroy(e));
     if (c->side) HIP_CHECK(hipStreamDestroy(c->side));
     for (void * p : c->allocs) HIP_CHECK(hipFree(p));
+    if (c->logits_pinned) HIP_CHECK(hipHostFree(c->logits_pinned));
     delete c;
 }
 
@@ -694,7 +699,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // process on the same resident Falcon-7B Q4_0 (scripts/gpu_par2_ab.py), one stream -> two branches: 16 tokens 8.66 -> 7.83
         // ms, 32: 9.17 -> 8.13, 128: 9.41 -> 8.82, 512: 26.75 -> 24.59, 1024: 49.3 -> 47.3, 2048: 104.9 -> 101.7.
         // (not where the mat-muls are passes of the Q4_K small-batch form: they fill the chip and share one partial-sum scratch)
-        const bool q4k_passes = N <= fq_skinny_kq_max_cols(L.qkv.type) && (fq_skinny_q4k_shape(L.qkv) || fq_skinny_q4k_shape(L.up) || fq_skinny_q4k_shape(L.wo) || fq_skinny_q4k_shape(L.down));
+        auto passes_of = [&](const fq_weight & w) { return N <= fq_skinny_kq_max_cols(w.type) && fq_skinny_q4k_shape(w); };      // per matrix: a block may mix k-quant formats with different column limits
+        const bool q4k_passes = passes_of(L.qkv) || passes_of(L.up) || passes_of(L.wo) || passes_of(L.down);
         const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
@@ -800,8 +806,10 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
             return 2;
         }
     }
+    if (c->sync_err_sticky) { fprintf(stderr, "falcon-hip: eval: an earlier step of this context lost an in-launch hand-off -- its KV cache is invalid, the context must be recreated\n"); return 3; }
     hipStream_t st = hc.stream;
     c->logits_pending = false;
+    c->logits_last = nullptr;
     HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
     if (m->first_stage()) HIP_CHECK(hipMemcpyAsync(c->tokens_dev, tokens, (size_t) N * 4, hipMemcpyHostToDevice, st));
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
@@ -850,36 +858,45 @@ extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, i
 }
 
 extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
-    if (c->logits_pending) {                                         // the last falcon_hip_eval_token left its row on the device
-        hipStream_t st = fq_ctx().stream;
-        const size_t V = (size_t) c->m->hp.n_vocab;
-        c->logits_host.resize(V);
-        HIP_CHECK(hipMemcpyAsync(c->logits_host.data(), c->logits_dev, V * 4, hipMemcpyDeviceToHost, st));
-        fetch_sync_error(c, st);
-        HIP_CHECK(hipStreamSynchronize(st));
+    if (c->logits_pending) {                                         // the last falcon_hip_eval_token's row copy (page-locked memory) is in flight behind its launches
+        HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
         c->logits_pending = false;
-        (void) report_sync_error(c, "eval");
+        (void) report_sync_error(c, "eval");                        // sticky: falcon_hip_context_last_error / the next eval report it (this call cannot)
     }
-    return c->logits_host.data();
+    return c->logits_last ? c->logits_last : c->logits_host.data();
 }
+// 0, or 3 when a step of this context lost an in-launch hand-off (every result since is invalid). Host state only: callers of
+// falcon_hip_get_logits, which cannot fail, ask here after it.
+extern "C" int falcon_hip_context_last_error(const falcon_hip_context * c) { return c->sync_err_sticky ? 3 : 0; }
 
 __global__ void k_set_i32(int * p, int v);
+__global__ void k_set2_i32(int * p, int v, int * q, int w);
+// the decode attention keeps a score row of max_n_kv floats in LDS; a captured step is sized for the whole context (its position is read
+// from device memory), so contexts longer than that buffer allows run their single-token steps as plain launches sized for n_past + 1
+static bool fused_graph_fits(const falcon_hip_context * c) { return fq_attn_decode_lds_bytes(c->n_ctx) <= 160 * 1024; }
 // One token at n_past (falcon_eval with n_tokens = 1, libfalcon.cpp:4566), asynchronous: the fused decode launches are replayed
-// from a hipGraph (captured on first use, position read from device memory), nothing is copied back and the host does not wait --
-// falcon_hip_get_logits fetches the row when, and only when, the caller asks for it. Returns 0, or 1 / 2 as falcon_hip_eval.
+// from a hipGraph (captured on first use, position read from device memory) and the logits row's copy into page-locked host memory is
+// enqueued right behind them; the host does not wait -- falcon_hip_get_logits does, when (and only when) the caller asks for the row.
+// Returns 0, 1 / 2 as falcon_hip_eval, or 3 once an earlier asynchronous step of this context has lost a hand-off.
 extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int n_past) {
     hip_context & hc = fq_ctx();
     falcon_hip_model * m = c->m;
     if (!m->first_stage() || !m->last_stage() || c->n_seq > 0) { fprintf(stderr, "falcon-hip: falcon_hip_eval_token needs the whole model in one process and a single sequence\n"); exit(1); }
+    if (c->sync_err_sticky) { fprintf(stderr, "falcon-hip: eval: an earlier step of this context lost an in-launch hand-off -- its KV cache is invalid, the context must be recreated\n"); return 3; }
     if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: eval of one token at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); return 1; }
     if (token < 0 || token >= m->hp.n_vocab) { fprintf(stderr, "falcon-hip: token id %d is outside [0, %d)\n", token, m->hp.n_vocab); return 2; }
     hipStream_t st = hc.stream;
+    if (c->logits_pending) {                                         // a row nobody asked for: its copy must land before the next one is enqueued into the same buffer
+        HIP_CHECK(hipStreamSynchronize(st));
+        c->logits_pending = false;
+        if (report_sync_error(c, "eval")) return 3;
+    }
     if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
-    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past);
-    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, (int *) c->tokens_dev, (int) token);
+    if (!c->logits_pinned) HIP_CHECK(hipHostMalloc((void **) &c->logits_pinned, (size_t) m->hp.n_vocab * 4, hipHostMallocDefault));
+    hipLaunchKernelGGL(k_set2_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past, (int *) c->tokens_dev, (int) token);
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
-    if (stage_fused(c) && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
+    if (stage_fused(c) && fused_graph_fits(c) && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
         if (!c->token_graph || c->token_sig != graph_signature(c)) {
             if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
             hipGraph_t g;
@@ -895,6 +912,9 @@ extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int 
         launch_stage(c, 1, n_past + 1, st);
     }
     c->keep_hidden = was_keep;
+    HIP_CHECK(hipMemcpyAsync(c->logits_pinned, c->logits_dev, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost, st));
+    fetch_sync_error(c, st);
+    c->logits_last = c->logits_pinned;
     c->logits_pending = true;
     return 0;
 }
@@ -990,6 +1010,7 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
 
 // ------------------------------------------------------------------------------------------------ pipeline step
 __global__ void k_set_i32(int * p, int v) { *p = v; }
+__global__ void k_set2_i32(int * p, int v, int * q, int w) { *p = v; *q = w; }
 __global__ void k_copy_i32(int32_t * dst, const int32_t * src, int n = 1) { for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i]; }
 // greedy sample of every row of a lock-step step: token[row] = argmax(logits[row]), lowest index on ties (as k_argmax_advance)
 __global__ void __launch_bounds__(1024) k_argmax_rows(const float * __restrict__ logits, int n, int32_t * __restrict__ token) {
@@ -1048,7 +1069,7 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
         }
         if (n_past_base < 0 && !advanced) hipLaunchKernelGGL(k_inc_i32, dim3(1), dim3(1), 0, st, c->n_past_dev);
     };
-    if (c->stage_graph && !fq_prof_active() && !fq_ctx().dbg_stamps) {
+    if (c->stage_graph && !fq_prof_active() && !fq_ctx().dbg_stamps && fused_graph_fits(c)) {
         // one hipGraph replay per step instead of ~70 launches from the host: a stage of a deep pipeline holds few blocks,
         // and the host side of a step would otherwise cost as much as its device side
         const bool same = c->step_graph && c->step_sig == graph_signature(c) && c->sg_in[0] == token_dev && c->sg_in[1] == hidden_in_dev && c->sg_out[0] == hidden_out_dev && c->sg_out[1] == next_token_dev;
@@ -1094,7 +1115,7 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
         else
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, s, c->logits_dev, (const int *) nullptr, m->hp.n_vocab, c->tokens_dev, c->n_past_dev, c->out_tokens_dev, n_past);
     };
-    if (c->use_graph) {
+    if (c->use_graph && fused_graph_fits(c)) {
         // the graph bakes n_past0 into k_argmax_advance's arguments: re-capture when the base position changes
         if (!c->decode_graph || c->graph_base != n_past || c->decode_sig != graph_signature(c)) {
             if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }

@@ -103,8 +103,9 @@ struct falcon_hip_pipeline {
     std::vector<float *>   mb_hidden; std::vector<int32_t *> mb_tok; // local transport: this rank's mailboxes, per group
     int32_t * hist = nullptr;                                       // last rank: [n_ctx][G * B] sampled tokens, by round
     int rounds_done = 0;
-    ncclComm_t comm = nullptr;                                      // world > 1 and not the local transport
+    ncclComm_t comm = nullptr;                                      // world > 1 and not the local transport (loop-back: rank 0 of the local job owns the one-rank communicator)
     bool local = false;
+    falcon_hip_pipeline * loop = nullptr;                           // local transport over RCCL's self send / recv: the rank that owns the communicator
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_compute[4] = {}, ev_comm[4] = {}, ev_start = nullptr;
     std::vector<void *> allocs;
@@ -217,8 +218,34 @@ falcon_hip_pipeline * falcon_hip_pipeline_create_local(falcon_hip_model * m, int
     return p;
 }
 
+// The local transport with every hand-off sent through RCCL instead of a device copy: ONE communicator of one rank (this process,
+// this GPU), every message an ncclSend addressed to rank 0 itself matched by an ncclRecv from rank 0, all sends and receives of a slot
+// inside one ncclGroupStart / ncclGroupEnd on the pipeline's second stream, ordered against the stage steps by the events of the
+// overlapped schedule. It runs the library's real RCCL binding (rccl_dyn.h: dlopen, ncclGetUniqueId, ncclCommInitRank, grouped
+// ncclSend / ncclRecv of f32 rows and i32 token ids, ncclCommCount, ncclCommDestroy) on a box with a single GPU, where a job of two
+// ranks is refused ("Duplicate GPU detected"). Returns 0, or -1 when RCCL is not available / refuses.
+int falcon_hip_pipeline_local_attach_rccl(falcon_hip_pipeline ** ranks, int world) {
+    if (world < 1 || !ranks || !ranks[0]) return -1;
+    for (int r = 0; r < world; ++r) if (!ranks[r] || !ranks[r]->local || ranks[r]->loop) return -1;
+    rccl_api * R = fq_rccl();
+    if (!R) return -1;
+    ncclUniqueId id;
+    ncclResult_t rc = R->ncclGetUniqueId(&id);
+    if (rc != ncclSuccess) { fprintf(stderr, "falcon-hip: pipeline: ncclGetUniqueId: %s\n", R->ncclGetErrorString(rc)); return -1; }
+    rc = R->ncclCommInitRank(&ranks[0]->comm, 1, id, 0);
+    if (rc != ncclSuccess) { fprintf(stderr, "falcon-hip: pipeline: ncclCommInitRank(rank 0 of 1): %s\n", R->ncclGetErrorString(rc)); ranks[0]->comm = nullptr; return -1; }
+    for (int r = 0; r < world; ++r) ranks[r]->loop = ranks[0];
+    return 0;
+}
+
 // ranks of the RCCL communicator the pipeline exchanges over (ncclCommCount): 1 for a one-rank pipeline, 0 for the local transport
+// (the loop-back transport: its one-rank communicator's count)
 int falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p) {
+    if (p && p->local && p->loop && p->loop->comm) {
+        int n = -1;
+        if (fq_rccl()->ncclCommCount(p->loop->comm, &n) != ncclSuccess) return -1;
+        return n;
+    }
     if (!p || p->local) return 0;
     if (!p->comm) return 1;
     int n = -1;
@@ -302,6 +329,53 @@ int falcon_hip_pipeline_run_local(falcon_hip_pipeline ** ranks, int world, int r
     hipStream_t st = fq_ctx().stream;
     const size_t nh = (size_t) B * ranks[0]->hp.n_embd * 4, nt = (size_t) B * 4;
     std::vector<pipe_slot> s((size_t) world);
+    falcon_hip_pipeline * lp = ranks[0]->loop;
+    if (lp) {
+        // loop-back over RCCL: a message's send and its receive fall into the same slot on both ends (slot_of), so the slot's whole traffic is
+        // one group on the second stream; message k of the group = send k and receive k, posted in the same order (RCCL matches them in order)
+        rccl_api * R = fq_rccl();
+        hipStream_t cs = lp->comm_stream;
+        HIP_CHECK(hipEventRecord(lp->ev_start, st));
+        HIP_CHECK(hipStreamWaitEvent(cs, lp->ev_start, 0));
+        for (int t = 0; t < T; ++t) {
+            for (int r = 0; r < world; ++r) s[(size_t) r] = slot_of(r, world, G, W, t);
+            if (t > 0) HIP_CHECK(hipStreamWaitEvent(cs, lp->ev_compute[(t - 1) & 3], 0));              // the results it sends
+            int n_msgs = 0;
+            for (int r = 0; r < world; ++r) for (int i = 0; i < s[(size_t) r].n_ops; ++i) n_msgs += s[(size_t) r].op[i].kind <= OP_SEND_TOKEN;
+            if (n_msgs) {
+                RCCL_CHECK(R->ncclGroupStart());
+                for (int r = 0; r < world; ++r) for (int i = 0; i < s[(size_t) r].n_ops; ++i) {
+                    const pipe_op & o = s[(size_t) r].op[i]; const size_t g = (size_t) o.group;
+                    if (o.kind == OP_SEND_HIDDEN) {
+                        RCCL_CHECK(R->ncclSend(ranks[r]->hidden_out[g], nh / 4, ncclFloat32, 0, lp->comm, cs));
+                        RCCL_CHECK(R->ncclRecv(ranks[o.peer]->hidden_in[g], nh / 4, ncclFloat32, 0, lp->comm, cs));
+                    } else if (o.kind == OP_SEND_TOKEN) {
+                        RCCL_CHECK(R->ncclSend(ranks[r]->tok_out[g], nt / 4, ncclInt32, 0, lp->comm, cs));
+                        RCCL_CHECK(R->ncclRecv(ranks[o.peer]->tok_in[g], nt / 4, ncclInt32, 0, lp->comm, cs));
+                    }
+                }
+                RCCL_CHECK(R->ncclGroupEnd());
+            }
+            HIP_CHECK(hipEventRecord(lp->ev_comm[t & 3], cs));
+            HIP_CHECK(hipStreamWaitEvent(st, lp->ev_comm[t & 3], 0));                                   // the inputs this slot's steps read
+            for (int r = 0; r < world; ++r) {
+                compute(ranks[r], s[(size_t) r], n_past0, st);
+                if (world == 1) {                                                                       // one stage: the sampled tokens are the next inputs, through RCCL too
+                    HIP_CHECK(hipEventRecord(lp->ev_start, st));
+                    HIP_CHECK(hipStreamWaitEvent(cs, lp->ev_start, 0));
+                    RCCL_CHECK(R->ncclGroupStart());
+                    RCCL_CHECK(R->ncclSend(ranks[0]->tok_out[(size_t) s[0].group], nt / 4, ncclInt32, 0, lp->comm, cs));
+                    RCCL_CHECK(R->ncclRecv(ranks[0]->tok_in[(size_t) s[0].group], nt / 4, ncclInt32, 0, lp->comm, cs));
+                    RCCL_CHECK(R->ncclGroupEnd());
+                }
+            }
+            HIP_CHECK(hipEventRecord(lp->ev_compute[t & 3], st));
+        }
+        HIP_CHECK(hipEventRecord(lp->ev_comm[T & 3], cs));
+        HIP_CHECK(hipStreamWaitEvent(st, lp->ev_comm[T & 3], 0));
+        for (int r = 0; r < world; ++r) ranks[r]->rounds_done += rounds;
+        return 0;
+    }
     for (int t = 0; t < T; ++t) {
         for (int r = 0; r < world; ++r) s[(size_t) r] = slot_of(r, world, G, W, t);
         for (int r = 0; r < world; ++r) for (int i = 0; i < s[(size_t) r].n_ops; ++i) {

@@ -4,6 +4,7 @@
 //
 //   -Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free
 //   -Wl,--wrap=llama_load_session_file,--wrap=llama_save_session_file,--wrap=falcon_copy_state_data,--wrap=falcon_set_state_data,--wrap=falcon_get_embeddings
+//   -Wl,--wrap=llama_apply_lora_from_file
 //   -L<repo>/ggllm.cpp_amd -lggml_hip
 //
 // The GNU linker then sends every call that falcon_main.cpp / falcon_perplexity.cpp / falcon_common.cpp make to these six
@@ -11,15 +12,21 @@
 // reference's own objects alive (tokenizer, samplers, sessions, timings structure: everything the CLIs touch besides the
 // evaluation still is the reference's code) and run the evaluation itself on the device:
 //
-//   falcon_init_from_file   the reference loads the file as usual but with n_gpu_layers = 0 (its per-op CUDA offload is
-//                           not used: nothing is uploaded twice), then falcon_hip_model_load_ggcc puts the same file's
-//                           weights into HBM and a falcon_hip_context gets the KV cache (libfalcon.cpp:1552-1959, 3755)
+//   falcon_init_from_file   n_gpu_layers > 0 (the CLIs' default is 200, examples/falcon_common.h:32): the reference loads the file as
+//                           usual but with n_gpu_layers = 0 (its per-op CUDA offload is not used: nothing is uploaded twice), then
+//                           falcon_hip_model_load_ggcc puts the same file's weights into HBM and a falcon_hip_context gets the KV
+//                           cache (libfalcon.cpp:1552-1959, 3755). ANY positive value keeps the whole model resident (288 GB of
+//                           HBM: the reference's partial offload, libfalcon.cpp:1813-1883, exists for cards the model does not fit).
+//                           n_gpu_layers == 0 (`-ngl 0`, BASELINE config 1's command) means what it means in the reference: no
+//                           device side at all, every call below falls through to the reference's own CPU path.
 //   falcon_context_prepare  a further context over the same model (falcon_main's system-prompt context, falcon_main.cpp:169)
 //   falcon_eval             falcon_hip_eval: the whole falcon_eval_internal graph (libfalcon.cpp:2011-2588) on the device
 //   falcon_get_logits       the logits falcon_hip_eval brought back (last row, or all rows with logits_all)
 //   falcon_print_timings    the reference's report (libfalcon.cpp:4700-4714) over this path's own clocks
 //   llama_free              releases the device side, then the reference's context
 //
+//   llama_apply_lora_from_file   would patch the reference's HOST tensors (libfalcon.h:187-191) while the device copy stays as loaded:
+//                           fails loudly (returns 1) for a context with a device side
 //   llama_load_session_file, llama_save_session_file, falcon_copy_state_data, falcon_set_state_data, falcon_get_embeddings
 //                           address the reference context's host KV cache / embedding buffer, which this path does not fill: for a
 //                           context with a device side they FAIL LOUDLY (false / 0 / NULL after a message) instead of silently
@@ -45,6 +52,7 @@ bool    __real_llama_save_session_file(struct falcon_context * ctx, const char *
 size_t  __real_falcon_copy_state_data(struct falcon_context * ctx, uint8_t * dst);
 size_t  __real_falcon_set_state_data(struct falcon_context * ctx, uint8_t * src);
 float * __real_falcon_get_embeddings(struct falcon_context * ctx);
+int     __real_llama_apply_lora_from_file(struct falcon_context * ctx, const char * path_lora, const char * path_base_model, int n_threads);
 void    __real_falcon_print_timings(struct falcon_context * ctx);
 void    __real_llama_free(struct falcon_context * ctx);
 }
@@ -85,6 +93,10 @@ extern "C" {
 
 struct falcon_context * __wrap_falcon_init_from_file(const char * path_model, struct falcon_context_params params) {
     if (disabled() || params.vocab_only) return __real_falcon_init_from_file(path_model, params);
+    if (params.n_gpu_layers <= 0) {                            // -ngl 0: the reference's own CPU path, as in the reference (libfalcon.cpp:1813-1826)
+        fprintf(stderr, "falcon-hip: n_gpu_layers = 0: %s stays on the host (the reference's ggml.c path); no device side\n", path_model);
+        return __real_falcon_init_from_file(path_model, params);
+    }
     falcon_context_params host = params;
     host.n_gpu_layers = 0;                                    // the reference keeps its mmap; the weights go to HBM once, below
     falcon_context * ctx = __real_falcon_init_from_file(path_model, host);
@@ -144,6 +156,12 @@ float * __wrap_falcon_get_logits(struct falcon_context * ctx) {
     if (it == g_ctx.end()) return __real_falcon_get_logits(ctx);
     const int64_t t0 = now_us();
     float * lg = const_cast<float *>(falcon_hip_get_logits(it->second.c));
+    if (falcon_hip_context_last_error(it->second.c)) {
+        // falcon_get_logits cannot report failure and the caller is about to sample from this row: errors of the device path are fatal,
+        // as in the reference's backend (CUDA_CHECK -> exit, ggml-cuda.cu:22-51)
+        fprintf(stderr, "falcon-hip: falcon_get_logits: the step that produced these logits lost an in-launch hand-off -- aborting instead of sampling from invalid logits\n");
+        exit(3);
+    }
     if (it->second.pending_one) { it->second.t_eval_us += now_us() - t0; it->second.pending_one = false; }     // (the step's device time ends here)
     return lg;
 }
@@ -165,9 +183,13 @@ void __wrap_falcon_print_timings(struct falcon_context * ctx) {
 static bool has_device_side(falcon_context * ctx, const char * what) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ctx.find(ctx) == g_ctx.end()) return false;
-    fprintf(stderr, "falcon-hip: %s is not supported for a context evaluated on the device (its KV cache and embeddings are not in the reference's host buffers); "
+    fprintf(stderr, "falcon-hip: %s is not supported for a context evaluated on the device (its weights, KV cache and embeddings are not in the reference's host buffers); "
                     "run with FALCON_HIP_WRAP=0 to use it\n", what);
     return true;
+}
+int __wrap_llama_apply_lora_from_file(struct falcon_context * ctx, const char * path_lora, const char * path_base_model, int n_threads) {
+    if (has_device_side(ctx, "llama_apply_lora_from_file")) return 1;      // (non-zero = failure, libfalcon.h:186)
+    return __real_llama_apply_lora_from_file(ctx, path_lora, path_base_model, n_threads);
 }
 bool __wrap_llama_load_session_file(struct falcon_context * ctx, const char * path_session, falcon_token * tokens_out, size_t n_token_capacity, size_t * n_token_count_out) {
     if (has_device_side(ctx, "llama_load_session_file")) { if (n_token_count_out) *n_token_count_out = 0; return false; }

@@ -109,6 +109,7 @@ struct fq_gemv_out_args {
     long long *     dbg;           // optional phase stamps (wall_clock64), 8 per workgroup
 };
 size_t fq_gemv_ln_lds(int type, int64_t E);
+size_t fq_attn_decode_lds_bytes(int max_n_kv);          // LDS of one decode-attention head group whose score row holds max_n_kv keys (<= 160 KiB to launch)
 void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st);       // fills seg[].block_begin
 void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
 // attention + output mat-vec in one launch (k_attn_out); returns false (nothing launched) when the grid would not be

@@ -421,6 +421,8 @@ __global__ void __launch_bounds__(256) k_attn_decode(fq_attn_decode_args a) {
 }
 
 
+size_t fq_attn_decode_lds_bytes(int max_n_kv) { return attn_decode_lds(max_n_kv); }
+
 void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                            float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st) {
     const size_t lds = attn_decode_lds(max_n_kv);

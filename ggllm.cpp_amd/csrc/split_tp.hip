@@ -18,6 +18,8 @@
 
 struct ggml_hip_split_comm {
     int rank = 0, world = 1;
+    int virtual_world = 0;                                     // > 0: a loop-back communicator (one RCCL rank standing for this many ranks)
+    float * tmp = nullptr; size_t tmp_bytes = 0;              // loop-back: the parts' results before they travel
     ncclComm_t comm = nullptr;
     float * stage = nullptr; size_t stage_bytes = 0;          // packed rows: [own part | one slot per peer]
 };
@@ -68,11 +70,30 @@ ggml_hip_split_comm * ggml_hip_split_comm_create(int rank, int world, const void
     }
     return c;
 }
+ggml_hip_split_comm * ggml_hip_split_comm_create_loopback(int virtual_world) {
+    if (virtual_world < 1) return nullptr;
+    rccl_api * R = fq_rccl();
+    if (!R) { fprintf(stderr, "ggml-hip: split: RCCL is not available\n"); return nullptr; }
+    ggml_hip_split_comm * c = new ggml_hip_split_comm();
+    c->rank = 0; c->world = 1; c->virtual_world = virtual_world;
+    ncclUniqueId id;
+    ncclResult_t rc = R->ncclGetUniqueId(&id);
+    if (rc == ncclSuccess) rc = R->ncclCommInitRank(&c->comm, 1, id, 0);
+    if (rc != ncclSuccess) { fprintf(stderr, "ggml-hip: split: one-rank communicator: %s\n", R->ncclGetErrorString(rc)); delete c; return nullptr; }
+    return c;
+}
+int ggml_hip_split_comm_rccl_ranks(ggml_hip_split_comm * c) {
+    if (!c || !c->comm) return 0;
+    int n = -1;
+    if (fq_rccl()->ncclCommCount(c->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
 void ggml_hip_split_comm_free(ggml_hip_split_comm * c) {
     if (!c) return;
     HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
     if (c->comm) fq_rccl()->ncclCommDestroy(c->comm);
     if (c->stage) HIP_CHECK(hipFree(c->stage));
+    if (c->tmp) HIP_CHECK(hipFree(c->tmp));
     delete c;
 }
 
@@ -128,6 +149,51 @@ int ggml_hip_mul_mat_q_split(ggml_hip_split_comm * c, const ggml_hip_weight * w_
         const int64_t prow = row_high[p] - row_low[p];
         if (p == c->rank || prow <= 0) continue;
         HIP_CHECK(hipMemcpy2DAsync(dst_dev + row_low[p], (size_t) M * 4, (uint8_t *) c->stage + slot * (size_t) p, (size_t) prow * 4, (size_t) prow * 4, (size_t) N, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// every rank's part in THIS process on one device, the exchange run for real over a one-rank RCCL communicator: part r's rows go into
+// a private result matrix, are packed like ggml_hip_mul_mat_q_split packs them, travel as a grouped ncclSend / ncclRecv addressed to
+// rank 0 itself, and are unpacked into dst (which nothing else writes)
+int ggml_hip_mul_mat_q_split_loopback(ggml_hip_split_comm * c, ggml_hip_weight * const * parts, const float * x_dev, int64_t K, int64_t N,
+                                      float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high) {
+    if (!c || !c->comm || c->virtual_world < 1) return 1;
+    const int W = c->virtual_world;
+    hipStream_t st = fq_ctx().stream;
+    rccl_api * R = fq_rccl();
+    int64_t max_rows = 0;
+    for (int r = 0; r < W; ++r) if (row_high[r] - row_low[r] > max_rows) max_rows = row_high[r] - row_low[r];
+    const size_t slot = (size_t) N * (size_t) max_rows * 4, need = 2 * slot * (size_t) W, full = (size_t) N * (size_t) M * 4;
+    if (need > c->stage_bytes) {
+        if (c->stage) HIP_CHECK(hipFree(c->stage));
+        HIP_CHECK(hipMalloc((void **) &c->stage, need ? need : 16)); c->stage_bytes = need;
+    }
+    if (full > c->tmp_bytes) {
+        if (c->tmp) HIP_CHECK(hipFree(c->tmp));
+        HIP_CHECK(hipMalloc((void **) &c->tmp, full)); c->tmp_bytes = full;
+    }
+    uint8_t * out_slots = (uint8_t *) c->stage, * in_slots = out_slots + slot * (size_t) W;
+    for (int r = 0; r < W; ++r) {
+        const int64_t rows = row_high[r] - row_low[r];
+        if (rows <= 0) continue;
+        if (!parts[r]) return 1;
+        ggml_hip_mul_mat_q(parts[r], x_dev, K, N, c->tmp + row_low[r], M);
+        HIP_CHECK(hipMemcpy2DAsync(out_slots + slot * (size_t) r, (size_t) rows * 4, c->tmp + row_low[r], (size_t) M * 4, (size_t) rows * 4, (size_t) N, hipMemcpyDeviceToDevice, st));
+    }
+    RCCL_CHECK(R->ncclGroupStart());
+    for (int r = 0; r < W; ++r) {
+        const int64_t rows = row_high[r] - row_low[r];
+        if (rows <= 0) continue;
+        RCCL_CHECK(R->ncclSend(out_slots + slot * (size_t) r, (size_t)(N * rows), ncclFloat32, 0, c->comm, st));
+        RCCL_CHECK(R->ncclRecv(in_slots + slot * (size_t) r, (size_t)(N * rows), ncclFloat32, 0, c->comm, st));
+    }
+    RCCL_CHECK(R->ncclGroupEnd());
+    for (int r = 0; r < W; ++r) {
+        const int64_t rows = row_high[r] - row_low[r];
+        if (rows <= 0) continue;
+        HIP_CHECK(hipMemcpy2DAsync(dst_dev + row_low[r], (size_t) M * 4, in_slots + slot * (size_t) r, (size_t) rows * 4, (size_t) rows * 4, (size_t) N, hipMemcpyDeviceToDevice, st));
     }
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;

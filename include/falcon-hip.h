@@ -103,8 +103,12 @@ int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * token_dev, con
 int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens);
 
 /* falcon_eval with n_tokens = 1 (libfalcon.cpp:4566) without a host round trip: the fused decode launches are replayed from a
- * hipGraph, the logits stay on the device until falcon_hip_get_logits is called (libfalcon.h:256, 263). Returns as falcon_hip_eval. */
+ * hipGraph and the logits row is copied into page-locked host memory behind them; falcon_hip_get_logits waits for that copy
+ * (libfalcon.h:256, 263). Returns as falcon_hip_eval; an in-launch hand-off that timed out in such an asynchronous step is
+ * noticed at the next falcon_hip_get_logits and is STICKY: falcon_hip_context_last_error reports 3 and every later eval of the
+ * context returns 3 (its KV cache holds invalid rows). */
 int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int n_past);
+int falcon_hip_context_last_error(const falcon_hip_context * c);      /* 0 or 3; host state only (no device wait) */
 /* the n_ctx ggml_rope is given may change per call (falcon_evaluation_config::n_max_real_ctx, libfalcon.cpp:2229-2230);
  * the table is rebuilt when the dynamic-NTK bucket n_ctx / 2048 changes (<= 0: the context's n_ctx)                       */
 void falcon_hip_context_set_rope_n_ctx(falcon_hip_context * c, int rope_n_ctx);
@@ -157,6 +161,11 @@ int   falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, in
    schedule and stage code, for tests and for sizing a pipeline before the GPUs are there */
 falcon_hip_pipeline * falcon_hip_pipeline_create_local(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx);
 int   falcon_hip_pipeline_run_local(falcon_hip_pipeline ** ranks, int world, int rounds, int n_past0);
+/* switches a local job's hand-offs from device copies to RCCL itself: one communicator of ONE rank (this process and GPU), every
+   message a grouped ncclSend / ncclRecv addressed to rank 0 on the pipeline's second stream, ordered by the events of the overlapped
+   schedule -- the library's RCCL binding and call sequence exercised on a box with a single GPU. 0, or -1 (RCCL missing / refused);
+   afterwards falcon_hip_pipeline_rccl_ranks reports the communicator's count (1) for every rank of the job */
+int   falcon_hip_pipeline_local_attach_rccl(falcon_hip_pipeline ** ranks, int world);
 /* host only: the slot schedule (see falcon_pipeline.hip); out: 9 ints; returns the number of slots of the run */
 int   falcon_hip_pipeline_schedule(int rank, int world, int n_groups, int rounds, int slot, int * out);
 

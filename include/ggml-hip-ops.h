@@ -63,6 +63,14 @@ int     ggml_hip_mul_mat_q_split(ggml_hip_split_comm * c, const ggml_hip_weight 
                                  float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
 int     ggml_hip_mul_mat_q_split_local(ggml_hip_weight * const * parts, int world, const float * x_dev, int64_t K, int64_t N,
                                        float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
+/* the local form with the EXCHANGE of ggml_hip_mul_mat_q_split run for real: a communicator of one RCCL rank (this process and GPU)
+ * standing for `world` virtual ranks; every part's rows are computed into a private buffer, packed, sent with a grouped ncclSend /
+ * ncclRecv addressed to rank 0 itself, and unpacked into dst -- pack, RCCL calls and unpack of a real job on a single-GPU box.
+ * ggml_hip_split_comm_create_loopback: NULL when RCCL is missing or refuses; ggml_hip_split_comm_rccl_ranks: ncclCommCount (0: no RCCL communicator). */
+ggml_hip_split_comm * ggml_hip_split_comm_create_loopback(int virtual_world);
+int     ggml_hip_split_comm_rccl_ranks(ggml_hip_split_comm * c);
+int     ggml_hip_mul_mat_q_split_loopback(ggml_hip_split_comm * c, ggml_hip_weight * const * parts, const float * x_dev, int64_t K, int64_t N,
+                                          float * dst_dev, int64_t M, const int64_t * row_low, const int64_t * row_high);
 /* staging-buffer pool of the ggml-cuda.h boundary (ggml_cuda_compute_forward's src1 / dst device copies; the reference's
  * ggml_cuda_pool_malloc, ggml-cuda.cu:1738-1816): buffers ever allocated, hand-outs served by reuse, buffers free now */
 void    ggml_hip_shim_pool_stats(size_t * n_alloc, size_t * n_reuse, size_t * n_free);

@@ -35,6 +35,11 @@ void * reff_load_ngl(const char * path, int n_ctx, int n_batch, int n_gpu_layers
     return (void *) falcon_init_from_file(path, p);
 }
 
+// llama_apply_lora_from_file (libfalcon.h:187-191); returns its result (0 = applied)
+int reff_apply_lora(void * ctx, const char * path_lora, int n_threads) {
+    return llama_apply_lora_from_file((falcon_context *) ctx, path_lora, nullptr, n_threads);
+}
+
 // falcon_model_quantize (the falcon_quantize tool's work, libfalcon.cpp:3914-3925) with one thread (deterministic)
 int reff_quantize(const char * path_in, const char * path_out, int ftype, int quantize_output_tensor, int allow_requantize) {
     init_once();

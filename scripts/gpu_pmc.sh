@@ -10,11 +10,11 @@ mkdir -p gpurun_out/pmc
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  timeout 900 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc -o $n -- python $R/bench.py --steps ${1:-8} --warmup 2 --no-cpu --no-graph > $R/gpurun_out/pmc/$n.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc -o $n -- python $R/bench.py --steps ${1:-8} --warmup 2 --no-cpu --no-ref-order --no-graph > $R/gpurun_out/pmc/$n.log 2>&1
   echo "$c rc=$?"
 done
 # matrix-pipe evidence for the prefill GEMM (one pass, SQ block only)
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc -o mfma -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-graph > $R/gpurun_out/pmc/mfma.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc -o mfma -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-ref-order --no-graph > $R/gpurun_out/pmc/mfma.log 2>&1
 echo "MFMA pass rc=$?"
 cd $R
 find gpurun_out/pmc -type f | head

@@ -6,7 +6,7 @@ R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o ${1:-r1} -- python $R/bench.py --steps ${2:-48} --no-cpu --no-graph > $R/gpurun_out/prof_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o ${1:-r1} -- python $R/bench.py --steps ${2:-48} --no-cpu --no-ref-order --no-graph > $R/gpurun_out/prof_run.log 2>&1
 echo "rocprof exit $?"
 cd $R
 find gpurun_out/prof -type f | head -20

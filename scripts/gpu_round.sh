@@ -28,7 +28,7 @@ if has bench; then
 fi
 if has prof; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o decode -- python $R/bench.py --steps 64 --no-cpu --no-graph --no-north-star --no-lock-step > $R/$OUT/prof_run.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o decode -- python $R/bench.py --steps 64 --no-cpu --no-ref-order --no-graph --no-north-star --no-lock-step > $R/$OUT/prof_run.log 2>&1
   echo "rocprof exit $?" | tee -a $R/$OUT/summary.txt
   cd $R
   db=$(find $OUT/prof -name "*results.db" | head -1)
@@ -40,7 +40,7 @@ if has pmc; then
   cd /tmp
   for c in FETCH_SIZE WRITE_SIZE; do
     n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-    timeout 900 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc -o $n -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-graph --no-north-star --no-lock-step > $R/$OUT/pmc/$n.log 2>&1
+    timeout 900 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc -o $n -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-ref-order --no-graph --no-north-star --no-lock-step > $R/$OUT/pmc/$n.log 2>&1
     echo "$c rc=$?"
   done
   cd $R
@@ -61,7 +61,7 @@ trace() {   # trace <name> <command...>: kernel trace -> $OUT/<name>_kernel_stat
 if has mfma; then
   mkdir -p $OUT/pmc
   cd /tmp
-  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc -o mfma -- python $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu --no-graph --no-north-star --no-lock-step --no-cli > $R/$OUT/pmc/mfma.log 2>&1
+  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc -o mfma -- python $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu --no-ref-order --no-graph --no-north-star --no-lock-step --no-cli > $R/$OUT/pmc/mfma.log 2>&1
   echo "mfma counters exit $?" | tee -a $R/$OUT/summary.txt
   cd $R
   mdb=$(find $OUT/pmc -name "mfma*results.db" | head -1)
@@ -69,15 +69,15 @@ if has mfma; then
   find $OUT/pmc -name "*.db" -delete
 fi
 if has prefill2048; then
-  trace prefill2048_7b_q4_0 python $R/bench.py --prompt 2048 --n-ctx 4096 --steps 8 --warmup 2 --repeats 1 --no-cpu --no-north-star --no-lock-step --no-cli --prefill-long 0
+  trace prefill2048_7b_q4_0 python $R/bench.py --prompt 2048 --n-ctx 4096 --steps 8 --warmup 2 --repeats 1 --no-cpu --no-ref-order --no-north-star --no-lock-step --no-cli --prefill-long 0
 fi
 if has b40; then
-  timeout 900 python bench.py --model 40b --quant q4_k --no-cpu --no-cli --no-lock-step --no-north-star --prefill-long 0 --steps 32 --warmup 4 --repeats 1 > $OUT/bench_40b_q4_k.json 2> $OUT/bench_40b.err; echo "bench 40b exit $?" | tee -a $OUT/summary.txt
+  timeout 900 python bench.py --model 40b --quant q4_k --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --steps 32 --warmup 4 --repeats 1 > $OUT/bench_40b_q4_k.json 2> $OUT/bench_40b.err; echo "bench 40b exit $?" | tee -a $OUT/summary.txt
   python scripts/bench_brief.py < $OUT/bench_40b_q4_k.json
-  trace decode_40b_q4_k python $R/bench.py --model 40b --quant q4_k --layers 12 --no-cpu --no-cli --no-graph --no-lock-step --no-north-star --prefill-long 0 --steps 16 --warmup 2 --repeats 1
+  trace decode_40b_q4_k python $R/bench.py --model 40b --quant q4_k --layers 12 --no-cpu --no-ref-order --no-cli --no-graph --no-lock-step --no-north-star --prefill-long 0 --steps 16 --warmup 2 --repeats 1
 fi
 if has lockstep; then
-  FALCON_HIP_STAGE_GRAPH=0 trace lockstep_b16 python $R/bench.py --force-pipeline --streams 1 --pipe-batch 16 --steps 16 --warmup 4 --no-cpu --no-cli
+  FALCON_HIP_STAGE_GRAPH=0 trace lockstep_b16 python $R/bench.py --force-pipeline --streams 1 --pipe-batch 16 --steps 16 --warmup 4 --no-cpu --no-ref-order --no-cli
 fi
 if has lockstep40; then
   LOCKSTEP_MODEL=40b_q4_k timeout 600 python scripts/gpu_lockstep.py 1 2 4 8 12 16 32 48 64 80 128 2>&1 | grep "streams per pass" | tee $OUT/lockstep_40b_q4_k.txt

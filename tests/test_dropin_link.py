@@ -82,7 +82,7 @@ def test_reference_libfalcon_links_against_libggml_hip(tree):
         assert sym in used, sym
 
 
-WRAP = "-Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free,--wrap=llama_load_session_file,--wrap=llama_save_session_file,--wrap=falcon_copy_state_data,--wrap=falcon_set_state_data,--wrap=falcon_get_embeddings"
+WRAP = "-Wl,--wrap=falcon_init_from_file,--wrap=falcon_context_prepare,--wrap=falcon_eval,--wrap=falcon_get_logits,--wrap=falcon_print_timings,--wrap=llama_free,--wrap=llama_load_session_file,--wrap=llama_save_session_file,--wrap=falcon_copy_state_data,--wrap=falcon_set_state_data,--wrap=falcon_get_embeddings,--wrap=llama_apply_lora_from_file"
 
 
 def test_reference_clis_link_unchanged_with_the_fast_path(tree):

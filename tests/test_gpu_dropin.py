@@ -147,6 +147,52 @@ def test_session_files_fail_loudly_on_the_fast_path(oracle, tmp_path):
     assert b"llama_load_session_file is not supported for a context evaluated on the device" in r.stderr
 
 
+def test_ngl_0_stays_on_the_host(oracle, golden, tmp_path):
+    """BASELINE config 1's command: `falcon_main -ngl 0` means the reference's CPU path (libfalcon.cpp:1813-1826) -- the wrap creates no
+    device side, says so, and the tool prints the CPU reference's bytes (default order: nothing of ours computes)"""
+    exe = _need("falcon_main_hip")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    _cli_model(oracle, path)
+    r = subprocess.run([exe, "-m", path, "-p", "The quick brown fox didn't jump", "-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1", "-ngl", "0"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert b"n_gpu_layers = 0" in r.stderr and b"stays on the host" in r.stderr
+    assert b"resident on the device" not in r.stderr and b"device-resident path" not in r.stderr
+    assert r.stdout == bytes(golden["cli"]["main_stdout"])
+
+
+_LORA_SCRIPT = r"""
+import ctypes as C, sys
+so, path, ngl = sys.argv[1], sys.argv[2], int(sys.argv[3])
+L = C.CDLL(so)
+L.reff_load_ngl.restype = C.c_void_p; L.reff_load_ngl.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+L.reff_apply_lora.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+L.reff_free.argtypes = [C.c_void_p]
+ctx = L.reff_load_ngl(path.encode(), 64, 16, ngl)
+assert ctx
+print("lora rc", L.reff_apply_lora(ctx, b"/nonexistent/adapter.bin", 1))
+L.reff_free(ctx)
+"""
+
+
+def test_lora_fails_loudly_on_a_device_context(oracle, tmp_path):
+    """llama_apply_lora_from_file (libfalcon.h:187-191) would patch the host tensors while the device copy keeps the unpatched weights:
+    for a context with a device side the wrap refuses before the adapter file is even opened"""
+    lib = _need("libfalcon_ref_hip.so")
+    import ggcc_writer
+    w = synth.make_model(oracle, synth.HP_TINY_MQA, ob.Q4_0, seed=4321)
+    path = str(tmp_path / "m.ggcc")
+    ggcc_writer.write_ggcc(path, w)
+    script = str(tmp_path / "lora.py")
+    open(script, "w").write(_LORA_SCRIPT)
+    r = subprocess.run([sys.executable, script, lib, path, "100"], capture_output=True, text=True, timeout=600)
+    if "undefined symbol: reff_apply_lora" in r.stderr:
+        pytest.skip("oracle/_ref/libfalcon_ref_hip.so predates reff_apply_lora (make -C oracle ref_falcon_hip)")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "lora rc 1" in r.stdout
+    assert "llama_apply_lora_from_file is not supported for a context evaluated on the device" in r.stderr
+
+
 def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path):
     """the reference's falcon_perplexity tool, unchanged, with falcon_eval on the device: the chunk perplexities it prints"""
     exe = _need("falcon_perplexity_hip")
