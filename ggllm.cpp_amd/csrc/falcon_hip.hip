@@ -98,7 +98,8 @@ struct falcon_hip_context {
     const void * sg_in[2] = { nullptr, nullptr }; void * sg_out[2] = { nullptr, nullptr };
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
-    bool ring_ln = false;                      // k_gemv_ln's launches in the ring form (kernels_ring.hip); FALCON_HIP_RING=0: never
+    bool ring_ln = false;                      // k_gemv_ln's launches in the ring form (kernels_ring.hip; k-quants: kernels_ringk.hip); FALCON_HIP_RING=0: never
+    bool ring_out = false;                     // the unmerged k_gemv_out launches in the ring form (kernels_ringk.hip); FALCON_HIP_RING_OUT=0: never
     // batched evaluation replayed from hipGraphs (FALCON_HIP_PREFILL_GRAPH=1; default: plain launches): the ~320 launches and 96 cross-stream joins of a
     // prompt batch are then scheduled by the graph instead of the host (the joins cost ~12 us of idle device each as stream events: 11 % of a
     // 128-token Falcon-7B prompt). Keyed by (tokens, keys, mode signature, keep_hidden); the position and the token ids are read from device memory.
@@ -260,6 +261,12 @@ static fq_act act_for(uint8_t * buf, const fq_weight & w, int64_t cols) {
     fq_act a{}; a.type = fq_desc(w.type).act_type; a.K = w.K; a.ncols = cols; a.base = buf; return a;
 }
 
+// the ring forms' per-shape schedules (device tables) must exist before any launch is captured into a graph: legacy formats kernels_ring.hip, k-quants kernels_ringk.hip
+static bool ring_prepare_any(const falcon_hip_model * m) {
+    const fq_weight & q = m->layers[0].qkv;
+    return fq_ring_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu) || fq_ringk_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu);
+}
+
 static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx, int n_seq) {
     const falcon_hip_hparams & hp = m->hp;
     for (size_t i = 0; i < m->layers.size(); ++i) {
@@ -320,7 +327,8 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
     c->ring_ln = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);      // (default on: a context starts in mode 2)
     if (const char * e = getenv("FALCON_HIP_PREFILL_GRAPH")) c->prefill_graph = atoi(e) != 0;
-    if (c->ring_ln && nl > 0) c->ring_ln = fq_ring_prepare(m->layers[0].qkv.type, E, FF, m->layers[0].qkv.M, fq_ctx().n_cu);
+    if (c->ring_ln && nl > 0) c->ring_ln = ring_prepare_any(m);
+    c->ring_out = getenv("FALCON_HIP_RING_OUT") && atoi(getenv("FALCON_HIP_RING_OUT")) != 0;      // (opt-in: measured slower than k_gemv_out with the fast k-quant dots)
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
@@ -379,8 +387,9 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     // the LayerNorm mat-vec launch in the ring form (kernels_ring.hip): mode 5 always, mode 2 unless FALCON_HIP_RING=0 (measured +1.6 % on
     // Falcon-7B Q4_0; legacy formats only, other models keep k_gemv_ln)
     static const bool ring_default = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);
-    c->ring_ln = (mode == 5 || (mode == 2 && ring_default)) && !c->m->layers.empty() &&
-                 fq_ring_prepare(c->m->layers[0].qkv.type, c->m->hp.n_embd, c->m->hp.n_ff, c->m->layers[0].qkv.M, fq_ctx().n_cu);
+    c->ring_ln = (mode == 5 || (mode == 2 && ring_default)) && !c->m->layers.empty() && ring_prepare_any(c->m);
+    static const bool ring_out_default = getenv("FALCON_HIP_RING_OUT") && atoi(getenv("FALCON_HIP_RING_OUT")) != 0;
+    c->ring_out = (mode == 5 || (mode == 2 && ring_out_default));
 }
 // 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)
 extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c);
@@ -589,9 +598,11 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 fq_launch_gemv_ln(gq, hc.n_cu, st);
             } else if (!ln_done) {
                 if (prof) fq_prof_open(st);
-                if (!(c->ring_ln && quant_epi && fq_launch_gemv_ln_ring(ga, c->sync_words + 1, hc.n_cu, st))) fq_launch_gemv_ln(ga, hc.n_cu, st);
+                bool ring = false;
+                if (c->ring_ln && quant_epi) ring = fq_launch_gemv_ln_ring(ga, c->sync_words + 1, hc.n_cu, st);
+                else if (c->ring_ln)         ring = fq_launch_ringk_ln(ga, c->sync_words + 1, hc.n_cu, st);      // k-quants: GELU stored as f32
+                if (!ring) fq_launch_gemv_ln(ga, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
-                if (!quant_epi) fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st);
             }
             ln_done = false;
             float * kc = c->k_cache + li * (size_t) n_caches * c->n_ctx * HKV * D;
@@ -601,8 +612,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_gemv_out_args go{ L.down, L.wo, c->buf_ff, c->att, att_q ? c->buf_att : nullptr, c->x, c->x,
                                  hc.dbg_stamps ? hc.dbg_stamps + 4096 * 8 : nullptr };
             if (dual) HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
+            // gelu(up) still f32 (k-quant consumers: a Q8_K block spans 256 rows, i.e. several workgroups of the launch above): quantized by its own launch
+            // ahead of the merged form, or by extra workgroups of the attention launch (the rider) in the three-launch form
+            bool ff_pending = !quant_epi && !dual;
+            const bool will_merge = c->merged_attn_out && !dual && fq_attn_out_fits(go, (int) H, max_n_kv, hc.n_cu);
+            if (ff_pending && will_merge) { fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st); ff_pending = false; }
             bool merged = false;
-            if (c->merged_attn_out && !dual) {
+            if (will_merge) {
                 // second phase: the next block's k_gemv_ln (its GELU output must be quantized in its epilogue: a separate
                 // quantizer launch cannot sit between the phases), or ln_f + lm_head after the last block
                 fq_gemv_ln_args next{}; bool have_next = false; double next_bytes = 0.0;
@@ -628,12 +644,23 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                     if (merged && prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
                 }
                 if (!merged && prof) fq_prof_cancel();
+                if (!merged) { fprintf(stderr, "falcon-hip: the merged attention + output launch refused a shape fq_attn_out_fits accepted\n"); exit(1); }
             }
             if (!merged) {
-                fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,
-                                      att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, st);
+                const fq_act a_ff1 = act_for(c->buf_ff, L.down, 1);
+                static const bool ride_on = !(getenv("FALCON_HIP_QUANT_RIDER") && atoi(getenv("FALCON_HIP_QUANT_RIDER")) == 0);
+                if (ff_pending && ride_on && a_ff1.type == FQ_Q8_K && FF % 256 == 0) {
+                    // attention of the one sequence + the rider: k_attn_decode's code (k_attn_decode_seqs at one sequence), gelu(up)'s Q8_K image by extra workgroups
+                    fq_launch_attn_decode_seqs(c->qkv, 1, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, 0, hc.exp_table_attn,
+                                               att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, (int64_t) fq_act_col_bytes(att_act, E), st, c->up, FF, &a_ff1);
+                    ff_pending = false;
+                } else {
+                    if (ff_pending) { fq_launch_quantize_act(c->up, FF, a_ff1, st); ff_pending = false; }
+                    fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,
+                                          att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, st);
+                }
                 if (prof) fq_prof_open(st);
-                fq_launch_gemv_out(go, hc.n_cu, st);
+                if (!(c->ring_out && fq_launch_ring_out(go, c->sync_words + 1, hc.n_cu, st))) fq_launch_gemv_out(go, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
             }
         }
@@ -859,7 +886,9 @@ extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, i
 
 extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
     if (c->logits_pending) {                                         // the last falcon_hip_eval_token's row copy (page-locked memory) is in flight behind its launches
-        HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
+        // (polled, not slept on: the caller samples the moment the row is there, and a blocking wait's wake-up costs tens of microseconds of a ~1 ms step)
+        hipStream_t st = fq_ctx().stream;
+        for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) break; if (e != hipErrorNotReady) HIP_CHECK(e); }
         c->logits_pending = false;
         (void) report_sync_error(c, "eval");                        // sticky: falcon_hip_context_last_error / the next eval report it (this call cannot)
     }

@@ -50,16 +50,15 @@ __device__ __forceinline__ void quant_q8K_wave(const float4 v, int lane, int64_t
     if (fabsf(v.y) > ax) { ax = fabsf(v.y); mx = v.y; idx = 4 * lane + 1; }
     if (fabsf(v.z) > ax) { ax = fabsf(v.z); mx = v.z; idx = 4 * lane + 2; }
     if (fabsf(v.w) > ax) { ax = fabsf(v.w); mx = v.w; idx = 4 * lane + 3; }
-    // butterfly over the 64 lanes; the winner rule is symmetric, so paired lanes always agree afterwards
-#define FQ_Q8K_STEP(oax, omx, oidx) do { const float a_ = (oax), m_ = (omx); const int i_ = (oidx); \
-        if (a_ > ax || (a_ == ax && i_ < idx)) { ax = a_; mx = m_; idx = i_; } } while (0)
-    FQ_Q8K_STEP(dpp_mov<0xB1>(ax),  dpp_mov<0xB1>(mx),  dpp_mov<0xB1>(idx));
-    FQ_Q8K_STEP(dpp_mov<0x4E>(ax),  dpp_mov<0x4E>(mx),  dpp_mov<0x4E>(idx));
-    FQ_Q8K_STEP(dpp_mov<0x141>(ax), dpp_mov<0x141>(mx), dpp_mov<0x141>(idx));
-    FQ_Q8K_STEP(dpp_mov<0x140>(ax), dpp_mov<0x140>(mx), dpp_mov<0x140>(idx));
-    FQ_Q8K_STEP(__shfl_xor(ax, 16), __shfl_xor(mx, 16), __shfl_xor(idx, 16));
-    FQ_Q8K_STEP(__shfl_xor(ax, 32), __shfl_xor(mx, 32), __shfl_xor(idx, 32));
-#undef FQ_Q8K_STEP
+    // over the 64 lanes: the largest magnitude by a plain max butterfly, then the LOWEST lane that holds it (elements are in lane order, and each
+    // lane kept its first on ties) hands out its signed value -- the strict '>' scan's winner with a third of the instructions of a
+    // (magnitude, value, index) butterfly
+    const float amax = wave_max(ax);
+    const unsigned long long holders = __ballot(ax == amax);
+    const int first = __builtin_amdgcn_readfirstlane(holders ? (int) __builtin_ctzll(holders) : 0);      // (no holder: a NaN in the block, the result is garbage either way)
+    mx = lane_get(mx, first);
+    ax = amax;
+    (void) idx;
     int8_t  * qo = o.qs + 256 * sb + 4 * lane;
     int16_t * bs = (int16_t *) o.aux + 16 * sb;
     if (ax == 0.0f) {
@@ -77,6 +76,50 @@ __device__ __forceinline__ void quant_q8K_wave(const float4 v, int lane, int64_t
     s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s);
     if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
     if (lane == 0) o.d[sb] = 1.0f / iscale;
+}
+
+// N super-blocks at once (sb[n] < 0: none): the same arithmetic per super-block, the N max-butterflies -- chains of dependent cross-lane steps -- advance
+// side by side, so a wave that owns several super-blocks (the ring forms' prologues: 3 per wave, two norms) pays the chain's latency once
+template <int N>
+__device__ __forceinline__ void quant_q8K_wave_n(const float4 (&v)[N], int lane, const int64_t (&sb)[N], const act_image_ptr (&o)[N]) {
+    float ax[N], mx[N]; int idx[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        ax[n] = fabsf(v[n].x); mx[n] = v[n].x; idx[n] = 4 * lane;
+        if (fabsf(v[n].y) > ax[n]) { ax[n] = fabsf(v[n].y); mx[n] = v[n].y; idx[n] = 4 * lane + 1; }
+        if (fabsf(v[n].z) > ax[n]) { ax[n] = fabsf(v[n].z); mx[n] = v[n].z; idx[n] = 4 * lane + 2; }
+        if (fabsf(v[n].w) > ax[n]) { ax[n] = fabsf(v[n].w); mx[n] = v[n].w; idx[n] = 4 * lane + 3; }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {                                          // (see quant_q8K_wave: max butterfly, then the lowest holder's signed value)
+        const float amax = wave_max(ax[n]);
+        const unsigned long long holders = __ballot(ax[n] == amax);
+        const int first = __builtin_amdgcn_readfirstlane(holders ? (int) __builtin_ctzll(holders) : 0);      // (no holder: a NaN in the block, the result is garbage either way)
+        mx[n] = lane_get(mx[n], first);
+        ax[n] = amax;
+        (void) idx[n];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        if (sb[n] < 0) continue;                                           // wave-uniform
+        int8_t  * qo = o[n].qs + 256 * sb[n] + 4 * lane;
+        int16_t * bs = (int16_t *) o[n].aux + 16 * sb[n];
+        if (ax[n] == 0.0f) {
+            *(uint32_t *) qo = 0u;
+            if ((lane & 3) == 0) bs[lane >> 2] = 0;
+            if (lane == 0) o[n].d[sb[n]] = 0.0f;
+            continue;
+        }
+        const float iscale = -128.0f / mx[n];
+        int q0 = (int) __builtin_rintf(iscale * v[n].x), q1 = (int) __builtin_rintf(iscale * v[n].y);
+        int q2 = (int) __builtin_rintf(iscale * v[n].z), q3 = (int) __builtin_rintf(iscale * v[n].w);
+        q0 = q0 > 127 ? 127 : q0; q1 = q1 > 127 ? 127 : q1; q2 = q2 > 127 ? 127 : q2; q3 = q3 > 127 ? 127 : q3;
+        *(uint32_t *) qo = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        int s = q0 + q1 + q2 + q3;
+        s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s);
+        if ((lane & 3) == 0) bs[lane >> 2] = (int16_t) s;
+        if (lane == 0) o[n].d[sb[n]] = 1.0f / iscale;
+    }
 }
 
 // quantize one f32 row of length K held in LDS (or global) into an image, by a whole 256-thread workgroup

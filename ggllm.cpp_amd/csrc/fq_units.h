@@ -89,6 +89,8 @@ FQ_HD fq_u4    ld_w4 (const void * p) {            // 16 bytes of a WEIGHT plane
     return *(const fq_u4 *) p;
 #endif
 }
+// NT = false: the same 16 bytes out of LDS (the ring forms stage raw weight rows there: plain loads)
+template <bool NT> FQ_HD fq_u4 ld_q4(const void * p) { if constexpr (NT) return ld_w4(p); else return ld_u4(p); }
 FQ_HD uint32_t ld_u32(const void * p) { return *(const uint32_t *) p; }
 FQ_HD uint16_t ld_u16(const void * p) { return *(const uint16_t *) p; }
 
@@ -126,8 +128,8 @@ FQ_HD float fq_bits2f(uint32_t b) { float f; __builtin_memcpy(&f, &b, 4); return
 // ---------------------------------------------------------------- Q4_0  (ggml.c:2591-2609)
 template <> struct fq_unit<FQ_Q4_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_0, 0>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q4_0, 1>(k, ju)); return r;
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_q4<NT>(fq_cp<FQ_Q4_0, 0>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q4_0, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
         int s = dot16r(and4(r.q, 0x0F0F0F0Fu), y.x0) + dot16r(and4(shr4(r.q, 4), 0x0F0F0F0Fu), y.x1);
@@ -139,8 +141,8 @@ template <> struct fq_unit<FQ_Q4_0> {
 // ---------------------------------------------------------------- Q4_1  (ggml.c:2716-2735)
 template <> struct fq_unit<FQ_Q4_1> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q4_1, 0>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q4_1, 1>(k, ju)); return r;
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_q4<NT>(fq_cp<FQ_Q4_1, 0>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q4_1, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
         const int s = dot16r(and4(r.q, 0x0F0F0F0Fu), y.x0) + dot16r(and4(shr4(r.q, 4), 0x0F0F0F0Fu), y.x1);
@@ -155,8 +157,8 @@ FQ_HD fq_u4 q5_hi(uint32_t qh, int base) {
 // ---------------------------------------------------------------- Q5_0  (ggml.c:2951-2972)
 template <> struct fq_unit<FQ_Q5_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_0, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_0, 1>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q5_0, 2>(k, ju)); return r;
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_q4<NT>(fq_cp<FQ_Q5_0, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_0, 1>(k, ju)); r.dm = ld_u16(fq_cp<FQ_Q5_0, 2>(k, ju)); return r;
     }
     FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
         int s = dot16r(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), y.x0) + dot16r(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), y.x1);
@@ -168,8 +170,8 @@ template <> struct fq_unit<FQ_Q5_0> {
 // ---------------------------------------------------------------- Q5_1  (ggml.c:3207-3228)
 template <> struct fq_unit<FQ_Q5_1> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
-        fq_unit_regs r{}; r.q = ld_w4(fq_cp<FQ_Q5_1, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_1, 1>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q5_1, 2>(k, ju)); return r;
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; r.q = ld_q4<NT>(fq_cp<FQ_Q5_1, 0>(k, ju)); r.s0 = ld_u32(fq_cp<FQ_Q5_1, 1>(k, ju)); r.dm = ld_u32(fq_cp<FQ_Q5_1, 2>(k, ju)); return r;
     }
     FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
         const int s = dot16r(or4(and4(r.q, 0x0F0F0F0Fu), q5_hi(r.s0, 0)), y.x0) + dot16r(or4(and4(shr4(r.q, 4), 0x0F0F0F0Fu), q5_hi(r.s0, 16)), y.x1);
@@ -180,8 +182,8 @@ template <> struct fq_unit<FQ_Q5_1> {
 // ---------------------------------------------------------------- Q8_0  (ggml.c:3317-3329)  unit = whole block (2 x 16 B)
 template <> struct fq_unit<FQ_Q8_0> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
-        fq_unit_regs r{}; const uint8_t * q = fq_cp<FQ_Q8_0, 0>(k, ju); r.q = ld_w4(q); r.q2 = ld_w4(q + 16); r.dm = ld_u16(fq_cp<FQ_Q8_0, 1>(k, ju)); return r;
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+        fq_unit_regs r{}; const uint8_t * q = fq_cp<FQ_Q8_0, 0>(k, ju); r.q = ld_q4<NT>(q); r.q2 = ld_q4<NT>(q + 16); r.dm = ld_u16(fq_cp<FQ_Q8_0, 1>(k, ju)); return r;
     }
     FQ_HDM static float dot_x(const fq_unit_regs & r, const fq_act32 & y) {
         const int s = dot16r(r.q, y.x0) + dot16r(r.q2, y.x1);
@@ -193,9 +195,9 @@ template <> struct fq_unit<FQ_Q8_0> {
 // unit u: super-block sb=u>>2, 128-half hf=(u>>1)&1, 16-byte group g=u&1; covers elements 128hf+32j+16g+l, j=0..3
 template <> struct fq_unit<FQ_Q2_K> {
     static constexpr int ELEMS = 64;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // ju: unit inside the column (4 per super-block)
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // ju: unit inside the column (4 per super-block)
         fq_unit_regs r{}; const int sb = ju >> 2, hf = (ju >> 1) & 1;
-        r.q = ld_w4(fq_cp<FQ_Q2_K, 0>(k, sb) + 16 * (ju & 3));
+        r.q = ld_q4<NT>(fq_cp<FQ_Q2_K, 0>(k, sb) + 16 * (ju & 3));
         const uint8_t * sc = fq_cp<FQ_Q2_K, 1>(k, sb) + 8 * hf;
         r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4);
         r.dm = ld_u32(fq_cp<FQ_Q2_K, 2>(k, sb)); return r;
@@ -227,10 +229,10 @@ FQ_HD int q3_scale(uint32_t s0, uint32_t s1, uint32_t s2, int is) {
 // ---------------------------------------------------------------- Q3_K  (k_quants.c:1684-1746)
 template <> struct fq_unit<FQ_Q3_K> {
     static constexpr int ELEMS = 64;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; const int sb = ju >> 2, g = ju & 1;
-        r.q  = ld_w4(fq_cp<FQ_Q3_K, 0>(k, sb) + 16 * (ju & 3));
-        r.q2 = ld_w4(fq_cp<FQ_Q3_K, 1>(k, sb) + 16 * g);                // hmask bytes of this 16-byte group
+        r.q  = ld_q4<NT>(fq_cp<FQ_Q3_K, 0>(k, sb) + 16 * (ju & 3));
+        r.q2 = ld_q4<NT>(fq_cp<FQ_Q3_K, 1>(k, sb) + 16 * g);                // hmask bytes of this 16-byte group
         const uint8_t * sc = fq_cp<FQ_Q3_K, 2>(k, sb);
         r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
         r.dm = ld_u16(fq_cp<FQ_Q3_K, 3>(k, sb)); return r;
@@ -262,9 +264,9 @@ FQ_HD void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j, int & sc, 
 // unit u: sb=u>>3, 64-chunk c=(u>>1)&3, group g=u&1; low nibbles -> elements 64c+16g+l (sub-block 2c), high -> +32 (2c+1)
 template <> struct fq_unit<FQ_Q4_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // 8 units per super-block
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {       // 8 units per super-block
         fq_unit_regs r{}; const int sb = ju >> 3;
-        r.q = ld_w4(fq_cp<FQ_Q4_K, 0>(k, sb) + 16 * (ju & 7));
+        r.q = ld_q4<NT>(fq_cp<FQ_Q4_K, 0>(k, sb) + 16 * (ju & 7));
         const uint8_t * sc = fq_cp<FQ_Q4_K, 1>(k, sb);
         r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
         r.dm = ld_u32(fq_cp<FQ_Q4_K, 2>(k, sb)); return r;
@@ -284,10 +286,10 @@ template <> struct fq_unit<FQ_Q4_K> {
 // ---------------------------------------------------------------- Q5_K  (k_quants.c:2340-2400)
 template <> struct fq_unit<FQ_Q5_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; const int sb = ju >> 3, g = ju & 1;
-        r.q  = ld_w4(fq_cp<FQ_Q5_K, 0>(k, sb) + 16 * (ju & 7));
-        r.q2 = ld_w4(fq_cp<FQ_Q5_K, 1>(k, sb) + 16 * g);                // qh bytes of this group
+        r.q  = ld_q4<NT>(fq_cp<FQ_Q5_K, 0>(k, sb) + 16 * (ju & 7));
+        r.q2 = ld_q4<NT>(fq_cp<FQ_Q5_K, 1>(k, sb) + 16 * g);                // qh bytes of this group
         const uint8_t * sc = fq_cp<FQ_Q5_K, 2>(k, sb);
         r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4); r.s2 = ld_u32(sc + 8);
         r.dm = ld_u32(fq_cp<FQ_Q5_K, 3>(k, sb)); return r;
@@ -310,10 +312,10 @@ template <> struct fq_unit<FQ_Q5_K> {
 // unit u: sb=u>>3, half h=(u>>2)&1, t01=(u>>1)&1, g=u&1; low nibbles -> quarter t01, high nibbles -> quarter t01+2
 template <> struct fq_unit<FQ_Q6_K> {
     static constexpr int ELEMS = 32;
-    FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
+    template <bool NT = true> FQ_HDM static fq_unit_regs load_at(const fq_col & k, int ju) {
         fq_unit_regs r{}; const int sb = ju >> 3, h = (ju >> 2) & 1, g = ju & 1;
-        r.q  = ld_w4(fq_cp<FQ_Q6_K, 0>(k, sb) + 16 * (ju & 7));
-        r.q2 = ld_w4(fq_cp<FQ_Q6_K, 1>(k, sb) + 32 * h + 16 * g);
+        r.q  = ld_q4<NT>(fq_cp<FQ_Q6_K, 0>(k, sb) + 16 * (ju & 7));
+        r.q2 = ld_q4<NT>(fq_cp<FQ_Q6_K, 1>(k, sb) + 32 * h + 16 * g);
         const uint8_t * sc = fq_cp<FQ_Q6_K, 2>(k, sb) + 8 * h;
         r.s0 = ld_u32(sc); r.s1 = ld_u32(sc + 4);                       // int8 scales[8h .. 8h+7]
         r.dm = ld_u16(fq_cp<FQ_Q6_K, 3>(k, sb)); return r;

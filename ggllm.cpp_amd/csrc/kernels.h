@@ -117,6 +117,7 @@ void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
 // each), zero-filled once; epoch_word: incremented by the k_gemv_ln launch (or phase) before it. With ln != nullptr the launch
 // is k_attn_out_ln: *ln (the next block's k_gemv_ln, or ln_f + lm_head) runs as a second phase of the same launch and takes
 // the residual row from xgran (>= n_embd granules, zero-filled once) instead of memory.
+bool   fq_attn_out_fits(const fq_gemv_out_args & g, int H, int max_n_kv, int n_cu);      // would fq_launch_attn_out (ln == nullptr) launch?
 bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
                           const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
                           int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st,
@@ -134,6 +135,14 @@ void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, 
 // false = outside its scope, nothing launched. fq_ring_prepare: builds the shape's schedule (allocates: not inside a stream capture)
 bool   fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu);
 bool   fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st);
+
+// kernels_ringk.hip -- ring forms beyond kernels_ring.hip's scope: k_gemv_ln's launch for the k-quants (GELU_STORE epilogue: the Q8_K image of gelu(up)
+// rides on the attention launch), and k_gemv_out's launch for all ten formats. false = outside the form's scope (or no prepared schedule): nothing launched.
+bool   fq_ringk_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu);      // builds the shape's schedule (allocates: not inside a stream capture)
+bool   fq_launch_ringk_ln(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st);
+bool   fq_launch_ring_out(const fq_gemv_out_args & g, unsigned * err, int n_cu, hipStream_t st);
+void   fq_ringk_free_plans();
+void   fq_ring_free_plans();
 
 // kernels_cols.hip -- the two mat-vec launches of a block for 2..4 lock-step sequences (one weight pass serves all columns)
 struct fq_gemv_cols_seg {

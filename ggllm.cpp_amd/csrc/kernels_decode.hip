@@ -17,6 +17,7 @@
 // Arithmetic is the stand-alone kernels' arithmetic (same device functions, same per-lane unit order, same reductions):
 // logits are bit-identical to the unfused path, which the tests check.
 #include "fq_block_dev.h"
+#include "fq_kdot.h"
 #include "fq_attn_dev.h"
 #include "fq_attn_decode_dev.h"
 #include "kernels.h"
@@ -52,9 +53,28 @@ __device__ __forceinline__ void rows_issue(const fq_wrow (&rows)[R], int units, 
         for (int r = 0; r < R; ++r) regs[i][r] = fq_unit_load_col<TYPE>(rows[r], i, lane, units);
     }
 }
+// k-quants, rows of whole columns (units % 64 == 0: Falcon-40B / 180B's matrices behind K = 8192 / 32768): the lane sits in the same slot ju = lane of every
+// column, so the unit dot is fq_kdot.h's (lane-constant index math hoisted, both sub-block scales decoded at once; the SAME f32 term, tests/test_units_host.py)
+template <int TYPE> __device__ __forceinline__ bool kq_fast_units(int units) {
+    if constexpr (fq_kdot<TYPE>::ok) return (units & 63) == 0; else return false;
+}
 template <int TYPE, int R, int NPRE>
 __device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R]) {
     const int lane = threadIdx.x & 63;
+    if constexpr (fq_kdot<TYPE>::ok) {
+        if (kq_fast_units<TYPE>(units)) {
+            typedef fq_kdot<TYPE> KD;
+            const typename KD::lane_t L = KD::lane_init(lane);
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const bool ok = 64 * i < units;                              // (wave-uniform; a pre-issued column beyond the row's end was clamped to its last one)
+                const typename KD::act_t y = KD::act_load(col, ok ? i : (units >> 6) - 1, L);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const float v = KD::dot(KD::from_regs(regs[i][r]), y, L); acc[r] += ok ? v : 0.0f; }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
         const int u = i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
@@ -65,6 +85,29 @@ __device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R]
 template <int TYPE, int R, int UNROLL>
 __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int units, int u_begin, const fq_actcol & col, float (&acc)[R]) {
     const int lane = threadIdx.x & 63;
+    if constexpr (fq_kdot<TYPE>::ok) {
+        if (kq_fast_units<TYPE>(units)) {
+            typedef fq_kdot<TYPE> KD;
+            const typename KD::lane_t L = KD::lane_init(lane);
+            const int ncol = units >> 6;
+            for (int c0 = u_begin >> 6; c0 < ncol; c0 += UNROLL) {
+                fq_unit_regs regs[UNROLL][R];
+#pragma unroll
+                for (int i = 0; i < UNROLL; ++i) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) regs[i][r] = fq_unit_load_col<TYPE>(rows[r], c0 + i, lane, units);
+                }
+#pragma unroll
+                for (int i = 0; i < UNROLL; ++i) {
+                    const bool ok = c0 + i < ncol;
+                    const typename KD::act_t y = KD::act_load(col, ok ? c0 + i : ncol - 1, L);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { const float v = KD::dot(KD::from_regs(regs[i][r]), y, L); acc[r] += ok ? v : 0.0f; }
+                }
+            }
+            return;
+        }
+    }
     for (int u0 = u_begin; u0 < units; u0 += 64 * UNROLL) {
         fq_unit_regs regs[UNROLL][R];
 #pragma unroll
@@ -440,6 +483,13 @@ __global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a,
                                                           int H, const float * __restrict__ qx, int64_t q_ldx, fq_act qa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int64_t t = blockIdx.y;
+    if ((int) blockIdx.x >= H && qa.type == FQ_Q8_K) {                     // k-quant consumers: one wave per 256-element super-block (k_quantize_q8K's code)
+        const int lane = threadIdx.x & 63;
+        const act_image_ptr o = act_image_at(qa.base + (size_t) t * fq_act_col_bytes(qa.type, qa.K), qa.type, qa.K);
+        for (int64_t sb = (int64_t)((int) blockIdx.x - H) * 4 + (threadIdx.x >> 6); sb < (qa.K >> 8); sb += (int64_t)((int) gridDim.x - H) * 4)
+            quant_q8K_wave(*(const float4 *)(qx + t * q_ldx + 256 * sb + 4 * lane), lane, sb, o);
+        return;
+    }
     if ((int) blockIdx.x >= H) {
         const int64_t quads = qa.K >> 2;                                   // (a multiple of 8: whole 32-blocks)
         const int nb = (int) gridDim.x - H;
@@ -464,8 +514,8 @@ void fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, co
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode_seqs, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     const fq_attn_decode_args a{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type, max_n_kv, nullptr, nullptr, nullptr, nullptr };
-    const bool ride = qx && qa && (qa->type == FQ_Q8_0 || qa->type == FQ_Q8_1) && qa->ncols >= n_seq;
-    const int extra = ride ? (int)(((qa->K >> 2) + 255) / 256) : 0;        // quantizer workgroups per column
+    const bool ride = qx && qa && (qa->type == FQ_Q8_0 || qa->type == FQ_Q8_1 || (qa->type == FQ_Q8_K && qa->K % 256 == 0)) && qa->ncols >= n_seq;
+    const int extra = !ride ? 0 : (qa->type == FQ_Q8_K ? (int)(((qa->K >> 8) + 3) / 4) : (int)(((qa->K >> 2) + 255) / 256));      // quantizer workgroups per column
     hipLaunchKernelGGL(k_attn_decode_seqs, dim3((unsigned)(H + extra), (unsigned) n_seq), dim3(256), lds, st, a, (int64_t)(H + 2 * HKV) * 64, seq_stride, (int64_t) H * 64,
                        image_stride, H, ride ? qx : nullptr, q_ldx, ride ? *qa : fq_act{});
 }
@@ -618,6 +668,22 @@ __global__ void __launch_bounds__(768) k_attn_out_ln(fq_attn_out_args a, fq_gemv
     attn_out_body<TYPE>(a, smem, epoch, fq_publish{ xgran, epoch });
     __syncthreads();
     if ((int) blockIdx.x < b.n_blocks) gemv_ln_body<TYPE, 768>(b, (int) blockIdx.x, smem, fq_xsrc{ xgran, epoch, a.err });
+}
+
+// the merged form's own conditions (fq_launch_attn_out with ln == nullptr launches exactly when this is true)
+bool fq_attn_out_fits(const fq_gemv_out_args & g, int H, int max_n_kv, int n_cu) {
+    const int act = fq_desc(g.w_wo.type).act_type;
+    const int nw = 12, hpw = 2;
+    const int n_attn = (H + hpw - 1) / hpw;
+    const int n_mv = (int)((g.w_wo.M + 2 * nw - 1) / (2 * nw));
+    const size_t lds_group = (attn_decode_lds(max_n_kv) + 15) & ~(size_t) 15;
+    const size_t lds_mv = fq_act_col_bytes(act, g.w_down.K) + fq_act_col_bytes(act, g.w_wo.K) + (g.att_image ? 0 : (size_t) g.w_wo.K * 4) + 16;
+    size_t lds = lds_group * hpw > lds_mv ? lds_group * hpw : lds_mv;
+    static const int rounds = getenv("FQ_ATTN_OUT_ROUNDS") ? atoi(getenv("FQ_ATTN_OUT_ROUNDS")) : 1;
+    if (lds > 160 * 1024) return false;
+    if (n_attn + n_mv > n_cu && !(rounds >= 2 && n_attn <= n_cu / 2 && n_attn + n_mv <= 2 * n_cu)) return false;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    return lds <= 160 * 1024;
 }
 
 // true (and launched) when the merged form applies: every workgroup resident at once

@@ -837,7 +837,7 @@ bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, f
         if (nbw) {
             const int nrb = (ntiles + T - 1) / T;
             int nslots = 8 * ((nrb + 7) / 8);
-            if (4 * nslots > n_cu) nslots = (n_cu / 32) * 8;
+            if (4 * nslots > n_cu) nslots = (n_cu / 32) * 8 > 8 ? (n_cu / 32) * 8 : 8;      // (never an empty grid on a part with fewer than 32 CUs)
             const unsigned g = (unsigned)(4 * nslots);
 #define FQ_KS_LAUNCH(TT, NB) { \
                 static bool set = false; \

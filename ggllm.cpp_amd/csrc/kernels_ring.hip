@@ -381,8 +381,9 @@ std::vector<ring_plan> g_plans;
 
 // rows [qg0, qg1) of Wqkv and 32-row groups [ug0, ug1) of Wup per workgroup: the groups are dealt evenly, the Wqkv rows fill the
 // workgroups with fewer groups up to the common row count
-const fq_engine_sched * ring_schedule(int type, int E, int FF, int qkv_rows, int n_wg) {
+const fq_engine_sched * ring_schedule(int type, int E, int FF, int qkv_rows, int n_wg, bool create) {
     for (const ring_plan & p : g_plans) if (p.type == type && p.E == E && p.FF == FF && p.qkv_rows == qkv_rows && p.n_wg == n_wg) return p.dev;
+    if (!create) return nullptr;                                            // (a launch may sit inside a stream capture: it never allocates; fq_ring_prepare does)
     const int groups = FF / 32;
     std::vector<fq_engine_sched> s((size_t) n_wg);
     std::vector<int> ng((size_t) n_wg);
@@ -406,11 +407,16 @@ const fq_engine_sched * ring_schedule(int type, int E, int FF, int qkv_rows, int
 }
 }   // namespace
 
+void fq_ring_free_plans() {
+    for (ring_plan & p : g_plans) (void) hipFree(p.dev);
+    g_plans.clear();
+}
+
 // the schedule of a shape must exist before a stream capture (it allocates): called at context set-up
 bool fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu) {
     if (!(type == FQ_Q4_0 || type == FQ_Q4_1 || type == FQ_Q5_0 || type == FQ_Q5_1 || type == FQ_Q8_0)) return false;
     if (E % 32 || E > 8448 || FF % 32 || FF > (int64_t) 32 * 12 * n_cu) return false;
-    ring_schedule(type, (int) E, (int) FF, (int) qkv_rows, n_cu);
+    ring_schedule(type, (int) E, (int) FF, (int) qkv_rows, n_cu, true);
     return true;
 }
 
@@ -431,7 +437,8 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
     a.ln_w = g.seg[1].ln_w; a.ln_b = g.seg[1].ln_b; a.ln2_w = two_norms ? g.seg[0].ln_w : nullptr; a.ln2_b = two_norms ? g.seg[0].ln_b : nullptr; a.two_norms = two_norms ? 1 : 0;
     a.qkv_dst = g.seg[0].dst; a.ff_image = g.seg[1].dst_image; a.gelu_tab = g.gelu_table;
     if (a.FF > 32 * 12 * n_cu) return false;
-    a.sched = ring_schedule(type, a.E, a.FF, a.qkv_rows, n_cu);
+    a.sched = ring_schedule(type, a.E, a.FF, a.qkv_rows, n_cu, false);
+    if (!a.sched) return false;                                            // shape not prepared (fq_ring_prepare at context set-up): the caller launches k_gemv_ln
     a.epoch_word = g.epoch_word; a.n_past_ptr = g.n_past_ptr; a.rope_cs = g.rope_cs; a.rope_cur = g.rope_cur;
     a.err = err; a.dbg = g.dbg;
     static const int dbg = getenv("FQ_RING_DEBUG") ? atoi(getenv("FQ_RING_DEBUG")) : 0;

@@ -1,6 +1,7 @@
 // Host-side check of ggllm.cpp_amd/csrc/fq_units.h (the exact header the GEMV kernels compile): re-tile one ggml
 // row into planes, re-tile ggml activation blocks into the SoA layout, and sum the per-unit dots.
 #include "fq_units.h"
+#include "fq_kdot.h"
 #include <vector>
 #include <cstring>
 #include <cstdlib>
@@ -14,7 +15,34 @@ static float row_dot(const fq_weight & w, const fq_actcol & a, int64_t K) {
     return acc;
 }
 
-extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks) {
+// fq_kdot.h (the ring consumers' restatement of the k-quant unit dots) against fq_unit<TYPE>::dot, unit by unit: number of units whose f32
+// term differs in any bit (rows of whole columns only: K a multiple of the column's elements)
+template <int TYPE>
+static int kdot_mismatches(const fq_weight & w, const fq_actcol & a, int64_t K) {
+    typedef fq_kdot<TYPE> KD;
+    const fq_wrow r = fq_row<TYPE>(w, 0);
+    const int units = (int)(K / fq_unit<TYPE>::ELEMS), npass = units / 64;
+    constexpr int COLB = fq_lay<TYPE>::CB * fq_lay<TYPE>::TS;
+    int bad = 0;
+    for (int p = 0; p < npass; ++p)
+        for (int ju = 0; ju < 64; ++ju) {
+            const typename KD::lane_t L = KD::lane_init(ju);
+            const float got = KD::dot(KD::w_load(r.p0 + (size_t) p * COLB, L), KD::act_load(a, p, L), L);
+            const int u = 64 * p + ju;
+            const float exp = fq_unit<TYPE>::dot(fq_unit_load<TYPE>(r, u), a, u);
+            if (memcmp(&got, &exp, 4) != 0) ++bad;
+        }
+    return bad;
+}
+template <int TYPE> static float kdot_or_row(int mode, const fq_weight & w, const fq_actcol & a, int64_t K) {
+    if (mode == 1) { if constexpr (fq_kdot<TYPE>::ok) return (float) kdot_mismatches<TYPE>(w, a, K); else return -1.0f; }
+    return row_dot<TYPE>(w, a, K);
+}
+
+static float units_entry(int mode, int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks);
+extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks) { return units_entry(0, type, K, row, act_blocks); }
+extern "C" int units_kdot_mismatches(int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks) { return (int) units_entry(1, type, K, row, act_blocks); }
+static float units_entry(int mode, int type, int64_t K, const uint8_t * row, const uint8_t * act_blocks) {
     const fq_type_desc d = fq_desc(type);
     const int64_t nblk = K / d.blck;
     fq_weight w{}; w.type = type; w.K = K; w.M = 1; w.nblk = nblk;
@@ -51,11 +79,11 @@ extern "C" float units_row_dot(int type, int64_t K, const uint8_t * row, const u
     }
     fq_actcol a{ qsa, dd.data(), aux.data() };
     switch (type) {
-        case FQ_Q4_0: return row_dot<FQ_Q4_0>(w, a, K); case FQ_Q4_1: return row_dot<FQ_Q4_1>(w, a, K);
-        case FQ_Q5_0: return row_dot<FQ_Q5_0>(w, a, K); case FQ_Q5_1: return row_dot<FQ_Q5_1>(w, a, K);
-        case FQ_Q8_0: return row_dot<FQ_Q8_0>(w, a, K); case FQ_Q2_K: return row_dot<FQ_Q2_K>(w, a, K);
-        case FQ_Q3_K: return row_dot<FQ_Q3_K>(w, a, K); case FQ_Q4_K: return row_dot<FQ_Q4_K>(w, a, K);
-        case FQ_Q5_K: return row_dot<FQ_Q5_K>(w, a, K); case FQ_Q6_K: return row_dot<FQ_Q6_K>(w, a, K);
+        case FQ_Q4_0: return kdot_or_row<FQ_Q4_0>(mode, w, a, K); case FQ_Q4_1: return kdot_or_row<FQ_Q4_1>(mode, w, a, K);
+        case FQ_Q5_0: return kdot_or_row<FQ_Q5_0>(mode, w, a, K); case FQ_Q5_1: return kdot_or_row<FQ_Q5_1>(mode, w, a, K);
+        case FQ_Q8_0: return kdot_or_row<FQ_Q8_0>(mode, w, a, K); case FQ_Q2_K: return kdot_or_row<FQ_Q2_K>(mode, w, a, K);
+        case FQ_Q3_K: return kdot_or_row<FQ_Q3_K>(mode, w, a, K); case FQ_Q4_K: return kdot_or_row<FQ_Q4_K>(mode, w, a, K);
+        case FQ_Q5_K: return kdot_or_row<FQ_Q5_K>(mode, w, a, K); case FQ_Q6_K: return kdot_or_row<FQ_Q6_K>(mode, w, a, K);
     }
     abort();
 }

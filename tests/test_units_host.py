@@ -17,11 +17,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def harness():
     src = os.path.join(ROOT, "tests", "host", "units_harness.cpp")
     out = os.path.join(ROOT, "tests", "host", "libunits_host.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "ggllm.cpp_amd", "csrc"), "-o", out, src])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "ggllm.cpp_amd", "csrc"), "-o", out, src])
     L = C.CDLL(out)
     L.units_row_dot.restype = C.c_float
     L.units_row_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    L.units_kdot_mismatches.restype = C.c_int
+    L.units_kdot_mismatches.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     return L
+
+
+@pytest.mark.parametrize("t", ob.KQUANTS)
+@pytest.mark.parametrize("K", [4096, 8192, 32768])
+def test_ring_consumer_unit_dots_equal_the_generic_ones(oracle, harness, t, K):
+    """csrc/fq_kdot.h (lane-constant index math hoisted, activation slices pre-loaded, packed scale decode: what the ring consumers of
+    kernels_ringk.hip run) gives the SAME f32 term as fq_unit<TYPE>::dot for every unit of rows of whole columns"""
+    rng = np.random.default_rng(7 * K + t)
+    w = synth.quantized_matrix(oracle, t, 4, K, rng)
+    for r in range(4):
+        x = (rng.standard_normal(K) * (1.0 + 3.0 * r)).astype(np.float32)
+        act = oracle.quantize_act(ob.VEC_DOT[t], x)
+        row = np.ascontiguousarray(w[r])
+        assert harness.units_kdot_mismatches(t, K, row.ctypes.data, act.ctypes.data) == 0
 
 
 @pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
