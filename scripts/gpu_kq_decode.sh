@@ -12,7 +12,7 @@ mkdir -p $OUT
 B="--model 40b --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --steps 32 --warmup 4 --repeats 3"
 for q in $FMTS; do
   for ring in 1 0; do
-    v=$(FALCON_HIP_RING=$ring FALCON_HIP_RING_OUT=$ring timeout 600 python bench.py $B --quant $q 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f tok/s  %.3f ms  step_frac %.3f  launch_frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['step_frac'], d['roofline']['frac'] or 0))")
+    v=$(FALCON_HIP_RING=$ring timeout 600 python bench.py $B --quant $q 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f tok/s  %.3f ms  step_frac %.3f  launch_frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['step_frac'], d['roofline']['frac'] or 0))")
     echo "40b $q ring=$ring: $v" | tee -a $OUT/kq_decode.txt
   done
   if [ "${TRACE:-1}" = 1 ]; then

@@ -12,7 +12,7 @@ mkdir -p $OUT
 for q in $FMTS; do
   for ring in 1 0; do
     cd /tmp
-    FALCON_HIP_RING=$ring FALCON_HIP_RING_OUT=$ring timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_k -o trace -- python $R/bench.py --model 40b --quant $q --layers 8 --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --no-graph --steps 16 --warmup 2 --repeats 1 > $R/$OUT/prof_k.log 2>&1
+    FALCON_HIP_RING=$ring timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_k -o trace -- python $R/bench.py --model 40b --quant $q --layers 8 --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --no-graph --steps 16 --warmup 2 --repeats 1 > $R/$OUT/prof_k.log 2>&1
     cd $R
     db=$(find $OUT/prof_k -name "*results.db" | head -1)
     [ -n "$db" ] && python scripts/prof_summary.py $db $OUT/kern_${q}_ring$ring > /dev/null 2>&1 && echo "== $q ring=$ring" && grep -E "k_ring|k_gemv_ln|k_gemv_out|k_attn_decode|k_quantize" $OUT/kern_${q}_ring${ring}_kernel_stats.md | grep -v " x 1 " | head -6 | cut -c1-110

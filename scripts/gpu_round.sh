@@ -8,6 +8,8 @@
 #   b40          Falcon-40B Q4_K, all 60 blocks, one GPU: bench line + kernel trace -> <tag>/bench_40b_q4_k.json, <tag>/decode_40b_q4_k_kernel_stats.{csv,md}
 #   lockstep     kernel trace of 16 lock-step streams per weight pass    -> <tag>/lockstep_b16_kernel_stats.{csv,md}
 #   q4kpmc       counters of the Q4_K small-batch launches on Falcon-40B shapes (16 columns): VALU / matrix pipe, HBM fetch / write -> <tag>/q4k_pmc_mfma.json, <tag>/q4k_pmc_traffic.json
+#   kq           k-quant single-stream decode on Falcon-40B (60 blocks): tok/s per format, ring form on / off, + a kernel trace per format -> <tag>/kq_decode.txt, <tag>/decode_40b_<fmt>_kernel_stats.{csv,md}
+#   kqpmc        counters of the k-quant decode launches (8 blocks): VALU busy + HBM fetch / write per format -> <tag>/kq_<fmt>_pmc_{mfma,traffic}.json
 #   lockstep40   Falcon-40B Q4_K, 60 blocks: lock-step streams 4..128 per pass + kernel trace of 16 per pass (12 blocks) -> <tag>/lockstep_40b_q4_k.txt, <tag>/lockstep40_b16_kernel_stats.{csv,md}
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -82,6 +84,25 @@ fi
 if has lockstep40; then
   LOCKSTEP_MODEL=40b_q4_k timeout 600 python scripts/gpu_lockstep.py 1 2 4 8 12 16 32 48 64 80 128 2>&1 | grep "streams per pass" | tee $OUT/lockstep_40b_q4_k.txt
   LOCKSTEP_MODEL=40b_q4_k LOCKSTEP_LAYERS=12 trace lockstep40_b16 python $R/scripts/gpu_lockstep.py 16
+fi
+if has kq; then
+  TRACE=1 scripts/gpu_kq_decode.sh $TAG q4_k q2_k q3_k q5_k q6_k
+fi
+if has kqpmc; then
+  mkdir -p $OUT/pmc
+  KB="--model 40b --layers 8 --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --no-graph --steps 8 --warmup 2 --repeats 1"
+  for q in q4_k q2_k q3_k q5_k q6_k; do
+    cd /tmp
+    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc -o kq${q}mfma -- python $R/bench.py $KB --quant $q > $R/$OUT/pmc/kq${q}mfma.log 2>&1
+    for c in FETCH_SIZE WRITE_SIZE; do
+      n=kq${q}$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+      timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/pmc -o $n -- python $R/bench.py $KB --quant $q > $R/$OUT/pmc/$n.log 2>&1
+    done
+    cd $R
+    python scripts/pmc_mfma_summary.py $(find $OUT/pmc -name "kq${q}mfma*results.db" | head -1) $OUT/kq_${q}_pmc_mfma.json 2>&1 | grep -E "k_ring|k_gemv" | cut -c1-170
+    python scripts/pmc_summary.py $(find $OUT/pmc -name "kq${q}fetch*results.db" | head -1) $(find $OUT/pmc -name "kq${q}write*results.db" | head -1) $OUT/kq_${q}_pmc_traffic.json 2>&1 | grep -E "k_ring|k_gemv" | cut -c1-170
+    find $OUT/pmc -name "*.db" -delete
+  done
 fi
 if has q4kpmc; then
   mkdir -p $OUT/pmc
