@@ -889,6 +889,7 @@ extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
         // (polled, not slept on: the caller samples the moment the row is there, and a blocking wait's wake-up costs tens of microseconds of a ~1 ms step)
         hipStream_t st = fq_ctx().stream;
         for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) break; if (e != hipErrorNotReady) HIP_CHECK(e); }
+        c->sync_err_host = *(const unsigned *)(c->logits_pinned + c->m->hp.n_vocab);
         c->logits_pending = false;
         (void) report_sync_error(c, "eval");                        // sticky: falcon_hip_context_last_error / the next eval report it (this call cannot)
     }
@@ -917,11 +918,12 @@ extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int 
     hipStream_t st = hc.stream;
     if (c->logits_pending) {                                         // a row nobody asked for: its copy must land before the next one is enqueued into the same buffer
         HIP_CHECK(hipStreamSynchronize(st));
+        c->sync_err_host = *(const unsigned *)(c->logits_pinned + m->hp.n_vocab);
         c->logits_pending = false;
         if (report_sync_error(c, "eval")) return 3;
     }
     if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
-    if (!c->logits_pinned) HIP_CHECK(hipHostMalloc((void **) &c->logits_pinned, (size_t) m->hp.n_vocab * 4, hipHostMallocDefault));
+    if (!c->logits_pinned) HIP_CHECK(hipHostMalloc((void **) &c->logits_pinned, (size_t) m->hp.n_vocab * 4 + 64, hipHostMallocDefault));      // (+ the hand-off error word: a copy into pageable memory would make this call wait for the whole step)
     hipLaunchKernelGGL(k_set2_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past, (int *) c->tokens_dev, (int) token);
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
@@ -942,7 +944,7 @@ extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int 
     }
     c->keep_hidden = was_keep;
     HIP_CHECK(hipMemcpyAsync(c->logits_pinned, c->logits_dev, (size_t) m->hp.n_vocab * 4, hipMemcpyDeviceToHost, st));
-    fetch_sync_error(c, st);
+    HIP_CHECK(hipMemcpyAsync(c->logits_pinned + m->hp.n_vocab, c->sync_words + 1, 4, hipMemcpyDeviceToHost, st));
     c->logits_last = c->logits_pinned;
     c->logits_pending = true;
     return 0;

@@ -196,48 +196,62 @@ __device__ __forceinline__ void ring_kacts_load(const fq_actcol & col, int pass0
 #pragma unroll
     for (int p = 0; p < U; ++p) A.a[p] = fq_kdot<TYPE>::act_load(col, pass0 + p, L);
 }
-// the f32 terms of this lane's units in U consecutive passes (= columns) of one row; column 0 starts at ring offset pos0 (< RING)
+// this lane's weight units of U consecutive passes (= columns) of one row out of the ring; column 0 starts at ring offset pos0 (< RING)
+template <int TYPE, int RING, int U> struct ring_kw { typename fq_kdot<TYPE>::w_t w[U]; };
 template <int TYPE, int RING, int U>
-__device__ __forceinline__ void ring_kterms(const uint8_t * ring, unsigned pos0, const ring_kacts<TYPE, U> & A, const typename fq_kdot<TYPE>::lane_t & L, float (&t)[U]) {
-    typedef fq_kdot<TYPE> KD;
+__device__ __forceinline__ void ring_kload(const uint8_t * ring, unsigned pos0, const typename fq_kdot<TYPE>::lane_t & L, ring_kw<TYPE, RING, U> & W) {
     constexpr unsigned COLB = (unsigned)(fq_lay<TYPE>::CB * fq_lay<TYPE>::TS);
-    typename KD::w_t ww[U];
 #pragma unroll
     for (int p = 0; p < U; ++p) {
         unsigned cb = pos0 + (unsigned) p * COLB;                          // scalar; a column never wraps (the mirror)
         cb = cb >= (unsigned) RING ? cb - (unsigned) RING : cb;
-        ww[p] = KD::w_load((const uint8_t *) __builtin_assume_aligned(ring + cb, 16), L);
+        W.w[p] = fq_kdot<TYPE>::w_load((const uint8_t *) __builtin_assume_aligned(ring + cb, 16), L);
     }
+}
+// ... and their f32 terms
+template <int TYPE, int RING, int U>
+__device__ __forceinline__ void ring_kterms(const uint8_t * ring, unsigned pos0, const ring_kacts<TYPE, U> & A, const typename fq_kdot<TYPE>::lane_t & L, float (&t)[U]) {
+    ring_kw<TYPE, RING, U> W;
+    ring_kload<TYPE, RING, U>(ring, pos0, L, W);
 #pragma unroll
-    for (int p = 0; p < U; ++p) t[p] = KD::dot(ww[p], A.a[p], L);
+    for (int p = 0; p < U; ++p) t[p] = fq_kdot<TYPE>::dot(W.w[p], A.a[p], L);
 }
 // ring_rows for rows of exactly U passes, R consecutive rows per trip (runs dealt round-robin): per row the lane's U terms added in ascending order, the
 // wave butterfly -- ring_rows' bits. R = 2 for short rows (Q2_K / Q3_K: two columns): the trip's fixed costs (poll, butterfly, bookkeeping) are paid once per pair
-template <int TYPE, int RING, int U, int R, typename SINK>
+struct ring_no_hook { __device__ __forceinline__ void operator()() const {} };
+// once(): called once, after the consumer's first trip (work that must not sit in front of the first rows but has to be done well before the segment ends)
+template <int TYPE, int RING, int U, int R, typename SINK, typename ONCE = ring_no_hook>
 __device__ __forceinline__ void ring_rows_k(const uint8_t * ring, unsigned ctl, int c, int NC, unsigned seg_pos, unsigned padded, int nrows, unsigned rs,
-                                            const ring_kacts<TYPE, U> & A, const typename fq_kdot<TYPE>::lane_t & L, int lane, eng_wait & w, bool nodots, SINK && sink) {
+                                            const ring_kacts<TYPE, U> & A, const typename fq_kdot<TYPE>::lane_t & L, int lane, eng_wait & w, bool nodots, SINK && sink,
+                                            ONCE && once = ring_no_hook()) {
+    bool first_trip = true;
     constexpr unsigned ROWB = (unsigned)(U * fq_lay<TYPE>::CB * fq_lay<TYPE>::TS);
     if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, R * c < nrows ? seg_pos + (unsigned)(R * c) * rs : seg_pos + padded);
     for (int i = R * c; i < nrows; i += R * NC) {
         const int last = i + R - 1 < nrows ? i + R - 1 : nrows - 1;
         const unsigned row0 = seg_pos + (unsigned) i * rs, need = seg_pos + (unsigned) last * rs + ROWB;
         for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) < 0;) { if (!w.spin(spins, ENG_W_LAND, need, 0)) break; __builtin_amdgcn_s_sleep(1); }
+        // the trip's weight units into registers, then the ring space is handed back BEFORE the arithmetic (the LDS serves requests in order: the reads
+        // are ahead of the LOW store): the loader's look-ahead is what is left of the ring beyond the oldest row still needed -- held through dots,
+        // butterfly and epilogue, ten rows kept ~46 KiB of the 96 busy and the stream ran at the latency-bound 22 KB/us per CU
+        ring_kw<TYPE, RING, U> W[R];
+        const unsigned p0 = row0 % (unsigned) RING;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rs;          // (a run's second row may not exist: the first is dotted twice, the copy dropped)
+            q = q >= (unsigned) RING ? q - (unsigned) RING : q;
+            ring_kload<TYPE, RING, U>(ring, q, L, W[r]);
+        }
+        const int nx_ = i + R * NC;
+        if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rs : seg_pos + padded);
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
         if (!nodots) {
-            float t[R][U];
-            const unsigned p0 = row0 % (unsigned) RING;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rs;      // (a run's second row may not exist: the first is dotted twice, the copy dropped)
-                q = q >= (unsigned) RING ? q - (unsigned) RING : q;
-                ring_kterms<TYPE, RING, U>(ring, q, A, L, t[r]);
-            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int p = 0; p < U; ++p) acc[r] += t[r][p];
+                for (int p = 0; p < U; ++p) acc[r] += fq_kdot<TYPE>::dot(W[r].w[p], A.a[p], L);
             }
         }
         float v[R];
@@ -245,9 +259,9 @@ __device__ __forceinline__ void ring_rows_k(const uint8_t * ring, unsigned ctl, 
         for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[r]);
 #pragma unroll
         for (int r = 0; r < R; ++r) if (i + r <= last) sink(i + r, v[r]);
-        const int nx_ = i + R * NC;
-        if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rs : seg_pos + padded);
+        if (first_trip) { first_trip = false; once(); }
     }
+    if (first_trip) once();
 }
 
 }   // namespace

@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
     // ---- the residual row -> LDS (chunks of 1024 values, one per helper wave, each with its f64 partial sum) -> statistics -> Q8_K image(s)
     // (the one-pass LayerNorm of kernels_ring.hip: ggml.c:10577-10591 with the sums in f64)
     ln_row_regs<NLN> wr, br, w2r, b2r;
+    float4 xv[NLN];                                                        // the lane's elements of the row: x - mean, later (x - mean) * scale
     {
         unsigned own = 0;
         float v[16]; int kown = -1;
@@ -139,7 +140,6 @@ __global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
         w.until(ctl + eng_ctl::LN_MEAN, 1u, ENG_W_STAT);
         if (h <= 1) RINGK_T(1 + h, 1);
         const float mean = ldsf_ld(eng_ctl::STAT);
-        float4 xv[NLN];
         double s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < NLN; ++k) {
@@ -169,36 +169,63 @@ __global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
         w.until(ctl + eng_ctl::LN_STAT, 1u, ENG_W_STAT);
         const float scale = ldsf_ld(eng_ctl::STAT + 4);
         // a helper wave holds whole super-blocks: float4 number q4 = k * 704 + 64 h + lane -> super-block k * 11 + h, elements 4 lane .. 4 lane + 3.
-        // Both norms of a two-norm block in one pass over the row (their weights were requested before the row: a dependent load here costs ~2 us with
-        // the chip streaming): the two quantizers of a super-block are independent instruction streams the scheduler interleaves
-        const act_image_ptr o1 = act_image_at(img_e, ACT, E), o2 = act_image_at(img_e2, ACT, E);
-        float4 qv[2 * NLN]; int64_t qsb[2 * NLN]; act_image_ptr qo[2 * NLN];
+        // Only the image the FIRST rows of the stream need (Wup's) is written here; the attention norm's image of a two-norm block -- needed once the
+        // Wqkv rows arrive, the last fifth of the stream -- is written by norm2_image() below, after the consumers have started freeing the ring (the
+        // ring holds 3.8 us of stream: with both images in the prologue it filled up and the stream stalled for ~2 us)
 #pragma unroll
-        for (int k = 0; k < NLN; ++k) {
-            const int q4 = k * KHT + ht;
-            const bool live = (q4 >> 6) < (E >> 8);                        // wave-uniform
-            float4 t = xv[k];
-            t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
-            const float4 ww = wr.t[k], bb = br.t[k];
-            float4 u = t;
-            u.x = u.x * ww.x + bb.x; u.y = u.y * ww.y + bb.y; u.z = u.z * ww.z + bb.z; u.w = u.w * ww.w + bb.w;
-            qv[k] = u; qsb[k] = live ? (q4 >> 6) : -1; qo[k] = o1;
-            const float4 w2 = w2r.t[k], b2 = b2r.t[k];
-            t.x = t.x * w2.x + b2.x; t.y = t.y * w2.y + b2.y; t.z = t.z * w2.z + b2.z; t.w = t.w * w2.w + b2.w;
-            qv[NLN + k] = t; qsb[NLN + k] = live && a.two_norms ? (q4 >> 6) : -1; qo[NLN + k] = o2;
-        }
-        if (a.two_norms) quant_q8K_wave_n<2 * NLN>(qv, lane, qsb, qo);
-        else {
-            const float4 (&q1)[NLN] = *(const float4 (*)[NLN]) &qv[0];
-            const int64_t (&s1)[NLN] = *(const int64_t (*)[NLN]) &qsb[0];
-            const act_image_ptr (&p1)[NLN] = *(const act_image_ptr (*)[NLN]) &qo[0];
-            quant_q8K_wave_n<NLN>(q1, lane, s1, p1);
+        for (int k = 0; k < NLN; ++k) { float4 t = xv[k]; t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale; xv[k] = t; }
+        {
+            const act_image_ptr o1 = act_image_at(img_e, ACT, E);
+            float4 qv[NLN]; int64_t qsb[NLN]; act_image_ptr qo[NLN];
+#pragma unroll
+            for (int k = 0; k < NLN; ++k) {
+                const int q4 = k * KHT + ht;
+                const float4 ww = wr.t[k], bb = br.t[k];
+                float4 u = xv[k];
+                u.x = u.x * ww.x + bb.x; u.y = u.y * ww.y + bb.y; u.z = u.z * ww.z + bb.z; u.w = u.w * ww.w + bb.w;
+                qv[k] = u; qsb[k] = (q4 >> 6) < (E >> 8) ? (q4 >> 6) : -1; qo[k] = o1;      // (wave-uniform)
+            }
+            quant_q8K_wave_n<NLN>(qv, lane, qsb, qo);
         }
         lds_drain();
         if (lane == 0) lds_add(ctl + eng_ctl::IMG_DONE, 1u);
         w.until(ctl + eng_ctl::IMG_DONE, (unsigned) KNH, ENG_W_IMG);
         if (h <= 1) RINGK_T(1 + h, 2);
+        if (isG && a.two_norms) {                                          // the epilogue wave has nothing to do until the first 32-row groups are complete
+            const act_image_ptr o2 = act_image_at(img_e2, ACT, E);
+            float4 qv[NLN]; int64_t qsb[NLN]; act_image_ptr qo[NLN];
+#pragma unroll
+            for (int k = 0; k < NLN; ++k) {
+                const int q4 = k * KHT + ht;
+                const float4 w2 = w2r.t[k], b2 = b2r.t[k];
+                float4 u = xv[k];
+                u.x = u.x * w2.x + b2.x; u.y = u.y * w2.y + b2.y; u.z = u.z * w2.z + b2.z; u.w = u.w * w2.w + b2.w;
+                qv[k] = u; qsb[k] = (q4 >> 6) < (E >> 8) ? (q4 >> 6) : -1; qo[k] = o2;
+            }
+            quant_q8K_wave_n<NLN>(qv, lane, qsb, qo);
+            lds_drain();
+            if (lane == 0) lds_add(ctl + eng_ctl::FG_DONE, 1u);
+        }
     }
+    // a consumer's share of the attention norm's image: written after its first trip of Wup rows (the ring's backlog from the prologue is being worked off by
+    // the other consumers then), so that nobody waits for it when the Wqkv rows arrive; norm2_wait: all eleven shares are there
+    auto norm2_wait = [&]() { if (a.two_norms) w.until(ctl + eng_ctl::FG_DONE, (unsigned) KNH, ENG_W_IMG); };
+    auto norm2_image = [&]() {
+        if (!a.two_norms) return;
+        const act_image_ptr o2 = act_image_at(img_e2, ACT, E);
+        float4 qv[NLN]; int64_t qsb[NLN]; act_image_ptr qo[NLN];
+#pragma unroll
+        for (int k = 0; k < NLN; ++k) {
+            const int q4 = k * KHT + ht;
+            const float4 w2 = w2r.t[k], b2 = b2r.t[k];
+            float4 u = xv[k];
+            u.x = u.x * w2.x + b2.x; u.y = u.y * w2.y + b2.y; u.z = u.z * w2.z + b2.z; u.w = u.w * w2.w + b2.w;
+            qv[k] = u; qsb[k] = (q4 >> 6) < (E >> 8) ? (q4 >> 6) : -1; qo[k] = o2;
+        }
+        quant_q8K_wave_n<NLN>(qv, lane, qsb, qo);
+        lds_drain();
+        if (lane == 0) lds_add(ctl + eng_ctl::FG_DONE, 1u);
+    };
 
     const fq_actcol col_e  = { (const int8_t *) img_e,  (const float *)(img_e + fq_act_d_off(ACT, E)),  (const void *)(img_e + fq_act_aux_off(ACT, E)) };
     const fq_actcol col_e2 = { (const int8_t *) img_e2, (const float *)(img_e2 + fq_act_d_off(ACT, E)), (const void *)(img_e2 + fq_act_aux_off(ACT, E)) };
@@ -233,8 +260,9 @@ __global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
         ring_kacts<TYPE, KU> A;
         ring_kacts_load<TYPE, KU>(col_e, 0, L, A);
         constexpr int KR = KU == 2 ? 2 : 1;                                 // rows per trip
-        ring_rows_k<TYPE, RING, KU, KR>(ring, ctl, c, KNC, 0u, pA2, nA2, rsE, A, L, lane, w, nodots, sink_up);
+        ring_rows_k<TYPE, RING, KU, KR>(ring, ctl, c, KNC, 0u, pA2, nA2, rsE, A, L, lane, w, nodots, sink_up, norm2_image);
         if (c == 0 || c == 9) RINGK_T(c == 0 ? 2 : 3, 3);
+        norm2_wait();
         if (a.two_norms) ring_kacts_load<TYPE, KU>(col_e2, 0, L, A);
         ring_rows_k<TYPE, RING, KU, KR>(ring, ctl, c, KNC, pA2, pA1, nA1, rsE, A, L, lane, w, nodots, sink_qkv);
         if (c == 0 || c == 9) RINGK_T(c == 0 ? 2 : 3, 4);
@@ -244,6 +272,8 @@ __global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
     if (r2) ring_rows<TYPE, RING, 2, 2>(ring, ctl, c, KNC, 0u, pA2, nA2, rsE, nblkE, col_e, lane, w, nodots, sink_up);
     else    ring_rows<TYPE, RING, 1, 4>(ring, ctl, c, KNC, 0u, pA2, nA2, rsE, nblkE, col_e, lane, w, nodots, sink_up);
     if (c == 0 || c == 9) RINGK_T(c == 0 ? 2 : 3, 3);
+    norm2_image();
+    norm2_wait();
     if (r2) ring_rows<TYPE, RING, 2, 2>(ring, ctl, c, KNC, pA2, pA1, nA1, rsE, nblkE, col_q, lane, w, nodots, sink_qkv);
     else    ring_rows<TYPE, RING, 1, 4>(ring, ctl, c, KNC, pA2, pA1, nA1, rsE, nblkE, col_q, lane, w, nodots, sink_qkv);
     if (c == 0 || c == 9) RINGK_T(c == 0 ? 2 : 3, 4);
