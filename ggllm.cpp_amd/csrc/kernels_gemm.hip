@@ -33,12 +33,12 @@
 #ifndef GQ_PACKED
 #define GQ_PACKED 0
 #endif
-// GQ_FMA=1 (experiment, changes the bits): acc = fma(dw * dx, (float) c, acc), the form the reference's AVX2 builds accumulate in --
-// 3 instead of 4 VALU operations per result. Measured: 128-token prompt 9.14 ms against 9.43, 2048 tokens 106.3 against 111.6
-// (3-5 %): the kernel is bound by its per-stage hand-offs (a barrier per 128 of K with one MFMA of work per wave), not by the
-// scaling's instruction count. OFF (the default order keeps the reference's two roundings per term).
+// GQ_FMA=1 (round 4: the default order of the legacy formats' K-split sums): acc = fma(dw * dx, (float) c, acc), the form the reference's AVX2
+// builds accumulate in (ggml.c:2415-2438) -- 3 instead of 4 VALU operations per result; measured 3-5 % of a prompt. The sequential sum
+// (S == 1, ggml_hip_gemm_sequential / reference order) keeps the scalar build's two roundings per term and its bit-identity with the reference.
+// GQ_FMA=0 at compile time restores the unfused K-split sums (the oracle then needs ORC_SPLIT_FMA=0 too).
 #ifndef GQ_FMA
-#define GQ_FMA 0
+#define GQ_FMA 1
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i  __attribute__((ext_vector_type(4)));
@@ -530,15 +530,19 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         else { const v2f sx = { sxv[i], sxv[i + 1] };           t = (dw2 * dx) * ci + mw2 * sx; }          // ggml.c:2731, 3227; k-quants
                         acc2[rb][i >> 1] = acc2[rb][i >> 1] + t;
                     }
-#elif GQ_FMA
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        const float ci = (float) c[i];
-                        float a = __builtin_fmaf(dw * dxv[i], ci, ACC(rb, i));
-                        if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
-                        ACC(rb, i) = a;
-                    }
 #else
+                    if constexpr (GQ_FMA && S > 1 && fq_desc(TYPE).blck == 32) {
+                        // the K-split partial sums of the legacy formats (the DEFAULT order) accumulate as the reference's AVX2 build does
+                        // (acc = _mm256_fmadd_ps(d, q, acc), ggml.c:2415-2438): 3 instead of 4 vector operations per result; the oracle's split orders
+                        // restate it with fmaf. S == 1 (ggml_hip_gemm_sequential: the reference ORDER) keeps the scalar build's two roundings per term
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) {
+                            const float ci = (float) c[i];
+                            float a = __builtin_fmaf(dw * dxv[i], ci, ACC(rb, i));
+                            if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
+                            ACC(rb, i) = a;
+                        }
+                    } else {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         const float ci = (float) c[i];
@@ -548,6 +552,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         else if constexpr (!HAS_MIN)                            t = (dw * dxv[i]) * ci;                    // Q3_K, Q6_K
                         else                                                    t = (dw * dxv[i]) * ci + mw * sxv[i];      // ggml.c:2731, 3227; k-quants
                         ACC(rb, i) = ACC(rb, i) + t;
+                    }
                     }
 #endif
                 }

@@ -27,6 +27,9 @@
 
 
 #include "fq_skinny_dev.h"
+#ifndef SK_FMA
+#define SK_FMA 1                                                           // the legacy formats' K-split sums in the fused form (kernels_gemm.hip GQ_FMA): must match the tile GEMM
+#endif
 
 namespace {
 
@@ -237,11 +240,17 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny(fq_weight w, f
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ci = (float) c[r];
-                float t;
-                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
-                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
-                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
-                acc[r] = acc[r] + t;
+                if constexpr (SK_FMA && S > 1) {                                        // K-split partial sums: the AVX2 build's fused form, as k_gemm_q<S > 1> (kernels_gemm.hip GQ_FMA)
+                    float a_ = __builtin_fmaf(dw * dxv[r], ci, acc[r]);
+                    if constexpr (F::HAS_MIN) a_ = __builtin_fmaf(mw, sxv[r], a_);
+                    acc[r] = a_;
+                } else {
+                    float t;
+                    if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                    else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                    else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                    acc[r] = acc[r] + t;
+                }
             }
         };
         if (dbg & 16) continue;
@@ -515,11 +524,17 @@ __global__ void __launch_bounds__(64 * (2 + 2 * S)) k_gemm_skinny_res(fq_weight 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ci = (float) c[r];
-                float t;
-                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
-                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
-                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
-                acc[r] = acc[r] + t;
+                if constexpr (SK_FMA && S > 1) {                                        // K-split partial sums: the AVX2 build's fused form, as k_gemm_q<S > 1> (kernels_gemm.hip GQ_FMA)
+                    float a_ = __builtin_fmaf(dw * dxv[r], ci, acc[r]);
+                    if constexpr (F::HAS_MIN) a_ = __builtin_fmaf(mw, sxv[r], a_);
+                    acc[r] = a_;
+                } else {
+                    float t;
+                    if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                    else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                    else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                    acc[r] = acc[r] + t;
+                }
             }
         };
         if (!(dbg & 16)) {
@@ -734,11 +749,17 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ci = (float) c[r];
-                float t;
-                if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
-                else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
-                else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
-                acc[r] = acc[r] + t;
+                if constexpr (SK_FMA) {                                        // K-split partial sums: the AVX2 build's fused form, as k_gemm_q<S > 1> (kernels_gemm.hip GQ_FMA)
+                    float a_ = __builtin_fmaf(dw * dxv[r], ci, acc[r]);
+                    if constexpr (F::HAS_MIN) a_ = __builtin_fmaf(mw, sxv[r], a_);
+                    acc[r] = a_;
+                } else {
+                    float t;
+                    if constexpr (TYPE == FQ_Q4_0)      t = (ci * dw) * dxv[r];                                      // ggml.c:2606
+                    else if constexpr (!F::HAS_MIN)     t = (dw * dxv[r]) * ci;                                      // ggml.c:2972, 3325
+                    else                                t = (dw * dxv[r]) * ci + mw * sxv[r];                       // ggml.c:2731, 3227
+                    acc[r] = acc[r] + t;
+                }
             }
         };
         if (njs == 8) {

@@ -538,6 +538,35 @@ static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t
     return sumf;
 }
 
+/* one legacy block against its Q8_0 / Q8_1 block: d_w * d_x (one f32 product), the exact integer sum (offsets folded in: Q4_0 / Q5_0), and for Q4_1 / Q5_1 the
+ * pair (m_w, s_x) -- the operands of the FMA form above */
+static void orc_legacy_block_parts(int wtype, const uint8_t * w, const uint8_t * a, float * dd, int * sumi_out, float * m, float * sx) {
+    const int at = orc_vec_dot_type(wtype);
+    const int8_t * q8 = (const int8_t *)(a + (at == ORC_Q8_0 ? 2 : 8));
+    int sumi = 0;
+    switch (wtype) {
+        case ORC_Q4_0:
+            for (int j = 0; j < 16; ++j) sumi += ((w[2 + j] & 15) - 8) * q8[j] + ((w[2 + j] >> 4) - 8) * q8[j + 16];
+            *dd = rd_f16(w) * rd_f16(a); break;
+        case ORC_Q4_1:
+            for (int j = 0; j < 16; ++j) sumi += (w[4 + j] & 15) * q8[j] + (w[4 + j] >> 4) * q8[j + 16];
+            *dd = rd_f16(w) * rd_f32(a); *m = rd_f16(w + 2); *sx = rd_f32(a + 4); break;
+        case ORC_Q5_0: { const uint32_t qh = rd_u32(w + 2);
+            for (int j = 0; j < 16; ++j)
+                sumi += (((w[6 + j] & 15) | (q5_bit(qh, j) << 4)) - 16) * q8[j] + (((w[6 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) - 16) * q8[j + 16];
+            *dd = rd_f16(w) * rd_f16(a); } break;
+        case ORC_Q5_1: { const uint32_t qh = rd_u32(w + 4);
+            for (int j = 0; j < 16; ++j)
+                sumi += ((w[8 + j] & 15) | (q5_bit(qh, j) << 4)) * q8[j] + ((w[8 + j] >> 4) | (q5_bit(qh, j + 16) << 4)) * q8[j + 16];
+            *dd = rd_f16(w) * rd_f32(a); *m = rd_f16(w + 2); *sx = rd_f32(a + 4); } break;
+        case ORC_Q8_0:
+            for (int j = 0; j < 32; ++j) sumi += ((const int8_t *) w)[2 + j] * q8[j];
+            *dd = rd_f16(w) * rd_f16(a); break;
+        default: abort();
+    }
+    *sumi_out = sumi;
+}
+
 float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     const uint8_t * w = (const uint8_t *) wv;
     const uint8_t * a = (const uint8_t *) av;
@@ -557,8 +586,21 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
         const int at = orc_vec_dot_type(wtype);
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int64_t i = 0; i < n / 32; ++i) {
-            const float one = orc_vec_dot(wtype, 32, w + i * orc_type_size(wtype), a + i * orc_type_size(at));
-            part[i & (g_split - 1)] = part[i & (g_split - 1)] + one;
+            const uint8_t * wb = w + i * orc_type_size(wtype), * ab = a + i * orc_type_size(at);
+            float * P = &part[i & (g_split - 1)];
+            if (g_split > 1) {
+                /* the K-split partial sums accumulate as the reference's AVX2 build does (ggml.c:2415-2438: acc = _mm256_fmadd_ps(d, q, acc)): one fused
+                 * multiply-add of (d_w * d_x) and the block's integer sum -- and one of (m_w, s_x) for the formats with a minimum -- per block
+                 * (kernels_gemm.hip / kernels_gemm_skinny.hip, S > 1). The single sum (g_split == 1: the reference ORDER) keeps the scalar build's
+                 * two roundings per term. */
+                float dd, ms_m = 0.0f, ms_s = 0.0f; int sumi;
+                orc_legacy_block_parts(wtype, wb, ab, &dd, &sumi, &ms_m, &ms_s);
+                *P = fmaf(dd, (float) sumi, *P);
+                if (wtype == ORC_Q4_1 || wtype == ORC_Q5_1) *P = fmaf(ms_m, ms_s, *P);
+            } else {
+                const float one = orc_vec_dot(wtype, 32, wb, ab);
+                *P = *P + one;
+            }
         }
         return ((part[0] + part[1]) + part[2]) + part[3];
     }
