@@ -99,7 +99,7 @@ struct falcon_hip_context {
     int step_next_n_past = -1;
     bool stage_graph = true;                   // FALCON_HIP_STAGE_GRAPH=0: plain launches
     bool ring_ln = false;                      // k_gemv_ln's launches in the ring form (kernels_ring.hip; k-quants: kernels_ringk.hip); FALCON_HIP_RING=0: never
-    bool ring_out = false;                     // the unmerged k_gemv_out launches in the ring form (kernels_ringk.hip); FALCON_HIP_RING_OUT=0: never
+    bool ring_out = false;                     // the unmerged k_gemv_out launches in the ring form (kernels_ringk.hip): FALCON_HIP_RING_OUT=1 always, 0 never, unset: where it measured faster (ring_out_auto)
     // batched evaluation replayed from hipGraphs (FALCON_HIP_PREFILL_GRAPH=1; default: plain launches): the ~320 launches and 96 cross-stream joins of a
     // prompt batch are then scheduled by the graph instead of the host (the joins cost ~12 us of idle device each as stream events: 11 % of a
     // 128-token Falcon-7B prompt). Keyed by (tokens, keys, mode signature, keep_hidden); the position and the token ids are read from device memory.
@@ -267,6 +267,16 @@ static bool ring_prepare_any(const falcon_hip_model * m) {
     return fq_ring_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu) || fq_ringk_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu);
 }
 
+// the ring form of the unmerged output mat-vec launch (k_ring_out, one wave per row in chunks): measured on Falcon-40B against k_gemv_out with the fast k-quant
+// dots -- Q2_K 234 -> 246 tok/s, Q3_K 188.5 -> 192, but Q4_K 198 -> 181, Q5_K 157 -> 146, Q6_K 153 -> 142: on by default for the two formats
+// with 64-element units only
+static bool ring_out_auto(const falcon_hip_model * m) {
+    if (const char * e = getenv("FALCON_HIP_RING_OUT")) return atoi(e) != 0;
+    if (m->layers.empty()) return false;
+    const int t = m->layers[0].down.type;
+    return t == FQ_Q2_K || t == FQ_Q3_K;
+}
+
 static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int n_batch, int rope_n_ctx, int n_seq) {
     const falcon_hip_hparams & hp = m->hp;
     for (size_t i = 0; i < m->layers.size(); ++i) {
@@ -328,7 +338,7 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     c->ring_ln = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);      // (default on: a context starts in mode 2)
     if (const char * e = getenv("FALCON_HIP_PREFILL_GRAPH")) c->prefill_graph = atoi(e) != 0;
     if (c->ring_ln && nl > 0) c->ring_ln = ring_prepare_any(m);
-    c->ring_out = getenv("FALCON_HIP_RING_OUT") && atoi(getenv("FALCON_HIP_RING_OUT")) != 0;      // (opt-in: measured slower than k_gemv_out with the fast k-quant dots)
+    c->ring_out = ring_out_auto(m);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
     if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
@@ -388,8 +398,7 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     // Falcon-7B Q4_0; legacy formats only, other models keep k_gemv_ln)
     static const bool ring_default = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);
     c->ring_ln = (mode == 5 || (mode == 2 && ring_default)) && !c->m->layers.empty() && ring_prepare_any(c->m);
-    static const bool ring_out_default = getenv("FALCON_HIP_RING_OUT") && atoi(getenv("FALCON_HIP_RING_OUT")) != 0;
-    c->ring_out = (mode == 5 || (mode == 2 && ring_out_default));
+    c->ring_out = mode == 5 || (mode == 2 && ring_out_auto(c->m));
 }
 // 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)
 extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c);

@@ -218,6 +218,53 @@ __device__ __forceinline__ void ring_kterms(const uint8_t * ring, unsigned pos0,
 }
 // ring_rows for rows of exactly U passes, R consecutive rows per trip (runs dealt round-robin): per row the lane's U terms added in ascending order, the
 // wave butterfly -- ring_rows' bits. R = 2 for short rows (Q2_K / Q3_K: two columns): the trip's fixed costs (poll, butterfly, bookkeeping) are paid once per pair
+// LONG rows (Wdown: 8 or 16 passes) by one wave per row, U passes per CHUNK: the chunk's weight units go into registers and its ring space is handed back at
+// once, so a row occupies the ring only while it is landed-but-not-yet-loaded -- eleven waves on eleven consecutive 18 KiB rows then need a fraction of the
+// ring instead of twice its size (the first k_ring_out held every row until its dot product was done: five consumers had data, 69 us). The activation slices
+// come out of the image in LDS (lane-constant offsets, fq_kdot.h); per lane the passes are added in ascending order, then the wave butterfly: ring_rows' bits.
+template <int TYPE, int RING, int U, typename SINK>
+__device__ __forceinline__ void ring_rows_kc(const uint8_t * ring, unsigned ctl, int c, int NC, unsigned seg_pos, unsigned padded, int nrows, unsigned rs, int npass,
+                                             const fq_actcol & col, const typename fq_kdot<TYPE>::lane_t & L, int lane, eng_wait & w, bool nodots, SINK && sink) {
+    constexpr unsigned COLB = (unsigned)(fq_lay<TYPE>::CB * fq_lay<TYPE>::TS);
+    if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, c < nrows ? seg_pos + (unsigned) c * rs : seg_pos + padded);
+    if (c >= nrows) return;
+    // the wave's chunks as one sequence (row i = c, c + NC, ..; chunk ch = 0, U, .. of each): chunk q + 1 is fetched into a second register set BEFORE
+    // chunk q is dotted when it has landed by then (else after), so a landed chunk waits in the ring for a free wave, not for its predecessor's arithmetic
+    auto chunk_pos = [&](int i, int ch) { return seg_pos + (unsigned) i * rs + (unsigned) ch * COLB; };
+    auto landed = [&](unsigned need) { return (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) >= 0; };
+    auto wait_landed = [&](unsigned need) { for (unsigned spins = 0; !landed(need);) { if (!w.spin(spins, ENG_W_LAND, need, 0)) break; __builtin_amdgcn_s_sleep(1); } };
+    // after chunk (i, ch) sits in registers this wave needs nothing below the chunk that follows it
+    auto release_after = [&](int i, int ch) {
+        unsigned nxt;
+        if (ch + U < npass) nxt = chunk_pos(i, ch + U);
+        else nxt = i + NC < nrows ? chunk_pos(i + NC, 0) : seg_pos + padded;
+        if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nxt);            // (behind the reads: the LDS serves a wave's requests in order)
+    };
+    ring_kw<TYPE, RING, U> Wa, Wb;
+    int i = c, ch = 0;
+    wait_landed(chunk_pos(i, ch) + (unsigned) U * COLB);
+    ring_kload<TYPE, RING, U>(ring, chunk_pos(i, ch) % (unsigned) RING, L, Wa);
+    release_after(i, ch);
+    float acc = 0.0f;
+    for (;;) {
+        // the chunk after (i, ch)
+        int ni = i, nch = ch + U;
+        if (nch >= npass) { ni = i + NC; nch = 0; }
+        const bool more = ni < nrows;
+        const unsigned npos = more ? chunk_pos(ni, nch) : 0u;
+        bool fetched = false;
+        if (more && landed(npos + (unsigned) U * COLB)) { ring_kload<TYPE, RING, U>(ring, npos % (unsigned) RING, L, Wb); release_after(ni, nch); fetched = true; }
+        if (!nodots) {
+#pragma unroll
+            for (int p = 0; p < U; ++p) acc += fq_kdot<TYPE>::dot(Wa.w[p], fq_kdot<TYPE>::act_load(col, ch + p, L), L);
+        }
+        if (ch + U >= npass) { sink(i, wave_sum(acc)); acc = 0.0f; }
+        if (!more) break;
+        if (!fetched) { wait_landed(npos + (unsigned) U * COLB); ring_kload<TYPE, RING, U>(ring, npos % (unsigned) RING, L, Wb); release_after(ni, nch); }
+        Wa = Wb; i = ni; ch = nch;
+    }
+}
+
 struct ring_no_hook { __device__ __forceinline__ void operator()() const {} };
 // once(): called once, after the consumer's first trip (work that must not sit in front of the first rows but has to be done well before the segment ends)
 template <int TYPE, int RING, int U, int R, typename SINK, typename ONCE = ring_no_hook>

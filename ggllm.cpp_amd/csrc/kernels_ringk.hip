@@ -376,6 +376,19 @@ __global__ void __launch_bounds__(KNT) k_ring_out(fq_ring_out_args a) {
     // row i of both segments belongs to the same wave (i == h mod 11): Wdown's dot waits in LDS for Wo's
     auto sink_d = [&](int i, float v) { if (lane == 0) ldsf_st(eng_ctl::OUTB + 4 * i, v); };
     auto sink_o = [&](int i, float v) { if (lane == 0) a.dst[r0 + i] = (ldsf_ld(eng_ctl::OUTB + 4 * i) + v) + ldsf_ld(eng_ctl::XRES + 4 * i); };      // libfalcon.cpp:2399-2400
+    if constexpr (fq_kdot<TYPE>::ok) {
+        // k-quants, rows of whole columns: the fast unit dots, a row in chunks of KU passes whose ring space is handed back as soon as they sit in registers
+        constexpr int KU = fq_unit<TYPE>::ELEMS == 64 ? 2 : 4;
+        constexpr int CBk = fq_lay<TYPE>::CB;
+        if (a.nblkE % (KU * CBk) == 0 && a.nblkF % (KU * CBk) == 0 && !(a.debug_mode & 32)) {
+            const typename fq_kdot<TYPE>::lane_t L = fq_kdot<TYPE>::lane_init(lane);
+            ring_rows_kc<TYPE, RING, KU>(ring, ctl, h, NC, 0u, pD, nrows, rsF, a.nblkF / CBk, col_ff, L, lane, w, nodots, sink_d);
+            if (h <= 1) RINGK_T(1 + h, 3);
+            ring_rows_kc<TYPE, RING, KU>(ring, ctl, h, NC, pD, pO, nrows, rsE, a.nblkE / CBk, col_att, L, lane, w, nodots, sink_o);
+            if (h <= 1) RINGK_T(1 + h, 4);
+            return;
+        }
+    }
     ring_rows<TYPE, RING, 1, 4>(ring, ctl, h, NC, 0u, pD, nrows, rsF, a.nblkF, col_ff, lane, w, nodots, sink_d);
     if (h <= 1) RINGK_T(1 + h, 3);
     ring_rows<TYPE, RING, 1, 4>(ring, ctl, h, NC, pD, pO, nrows, rsE, a.nblkE, col_att, lane, w, nodots, sink_o);
@@ -638,7 +651,7 @@ bool fq_launch_ring_out(const fq_gemv_out_args & g, unsigned * err, int n_cu, hi
     static const int dbg = getenv("FQ_RING_DEBUG") ? atoi(getenv("FQ_RING_DEBUG")) : 0;
     a.debug_mode = dbg;
     // k-quants at widths of whole columns: the systolic form (k_ring_out_sys)
-    static const bool sys_on = !(getenv("FQ_RING_OUT_SYS") && atoi(getenv("FQ_RING_OUT_SYS")) == 0);
+    static const bool sys_on = getenv("FQ_RING_OUT_SYS") && atoi(getenv("FQ_RING_OUT_SYS")) != 0;      // (opt-in: measured slower than the row-chunk form)
     if (sys_on && act == FQ_Q8_K) {
         const int cb = 1024 / fq_desc(type).plane[0].bytes, ku = fq_desc(type).unit_elems == 64 ? 2 : 4;
         const int sd = (int)(wd.nblk / (ku * cb)), S = sd + 1;

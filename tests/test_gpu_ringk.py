@@ -102,3 +102,44 @@ def test_ringk_against_the_oracle_at_40b_width(oracle):
         oracle.lib.orc_set_sum_order(0)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+_SYS_SCRIPT = r"""
+import sys, numpy as np
+sys.path[:0] = [%(root)r, %(tests)r]
+import ggllm_cpp_amd as g
+import synth
+from oracle import binding as ob
+g.init(0)
+hp = dict(synth.HP_40B); hp["n_layer"] = 2; hp["n_vocab"] = 4096
+t = int(sys.argv[1])
+w = synth.make_model_fast(hp, t, seed=5)
+toks = synth.tokens(12, hp["n_vocab"], seed=9)
+res = {}
+for mode in (1, 5):
+    m = g.FalconModel(w, n_ctx=64, n_batch=16)
+    m.set_fused(mode)
+    m.eval(toks, 0)
+    lg, hid = m.eval(toks[-1:], 12, want_hidden=True)
+    dev = m.decode_greedy(int(lg[0].argmax()), 13, 16, use_graph=True)
+    assert m.sync_error() == 0
+    res[mode] = (lg, hid, dev)
+    m.free()
+for a, b in zip(res[1], res[5]):
+    assert np.array_equal(a, b)
+print("systolic ok")
+"""
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q2_K])
+def test_systolic_output_form_is_bit_identical(tmp_path, t):
+    """k_ring_out_sys (the systolic chain of consumers, opt-in: FQ_RING_OUT_SYS=1 -- measured slower) still reproduces the register-streaming
+    kernels: run in a child process, the switch is read once per process"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sys.py"
+    script.write_text(_SYS_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")})
+    env = dict(os.environ, FQ_RING_OUT_SYS="1", FALCON_HIP_RING_OUT="1")
+    r = subprocess.run([sys.executable, str(script), str(t)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "systolic ok" in r.stdout
