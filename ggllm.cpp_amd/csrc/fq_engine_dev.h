@@ -190,6 +190,38 @@ __device__ __forceinline__ void eng_pass_group_pre(const uint8_t * ring, const u
         for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
     }
 }
+// eng_pass_group_pre in two steps, so that the caller can hand the ring space back between them (kernels_ring.hip): the weight units of U passes of R rows
+// into registers, then their dots with the lane's resident activation slices -- the same loads, the same arithmetic in the same order
+template <int R, int U> struct eng_regs { fq_unit_regs r[U][R]; };
+template <int TYPE, int RING, int R, int U>
+__device__ __forceinline__ void eng_pass_load(const uint8_t * ring, const unsigned (&pos)[R], int nblk, int u0, int lane, eng_regs<R, U> & G) {
+#pragma unroll
+    for (int p = 0; p < U; ++p) {
+        if constexpr (fq_lay<TYPE>::CB == 64) {
+            constexpr unsigned COLB = 64u * (unsigned) fq_lay<TYPE>::TS;
+            const int c = (u0 >> 6) + p;
+            const int rem = nblk - 64 * c, nbc = rem < 64 ? rem : 64;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                unsigned cb = pos[r] + (unsigned) c * COLB;
+                cb = cb >= (unsigned) RING ? cb - (unsigned) RING : cb;
+                G.r[p][r] = eng_unit_load_col<TYPE>(ring, cb, nbc, lane);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) G.r[p][r] = eng_unit_load_q8<RING>(ring, pos[r], u0 + 64 * p, lane, nblk);
+        }
+    }
+}
+template <int TYPE, int R, int U>
+__device__ __forceinline__ void eng_pass_dot_pre(const eng_regs<R, U> & G, int nblk, int u0, const fq_act32 * act, int lane, float (&acc)[R]) {
+#pragma unroll
+    for (int p = 0; p < U; ++p) {
+        const bool ok = u0 + 64 * p + lane < nblk;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(G.r[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
+    }
+}
 struct eng_wait {                 // per-wave state of the bounded waits
     unsigned * err; bool dead; long long * dbg; int blk;
     __device__ __forceinline__ bool spin(unsigned & spins, unsigned code, unsigned x0 = 0, unsigned x1 = 0) {      // true = keep waiting

@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     const int nv = E >> 2;
     const unsigned nx = (unsigned)((E + ENG_CHUNK - 1) / ENG_CHUNK);
     const bool nodots = (a.debug_mode & 2) != 0;
+    const bool early = !(a.debug_mode & 64);                               // (tuning aid, FQ_RING_DEBUG bit 64: ring space handed back after the arithmetic, as in round 3)
 
     // ---- the residual row -> LDS (chunks of 1024 values, one per helper wave, each with its f64 partial sum) -> statistics -> Q8 image(s)
     // (the engine's one-pass LayerNorm, kernels_engine.hip: ggml.c:10577-10591 with the sums in f64)
@@ -324,11 +325,23 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
             const unsigned p0 = row0 % (unsigned) RING;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rsE; pr[r] = q >= (unsigned) RING ? q - (unsigned) RING : q; acc[r] = 0.0f; }
+            const int nx_ = i + R * RNC;
+            const unsigned next_low = nx_ < nrows ? seg_pos + (unsigned) nx_ * rsE : seg_pos + padded;
             for (int ps = 0; ps < npass; ps += 3) {
                 const int np = npass - ps < 3 ? npass - ps : 3;
                 const unsigned upto = (unsigned)((ps + np) * 64 * TS);
                 const unsigned need = rowl + (upto < row_bytes ? upto : row_bytes);
                 for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::LANDED) - need) < 0;) { if (!w.spin(spins, ENG_W_LAND, need, 0)) break; __builtin_amdgcn_s_sleep(1); }
+                const unsigned low_after = ps + 3 < npass ? row0 + upto : next_low;
+                if (PRE && early && !nodots) {
+                    // rows of <= 3 passes with the lane's activation slices resident: the run's weight units into registers, the ring space handed back
+                    // BEFORE the arithmetic (the LDS serves a wave's requests in order: the reads are ahead of the LOW store) -- the loader's look-ahead is
+                    // the part of the ring beyond the oldest bytes still needed, and rows held through dots + butterflies kept the stream 1 us longer
+                    if (np == 3)      { eng_regs<R, 3> G; eng_pass_load<TYPE, RING, R, 3>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 3>(G, nblkE, 0, pre, lane, acc); }
+                    else if (np == 2) { eng_regs<R, 2> G; eng_pass_load<TYPE, RING, R, 2>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 2>(G, nblkE, 0, pre, lane, acc); }
+                    else              { eng_regs<R, 1> G; eng_pass_load<TYPE, RING, R, 1>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 1>(G, nblkE, 0, pre, lane, acc); }
+                    continue;
+                }
                 if (!nodots) {
                     if (PRE) {                                  // rows of <= 3 passes: the lane's activation slices were loaded once, before the row loop
                         if (np == 3)      eng_pass_group_pre<TYPE, RING, R, 3>(ring, pr, nblkE, 0, pre, lane, acc);
@@ -339,14 +352,12 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
                     else if (np == 2) eng_pass_group<TYPE, RING, R, 2>(ring, pr, nblkE, 64 * ps, col, lane, acc);
                     else              eng_pass_group<TYPE, RING, R, 1>(ring, pr, nblkE, 64 * ps, col, lane, acc);
                 }
-                if (ps + 3 < npass && lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, row0 + upto);
+                if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[r]);
 #pragma unroll
             for (int r = 0; r < R; ++r) if (i + r <= last) sink(i + r, v[r]);
-            const int nx_ = i + R * RNC;
-            if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, nx_ < nrows ? seg_pos + (unsigned) nx_ * rsE : seg_pos + padded);
         }
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
