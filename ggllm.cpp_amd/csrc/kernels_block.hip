@@ -465,7 +465,9 @@ size_t fq_attention_scratch_need(int N, int H, int max_n_kv) {
     const size_t row = (size_t)((max_n_kv + 3) & ~3) * 4;
     const size_t b = (16 * 4 + 16 * 64 * 8) + 4 * row > 56 * 1024 ? (size_t)((N + 3) / 4) * (size_t) H * 4 * row : 0;   // 4 tokens per workgroup, once their rows leave LDS
     const size_t need = a > b ? a : b;
-    return need > att_scratch_cap() ? 0 : need;
+    // beyond the cap the context still gets cap bytes: att_scratch() checks every launch's own byte count, so batches at low n_past (whose score rows are
+    // short) keep the MFMA / 4-row forms in a context whose (n_batch, n_ctx) corner would not fit
+    return need > att_scratch_cap() ? att_scratch_cap() : need;
 }
 static float * g_att_scratch = nullptr;
 static size_t  g_att_scratch_bytes = 0;
