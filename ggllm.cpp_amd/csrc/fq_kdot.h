@@ -19,7 +19,24 @@ FQ_HD int fq_dot2(uint32_t a, uint32_t b, int c) {         // 2 x int16 . int16 
     return c + (int)(int16_t)(a & 0xFFFFu) * (int)(int16_t)(b & 0xFFFFu) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
 #endif
 }
-FQ_HD uint32_t fq_pack16(int lo, int hi) { return ((uint32_t) lo & 0xFFFFu) | ((uint32_t) hi << 16); }
+FQ_HD uint32_t fq_pack16(int lo, int hi) {                  // the low 16 bits of two integers side by side (v_perm_b32)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm((uint32_t) hi, (uint32_t) lo, 0x05040100u);
+#else
+    return ((uint32_t) lo & 0xFFFFu) | ((uint32_t) hi << 16);
+#endif
+}
+FQ_HD uint32_t fq_pk_sub16(uint32_t a, uint32_t b) {         // two int16 lanes: a - b per lane (v_pk_sub_i16)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short fq_s2v __attribute__((ext_vector_type(2)));
+    const fq_s2v r = __builtin_bit_cast(fq_s2v, a) - __builtin_bit_cast(fq_s2v, b);
+    return __builtin_bit_cast(uint32_t, r);
+#else
+    const uint32_t lo = (uint32_t)((int)(int16_t)(a & 0xFFFFu) - (int)(int16_t)(b & 0xFFFFu)) & 0xFFFFu;
+    const uint32_t hi = (uint32_t)((int)(int16_t)(a >> 16) - (int)(int16_t)(b >> 16)) & 0xFFFFu;
+    return lo | (hi << 16);
+#endif
+}
 FQ_HD int fq_sext8(uint32_t v, int sh) { return (int)(int8_t)(v >> sh); }
 
 template <int TYPE> struct fq_kdot { static constexpr bool ok = false; };
@@ -162,10 +179,13 @@ template <> struct fq_kdot<FQ_Q2_K> {
         // scales[8hf + 2j + g]: bytes g, 2 + g of s0 (j = 0, 1) and of s1 (j = 2, 3); low nibble = scale, high nibble = min
         const uint32_t b0 = w.s0 >> L.gsh, b1 = w.s1 >> L.gsh;
         const uint32_t sc01 = b0 & 0x000F000Fu, sc23 = b1 & 0x000F000Fu, mn01 = (b0 >> 4) & 0x000F000Fu, mn23 = (b1 >> 4) & 0x000F000Fu;
-        int isum = (int)(sc01 & 0xFFFFu) * dot16r(and4(w.q, 0x03030303u), y.x[0]);
-        isum += (int)(sc01 >> 16) * dot16r(and4(shr4(w.q, 2), 0x03030303u), y.x[1]);
-        isum += (int)(sc23 & 0xFFFFu) * dot16r(and4(shr4(w.q, 4), 0x03030303u), y.x[2]);
-        isum += (int)(sc23 >> 16) * dot16r(and4(shr4(w.q, 6), 0x03030303u), y.x[3]);
+        // the four 2-bit fields stay where they are: q & (3 << 2j) is 4^j times the field (the last one one bit lower: 0x60 keeps the byte a positive int8), the
+        // 16-element dot is shifted back exactly; scales and dots then meet as int16 pairs in two v_dot2_i32_i16 (|dot| <= 16 * 3 * 128)
+        const int d0 = dot16r(and4(w.q, 0x03030303u), y.x[0]);
+        const int d1 = dot16r(and4(w.q, 0x0C0C0C0Cu), y.x[1]) >> 2;
+        const int d2 = dot16r(and4(w.q, 0x30303030u), y.x[2]) >> 4;
+        const int d3 = dot16r(and4(shr4(w.q, 1), 0x60606060u), y.x[3]) >> 5;
+        const int isum = fq_dot2(sc23, fq_pack16(d2, d3), fq_dot2(sc01, fq_pack16(d0, d1), 0));
         const int msum = fq_dot2(mn23, y.bs23, fq_dot2(mn01, y.bs01, 0));
         return (y.dy * fq_h2f((uint16_t) w.dm)) * (float) isum - (y.dy * fq_h2f((uint16_t)(w.dm >> 16))) * (float) msum;
     }
@@ -214,10 +234,10 @@ template <> struct fq_kdot<FQ_Q3_K> {
         const fq_u4 q1 = or4(and4(shr4(w.q, 2), 0x03030303u), and4(shl4(u, 1), 0x04040404u));
         const fq_u4 q2 = or4(and4(shr4(w.q, 4), 0x03030303u), and4(u, 0x04040404u));
         const fq_u4 q3 = or4(and4(shr4(w.q, 6), 0x03030303u), and4(shr4(u, 1), 0x04040404u));
-        int isum = ((int)(s01 & 0xFFFFu) - 32) * (dot16r(q0, y.x[0]) - y.b4[0]);
-        isum += ((int)(s01 >> 16) - 32) * (dot16r(q1, y.x[1]) - y.b4[1]);
-        isum += ((int)(s23 & 0xFFFFu) - 32) * (dot16r(q2, y.x[2]) - y.b4[2]);
-        isum += ((int)(s23 >> 16) - 32) * (dot16r(q3, y.x[3]) - y.b4[3]);
+        // (scale - 32) of both 16-bit lanes at once, the four sub-block dots (|dot - 4 bsum| <= 22 464) as int16 pairs: two v_dot2_i32_i16
+        const uint32_t c01 = fq_pk_sub16(s01, 0x00200020u), c23 = fq_pk_sub16(s23, 0x00200020u);
+        const int e0 = dot16r(q0, y.x[0]) - y.b4[0], e1 = dot16r(q1, y.x[1]) - y.b4[1], e2 = dot16r(q2, y.x[2]) - y.b4[2], e3 = dot16r(q3, y.x[3]) - y.b4[3];
+        const int isum = fq_dot2(c23, fq_pack16(e2, e3), fq_dot2(c01, fq_pack16(e0, e1), 0));
         return (fq_h2f((uint16_t) w.d) * y.dy) * (float) isum;
     }
 };
