@@ -38,6 +38,13 @@ FQ_HD uint32_t fq_pk_sub16(uint32_t a, uint32_t b) {         // two int16 lanes:
 #endif
 }
 FQ_HD int fq_sext8(uint32_t v, int sh) { return (int)(int8_t)(v >> sh); }
+FQ_HD int fq_mul24(int a, int b) {                            // a * b for operands inside 24 signed bits (v_mul_i32_i24 / v_mad_i32_i24: full rate; a 32-bit multiply is quarter rate)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
 
 template <int TYPE> struct fq_kdot { static constexpr bool ok = false; };
 
@@ -89,7 +96,7 @@ template <int TYPE> struct fq_kdot45 {
             lo = or4(lo, shl4(and4(t, 0x01010101u), 4));
             hi = or4(hi, shl4(and4(t, 0x02020202u), 3));
         }
-        const int isum = (int)(psc & 0xFFu) * dot16r(lo, y.x0) + (int)(psc >> 8) * dot16r(hi, y.x1);
+        const int isum = fq_mul24((int)(psc & 0xFFu), dot16r(lo, y.x0)) + fq_mul24((int)(psc >> 8), dot16r(hi, y.x1));      // (|dot| <= 16 * 31 * 128)
         const int msum = fq_dot2((pmn | (pmn << 8)) & 0x00FF00FFu, y.bs, 0);
         return (fq_h2f((uint16_t) w.dm) * y.dy) * (float) isum - (fq_h2f((uint16_t)(w.dm >> 16)) * y.dy) * (float) msum;
     }
@@ -136,7 +143,7 @@ template <> struct fq_kdot<FQ_Q6_K> {
         const fq_u4 t = shr4(w.qh, (int) L.tsh);                          // bits 0-1 of a byte: quarter t, bits 4-5: quarter t + 2
         const fq_u4 lo = or4(and4(w.q, 0x0F0F0F0Fu), shl4(and4(t, 0x03030303u), 4));
         const fq_u4 hi = or4(and4(shr4(w.q, 4), 0x0F0F0F0Fu), and4(t, 0x30303030u));
-        const int isum = sc_lo * (dot16r(lo, y.x0) - y.b0) + sc_hi * (dot16r(hi, y.x1) - y.b1);
+        const int isum = fq_mul24(sc_lo, dot16r(lo, y.x0) - y.b0) + fq_mul24(sc_hi, dot16r(hi, y.x1) - y.b1);      // (|dot - 32 bsum| < 2^18)
         return (fq_h2f((uint16_t) w.d) * y.dy) * (float) isum;
     }
 };
