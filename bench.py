@@ -282,9 +282,9 @@ def pmc_decode_traffic():
             d = json.load(open(os.path.join(pdir, f)))
         except (OSError, ValueError):
             continue
-        if not (any(k.startswith("k_gemv_ln") for k in d) and any(k.startswith("k_attn_out") or k.startswith("k_ring_out") for k in d)):
+        if not (any(k.startswith("k_gemv_ln") for k in d) and any(k.startswith("k_attn_out") for k in d)):      # (the merged attention + output launch: only the headline workload has it)
             continue
-        ks = [v for k, v in d.items() if k.startswith(("k_gemv_ln", "k_attn_out", "k_gemv_out", "k_ring_out"))]
+        ks = [v for k, v in d.items() if k.startswith(("k_gemv_ln", "k_attn_out"))]
         n = sum(v["launches"] for v in ks)
         if n:
             return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n,
