@@ -28,7 +28,7 @@
 
 // workgroup barriers attn_head_block executes (scores+maxima, sums, probabilities, V.P partials): waves of the workgroup that
 // do NOT take part in an attention group must execute as many (k_attn_out_ln), see attn_decode_group_idle
-#define FQ_ATTN_HEAD_BARRIERS 4
+#define FQ_ATTN_HEAD_BARRIERS 3
 
 struct attn_lds {
     float  * redf;     // >= 16 floats
@@ -115,14 +115,17 @@ __device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_
         lmax = fq_max_f32(lmax, j < n_kv ? sc : -INFINITY);
     }
 }
-template <bool F64 = false>
+// SCALE: p holds the soft_max's exp() values and the probability is formed here, p[j] * inv -- the f32 product ggml_vec_scale_f32 stores (ggml.c:12441-12450),
+// so the same number, without a pass over p and the barrier behind it
+template <bool F64 = false, bool SCALE = false>
 __device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cached, int tid, const float * p, typename attn_acc<F64>::t & a0,
-                                             typename attn_acc<F64>::t & a1, typename attn_acc<F64>::t & a2, typename attn_acc<F64>::t & a3) {
+                                             typename attn_acc<F64>::t & a1, typename attn_acc<F64>::t & a2, typename attn_acc<F64>::t & a3, float inv = 1.0f) {
     const int rowi = tid >> 4;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int j = j0 + 16 * b + rowi;
-        const float pv = p[j < n_cached ? j : 0];
+        float pv = p[j < n_cached ? j : 0];
+        if constexpr (SCALE) pv *= inv;
         const float pj = j < n_cached ? pv : 0.0f;                // (a row beyond the end is a clamped, finite re-read: v * 0 adds nothing)
         const f32x4 v4 = v8[b];
         attn_mac<F64>(a0, v4.x, pj); attn_mac<F64>(a1, v4.y, pj); attn_mac<F64>(a2, v4.z, pj); attn_mac<F64>(a3, v4.w, pj);
@@ -156,7 +159,7 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
     f32x4 v1[8];                                                   // values of the odd steps (the key registers are free now)
     if (128 < n_cached) attn_load_v(vc, HKV, hk, n_cached, 128, tid, v1);
     FQ_ATTN_STAMP(dbg, 3);
-    // ---- soft_max (three barriers: scores + maxima visible, sums visible, probabilities visible)
+    // ---- soft_max (two barriers: scores + maxima visible, exp() values + sums visible; the scaling by 1 / sum is applied where V.P reads the values)
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) L.redf[tid >> 6] = lmax;
     __syncthreads();
@@ -168,31 +171,32 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
         lsum += (double) e;
     }
     lsum = wave_sum(lsum);
-    if ((tid & 63) == 0) L.red[tid >> 6] = lsum;
+    // (the per-wave sums sit in the half of `red` the f32 V.P partials below never touch: no barrier separates their readers from those writers any more)
+    double * const sred = F64 ? L.red : L.red + 512;
+    if ((tid & 63) == 0) sred[tid >> 6] = lsum;
     __syncthreads();
-    const double sum = waves_combine(L.red, NT >> 6, op_add());
+    const double sum = waves_combine(sred, NT >> 6, op_add());
     const float inv = (float)(1.0 / sum);
-    for (int j = tid; j < n_kv; j += NT) L.p[j] *= inv;
-    __syncthreads();
     FQ_ATTN_STAMP(dbg, 4);
     // ---- V.P
     typedef typename attn_acc<F64>::t acc_t;
     acc_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     acc_t * const pvred = (acc_t *) L.red;                         // 16 row classes x 64 dims
     for (int j0 = 0; j0 < n_cached; j0 += 256) {
-        attn_pv_step<F64>(P.v, j0, n_cached, tid, L.p, a0, a1, a2, a3);
+        attn_pv_step<F64, true>(P.v, j0, n_cached, tid, L.p, a0, a1, a2, a3, inv);
         if (j0 + 256 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 256, tid, P.v);
         if (j0 + 128 < n_cached) {
-            attn_pv_step<F64>(v1, j0 + 128, n_cached, tid, L.p, a0, a1, a2, a3);
+            attn_pv_step<F64, true>(v1, j0 + 128, n_cached, tid, L.p, a0, a1, a2, a3, inv);
             if (j0 + 384 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 384, tid, v1);
         }
     }
     if (new_v && rowi == (n_cached & 15)) {
         const float4 v = *(const float4 *)(new_v + 4 * sub);
-        const float pj = L.p[n_cached];
+        const float pj = L.p[n_cached] * inv;
         attn_mac<F64>(a0, v.x, pj); attn_mac<F64>(a1, v.y, pj); attn_mac<F64>(a2, v.z, pj); attn_mac<F64>(a3, v.w, pj);
     }
     FQ_ATTN_STAMP(dbg, 5);
+    if constexpr (F64) __syncthreads();                            // (f64 partials fill all of `red`, the sums included: every reader of those must be through)
     pvred[rowi * 64 + 4 * sub + 0] = a0; pvred[rowi * 64 + 4 * sub + 1] = a1;
     pvred[rowi * 64 + 4 * sub + 2] = a2; pvred[rowi * 64 + 4 * sub + 3] = a3;
     __syncthreads();
