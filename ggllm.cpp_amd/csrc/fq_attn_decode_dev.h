@@ -33,38 +33,45 @@ __device__ __forceinline__ void attn_decode_group_p(const fq_attn_decode_args & 
     constexpr int D = 64, HALF = 32;
     const int H = a.H, HKV = a.HKV;
     const int group = H / HKV, hk = h / group;
-    float * qr = (float *) smem;                    // rotated q [64]
-    float * kr = qr + D;                            // rotated new k [64]
-    float * vn = kr + D;                            // new v [64]
     const attn_lds L = attn_lds_carve(smem + 3 * D * 4);
     const float * qh = a.q_src ? a.q_src : a.qkv + (int64_t) h * D;
     const float * kh = a.k_src ? a.k_src : a.qkv + (int64_t)(H + hk) * D;
     const float * vh = a.v_src ? a.v_src : a.qkv + (int64_t)(H + HKV + hk) * D;
-    // requests in the order they are needed: n_past, the rope's inputs (every thread asks, 128 use them), then the first
-    // 256 key / 128 value rows (whatever n_past is: rows beyond it are never used)
+    // Every thread rotates ITS OWN dims of q and of the new key (dims 4 s8 .. and 32 + 4 s8 ..: what its score lanes multiply) and fetches its own 4 dims of the
+    // new value: no trip of the three rows through LDS and no workgroup barrier in front of the scores (round 4; the rotation is ggml.c:12957-12978's, the same
+    // two products and one sum / difference per element). Requests in the order they are needed: n_past, the rope's inputs, then the first 256 key / 128 value rows
+    // (whatever n_past is: rows beyond it are never used)
+    // (a caller that runs head after head in one launch -- the persistent engine -- has its own workgroup barrier between two heads: the hand-over of q / k / v)
     const int np = *a.n_past_ptr;
-    const int k = tid & (HALF - 1);
-    const float * src = tid < HALF ? qh : kh;
+    const int s8 = tid & 7, sub = tid & 15;
     const float * csr = a.cs_cur ? a.cs_cur : a.cs + (int64_t) np * HALF * 2;
-    const float x0 = src[k], x1 = src[k + HALF];
-    const float c = csr[2 * k], s = csr[2 * k + 1];
-    const float vnew = vh[tid & (D - 1)];
+    const f32x4 x0q = *(const f32x4 *)(qh + 4 * s8), x1q = *(const f32x4 *)(qh + HALF + 4 * s8);
+    const f32x4 x0k = *(const f32x4 *)(kh + 4 * s8), x1k = *(const f32x4 *)(kh + HALF + 4 * s8);
+    const f32x4 cs0 = *(const f32x4 *)(csr + 8 * s8), cs1 = *(const f32x4 *)(csr + 8 * s8 + 4);      // (cos, sin) of dims 4 s8 .. 4 s8 + 3
+    attn_new nw;
+    nw.v4 = *(const f32x4 *)(vh + 4 * sub);
+    // the key / value row this head's kv group appends (first head of the group): threads 32..63 rotate one pair of key dims each, 64..127 copy one value dim
+    const bool append = live && h % group == 0;
+    const int k = tid & (HALF - 1);
+    float ax0 = 0.0f, ax1 = 0.0f, ac = 0.0f, as = 0.0f, av = 0.0f;
+    if (append && tid >= HALF && tid < 2 * HALF) { ax0 = kh[k]; ax1 = kh[k + HALF]; ac = csr[2 * k]; as = csr[2 * k + 1]; }
+    if (append && tid >= 2 * HALF && tid < 2 * HALF + D) av = vh[tid - 2 * HALF];
     if constexpr (!PRE) attn_prefetch(a.kc, a.vc, HKV, hk, a.cache_rows, tid, P);
     FQ_STAMP(dbg, 1);
-    const bool append = live && h % group == 0;
-    if (tid < 2 * HALF) {
-        const float r0 = x0 * c - x1 * s, r1 = x0 * s + x1 * c;                      // ggml.c:12974-12975
-        float * dst = tid < HALF ? qr : kr;
-        dst[k] = r0; dst[k + HALF] = r1;
-        if (tid >= HALF && append) { float * o = a.kc + ((int64_t) np * HKV + hk) * D; o[k] = r0; o[k + HALF] = r1; }
-    } else if (tid < 2 * HALF + D) {
-        const int d = tid - 2 * HALF;
-        vn[d] = vnew;
-        if (append) a.vc[((int64_t) np * HKV + hk) * D + d] = vnew;
+    {
+        const f32x4 c = { cs0.x, cs0.z, cs1.x, cs1.z }, sn = { cs0.y, cs0.w, cs1.y, cs1.w };
+        nw.qa = f32x4{ x0q.x * c.x - x1q.x * sn.x, x0q.y * c.y - x1q.y * sn.y, x0q.z * c.z - x1q.z * sn.z, x0q.w * c.w - x1q.w * sn.w };      // ggml.c:12974
+        nw.qb = f32x4{ x0q.x * sn.x + x1q.x * c.x, x0q.y * sn.y + x1q.y * c.y, x0q.z * sn.z + x1q.z * c.z, x0q.w * sn.w + x1q.w * c.w };      // ggml.c:12975
+        nw.ka = f32x4{ x0k.x * c.x - x1k.x * sn.x, x0k.y * c.y - x1k.y * sn.y, x0k.z * c.z - x1k.z * sn.z, x0k.w * c.w - x1k.w * sn.w };
+        nw.kb = f32x4{ x0k.x * sn.x + x1k.x * c.x, x0k.y * sn.y + x1k.y * c.y, x0k.z * sn.z + x1k.z * c.z, x0k.w * sn.w + x1k.w * c.w };
     }
-    __syncthreads();
+    if (append && tid >= HALF && tid < 2 * HALF) {
+        const float r0 = ax0 * ac - ax1 * as, r1 = ax0 * as + ax1 * ac;
+        float * o = a.kc + ((int64_t) np * HKV + hk) * D; o[k] = r0; o[k + HALF] = r1;
+    }
+    if (append && tid >= 2 * HALF && tid < 2 * HALF + D) a.vc[((int64_t) np * HKV + hk) * D + (tid - 2 * HALF)] = av;
     FQ_STAMP(dbg, 2);
-    const float o = attn_head_block(qr, a.kc, a.vc, HKV, hk, np, kr, vn, a.exp_tab, L, tid, P, dbg);
+    const float o = attn_head_block<false, true>(nullptr, a.kc, a.vc, HKV, hk, np, nullptr, nullptr, a.exp_tab, L, tid, P, dbg, &nw);
     FQ_STAMP(dbg, 6);
     if (tid < 64) {
         if (a.att && live) out_store<PUBLISH>(a.att, (int64_t) h * D + tid, o, pub);
@@ -101,10 +108,10 @@ __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a,
     attn_decode_group_p<PUBLISH, false>(a, h, live, tid, smem, dbg, pub, P);
 }
 
-// the barriers of attn_decode_group (1 after the rope + attn_head_block's), for waves of the same workgroup that sit a group out
+// the barriers of attn_decode_group (attn_head_block's; the rope in front of it needs none since round 4), for waves of the same workgroup that sit a group out
 __device__ __forceinline__ void attn_decode_group_idle() {
 #pragma unroll
-    for (int i = 0; i < 1 + FQ_ATTN_HEAD_BARRIERS; ++i) __syncthreads();
+    for (int i = 0; i < FQ_ATTN_HEAD_BARRIERS; ++i) __syncthreads();
 }
 
 static inline size_t attn_decode_lds(int max_n_kv) { return 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) max_n_kv * 4 + 15) & ~(size_t) 15); }

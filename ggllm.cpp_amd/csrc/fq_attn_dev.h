@@ -101,15 +101,19 @@ __device__ __forceinline__ void attn_mac(typename attn_acc<F64>::t & a, float v,
     if constexpr (F64) a += (double)(v * p); else a = __builtin_fmaf(v, p, a);
 }
 
-template <bool F64 = false>
+// the newest key / value of a decode step, not yet in the cache for other workgroups to see: either 64 floats each in LDS (new_k / new_v pointers) or, REGS,
+// this thread's own dims in registers (attn_new: dims 4 s8 .. and 32 + 4 s8 .. of the rotated q and key, dims 4 sub .. of the value)
+struct attn_new { f32x4 qa, qb, ka, kb, v4; };
+template <bool F64 = false, bool REGS = false>
 __device__ __forceinline__ void attn_score_step(const f32x4 * k8, int j0, int n_cached, int n_kv, const float * new_k, const f32x4 qa, const f32x4 qb,
-                                                int tid, float * p, float & lmax) {
+                                                int tid, float * p, float & lmax, const f32x4 nka = f32x4{0, 0, 0, 0}, const f32x4 nkb = f32x4{0, 0, 0, 0}) {
     const int s8 = tid & 7, rowg = tid >> 3;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int j = j0 + 32 * b + rowg;
         f32x4 ka = k8[2 * b], kb = k8[2 * b + 1];
-        if (new_k && j == n_cached) { ka = *(const f32x4 *)(new_k + 4 * s8); kb = *(const f32x4 *)(new_k + 32 + 4 * s8); }
+        if constexpr (REGS) { if (j == n_cached) { ka = nka; kb = nkb; } }
+        else if (new_k && j == n_cached) { ka = *(const f32x4 *)(new_k + 4 * s8); kb = *(const f32x4 *)(new_k + 32 + 4 * s8); }
         const float sc = attn_dot8<F64>(ka, kb, qa, qb) * 0.125f;
         if (j < n_kv && s8 == 0) p[j] = sc;
         lmax = fq_max_f32(lmax, j < n_kv ? sc : -INFINITY);
@@ -132,26 +136,29 @@ __device__ __forceinline__ void attn_pv_step(const f32x4 * v8, int j0, int n_cac
     }
 }
 
-// q: 64 floats (rotated) in LDS or global; returns out[d] for d = tid (valid for tid < 64)
-template <bool F64 = false>
+// q: 64 floats (rotated) in LDS or global; returns out[d] for d = tid (valid for tid < 64). REGS: q, the newest key and value come in `nw` (registers), the
+// three pointers are unused and the newest key / value always exist
+template <bool F64 = false, bool REGS = false>
 __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, const float * __restrict__ kc, const float * __restrict__ vc,
                                                  int HKV, int hk, int n_cached, const float * new_k, const float * new_v,
                                                  const uint16_t * __restrict__ exp_tab, const attn_lds & L, const int tid, attn_pre & P,
-                                                 long long * dbg = nullptr) {
+                                                 long long * dbg = nullptr, const attn_new * nw = nullptr) {
     constexpr int NT = 256;
     const int sub = tid & 15, rowi = tid >> 4;
-    const int n_kv = n_cached + (new_k ? 1 : 0);
+    const int n_kv = n_cached + ((REGS || new_k) ? 1 : 0);
 
     // ---- scores: 8 lanes per key row (two float4 each), 4 rows per thread and step, 128 rows per step
     float lmax = -INFINITY;
     {
         const int s8 = tid & 7;
-        const f32x4 qa = *(const f32x4 *)(q + 4 * s8), qb = *(const f32x4 *)(q + 32 + 4 * s8);
+        f32x4 qa, qb, nka = f32x4{0, 0, 0, 0}, nkb = f32x4{0, 0, 0, 0};
+        if constexpr (REGS) { qa = nw->qa; qb = nw->qb; nka = nw->ka; nkb = nw->kb; }
+        else { qa = *(const f32x4 *)(q + 4 * s8); qb = *(const f32x4 *)(q + 32 + 4 * s8); }
         for (int j0 = 0; j0 < n_kv; j0 += 256) {
-            attn_score_step<F64>(P.k, j0, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+            attn_score_step<F64, REGS>(P.k, j0, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax, nka, nkb);
             if (j0 + 256 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 256, tid, P.k);
             if (j0 + 128 < n_kv) {
-                attn_score_step<F64>(P.k + 8, j0 + 128, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax);
+                attn_score_step<F64, REGS>(P.k + 8, j0 + 128, n_cached, n_kv, new_k, qa, qb, tid, L.p, lmax, nka, nkb);
                 if (j0 + 384 < n_kv) attn_load_k(kc, HKV, hk, n_cached, j0 + 384, tid, P.k + 8);
             }
         }
@@ -190,8 +197,9 @@ __device__ __forceinline__ float attn_head_block(const float * __restrict__ q, c
             if (j0 + 384 < n_cached) attn_load_v(vc, HKV, hk, n_cached, j0 + 384, tid, v1);
         }
     }
-    if (new_v && rowi == (n_cached & 15)) {
-        const float4 v = *(const float4 *)(new_v + 4 * sub);
+    if ((REGS || new_v) && rowi == (n_cached & 15)) {
+        float4 v;
+        if constexpr (REGS) v = make_float4(nw->v4.x, nw->v4.y, nw->v4.z, nw->v4.w); else v = *(const float4 *)(new_v + 4 * sub);
         const float pj = L.p[n_cached] * inv;
         attn_mac<F64>(a0, v.x, pj); attn_mac<F64>(a1, v.y, pj); attn_mac<F64>(a2, v.z, pj); attn_mac<F64>(a3, v.w, pj);
     }
