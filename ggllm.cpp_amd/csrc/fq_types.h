@@ -83,7 +83,11 @@ struct fq_weight {
     uint8_t * plane[FQ_MAX_PLANES];   // plane[0] = device pointer of row 0 (the other entries repeat it)
     size_t  row_stride;               // bytes from one row to the next
     size_t  bytes;                    // total device bytes = M * nblk * tsize  (== ggml_nbytes)
+    int64_t form_M;                   // a row range of a larger matrix (row-split tensor parallelism): the rows of the WHOLE matrix, 0 otherwise. Every choice that
+                                      // fixes the association of a row's sum (the GEMM's K split, the k-quants' small-batch form) is made from fq_form_rows(), so
+                                      // that a part sums its rows exactly as the unsplit matrix would
 };
+static inline int64_t fq_form_rows(const fq_weight & w) { return w.form_M > 0 ? w.form_M : w.M; }
 
 // Quantized activations on the device. Every column (token) is ONE contiguous, 16-byte aligned image
 //      [ qs int8 x K | d f32 x nd | aux ]          image stride = fq_act_col_bytes(type, K)

@@ -9,7 +9,7 @@
 #include <string.h>
 #include <vector>
 
-struct ggml_hip_weight { fq_weight w; void * slab; };
+struct ggml_hip_weight { fq_weight w; void * slab; int64_t valid_rows = 0; };      // valid_rows > 0: a row-split part padded with zero rows (fq_weight_upload_part)
 struct ggml_hip_acts   { fq_act a; int64_t max_cols; void * slab; };
 
 static hip_context g_ctx;
@@ -144,13 +144,16 @@ fq_weight fq_weight_alloc(int type, int64_t K, int64_t M, void ** slab_out) {
     return w;
 }
 
-extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_blocks, int64_t K, int64_t M) {
+// rows [0, rows) from host_blocks; alloc_rows >= rows: the rest are zero rows (all-zero blocks: every weight 0.0)
+static ggml_hip_weight * weight_upload_rows(int type, const void * host_blocks, int64_t K, int64_t rows, int64_t alloc_rows) {
     hip_context & c = fq_ctx();
     ggml_hip_weight * hw = new ggml_hip_weight();
-    hw->w = fq_weight_alloc(type, K, M, &hw->slab);
+    hw->w = fq_weight_alloc(type, K, alloc_rows, &hw->slab);
+    if (alloc_rows > rows) HIP_CHECK(hipMemsetAsync(hw->w.plane[0] + (size_t) rows * hw->w.row_stride, 0, (size_t)(alloc_rows - rows) * hw->w.row_stride, c.stream));
     // stage the ggml bytes in HBM in bounded chunks of rows, re-tile on the device
     const fq_type_desc d = fq_desc(type);
     const size_t row_bytes = (size_t) hw->w.nblk * d.tsize;
+    const int64_t M = rows;
     int64_t rows_per_chunk = (int64_t) ((256u << 20) / (row_bytes ? row_bytes : 1));
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (rows_per_chunk > M) rows_per_chunk = M;
@@ -167,6 +170,19 @@ extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_
         HIP_CHECK(hipStreamSynchronize(c.stream));
     }
     HIP_CHECK(hipFree(stage));
+    return hw;
+}
+extern "C" ggml_hip_weight * ggml_hip_weight_upload(int type, const void * host_blocks, int64_t K, int64_t M) { return weight_upload_rows(type, host_blocks, K, M, M); }
+// A row range of a matrix of `whole_rows` rows (row-split tensor parallelism, split_tp.hip): it must sum every row in the association the UNSPLIT matrix would
+// use, whatever its own shape. form_M carries the whole matrix's rows to the choices that fix the association (fq_types.h); the k-quants' small-batch form works
+// in whole 16-row tiles and the reference's row ranges are not rounded (ggml-cuda.cu:3046-3047), so a k-quant part is padded with zero rows to a multiple of 16
+// and ggml_hip_mul_mat_q keeps the padding's results out of dst.
+ggml_hip_weight * fq_weight_upload_part(int type, const void * host_blocks, int64_t K, int64_t rows, int64_t whole_rows) {
+    const bool kq = type == FQ_Q2_K || type == FQ_Q3_K || type == FQ_Q4_K || type == FQ_Q5_K || type == FQ_Q6_K;
+    const int64_t alloc_rows = kq && whole_rows % 16 == 0 ? (rows + 15) & ~(int64_t) 15 : rows;
+    ggml_hip_weight * hw = weight_upload_rows(type, host_blocks, K, rows, alloc_rows);
+    hw->w.form_M = whole_rows;
+    if (alloc_rows > rows) hw->valid_rows = rows;
     return hw;
 }
 extern "C" void ggml_hip_weight_free(ggml_hip_weight * w) { if (!w) return; HIP_CHECK(hipFree(w->slab)); delete w; }
@@ -390,9 +406,15 @@ extern "C" void ggml_hip_mul_mat_q(const ggml_hip_weight * w, const float * x_de
     void * slab = nullptr;
     fq_act a = fq_act_alloc(fq_desc(w->w.type).act_type, w->w.K, N, &slab);
     fq_launch_quantize_act(x_dev, ldx, a, c.stream);
-    fq_gemv_epi ep{ FQ_EPI_STORE, c.gelu_table, nullptr, nullptr, ldd };
-    fq_mul_mat_q_acts(w->w, a, N, dst_dev, ldd, ep, c.stream);
+    // a padded row-split part (fq_weight_upload_part): all its rows into a private matrix, the real ones from there into dst
+    const bool padded = w->valid_rows > 0 && w->valid_rows < w->w.M;
+    float * out = dst_dev; int64_t ldo = ldd;
+    if (padded) { ldo = w->w.M; HIP_CHECK(hipMalloc((void **) &out, (size_t) N * (size_t) ldo * 4)); }
+    fq_gemv_epi ep{ FQ_EPI_STORE, c.gelu_table, nullptr, nullptr, ldo };
+    fq_mul_mat_q_acts(w->w, a, N, out, ldo, ep, c.stream);
+    if (padded) HIP_CHECK(hipMemcpy2DAsync(dst_dev, (size_t) ldd * 4, out, (size_t) ldo * 4, (size_t) w->valid_rows * 4, (size_t) N, hipMemcpyDeviceToDevice, c.stream));
     HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (padded) HIP_CHECK(hipFree(out));
     HIP_CHECK(hipFree(slab));
 }
 

@@ -36,6 +36,8 @@ bool      fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, con
 void      fq_mul_mat_q_acts_from3(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st);
 bool      fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & a, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                                  float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st);
+struct ggml_hip_weight;
+ggml_hip_weight * fq_weight_upload_part(int type, const void * host_blocks, int64_t K, int64_t rows, int64_t whole_rows);      // a row range of a larger matrix (split_tp.hip)
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_reference_order();
 int       fq_config_epoch();        // bumped by every global switch that changes a launch list (reference order, forced mat-vec, sequential GEMM, debug modes)

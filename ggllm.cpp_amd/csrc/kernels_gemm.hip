@@ -703,7 +703,7 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     //   512 tokens   <S 1, 4 tiles>  94 / 93 / 265 / 340    <S 2, 4 tiles>  83 / 83 / 242 / 296    <S 4, 4 tiles>  94 / 94 / 290 / 331
     //   2048 tokens  <S 1, 4 tiles> 287 / 266 / 1043 / 1038 <S 2, 4 tiles> 259 / 238 / 969 / 929   <S 4, 4 tiles> 316 / 289 / 1157 / 1061
     // -> four partial sums per row below 4 x #CU tiles, two above; one (the reference's order) only on request
-    const int64_t tiles = ((w.M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
+    const int64_t tiles = ((fq_form_rows(w) + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);            // (a row-split part: the whole matrix's tiles, fq_types.h)
     int cfg = g_gemm_sequential ? 0 : (tiles < 4 * (int64_t) n_cu ? 2 : 3);
     // small batches: the streaming form (kernels_gemm_skinny.hip), same K split -> same bits (FQ_GEMM_SKINNY=0: this kernel for every N)
     static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0);

@@ -755,9 +755,12 @@ __global__ void __launch_bounds__(256) k_skinny_sum4_gelu_q8k(const float * __re
 bool fq_skinny_q4k_shape(const fq_weight & w) {
     static const bool on = !(getenv("FQ_SKINNY_Q4K") && atoi(getenv("FQ_SKINNY_Q4K")) == 0);
     const int seg = (w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) ? K2_SEG : KQ_SEG;
-    const int64_t nseg = (w.nblk + seg - 1) / seg, mstride = (w.M + 63) & ~(int64_t) 63;
-    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) && w.M % 16 == 0 && nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) &&
-           w.row_stride * 16 < ((size_t) 1 << 31);
+    // the decision from the rows of the whole matrix (a row-split part follows the matrix it is a part of; ggml_hip_weight_upload_rows pads a part to whole
+    // 16-row tiles so that it can), the part's own rows only have to fit the form
+    const int64_t Mf = fq_form_rows(w);
+    const int64_t nseg = (w.nblk + seg - 1) / seg, mstride = (Mf + 63) & ~(int64_t) 63;
+    return on && (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) && Mf % 16 == 0 && w.M % 16 == 0 && w.M <= Mf &&
+           nseg * 4 * SK_TN * mstride <= (int64_t) FQ_KS_FLOATS && w.nblk >= 8 && w.K < ((int64_t) 1 << 24) && w.row_stride * 16 < ((size_t) 1 << 31);
 }
 static bool q6k_main(const fq_weight & w, const fq_act & act, int64_t N, float * part, int64_t & mstride, int & nseg, hipStream_t st) {
     if (!fq_skinny_q4k_shape(w) || w.type != FQ_Q6_K || act.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;

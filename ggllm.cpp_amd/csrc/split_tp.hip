@@ -5,7 +5,8 @@
 //   row ranges   ggml_cuda_set_tensor_split (ggml-cuda.cu:2050-2077) + ggml_cuda_transform_tensor (:3044-3052), same float arithmetic
 //   upload       rows [row_low, row_high) of the ggml block bytes (offset row_low * nb1, :3057-3066)
 //   mat-mul      ggml_hip_mul_mat_q on the range, written straight into its rows of dst -- a row's dot products do not
-//                depend on which rank computes them, so the gathered result is bit-identical to the unsplit mat-mul
+//                depend on which rank computes them, so the gathered result is bit-identical to the unsplit mat-mul: the part
+//                takes the form and the K split the WHOLE matrix's shape selects (fq_weight::form_M, fq_weight_upload_part)
 // A local form runs every rank's part in one process on one device (tests/test_gpu_split.py).
 #include "../../include/ggml-hip-ops.h"
 #include "fq_device.h"
@@ -54,7 +55,7 @@ ggml_hip_weight * ggml_hip_weight_upload_rows(int type, const void * host_blocks
     const fq_type_desc d = fq_desc(type);
     if (d.blck == 0 || K % d.blck != 0) { fprintf(stderr, "ggml-hip: split upload: type %d with K=%lld unsupported\n", type, (long long) K); return nullptr; }
     const size_t nb1 = (size_t)(K / d.blck) * d.tsize;
-    return ggml_hip_weight_upload(type, (const uint8_t *) host_blocks + (size_t) row_low * nb1, K, row_high - row_low);
+    return fq_weight_upload_part(type, (const uint8_t *) host_blocks + (size_t) row_low * nb1, K, row_high - row_low, nrows);
 }
 
 ggml_hip_split_comm * ggml_hip_split_comm_create(int rank, int world, const void * unique_id) {

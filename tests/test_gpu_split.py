@@ -22,9 +22,22 @@ def _init():
 @pytest.mark.parametrize("ts", [[1, 1], [3, 1, 2], [0, 0, 0, 0], [1, 0, 1], [1] * 8])
 @pytest.mark.parametrize("t,N", [(ob.Q4_0, 1), (ob.Q4_0, 40), (ob.Q5_1, 3), (ob.Q4_K, 1), (ob.Q6_K, 40), (ob.Q8_0, 2)])
 def test_row_split_equals_unsplit(oracle, ts, t, N):
+    _row_split(oracle, ts, t, N, 1024, 1000 if t not in ob.KQUANTS else 777)
+
+
+@pytest.mark.parametrize("ts", [[3, 1, 2], [1] * 8])
+@pytest.mark.parametrize("t,N", [(ob.Q4_K, 8), (ob.Q4_K, 40), (ob.Q2_K, 12), (ob.Q6_K, 20), (ob.Q3_K, 3), (ob.Q5_K, 300), (ob.Q4_0, 12)])
+def test_row_split_of_a_long_row_matrix(oracle, ts, t, N):
+    """K = 16384 (64 super-blocks: two / four segments of the k-quants' small-batch form, whose partial sums are a different association from the tile GEMM's),
+    M = 1040 (a multiple of 16, so the unsplit matrix takes that form at 5..80 / 112 columns) cut into ranges that are NOT multiples of 16 (the reference does
+    not round them, ggml-cuda.cu:3046-3047): a part takes the form and the K split of the matrix it belongs to (fq_weight::form_M, zero rows up to a whole
+    tile) -- the assembled rows equal the unsplit mat-mul and the oracle bit for bit"""
+    _row_split(oracle, ts, t, N, 16384, 1040)
+
+
+def _row_split(oracle, ts, t, N, K, M):
     L = g.load()
     rng = np.random.default_rng(t * 100 + N + len(ts))
-    K, M = 1024, 1000 if t not in ob.KQUANTS else 777
     w = np.ascontiguousarray(synth.quantized_matrix(oracle, t, M, K, rng))
     x = rng.standard_normal((N, K)).astype(np.float32)
     whole = g.Weight(t, w, K, M)
