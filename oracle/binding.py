@@ -128,6 +128,7 @@ class Oracle(_Base):
         L.orc_falcon_eval.argtypes = [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_set_sum_order.argtypes = [C.c_int]
         L.orc_set_backend_batch.argtypes = [C.c_int]
+        L.orc_set_kq_min_cols.argtypes = [C.c_int]
         L.orc_falcon_block_sampled.argtypes = [C.POINTER(Model), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_falcon_head_rows.argtypes = [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_tables_init()

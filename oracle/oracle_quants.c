@@ -389,6 +389,10 @@ static int g_kseg = 0;
  * the backend chose its order for the whole batch) */
 static int g_backend_batch = 0;
 void orc_set_backend_batch(int n) { g_backend_batch = n > 0 ? n : 0; }
+/* mode 2 only: the fewest columns at which the k-quants' small-batch form is taken. 5 = a mat-mul on its own (ggml_hip_mul_mat_q, falcon_hip_eval: up to 4 columns
+ * go through the mat-vec kernels); 3 = a lock-step context (falcon_hip_context_create_seqs: fq_mul_mat_q_acts_from3, ggllm.cpp_amd/csrc/ggml_hip_ops.hip) */
+static int g_kq_min_cols = 5;
+void orc_set_kq_min_cols(int n) { g_kq_min_cols = n >= 1 ? n : 5; }
 int  orc_backend_batch(void) { return g_backend_batch; }
 int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 = "as the backend" for the attention too */
 void orc_set_sum_order(int mode) {
@@ -688,11 +692,11 @@ void orc_mul_mat_q(int wtype, const void * w, int64_t K, int64_t M, const float 
         g_split = (((M + 31) / 32) * ((Nb + 31) / 32) < 4 * 256) ? 4 : 2;
         /* Q4_K / Q5_K with 5..80 columns: the backend's small-batch form (k_gemm_skinny_q4k): four partial sums per segment of 32 super-blocks */
         g_kseg = 0;
-        if ((wtype == ORC_Q4_K || wtype == ORC_Q5_K) && Nb > 4 && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
-            ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; }
+        if ((wtype == ORC_Q4_K || wtype == ORC_Q5_K) && Nb >= g_kq_min_cols && Nb <= 80 && M % 16 == 0 && K / 256 >= 8 &&
+            ((K / 256 + 31) / 32) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 32; g_sum_order = 2; }
         /* Q2_K, Q3_K (k_gemm_skinny_q2k) and Q6_K (k_gemm_skinny_q6k, up to 80 columns) likewise: segments of 16 super-blocks */
-        if ((wtype == ORC_Q2_K || wtype == ORC_Q3_K || (wtype == ORC_Q6_K && Nb <= 80)) && Nb > 4 && Nb <= 112 && M % 16 == 0 && K / 256 >= 8 &&
-            ((K / 256 + 15) / 16) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 16; }
+        if ((wtype == ORC_Q2_K || wtype == ORC_Q3_K || (wtype == ORC_Q6_K && Nb <= 80)) && Nb >= g_kq_min_cols && Nb <= 112 && M % 16 == 0 && K / 256 >= 8 &&
+            ((K / 256 + 15) / 16) * 64 * ((M + 63) / 64 * 64) <= ((int64_t) 16 << 20)) { g_split = 4; g_kseg = 16; g_sum_order = 2; }
     }
     uint8_t * act = (uint8_t *) malloc(act_row * (size_t) N);
     /* INIT phase: every src1 row is quantized by one thread (ggml.c:11462-11476) */

@@ -79,6 +79,30 @@ def test_lock_step_at_falcon40b_width(oracle, t):
             assert float(np.abs(out[8][i][b] - ref).max() / (np.sqrt((ref ** 2).mean()) + 1e-30)) <= 5e-2, (b, i)
 
 
+@pytest.mark.parametrize("t,B", [(ob.Q4_K, 4), (ob.Q2_K, 3)])
+def test_lock_step_small_batch_form_against_the_oracle(oracle, t, B):
+    """contexts of 3 and 4 lock-step sequences at Falcon-40B width: every mat-mul of a step (Wqkv, Wup, Wo, Wdown, lm_head) runs the k-quants' small-batch form
+    (fq_mul_mat_q_acts_from3, from 3 columns up) -- each sequence's logits equal the oracle evaluating that sequence alone with the backend's rule for such a
+    context (orc_set_backend_batch(B) + orc_set_kq_min_cols(3): four partial sums per segment of 32 / 16 super-blocks), bit for bit"""
+    hp = dict(synth.HP_40B); hp["n_layer"] = 1; hp["n_vocab"] = 512
+    w = synth.make_model(oracle, hp, t, seed=13)
+    streams = [synth.tokens(3, hp["n_vocab"], seed=80 + b) for b in range(B)]
+    m = g.FalconModel(w, n_ctx=16, n_batch=8)
+    sc = g.SeqContext(m, 16, B)
+    got = [sc.eval([int(streams[b][i]) for b in range(B)], i) for i in range(3)]
+    sc.free()
+    m.free()
+    oracle.lib.orc_set_sum_order(2); oracle.lib.orc_set_backend_batch(B); oracle.lib.orc_set_kq_min_cols(3)
+    try:
+        for b in range(B):
+            mo = oracle.model(w, 16)
+            for i in range(3):
+                want = mo.eval(streams[b][i:i + 1], i, 16)[0]
+                assert np.array_equal(got[i][b], want), (b, i)
+    finally:
+        oracle.lib.orc_set_sum_order(0); oracle.lib.orc_set_backend_batch(0); oracle.lib.orc_set_kq_min_cols(5)
+
+
 def _greedy_reference(w, hp, first, rounds):
     m = g.FalconModel(w, n_ctx=64, n_batch=4)
     out = np.stack([m.decode_greedy(int(t), 0, rounds) for t in first], axis=1)      # [round][sequence]

@@ -108,3 +108,32 @@ def test_backend_mode_pass_limits_per_format(oracle):
         finally:
             oracle.lib.orc_set_sum_order(0)
         assert np.array_equal(got, whole) != segmented, ob.TYPE_NAME[t]
+
+
+@pytest.mark.parametrize("t", [ob.Q4_K, ob.Q2_K])
+def test_backend_mode_from_three_columns_in_lock_step_contexts(oracle, t):
+    """a lock-step context takes the small-batch form from 3 sequences up (fq_mul_mat_q_acts_from3): orc_set_kq_min_cols(3) moves mode 2's threshold; a
+    column's value in that form does not depend on the other columns (3 columns = the first 3 of 5), and the default threshold keeps 3 columns in unit order"""
+    rng = np.random.default_rng(21 + t)
+    K, M = 16384, 32
+    w = synth.random_blocks(t, M, K, rng)
+    x = rng.standard_normal((5, K)).astype(np.float32)
+    try:
+        oracle.lib.orc_set_sum_order(2)
+        five = oracle.mul_mat(t, w, K, M, x, 2)
+        three_default = oracle.mul_mat(t, w, K, M, x[:3], 2)
+        oracle.lib.orc_set_kq_min_cols(3)
+        three = oracle.mul_mat(t, w, K, M, x[:3], 2)
+        two = oracle.mul_mat(t, w, K, M, x[:2], 2)
+        oracle.lib.orc_set_backend_batch(4)
+        one_of_four = oracle.mul_mat(t, w, K, M, x[:1], 2)
+        oracle.lib.orc_set_backend_batch(0)
+        oracle.lib.orc_set_sum_order(1)
+        unit = oracle.mul_mat(t, w, K, M, x[:3], 2)
+    finally:
+        oracle.lib.orc_set_sum_order(0); oracle.lib.orc_set_kq_min_cols(5); oracle.lib.orc_set_backend_batch(0)
+    assert np.array_equal(three, five[:3])
+    assert np.array_equal(one_of_four, five[:1])
+    assert np.array_equal(three_default, unit)
+    assert np.array_equal(two, unit[:2])
+    assert not np.array_equal(three, unit)
