@@ -25,7 +25,7 @@ TYPE_NAME = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0
              Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
 VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}
 
-EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_split_comm_create_loopback ggml_hip_split_comm_rccl_ranks ggml_hip_mul_mat_q_split_loopback ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
+EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_split_comm_create_loopback ggml_hip_split_comm_rccl_ranks ggml_hip_mul_mat_q_split_loopback ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_debug_attention_form ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
 ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
 ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_quantize_rows ggml_hip_weight_quantize ggml_hip_fp16_to_fp32_row ggml_hip_acts_alloc ggml_hip_acts_free
@@ -69,7 +69,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
     sig = {
-        "ggml_hip_init": (C.c_int, [C.c_int]), "ggml_hip_selftest": (C.c_int, []), "ggml_hip_exp_formula_mismatches": (C.c_int, []), "ggml_hip_debug_force_gemv": (None, [C.c_int]), "ggml_hip_debug_stamps": (None, [C.c_int, vp]), "ggml_hip_device_count": (C.c_int, []), "ggml_hip_stream": (vp, []),
+        "ggml_hip_init": (C.c_int, [C.c_int]), "ggml_hip_selftest": (C.c_int, []), "ggml_hip_exp_formula_mismatches": (C.c_int, []), "ggml_hip_debug_force_gemv": (None, [C.c_int]), "ggml_hip_debug_attention_form": (None, [C.c_int]), "ggml_hip_debug_stamps": (None, [C.c_int, vp]), "ggml_hip_device_count": (C.c_int, []), "ggml_hip_stream": (vp, []),
         "ggml_hip_malloc": (vp, [sz]), "ggml_hip_free": (None, [vp]),
         "ggml_hip_memcpy_h2d": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2h": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2d": (None, [vp, vp, sz]),
         "ggml_hip_memset": (None, [vp, C.c_int, sz]), "ggml_hip_synchronize": (None, []),

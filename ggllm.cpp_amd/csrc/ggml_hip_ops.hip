@@ -261,6 +261,7 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
 
 static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
 extern "C" void ggml_hip_debug_force_gemv(int on) { ++g_config_epoch; g_force_gemv = on != 0; }
+extern "C" void ggml_hip_debug_attention_form(int form) { ++g_config_epoch; fq_attn_set_form(form); }
 extern "C" void ggml_hip_gemm_sequential(int on) { ++g_config_epoch; fq_gemm_set_sequential(on); }
 // reference order: every mat-mul through the per-thread scalar restatement (kernels_ref.hip: the reference's own block /
 // lane order for all ten formats and any N), attention with f64 accumulation (the portable ggml_vec_dot_f32)

@@ -37,6 +37,7 @@ void   fq_gemm_debug_mode(int m);       // tuning aid. bit 1: no MFMA / scaling;
 int    fq_gemm_debug_get();
 void   fq_gemm_set_sequential(int on);
 void   fq_attn_set_f64(int on);
+void   fq_attn_set_form(int form);        // prefill attention on the matrix pipe: 0 default, 16 = 16 rows with f32 scores in LDS, 17 = 16 rows with fp16 probabilities in LDS (two workgroups per CU)
 int    fq_attn_f64();
 void   fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd,
                       const fq_gemv_epi & ep, int n_cu, hipStream_t st);

@@ -441,8 +441,156 @@ __global__ void __launch_bounds__(512) k_attention_mfma16(const float * __restri
     }
 }
 
+// ---- the 16-row form with TWO workgroups per CU: the probabilities in LDS as the fp16 values they are -------------------------------
+// exp() of the soft_max comes out of a table of fp16 values (ggml.c:10911-10960: table_exp_f16), so an (unscaled) probability is
+// stored exactly in 2 bytes: 16 rows x 2048 keys = 64 KiB and two 8-wave workgroups share a CU (k_attention_mfma16 keeps f32 scores:
+// 128 KiB, one workgroup). The price: a score must be known in f32 until its row's maximum is, so K.Q runs twice -- pass A keeps only
+// the row maxima, pass B repeats the same MFMA chains (same operands, same order: same bits) and stores table[f16(s - max)]; the
+// f64 sum of those values is exact in any order (<= 2^13 fp16-valued terms), V.P reads p = (float) e16 * inv as before. Results
+// bit-identical to k_attention_mfma / k_attention_mfma16 and to the oracle's dot_qk_mfma / dot_pv_mfma. Measured (Falcon-7B block, 71 heads, one launch;
+// profiles/r04_attn_forms.txt): 2048 tokens 1.364 ms against 0.978 (k_attention_mfma) and 1.292 (k_attention_mfma16); 512 tokens 0.137 / 0.114 / 0.103 --
+// two workgroups per CU do not pay for the second K.Q: a 16-token tile fetches every key / value row twice as often per query as a 32-token one, and that
+// traffic (L2), not the score matrix's trips through HBM, is what the 16-row forms wait for. Opt-in (FQ_ATTN_MFMA16H=1 / ggml_hip_debug_attention_form(17)),
+// kept with its test. ps: uint16 elements per row (32 ntile_max + 8).
+__global__ void __launch_bounds__(512, 4) k_attention_mfma16h(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                              const float * __restrict__ kc, const float * __restrict__ vc,
+                                                              const uint16_t * __restrict__ exp_tab, float * __restrict__ att, int ps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float  * rmax = (float *) smem;                                 // [8 waves][16 rows]
+    double * rsum = (double *)(rmax + 8 * 16);                      // [8 waves][16 rows]
+    float  * xch  = (float *)(rsum + 8 * 16);                       // [4 dim tiles][4][64]
+    uint16_t * p  = (uint16_t *)(xch + 4 * 4 * 64);                 // [16][ps]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int h = blockIdx.x, i0 = blockIdx.y * 16, hk = h / (H / HKV), heads = H + 2 * HKV;
+    const int n_past = *n_past_ptr;
+    const int nrows = N - i0 < 16 ? N - i0 : 16;
+    const int n_kv_max = n_past + i0 + nrows;                       // keys the tile's last token sees
+    const int n_rows_cache = n_past + N;                            // key / value rows that exist
+    const int ntile = (n_kv_max + 31) >> 5, nsub = 2 * ntile;
+    const int eo = kq >> 1, hi = kq & 1;                            // the lane group's elements: odd (1) / even (0) ones of the high (1) / low (0) half
+    // ---- scores, twice
+    {
+        float q16[16];
+        {
+            const float * qrow = qkv + ((int64_t)(i0 + (l16 < nrows ? l16 : nrows - 1)) * heads + h) * 64 + 32 * hi;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { const f32x4 t = ((const f32x4 *) qrow)[v]; q16[2 * v] = eo ? t.y : t.x; q16[2 * v + 1] = eo ? t.w : t.z; }
+        }
+        auto load_k = [&](int U, float (&k16)[16]) {
+            const int j = 16 * U + l16;
+            const float * krow = kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hi;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { const f32x4 t = ((const f32x4 *) krow)[v]; k16[2 * v] = eo ? t.y : t.x; k16[2 * v + 1] = eo ? t.w : t.z; }
+        };
+        float ka[16], kb[16];
+        float mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        // pass A: the row maxima
+        if (wid < nsub) load_k(wid, ka);
+        for (int U = wid; U < nsub; U += 8) {
+            if (U + 8 < nsub) load_k(U + 8, kb);
+            v4f_ c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 16; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(q16[m], ka[m], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = 4 * kq + r, j = 16 * U + l16;
+                mx[r] = fq_max_f32(mx[r], (ir < nrows && j <= n_past + i0 + ir) ? c[r] * 0.125f : -INFINITY);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ka[v] = kb[v];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = reduce16(mx[r], op_max());
+            if (l16 == 0) rmax[wid * 16 + 4 * kq + r] = m;
+        }
+        if (wid < nsub) load_k(wid, ka);                            // (pass B's first keys: requested before the barrier)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = rmax[4 * kq + r];
+#pragma unroll
+            for (int w2 = 1; w2 < 8; ++w2) m = fq_max_f32(m, rmax[w2 * 16 + 4 * kq + r]);
+            mx[r] = m;
+        }
+        // pass B: the same chains again; exp() of the visible keys as fp16 bits, zeros up to the last tile, the sums aside
+        double ls[4] = { 0.0, 0.0, 0.0, 0.0 };
+        for (int U = wid; U < nsub; U += 8) {
+            if (U + 8 < nsub) load_k(U + 8, kb);
+            v4f_ c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 16; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(q16[m], ka[m], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = 4 * kq + r, j = 16 * U + l16;
+                uint16_t e = 0;
+                if (ir < nrows && j <= n_past + i0 + ir) { const uint16_t hb = f2h_bits(c[r] * 0.125f - mx[r]); e = exp_tab ? exp_tab[hb] : exp_f16_formula(hb); }
+                p[ir * ps + j] = e;
+                ls[r] += (double) h2f_bits(e);                                                           // (exact in any order)
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ka[v] = kb[v];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double t = ls[r];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+            if (l16 == 0) rsum[wid * 16 + 4 * kq + r] = t;
+        }
+    }
+    __syncthreads();
+    // ---- V.P: wave = (16-dim tile dt, tile parity par)
+    {
+        const int dt = wid & 3, par = wid >> 2;
+        const uint16_t * prow = p + l16 * ps + 16 * hi;             // keys 16 hi .. 16 hi + 15 of a tile: the even or the odd ones
+        double sum = rsum[l16];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) sum += rsum[w2 * 16 + l16];
+        const float inv = (float)(1.0 / sum);
+        auto load_pv = [&](int T, fq_u4 (&p2)[2], float (&v8)[8]) {
+            p2[0] = *(const fq_u4 *)(prow + 32 * T); p2[1] = *(const fq_u4 *)(prow + 32 * T + 8);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int j = 32 * T + 16 * hi + 2 * m + eo;
+                v8[m] = vc[((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 16 * dt + l16];
+            }
+        };
+        // element 2 m + eo of the 16 halves: the low (eo = 0) or high half of word m
+        auto pe = [&](const fq_u4 (&p2)[2], int m) {
+            const fq_u4 & q = p2[m >> 2];
+            const uint32_t w = (m & 3) == 0 ? q.x : ((m & 3) == 1 ? q.y : ((m & 3) == 2 ? q.z : q.w));
+            return h2f_bits((uint16_t)(eo ? w >> 16 : w & 0xFFFFu));
+        };
+        fq_u4 pa[2], pb[2]; float va[8], vb[8];
+        if (par < ntile) load_pv(par, pa, va);
+        v4f_ c = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int T = par; T < ntile; T += 2) {
+            if (T + 2 < ntile) load_pv(T + 2, pb, vb);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pe(pa, m) * inv, va[m], c, 0, 0, 0);      // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32)
+            pa[0] = pb[0]; pa[1] = pb[1];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) va[m] = vb[m];
+        }
+        if (par == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[(dt * 4 + r) * 64 + lane] = c[r];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = 4 * kq + r;
+                if (ir < nrows) att[(int64_t)(i0 + ir) * H * 64 + (int64_t) h * 64 + 16 * dt + l16] = c[r] + xch[(dt * 4 + r) * 64 + lane];
+            }
+        }
+    }
+}
+
 // 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
 static int g_attn_f64 = 0;
+static int g_attn_form = 0;      // prefill attention on the matrix pipe: 0 = default (32 rows, scores in the global scratch), 16 = k_attention_mfma16, 17 = k_attention_mfma16h
+void fq_attn_set_form(int form) { g_attn_form = form; }
 void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
 int  fq_attn_f64() { return g_attn_f64; }
 template <int R>
@@ -505,14 +653,23 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
     static const int use_mfma = getenv("FQ_ATTN_MFMA") ? atoi(getenv("FQ_ATTN_MFMA")) : 1;
     if (use_mfma && N >= 32 && !g_attn_f64 && !seq_stride && force < 0) {
         // the score rows of 16 query tokens in LDS while they fit (~2400 keys); beyond that 32 tokens per workgroup and the global scratch
-        static const int use_16 = getenv("FQ_ATTN_MFMA16") ? atoi(getenv("FQ_ATTN_MFMA16")) : 0;      // (measured slower than the scratch form at every prompt length: one 8-wave workgroup per CU; kept for its tests)
+        static const int env_form = (getenv("FQ_ATTN_MFMA16H") && atoi(getenv("FQ_ATTN_MFMA16H"))) ? 17 : ((getenv("FQ_ATTN_MFMA16") && atoi(getenv("FQ_ATTN_MFMA16"))) ? 16 : 0);
+        const int form = g_attn_form ? g_attn_form : env_form;      // (16 and 17: measured slower than the scratch form at 2048 tokens, see k_attention_mfma16h)
         static const int max_kv16 = getenv("FQ_ATTN_MFMA16_MAXKV") ? atoi(getenv("FQ_ATTN_MFMA16_MAXKV")) : 4096;
         const int ps16 = ((max_n_kv + 31) & ~31) + 4;
         const size_t lds16 = ((size_t) 16 * ps16 + 8 * 16 + 16 + 4 * 4 * 64) * 4;
-        if (use_16 && lds16 <= 158 * 1024 && max_n_kv <= max_kv16) {
+        if (form == 16 && lds16 <= 158 * 1024 && max_n_kv <= max_kv16) {
             static size_t g16 = 0;
             if (lds16 > 64 * 1024 && lds16 > g16) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_mfma16, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds16)); g16 = lds16; }
             hipLaunchKernelGGL(k_attention_mfma16, dim3((unsigned) H, (unsigned)((N + 15) / 16)), dim3(512), lds16, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, ps16);
+            return;
+        }
+        const int ps16h = ((max_n_kv + 31) & ~31) + 8;                                   // uint16 elements per row
+        const size_t lds16h = (8 * 16) * 4 + (8 * 16) * 8 + (4 * 4 * 64) * 4 + (size_t) 16 * ps16h * 2;
+        if (form == 17 && lds16h <= 158 * 1024) {
+            static size_t g16h = 0;
+            if (lds16h > 64 * 1024 && lds16h > g16h) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_mfma16h, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds16h)); g16h = lds16h; }
+            hipLaunchKernelGGL(k_attention_mfma16h, dim3((unsigned) H, (unsigned)((N + 15) / 16)), dim3(512), lds16h, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, ps16h);
             return;
         }
         const int ps = (max_n_kv + 31) & ~31;

@@ -167,3 +167,33 @@ def test_softmax_golden_through_attention(oracle, golden):
             L.ggml_hip_attention(qb.ptr, 1, 1, 1, D, nk - 1, kb.ptr, vb.ptr, o.ptr)
             got = o.to_host(np.float32, (D,))
             assert np.array_equal(got[:min(nk, D)], gb["sm_p"][h, t, :min(nk, D)])
+
+
+@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 32, 0), (8, 2, 45, 5), (3, 1, 100, 37), (2, 2, 33, 64), (5, 1, 700, 0), (2, 1, 17 * 16, 1500)])
+def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
+    """the three prefill attention kernels on the f32 matrix pipe -- k_attention_mfma (32-token tiles, scores in the global scratch: the default, pinned against
+    the oracle's dot_qk_mfma / dot_pv_mfma by the whole-model tests), k_attention_mfma16 (16-token tiles, f32 scores in LDS) and k_attention_mfma16h (16-token
+    tiles, K.Q run twice and the probabilities kept in LDS as the fp16 values the soft_max's exp table yields: two workgroups per CU) -- give the same bits:
+    ragged last tiles, a context that does not start at 0, MQA and GQA (ggml.c:10911-11102 soft_max, 12389-12456 the two dot products)"""
+    L = g.load()
+    D = 64
+    rng = np.random.default_rng(H * 1000 + N + n_past)
+    n_kv = n_past + N
+    qkv = rng.standard_normal((N, H + 2 * HKV, D)).astype(np.float32)
+    kc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    vc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    qb, kb, vb, ob_ = g.DevBuf(host=qkv), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(N * H * D * 4)
+    outs = {}
+    try:
+        for form in (0, 16, 17):
+            L.ggml_hip_debug_attention_form(form)
+            L.ggml_hip_memset(ob_.ptr, 0xFF, N * H * D * 4)
+            L.ggml_hip_attention(qb.ptr, N, H, HKV, D, n_past, kb.ptr, vb.ptr, ob_.ptr)
+            outs[form] = ob_.to_host(np.float32, (N, H * D))
+    finally:
+        L.ggml_hip_debug_attention_form(0)
+        for b in (qb, kb, vb, ob_):
+            b.free()
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[16], outs[0])
+    assert np.array_equal(outs[17], outs[0])
