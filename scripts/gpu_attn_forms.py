@@ -1,6 +1,6 @@
 """time the prefill attention kernels on a Falcon-7B block's shape (71 heads, MQA): python scripts/gpu_attn_forms.py [N ...]
 form 0 = k_attention_mfma (32-token tiles, scores through the global scratch), 16 = k_attention_mfma16 (f32 scores in LDS), 17 = k_attention_mfma16h (fp16
-probabilities in LDS, K.Q twice, two workgroups per CU); also checks that the three agree bit for bit"""
+probabilities in LDS, K.Q twice, two workgroups per CU); FORMS=0,17 selects; also checks that the three agree bit for bit"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ggllm_cpp_amd as g
 g.init(0); L = g.load()
 H, HKV, D = 71, 1, 64
+FORMS = [int(f) for f in os.environ.get("FORMS", "0,16,17").split(",")]
 for N in [int(a) for a in sys.argv[1:]] or [2048, 512, 128]:
     rng = np.random.default_rng(N)
     qkv = rng.standard_normal((N, H + 2 * HKV, D)).astype(np.float32)
@@ -15,7 +16,7 @@ for N in [int(a) for a in sys.argv[1:]] or [2048, 512, 128]:
     vc = rng.standard_normal((N, HKV, D)).astype(np.float32)
     qb, kb, vb, ob_ = g.DevBuf(host=qkv), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(N * H * D * 4)
     ref = None
-    for form in (0, 16, 17):
+    for form in FORMS:
         L.ggml_hip_debug_attention_form(form)
         for _ in range(2): L.ggml_hip_attention(qb.ptr, N, H, HKV, D, 0, kb.ptr, vb.ptr, ob_.ptr)
         e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
