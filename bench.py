@@ -407,7 +407,7 @@ def main():
             ovh = L.ggml_hip_profile_bracket_overhead_us()
             avg_us = us.value / nl.value
             ach = (by.value / nl.value) / (avg_us * 1e-6) / 1e9
-            roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln_ring (lm_head: k_gemv_ln) + k_attn_out (fused quantized mat-vec launches; lm_head included)",
+            roof.update(launch_achieved=ach, launch_frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln_ring (lm_head: k_gemv_ln) + k_attn_out (fused quantized mat-vec launches; lm_head included)",
                         launches=nl.value, avg_launch_us=avg_us, empty_event_pair_us=ovh, bytes_per_launch=by.value / nl.value)
     # HBM traffic per launch from the PMC counters: collected off-line (scripts/gpu_pmc.sh: one rocprofv3 --pmc pass per
     # counter over this same command, corrected by scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes) and committed
@@ -419,7 +419,11 @@ def main():
             roof["traffic_error"] = "no profiles/*pmc_traffic.json holds the decode launches (k_gemv_ln* + k_attn_out*): run scripts/gpu_round.sh <tag> pmc and commit its summary"
             sys.stderr.write("bench.py: ERROR: roofline.traffic is null -- " + roof["traffic_error"] + "\n")
     step_gbs = b_tok * tok_s / 1e9
-    roof.update(step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok)
+    # `achieved` / `frac` = the TIMED (hipGraph) region: algorithmic bytes per token x tokens/s -- launch boundaries, attention and argmax included;
+    # `launch_*` = the dominant kernels alone (algorithmic weight bytes per launch / average launch duration, events stamped by the dispatches of an
+    # instrumented plain-launch repeat; agrees with profiles/*decode_7b_q4_0_kernel_stats.md)
+    roof.update(achieved=step_gbs, frac=step_gbs / HBM_PEAK_GBS, step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok,
+                note="frac = whole timed step (B_tok x tok/s over 8 TB/s); launch_frac = the two fused mat-vec launches + lm_head alone")
 
     # ---- prefill: flops / time against the matrix pipe (2 N sum(ne00 ne01) + attention 4 64 n_head n_layer N(N+1)/2)
     def prefill_roof(N, ms):

@@ -25,7 +25,7 @@ TYPE_NAME = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0
              Q2_K: "q2_K", Q3_K: "q3_K", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
 VEC_DOT = {Q4_0: Q8_0, Q5_0: Q8_0, Q8_0: Q8_0, Q4_1: Q8_1, Q5_1: Q8_1, Q2_K: Q8_K, Q3_K: Q8_K, Q4_K: Q8_K, Q5_K: Q8_K, Q6_K: Q8_K}
 
-EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_split_comm_create_loopback ggml_hip_split_comm_rccl_ranks ggml_hip_mul_mat_q_split_loopback ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_debug_attention_form ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
+EXPORTS_OPS = """ggml_hip_init ggml_hip_split_configure ggml_hip_tensor_split_rows ggml_hip_weight_upload_rows ggml_hip_split_comm_create ggml_hip_split_comm_free ggml_hip_split_comm_agree ggml_hip_mul_mat_q_split ggml_hip_mul_mat_q_split_local ggml_hip_split_comm_create_loopback ggml_hip_split_comm_rccl_ranks ggml_hip_mul_mat_q_split_loopback ggml_hip_shim_pool_stats ggml_hip_get_reference_order ggml_hip_debug_force_gemv ggml_hip_debug_attention_form ggml_hip_debug_exp_boundary ggml_hip_gemm_sequential ggml_hip_reference_order ggml_hip_debug_stamps ggml_hip_selftest ggml_hip_exp_formula_mismatches ggml_hip_device_count ggml_hip_stream ggml_hip_malloc ggml_hip_free ggml_hip_memcpy_h2d
 ggml_hip_memcpy_d2h ggml_hip_memcpy_d2d ggml_hip_memset ggml_hip_synchronize ggml_hip_event_create ggml_hip_event_record
 ggml_hip_event_elapsed_ms ggml_hip_event_destroy ggml_hip_profile_begin ggml_hip_profile_end ggml_hip_profile_bracket_overhead_us ggml_hip_gelu_table_dev ggml_hip_exp_table_dev ggml_hip_weight_upload
 ggml_hip_weight_free ggml_hip_weight_nbytes ggml_hip_dequantize_rows ggml_hip_quantize_rows ggml_hip_weight_quantize ggml_hip_fp16_to_fp32_row ggml_hip_acts_alloc ggml_hip_acts_free
@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_last_error falcon_hip_context_set_rope_n_ctx
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
+falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_engine_compiled falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
@@ -47,7 +47,7 @@ def build(verbose=False):
     cmd = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-j", str(min(16, os.cpu_count() or 4))]
     if not verbose:
         cmd.insert(1, "-s")
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd + ["all", "check_engine"])            # (check_engine: the opt-in mode-4 source still compiles; linked only with ENGINE=1)
     return LIB_PATH
 
 
@@ -69,7 +69,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
     sig = {
-        "ggml_hip_init": (C.c_int, [C.c_int]), "ggml_hip_selftest": (C.c_int, []), "ggml_hip_exp_formula_mismatches": (C.c_int, []), "ggml_hip_debug_force_gemv": (None, [C.c_int]), "ggml_hip_debug_attention_form": (None, [C.c_int]), "ggml_hip_debug_stamps": (None, [C.c_int, vp]), "ggml_hip_device_count": (C.c_int, []), "ggml_hip_stream": (vp, []),
+        "ggml_hip_init": (C.c_int, [C.c_int]), "ggml_hip_selftest": (C.c_int, []), "ggml_hip_exp_formula_mismatches": (C.c_int, []), "ggml_hip_debug_force_gemv": (None, [C.c_int]), "ggml_hip_debug_attention_form": (None, [C.c_int]), "ggml_hip_debug_exp_boundary": (C.c_int, [vp, C.c_int]), "ggml_hip_debug_stamps": (None, [C.c_int, vp]), "ggml_hip_device_count": (C.c_int, []), "ggml_hip_stream": (vp, []),
         "ggml_hip_malloc": (vp, [sz]), "ggml_hip_free": (None, [vp]),
         "ggml_hip_memcpy_h2d": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2h": (None, [vp, vp, sz]), "ggml_hip_memcpy_d2d": (None, [vp, vp, sz]),
         "ggml_hip_memset": (None, [vp, C.c_int, sz]), "ggml_hip_synchronize": (None, []),
@@ -118,7 +118,7 @@ def load():
         "falcon_hip_tokenize": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int]),
         "falcon_hip_token_to_bytes": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p)]),
         "falcon_hip_token_bos": (C.c_int32, []), "falcon_hip_token_eos": (C.c_int32, []),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_engine_compiled": (C.c_int, []), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_plan_stages": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),

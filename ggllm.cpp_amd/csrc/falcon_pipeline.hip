@@ -20,6 +20,11 @@
 // librccl.so.1, the copy already in the process if there is one): single-GPU users of libggml_hip.so do not need it.
 // A LOCAL transport (every rank a falcon_hip_pipeline of the same process and device, hand-off by device copies) runs the
 // identical schedule and stage code on one GPU: falcon_hip_pipeline_run_local, used by tests/test_gpu_pipeline.py.
+// A HOST-STAGED transport between PROCESSES of one node (FALCON_PIPE_TRANSPORT=shm, round 5): the ranks are real processes -- spawned,
+// handed the unique id, each with its own HIP context, stage graphs and slot schedule, exactly as the RCCL job -- and only the bytes of a
+// hand-off travel differently: device -> pinned host -> a POSIX shared-memory mailbox of the receiver -> pinned host -> device, sequenced
+// by a {seq, ack} word pair per mailbox. It exists because RCCL refuses two ranks on one device ("Duplicate GPU detected"): with it
+// `bench.py --gpus N` runs end to end with every rank on GPU 0 of a one-GPU box (FALCON_PIPE_SAME_DEVICE=1), tests/test_gpu_pipeline_procs.py.
 #include "../../include/falcon-hip.h"
 #include "../../include/ggml-hip-ops.h"
 #include "fq_device.h"
@@ -33,6 +38,13 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 
 // ------------------------------------------------------------------------------------------------ RCCL, bound at run time (rccl_dyn.h)
 rccl_api * fq_rccl() {
@@ -109,6 +121,27 @@ struct falcon_hip_pipeline {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_compute[4] = {}, ev_comm[4] = {}, ev_start = nullptr;
     std::vector<void *> allocs;
+    struct shm_transport * shm = nullptr;                           // FALCON_PIPE_TRANSPORT=shm: mailboxes in POSIX shared memory (ranks = processes of one node)
+};
+
+// ------------------------------------------------------------------------------------------------ the host-staged transport (shm)
+// One segment per job, named after the job's unique id: a header, then one mailbox per (receiving rank, group) and kind:
+//   { seq, ack } (64 bytes)  |  payload (residual rows [B][n_embd] f32, or B token ids)
+// A sender waits for ack == its count (the receiver has taken the previous message of that mailbox: always true already, by the
+// schedule's own data dependencies -- the check makes it hold by construction), writes the payload, then seq = ++count (release). A
+// receiver waits for seq == its count + 1 (acquire), copies the payload to the device, then ack = ++count. Waits are bounded
+// (FALCON_PIPE_SHM_TIMEOUT_S, default 300): a dead peer ends the job with a message instead of hanging it.
+struct shm_box { volatile uint32_t seq, ack; uint32_t pad[14]; };
+static_assert(sizeof(shm_box) == 64, "mailbox header");
+struct shm_header { volatile uint32_t ready, attached; uint32_t world, G, B, E; uint32_t pad[10]; };
+static_assert(sizeof(shm_header) == 64, "segment header");
+struct shm_transport {
+    int fd = -1; uint8_t * base = nullptr; size_t bytes = 0; char name[64] = {0}; bool owner = false;
+    size_t hid_bytes = 0, tok_bytes = 0, box_stride = 0;            // payload sizes (rounded to 64), bytes per (rank, group)
+    void * stage_out = nullptr, * stage_in = nullptr;               // pinned staging rows
+    std::vector<uint32_t> sent_h, sent_t, got_h, got_t;             // per group: messages this rank has sent to / taken from a mailbox
+    double timeout_s = 300.0;
+    shm_box * box(int rank, int G, int g, bool token) const { return (shm_box *)(base + 64 + ((size_t) rank * G + g) * box_stride + (token ? 64 + hid_bytes : 0)); }
 };
 
 namespace {
@@ -151,6 +184,109 @@ void exchange_rccl(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st)
     RCCL_CHECK(R->ncclGroupEnd());
 }
 
+double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
+// spin (politely) until *word == want; false after the transport's time-out
+bool shm_wait(const shm_transport * t, const volatile uint32_t * word, uint32_t want, const char * what, int rank, int group) {
+    const double t0 = now_s();
+    for (unsigned spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; ++spins) {
+        if (spins > 2000) usleep(20); else if (spins > 200) sched_yield();
+        if ((spins & 1023) == 1023 && now_s() - t0 > t->timeout_s) {
+            fprintf(stderr, "falcon-hip: pipeline (shm transport): rank %d waited %.0f s for %s of group %d (have %u, want %u) -- a peer is gone or stuck\n",
+                    rank, t->timeout_s, what, group, (unsigned) *word, want);
+            return false;
+        }
+    }
+    return true;
+}
+uint64_t fnv64(const void * data, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= ((const uint8_t *) data)[i]; h *= 1099511628211ull; } return h; }
+
+// every rank of the job calls this with the same unique id: rank 0 creates the segment, the others attach; returns when all have
+bool shm_attach(falcon_hip_pipeline * p, const void * unique_id) {
+    shm_transport * t = new shm_transport();
+    if (const char * e = getenv("FALCON_PIPE_SHM_TIMEOUT_S")) t->timeout_s = atof(e) > 0 ? atof(e) : t->timeout_s;
+    const size_t E = (size_t) p->hp.n_embd, G = (size_t) p->G, B = (size_t) p->B;
+    t->hid_bytes = (B * E * 4 + 63) & ~(size_t) 63; t->tok_bytes = (B * 4 + 63) & ~(size_t) 63;
+    t->box_stride = 64 + t->hid_bytes + 64 + t->tok_bytes;
+    t->bytes = 64 + (size_t) p->world * G * t->box_stride;
+    snprintf(t->name, sizeof(t->name), "/falcon_pipe_%016llx", (unsigned long long) fnv64(unique_id, FALCON_HIP_PIPELINE_ID_BYTES));
+    t->owner = p->rank == 0;
+    const double t0 = now_s();
+    if (t->owner) {
+        shm_unlink(t->name);                                        // (a stale segment of a job that died under this very id)
+        t->fd = shm_open(t->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (t->fd < 0 || ftruncate(t->fd, (off_t) t->bytes) != 0) { fprintf(stderr, "falcon-hip: pipeline: shm_open / ftruncate(%s, %zu): %s\n", t->name, t->bytes, strerror(errno)); delete t; return false; }
+    } else {
+        for (;;) {
+            t->fd = shm_open(t->name, O_RDWR, 0600);
+            struct stat st;
+            if (t->fd >= 0 && fstat(t->fd, &st) == 0 && (size_t) st.st_size >= t->bytes) break;
+            if (t->fd >= 0) { close(t->fd); t->fd = -1; }
+            if (now_s() - t0 > t->timeout_s) { fprintf(stderr, "falcon-hip: pipeline: rank %d found no segment %s of %zu bytes within %.0f s\n", p->rank, t->name, t->bytes, t->timeout_s); delete t; return false; }
+            usleep(2000);
+        }
+    }
+    t->base = (uint8_t *) mmap(nullptr, t->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+    if (t->base == (uint8_t *) MAP_FAILED) { fprintf(stderr, "falcon-hip: pipeline: mmap(%s): %s\n", t->name, strerror(errno)); close(t->fd); delete t; return false; }
+    shm_header * h = (shm_header *) t->base;
+    if (t->owner) {
+        memset(t->base, 0, t->bytes);
+        h->world = (uint32_t) p->world; h->G = (uint32_t) G; h->B = (uint32_t) B; h->E = (uint32_t) E;
+        __atomic_store_n(&h->ready, 0x46504950u, __ATOMIC_RELEASE);
+    } else if (!shm_wait(t, &h->ready, 0x46504950u, "the segment header", p->rank, -1)) { munmap(t->base, t->bytes); close(t->fd); delete t; return false; }
+    if (h->world != (uint32_t) p->world || h->G != G || h->B != B || h->E != E) {
+        fprintf(stderr, "falcon-hip: pipeline: rank %d: the job's segment says world %u, %u groups of %u, n_embd %u -- this rank was created with %d, %zu, %zu, %zu\n",
+                p->rank, h->world, h->G, h->B, h->E, p->world, G, B, E);
+        munmap(t->base, t->bytes); close(t->fd); delete t; return false;
+    }
+    __atomic_add_fetch(&h->attached, 1u, __ATOMIC_ACQ_REL);
+    if (!shm_wait(t, &h->attached, (uint32_t) p->world, "every rank to attach", p->rank, -1)) { munmap(t->base, t->bytes); close(t->fd); if (t->owner) shm_unlink(t->name); delete t; return false; }
+    HIP_CHECK(hipHostMalloc(&t->stage_out, t->hid_bytes, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&t->stage_in, t->hid_bytes, hipHostMallocDefault));
+    t->sent_h.assign(G, 0); t->sent_t.assign(G, 0); t->got_h.assign(G, 0); t->got_t.assign(G, 0);
+    p->shm = t;
+    return true;
+}
+void shm_detach(falcon_hip_pipeline * p) {
+    shm_transport * t = p->shm;
+    if (!t) return;
+    if (t->stage_out) HIP_CHECK(hipHostFree(t->stage_out));
+    if (t->stage_in) HIP_CHECK(hipHostFree(t->stage_in));
+    munmap(t->base, t->bytes); close(t->fd);
+    if (t->owner) shm_unlink(t->name);                              // (the others keep their mappings until they detach)
+    delete t; p->shm = nullptr;
+}
+// the slot's exchange over the mailboxes, BLOCKING on the host: sends first (they wait for nobody but the mailbox's ack), then the
+// receives. `st` is the stream the copies run on; the caller has made it wait for the compute whose result is sent.
+bool exchange_shm(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st) {
+    shm_transport * t = p->shm;
+    const size_t nh = (size_t) p->B * p->hp.n_embd * 4, nt = (size_t) p->B * 4;
+    for (int i = 0; i < s.n_ops; ++i) {
+        const pipe_op & o = s.op[i];
+        if (o.kind != OP_SEND_HIDDEN && o.kind != OP_SEND_TOKEN) continue;
+        const bool tok = o.kind == OP_SEND_TOKEN; const size_t g = (size_t) o.group, n = tok ? nt : nh;
+        shm_box * b = t->box(o.peer, p->G, o.group, tok);
+        uint32_t & cnt = tok ? t->sent_t[g] : t->sent_h[g];
+        HIP_CHECK(hipMemcpyAsync(t->stage_out, tok ? (const void *) p->tok_out[g] : (const void *) p->hidden_out[g], n, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (!shm_wait(t, &b->ack, cnt, tok ? "the receiver to take the previous tokens" : "the receiver to take the previous residual rows", p->rank, o.group)) return false;
+        memcpy((uint8_t *) b + 64, t->stage_out, n);
+        __atomic_store_n(&b->seq, ++cnt, __ATOMIC_RELEASE);
+    }
+    for (int i = 0; i < s.n_ops; ++i) {
+        const pipe_op & o = s.op[i];
+        if (o.kind != OP_RECV_HIDDEN && o.kind != OP_RECV_TOKEN) continue;
+        const bool tok = o.kind == OP_RECV_TOKEN; const size_t g = (size_t) o.group, n = tok ? nt : nh;
+        shm_box * b = t->box(p->rank, p->G, o.group, tok);
+        uint32_t & cnt = tok ? t->got_t[g] : t->got_h[g];
+        if (!shm_wait(t, &b->seq, cnt + 1, tok ? "the sampled tokens" : "the residual rows", p->rank, o.group)) return false;
+        memcpy(t->stage_in, (const uint8_t *) b + 64, n);
+        HIP_CHECK(hipMemcpyAsync(tok ? (void *) p->tok_in[g] : (void *) p->hidden_in[g], t->stage_in, n, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        __atomic_store_n(&b->ack, ++cnt, __ATOMIC_RELEASE);
+    }
+    return true;
+}
+
 falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_groups, int batch, int n_ctx) {
     if (!m || world < 1 || rank < 0 || rank >= world || n_groups < 1 || batch < 1 || batch > 256 || n_ctx < 1) {
         fprintf(stderr, "falcon-hip: pipeline: bad arguments (rank %d of %d, %d groups of %d sequences, n_ctx %d)\n", rank, world, n_groups, batch, n_ctx);
@@ -190,8 +326,16 @@ falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_gr
 
 extern "C" {
 
+static bool shm_transport_selected() { const char * e = getenv("FALCON_PIPE_TRANSPORT"); return e && !strcmp(e, "shm"); }
+
 int falcon_hip_pipeline_unique_id(void * id_out) {
     rccl_api * R = fq_rccl();
+    if (!R && shm_transport_selected()) {                           // the host-staged transport only needs 128 bytes no other job has
+        int fd = open("/dev/urandom", O_RDONLY);
+        const bool ok = fd >= 0 && read(fd, id_out, FALCON_HIP_PIPELINE_ID_BYTES) == FALCON_HIP_PIPELINE_ID_BYTES;
+        if (fd >= 0) close(fd);
+        return ok ? 0 : -1;
+    }
     if (!R) return -1;
     ncclUniqueId id;
     if (R->ncclGetUniqueId(&id) != ncclSuccess) return -1;
@@ -203,6 +347,10 @@ falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank,
     static_assert(sizeof(ncclUniqueId) == FALCON_HIP_PIPELINE_ID_BYTES, "unique id size");
     falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
     if (!p || world == 1) return p;
+    if (shm_transport_selected()) {                                 // ranks = processes of one node, hand-offs through host shared memory
+        if (!unique_id || !shm_attach(p, unique_id)) { fprintf(stderr, "falcon-hip: pipeline: the shm transport could not be set up (rank %d of %d)\n", rank, world); falcon_hip_pipeline_free(p); return nullptr; }
+        return p;
+    }
     rccl_api * R = fq_rccl();
     if (!R || !unique_id) { fprintf(stderr, "falcon-hip: pipeline: %s\n", R ? "no unique id" : "RCCL is not available"); falcon_hip_pipeline_free(p); return nullptr; }
     ncclUniqueId id;
@@ -253,11 +401,21 @@ int falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p) {
     return n;
 }
 
+// how this rank's hand-offs travel: 0 = nowhere (one stage), 1 = RCCL send / recv, 2 = device copies in one process (local), 3 = the local job
+// over a one-rank RCCL communicator (loop-back), 4 = host shared memory between processes (FALCON_PIPE_TRANSPORT=shm)
+int falcon_hip_pipeline_transport(falcon_hip_pipeline * p) {
+    if (!p) return -1;
+    if (p->local) return p->loop ? 3 : 2;
+    if (p->shm) return 4;
+    return p->comm ? 1 : 0;
+}
+
 void falcon_hip_pipeline_free(falcon_hip_pipeline * p) {
     if (!p) return;
     HIP_CHECK(hipStreamSynchronize(fq_ctx().stream));
     if (p->comm_stream) HIP_CHECK(hipStreamSynchronize(p->comm_stream));
     if (p->comm) fq_rccl()->ncclCommDestroy(p->comm);
+    shm_detach(p);
     for (falcon_hip_context * c : p->ctx) falcon_hip_context_free(c);
     for (int i = 0; i < 4; ++i) { if (p->ev_compute[i]) HIP_CHECK(hipEventDestroy(p->ev_compute[i])); if (p->ev_comm[i]) HIP_CHECK(hipEventDestroy(p->ev_comm[i])); }
     if (p->ev_start) HIP_CHECK(hipEventDestroy(p->ev_start));
@@ -281,9 +439,36 @@ int falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * toke
 // (falcon_hip_pipeline_get_history or ggml_hip_synchronize waits). Every rank of the job makes the same call.
 int falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0) {
     if (rounds < 1 || n_past0 < 0 || n_past0 + rounds > p->n_ctx) { fprintf(stderr, "falcon-hip: pipeline: %d rounds from position %d exceed n_ctx %d\n", rounds, n_past0, p->n_ctx); return 1; }
-    if (p->world > 1 && (p->local || !p->comm)) { fprintf(stderr, "falcon-hip: pipeline: this rank has no RCCL communicator (local transport: falcon_hip_pipeline_run_local)\n"); return 1; }
+    if (p->world > 1 && (p->local || (!p->comm && !p->shm))) { fprintf(stderr, "falcon-hip: pipeline: this rank has no RCCL communicator (local transport: falcon_hip_pipeline_run_local)\n"); return 1; }
     hipStream_t st = fq_ctx().stream;
     const int P = p->world, G = p->G, W = rounds * G, T = slot_count(P, G, W);
+    if (P > 1 && p->shm) {
+        // the same slots, the exchange blocking on the host. Overlapped schedule: the exchange of slot t (result of slot t - 1 out, input of slot
+        // t + 1 in) is run AFTER slot t's stage step has been enqueued, on the second stream behind the event of slot t - 1's step -- the host
+        // waits in it while the device computes slot t, the overlap the RCCL form gets from its second stream.
+        if (!overlapped(P, G)) {
+            for (int t = 0; t < T; ++t) {
+                const pipe_slot s = slot_of(p->rank, P, G, W, t);
+                if (!exchange_shm(p, s, st)) return 4;
+                compute(p, s, n_past0, st);
+            }
+        } else {
+            HIP_CHECK(hipEventRecord(p->ev_start, st));
+            HIP_CHECK(hipStreamWaitEvent(p->comm_stream, p->ev_start, 0));
+            for (int t = 0; t < T; ++t) {
+                const pipe_slot s = slot_of(p->rank, P, G, W, t);
+                if (t > 0) HIP_CHECK(hipStreamWaitEvent(st, p->ev_comm[(t - 1) & 3], 0));                  // the input it received one slot ago
+                compute(p, s, n_past0, st);
+                HIP_CHECK(hipEventRecord(p->ev_compute[t & 3], st));
+                if (t > 0) HIP_CHECK(hipStreamWaitEvent(p->comm_stream, p->ev_compute[(t - 1) & 3], 0));   // the result it sends
+                if (!exchange_shm(p, s, p->comm_stream)) return 4;
+                HIP_CHECK(hipEventRecord(p->ev_comm[t & 3], p->comm_stream));
+            }
+            HIP_CHECK(hipStreamWaitEvent(st, p->ev_comm[(T - 1) & 3], 0));
+        }
+        p->rounds_done += rounds;
+        return 0;
+    }
     if (P == 1) {
         for (int t = 0; t < T; ++t) {
             const pipe_slot s = slot_of(0, 1, G, W, t);

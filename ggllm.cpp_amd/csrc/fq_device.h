@@ -80,14 +80,16 @@ __device__ __forceinline__ float  wave_max(float v)  { return wave_reduce(v, op_
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16) f); }   // RNE, keeps subnormals
 __device__ __forceinline__ float    h2f_bits(uint16_t h) { return (float) __builtin_bit_cast(_Float16, h); }
 
-// fp16 EXP "table" without the table: table_exp_f16[h] = fp16(expf(fp32(h))) (ggml.c:4276-4290) recomputed as
-// fp16((float) exp((double) fp32(h))). ggml_hip_init compares this against the host-built table for all 63488 non-NaN
-// inputs and only then lets the attention kernels use it (a dependent gather costs a memory round trip, 1-2 us while the
-// chip streams weights; this costs ~60 instructions).
+// fp16 EXP "table" without the table: table_exp_f16[h] = fp16(expf(fp32(h))) (ggml.c:4276-4290) recomputed in registers.
+// ggml_hip_init compares the recomputation against the host-built table for all 63488 non-NaN inputs and only then lets
+// the attention kernels use it (a dependent gather costs a memory round trip, 1-2 us while the chip streams weights).
 // Fast path: f32 with a compensated exponent (x log2(e) as a hi + lo pair, v_exp_f32, first-order correction: ~1.5 ulp),
-// accepted only where rounding to fp16 gives the same bits 4 f32-ulps to either side; the rare inputs that sit closer
-// than that to an fp16 rounding boundary take the f64 path. ~16 instructions instead of ~60 plus an f64 exp.
-__device__ __forceinline__ uint16_t exp_f16_formula(uint16_t hbits) {
+// accepted only where rounding to fp16 gives the same bits 4 f32-ulps to either side; the few inputs that sit closer
+// than that to an fp16 rounding boundary are looked up in a short constant list (fq_exp_fix.h). ~20 instructions.
+// exp_f16_fast: the value the f32 evaluation gives and whether it DECIDES the table entry: true where rounding to fp16 gives the same bits 4 f32-ulps to either
+// side (-16 < x < 11), and for the two ranges whose entries follow from the input's bits alone -- x <= -16 (incl. -inf): the fp16 subnormals 2, 1 or 0
+// (exp(-16) = 1.9 x 2^-24, exp(-17.33) = half of 2^-24; round 5: a real prompt's far-away keys all land here), x >= 11.09375 (incl. +inf): +inf.
+__device__ __forceinline__ bool exp_f16_fast(uint16_t hbits, uint16_t & out) {
     const float x = h2f_bits(hbits);
     const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;      // log2(e) = hi + lo
     const float t_hi = x * L2E_HI;
@@ -95,9 +97,26 @@ __device__ __forceinline__ uint16_t exp_f16_formula(uint16_t hbits) {
     const float p = __builtin_amdgcn_exp2f(t_hi);
     const float r = __builtin_fmaf(p * 0.693147182464599609375f, t_lo, p);
     const uint16_t h = f2h_bits(r);
+    const bool tiny = hbits >= 0xCC00u && hbits <= 0xFC00u, big = hbits >= 0x498Cu && hbits <= 0x7C00u;
+    const uint16_t hr = tiny ? (hbits <= 0xCC0Eu ? (uint16_t) 2 : (hbits <= 0xCC55u ? (uint16_t) 1 : (uint16_t) 0)) : (uint16_t) 0x7C00u;
     const bool robust = f2h_bits(r * 1.00000048f) == h && f2h_bits(r * 0.99999952f) == h && x > -16.0f && x < 11.0f;
-    if (__builtin_expect(robust, 1)) return h;
-    return f2h_bits((float) exp((double) x));
+    out = (tiny || big) ? hr : h;
+    return robust || tiny || big;
+}
+// The inputs the fast path cannot decide sit within 4 f32-ulps of an fp16 rounding boundary: a FIXED set for this hardware's v_exp_f32 (FQ_EXP_FIX_N inputs of
+// 63488; listed by ggml_hip_debug_exp_boundary on an MI355X, scripts/gpu_exp_boundary.py) with their table entries -- a search through a constant list instead
+// of an f64 exp() inlined into every soft_max loop (round 5: ~150 instructions and a dozen registers per call site went with it). ggml_hip_init compares formula
+// and table for EVERY input before the kernels may use the formula: an input missing from the list (another chip's v_exp_f32) sends them back to the table.
+#include "fq_exp_fix.h"
+__device__ __forceinline__ uint16_t exp_f16_undecided(uint16_t hbits, uint16_t h) {
+#pragma unroll 1
+    for (int i = 0; i < FQ_EXP_FIX_N; ++i) if ((fq_exp_fix[i] >> 16) == hbits) h = (uint16_t)(fq_exp_fix[i] & 0xFFFFu);
+    return h;
+}
+__device__ __forceinline__ uint16_t exp_f16_formula(uint16_t hbits) {
+    uint16_t h;
+    if (__builtin_expect(exp_f16_fast(hbits, h), 1)) return h;
+    return exp_f16_undecided(hbits, h);
 }
 __device__ __forceinline__ float soft_max_exp(const uint16_t * __restrict__ exp_tab, float x) {      // exp_tab == nullptr: verified formula
     const uint16_t hb = f2h_bits(x);

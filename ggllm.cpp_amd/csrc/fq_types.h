@@ -25,6 +25,12 @@
 //   Q5_K   qs 128            qh 32           scales 12      d,dmin 4     d@0 dmin@2 sc@4 qh@16 qs@48 (k_quants.h:56-62)
 //   Q6_K   ql 128            qh 64           scales 16 i8   d 2          ql@0 qh@128 sc@192 d@208  (k_quants.h:69-74)
 #pragma once
+// ONE switch for the fused form of the legacy formats' K-split partial sums, acc = fma(d_w * d_x, (float) isum, acc), in the tile GEMM (kernels_gemm.hip) and
+// the streaming small-batch forms (kernels_gemm_skinny.hip): both must agree ("same K split -> same bits"), and the oracle's split orders restate the same
+// form with fmaf (oracle_quants.c orc_legacy_block_parts). FMA form, oracle-pinned; the single sequential sum (reference order) keeps two roundings per term.
+#ifndef FQ_SPLIT_FMA
+#define FQ_SPLIT_FMA 1
+#endif
 #include <stdint.h>
 #include <stddef.h>
 

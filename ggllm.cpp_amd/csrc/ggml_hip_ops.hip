@@ -186,7 +186,11 @@ ggml_hip_weight * fq_weight_upload_part(int type, const void * host_blocks, int6
     return hw;
 }
 extern "C" void ggml_hip_weight_free(ggml_hip_weight * w) { if (!w) return; HIP_CHECK(hipFree(w->slab)); delete w; }
-extern "C" size_t ggml_hip_weight_nbytes(const ggml_hip_weight * w) { return w->w.bytes; }
+// (a row-split part of a k-quant matrix is padded with zero rows to whole 16-row tiles on the device: report the bytes of its real rows)
+extern "C" size_t ggml_hip_weight_nbytes(const ggml_hip_weight * w) {
+    if (w->valid_rows > 0 && w->valid_rows < w->w.M) return (size_t)((w->w.bytes / (size_t) w->w.M) * (size_t) w->valid_rows);
+    return w->w.bytes;
+}
 
 // ---- weight quantizers (kernels_wquant.hip): what ggml_quantize_chunk (ggml.c:19479-19560) writes into a model file
 extern "C" int ggml_hip_quantize_rows(int type, const float * x_dev, int64_t K, int64_t nrows, void * blocks_dev, int64_t * hist_dev) {
@@ -262,6 +266,8 @@ static fq_act act_cols(const fq_act & a, int64_t c0, int64_t n) {
 static bool g_force_gemv = false;      // tests: run N > 4 through the mat-vec kernel (column chunks) instead of the MFMA GEMM
 extern "C" void ggml_hip_debug_force_gemv(int on) { ++g_config_epoch; g_force_gemv = on != 0; }
 extern "C" void ggml_hip_debug_attention_form(int form) { ++g_config_epoch; fq_attn_set_form(form); }
+// diagnostic (scripts/gpu_exp_boundary.py generates csrc/fq_exp_fix.h from it): fp16 inputs whose exp() the f32 fast path of the in-kernel formula cannot decide
+extern "C" int ggml_hip_debug_exp_boundary(unsigned * out_host, int cap) { return fq_exp_boundary(fq_ctx().exp_table, out_host, cap, fq_ctx().stream); }
 extern "C" void ggml_hip_gemm_sequential(int on) { ++g_config_epoch; fq_gemm_set_sequential(on); }
 // reference order: every mat-mul through the per-thread scalar restatement (kernels_ref.hip: the reference's own block /
 // lane order for all ten formats and any N), attention with f64 accumulation (the portable ggml_vec_dot_f32)
@@ -398,6 +404,11 @@ void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float *
 
 extern "C" void ggml_hip_mul_mat_q_acts(const ggml_hip_weight * w, const ggml_hip_acts * a, int64_t N, float * dst_dev,
                                         int64_t ldd, int epilogue, const float * add1_dev, const float * add2_dev) {
+    if (w->valid_rows > 0 && w->valid_rows < w->w.M) {      // a padded row-split part would write its zero rows over the next rank's rows of dst
+        fprintf(stderr, "ggml-hip: ggml_hip_mul_mat_q_acts on a padded row-split part (%lld of %lld device rows are real): use ggml_hip_mul_mat_q / _split\n",
+                (long long) w->valid_rows, (long long) w->w.M);
+        exit(1);
+    }
     fq_gemv_epi ep{ epilogue, fq_ctx().gelu_table, add1_dev, add2_dev, ldd };
     fq_mul_mat_q_acts(w->w, a->a, N, dst_dev, ldd, ep, fq_ctx().stream);
 }
@@ -410,12 +421,17 @@ extern "C" void ggml_hip_mul_mat_q(const ggml_hip_weight * w, const float * x_de
     // a padded row-split part (fq_weight_upload_part): all its rows into a private matrix, the real ones from there into dst
     const bool padded = w->valid_rows > 0 && w->valid_rows < w->w.M;
     float * out = dst_dev; int64_t ldo = ldd;
-    if (padded) { ldo = w->w.M; HIP_CHECK(hipMalloc((void **) &out, (size_t) N * (size_t) ldo * 4)); }
+    static float * priv = nullptr; static size_t priv_bytes = 0;      // grow-only private matrix of the padded parts (the call synchronises before it returns)
+    if (padded) {
+        ldo = w->w.M;
+        const size_t need = (size_t) N * (size_t) ldo * 4;
+        if (need > priv_bytes) { if (priv) HIP_CHECK(hipFree(priv)); HIP_CHECK(hipMalloc((void **) &priv, need)); priv_bytes = need; }
+        out = priv;
+    }
     fq_gemv_epi ep{ FQ_EPI_STORE, c.gelu_table, nullptr, nullptr, ldo };
     fq_mul_mat_q_acts(w->w, a, N, out, ldo, ep, c.stream);
     if (padded) HIP_CHECK(hipMemcpy2DAsync(dst_dev, (size_t) ldd * 4, out, (size_t) ldo * 4, (size_t) w->valid_rows * 4, (size_t) N, hipMemcpyDeviceToDevice, c.stream));
     HIP_CHECK(hipStreamSynchronize(c.stream));
-    if (padded) HIP_CHECK(hipFree(out));
     HIP_CHECK(hipFree(slab));
 }
 

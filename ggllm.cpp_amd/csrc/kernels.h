@@ -71,12 +71,13 @@ void   fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * 
 // fq_attention_scratch_need(n_batch, H, n_ctx); never grown inside a launch); nullptr: a process-wide buffer grown on demand
 // (op-level API only: it synchronizes and reallocates).
 struct fq_att_scratch { float * p; size_t bytes; };
-size_t fq_attention_scratch_need(int N, int H, int max_n_kv);          // 0: no launch of that size uses a scratch
+size_t fq_attention_scratch_need(int N, int H, int max_n_kv, int HKV = 1);          // 0: no launch of that size uses a scratch
 void   fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                            const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride = 0,
                            fq_att_scratch * own_scratch = nullptr);
 
 int    fq_selftest_reduce(hipStream_t st);
+int    fq_exp_boundary(const uint16_t * exp_table, unsigned * out_host, int cap, hipStream_t st);   // diagnostic: the inputs the f32 fast path of exp_f16_formula leaves undecided
 int    fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st);   // number of non-NaN inputs where the formula != table   // 0 = DPP wave reductions agree with the __shfl_xor butterfly
 
 // kernels_decode.hip -- fused N = 1 decode kernels

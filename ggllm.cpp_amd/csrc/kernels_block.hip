@@ -13,6 +13,7 @@
 #include "fq_block_dev.h"
 #include "fq_attn_dev.h"
 #include "kernels.h"
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------ layer norm
 // one 256-thread workgroup per row; the row lives in LDS between the passes
@@ -588,8 +589,283 @@ __global__ void __launch_bounds__(512, 4) k_attention_mfma16h(const float * __re
 }
 
 // 1: the two dot products of the attention accumulate f32 products in f64 like the reference's portable build (fq_attn_dev.h)
+
+// ---- prefill attention with the probabilities resident in LDS, 32 query tokens per workgroup ("flash" form, round 5: the default while the rows fit) -------
+// The arithmetic of k_attention_mfma, operand for operand (v_mfma_f32_32x32x2_f32 chains: score(i, j) over s = 0..31 of dims s, 32 + s; out = E + O, the chains
+// over the even / odd 32-key tiles, in a tile over s = 0..15 of keys s, 16 + s; soft_max: max, table[f16(s - max)], exact f64 sum, p = e * (float)(1 / sum)) --
+// bit-identical to it and to the oracle's dot_qk_mfma / dot_pv_mfma -- but no score ever leaves the CU: the scratch form moves the N x n_kv score matrix through
+// HBM four times (1.25 GB per Falcon-7B launch at 2048 tokens, 17 x the q / K / V / output bytes). A score must be known in f32 until its row's maximum is, and
+// exp() comes out of a table of fp16 values (ggml.c:10911-10960), so:
+//   pass A   K.Q on the matrix pipe, only the row maxima are kept (registers -> 1 KiB of LDS)
+//   pass B   the same chains again (same operands, same order: the same bits), e = table[f16(s - max)] stored as the 2-byte value it is: 32 rows x n_kv x 2 B
+//            of LDS (128 KiB at 2048 keys); f64 row sums (exact in any order: <= 2^13 fp16-valued terms)
+//   pass C   V.P with p = (float) e16 * inv formed on the way into the matrix instruction
+// 8 waves: passes A and B deal the 32-key tiles round-robin (two waves per SIMD: one wave's exp() arithmetic -- ~25 VALU instructions per score -- runs under the
+// other's 64-cycle matrix instructions; key tiles go from L2 straight to registers one tile ahead, a tile is used by one wave only); pass C is four chains
+// (dim half x tile parity: the association fixes that) on waves 0-3, one per SIMD, loads two tiles ahead. Heavy query tiles (the last tokens of the prompt) are
+// dispatched first. 3 units of matrix work (K.Q twice, V.P once) instead of 2, at the f32 pipe's 157 TFLOP/s: 0.37 ms per Falcon-7B block at 2048 tokens.
+// pitch_h: halfwords per LDS row = 32 ntile_max + 8 (row pitch 16 bytes off a multiple of 64: conflict-free b128 reads down a column of rows).
+// Loads as inline assembly: hipcc sinks a plain prefetch load down to its first use (it reloads the tile just in time, two requests in flight: measured,
+// the first version of this kernel ran at the scratch form's speed), so the tiles are requested with explicit instructions and awaited with explicit counts.
+// The destination registers are tied through the s_waitcnt statement ("+v"): nothing the compiler schedules can read them before the data has landed.
+#ifndef FQ_FLASH_PLAIN
+#define FQ_FLASH_PLAIN 1            // 1 (default): compiler-managed loads. 0: the tiles requested by inline-asm loads one / two tiles ahead with hand-counted waits -- measured the SAME speed on MI355X (0.926 against 0.922 ms per 2048-token Falcon-7B launch: the passes are not bound by load latency) and, on one box of the pool, intermittently wrong in tiles whose waves do not all hold keys (scripts/gpu_attn_bisect.py): off
+#endif
+#if FQ_FLASH_PLAIN
+template <int OFF> __device__ __forceinline__ void fl_gload4(f32x4 & d, const float * p) { d = *(const f32x4 *)((const char *) p + OFF); }
+__device__ __forceinline__ void fl_gload1(float & d, const float * p) { d = *p; }
+#define FL_WAIT8(n, a)  do { } while (0)
+#define FL_WAIT16(n, a) do { } while (0)
+#else
+template <int OFF> __device__ __forceinline__ void fl_gload4(f32x4 & d, const float * p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF)); }
+__device__ __forceinline__ void fl_gload1(float & d, const float * p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+#define FL_WAIT8(n, a)  asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+#define FL_WAIT16(n, a) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
+                                                                "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]))
+#endif
+#define FL_QK(c, k8) _Pragma("unroll") for (int v_ = 0; v_ < 8; ++v_) { \
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v_].x, k8[v_].x, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v_].y, k8[v_].y, c, 0, 0, 0); \
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v_].z, k8[v_].z, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v_].w, k8[v_].w, c, 0, 0, 0); }
+// k_attn_pack_k: the keys [0, 32 nt) of every KV head re-laid in the matrix instruction's operand order -- tile T, register v, lane (hf, li): the four floats
+// K[32 T + li][32 hf + 4 v ..] -- so that a wave's request for a tile is eight instructions of 1 KiB of CONSECUTIVE bytes each. Read from the cache as it
+// lies, lane (hf, li) of a request touches its own 128-byte line: 64 lines per instruction, 512 tag look-ups per tile, and eight waves of them keep a CU's
+// vector cache busy for as long as the matrix pipe needs for the tile -- the first versions of k_attention_flash ran at the scratch form's speed whatever
+// their inside looked like. 512 KiB per Falcon-7B launch at 2048 keys; rows beyond the cache re-read its last row.
+__global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ kc, int N, int HKV, const int * __restrict__ n_past_ptr, float * __restrict__ kt, int nt_total) {
+    const int T = blockIdx.x, hk = blockIdx.y, n_rows_cache = *n_past_ptr + N;
+    f32x4 * const dst = (f32x4 *) kt + ((size_t) hk * nt_total + T) * 512;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int o = threadIdx.x + 256 * u;                          // slot of the packed tile: (v, hf, li)
+        const int v = o >> 6, hf = (o >> 5) & 1, li = o & 31;
+        const int j = 32 * T + li;
+        dst[o] = *(const f32x4 *)(kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hf + 4 * v);
+    }
+}
+template <bool TAB, int NT, bool PACKED>
+__global__ void __launch_bounds__(512) k_attention_flash(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
+                                                         const float * __restrict__ kc, const float * __restrict__ vc,
+                                                         const uint16_t * __restrict__ exp_tab, float * __restrict__ att, const float * __restrict__ kt, int nt_total, int dbg) {
+    constexpr int PH = 32 * NT + 8;                                               // halfwords per LDS row (a compile-time pitch: the 16 rows of a lane are immediate offsets)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t * const eh   = (uint16_t *) smem;                                    // [32][PH] fp16 bits of exp()
+    float    * const rmax = (float *)(smem + (size_t) 32 * PH * 2);               // [8 waves][32 rows]
+    double   * const rsum = (double *)(rmax + 8 * 32);                            // [8 waves][32 rows]
+    float    * const xch  = (float *)(rsum + 8 * 32);                             // [2 dim halves][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, hf = lane >> 5;
+    const int h = blockIdx.x, i0 = ((int) gridDim.y - 1 - (int) blockIdx.y) * 32, hk = h / (H / HKV), heads = H + 2 * HKV;
+    const int n_past = *n_past_ptr;
+    const int nrows = N - i0 < 32 ? N - i0 : 32;
+    const int n_kv_max = n_past + i0 + nrows;                       // keys the tile's last token sees
+    const int n_rows_cache = n_past + N;                            // key / value rows that exist
+    const int ntile_real = (n_kv_max + 31) >> 5;
+    // (tuning aid, FQ_ATTN_DBG: bits 1 / 2 / 4 run pass A / B / C over no tiles -- results are garbage, the time is what the other passes cost)
+    const int ntileA = (dbg & 1) ? 0 : ntile_real, ntileB = (dbg & 2) ? 0 : ntile_real, ntileC = (dbg & 4) ? 0 : ntile_real;
+    // ---- passes A and B: K.Q, tiles wid, wid + 8, ...; the next tile is requested before a tile's matrix instructions start (rows beyond the cache
+    // re-read its last row: every request is unconditional, the counts in the waits are exact)
+    {
+        f32x4 q8[8];
+        const float * qrow = qkv + ((int64_t)(i0 + (li < nrows ? li : nrows - 1)) * heads + h) * 64 + 32 * hf;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) q8[v] = ((const f32x4 *) qrow)[v];
+        const float * const kbase = PACKED ? kt + (int64_t) hk * nt_total * 2048 + 4 * lane : kc + (int64_t) hk * 64 + 32 * hf;
+        auto load_k = [&](int T, f32x4 (&k8)[8]) {
+            if constexpr (PACKED) {                                   // (k_attn_pack_k's layout: register v of the tile is 1 KiB of consecutive bytes over the wave)
+                const float * kp = kbase + (int64_t)(T < nt_total ? T : nt_total - 1) * 2048;
+                const float * kq = kp + 1024;                          // (the instruction's offset field is 13 bits, signed)
+                fl_gload4<0>(k8[0], kp); fl_gload4<1024>(k8[1], kp); fl_gload4<2048>(k8[2], kp); fl_gload4<3072>(k8[3], kp);
+                fl_gload4<0>(k8[4], kq); fl_gload4<1024>(k8[5], kq); fl_gload4<2048>(k8[6], kq); fl_gload4<3072>(k8[7], kq);
+            } else {
+                const int j = 32 * T + li;
+                const float * krow = kbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64;
+                fl_gload4<0>(k8[0], krow);  fl_gload4<16>(k8[1], krow); fl_gload4<32>(k8[2], krow); fl_gload4<48>(k8[3], krow);
+                fl_gload4<64>(k8[4], krow); fl_gload4<80>(k8[5], krow); fl_gload4<96>(k8[6], krow); fl_gload4<112>(k8[7], krow);
+            }
+        };
+        f32x4 ka[8], kb[8];
+        load_k(wid, ka);
+        {   // pass A: row maxima
+            float mx[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+            for (int T = wid; T < ntileA; T += 8) {
+                load_k(T + 8, kb);
+                FL_WAIT8(8, ka);
+                __builtin_amdgcn_sched_barrier(0);                    // (the scheduler moves an asm statement wherever its operands allow: the wait for the NEXT tile went in front of this tile's matrix instructions)
+                v16f c = {0};
+                FL_QK(c, ka);
+                const int lim = n_past + i0 - 32 * T - li;           // key 32 T + li is visible to row ir iff ir + lim >= 0
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    const float sc = c[r] * 0.125f;
+                    mx[r] = fq_max_f32(mx[r], (ir < nrows && ir + lim >= 0) ? sc : -INFINITY);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FL_WAIT8(0, kb);                                      // (requested a whole tile of matrix instructions ago)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+            }
+            FL_WAIT8(0, ka);                                          // (a wave without tiles: its one request has landed before the registers are used for anything else)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = reduce32(mx[r], op_max());
+                if (li == 0) rmax[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = m;
+            }
+        }
+        load_k(wid, ka);                                              // (pass B's first tile is in flight across the barrier)
+        __syncthreads();
+        float mrow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            float m = rmax[ir];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fq_max_f32(m, rmax[w * 32 + ir]);
+            mrow[r] = m;
+        }
+        {   // pass B: exp() values into LDS, row sums. Software-pipelined by hand: the exp() arithmetic of the wave's previous tile (~25 VALU instructions per
+            // score, 16 scores per lane) is issued BETWEEN the matrix instructions of the current one -- a 64-cycle v_mfma_f32_32x32x2_f32 leaves ~14 issue
+            // slots, and a wave that ran its 32 dependent matrix instructions back to back and its 400 VALU instructions after them would keep the pipe idle
+            // for half of the pass. Row sums as integers: a probability's exp() is an fp16 value <= 1, i.e. k x 2^-24 with k <= 2^24, and a lane adds at most
+            // ten of them per row -- exact in 32 bits (and in f64 across lanes and waves afterwards).
+            unsigned lsum[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum[r] = 0u;
+            v16f cp = {0}; int Tp = 0;
+            uint16_t * const ecol = eh + (size_t)(4 * hf) * PH + li;
+            auto epi = [&](int r) {                                   // one score of the previous tile (r is a compile-time constant after unrolling)
+                const int irl = (r & 3) + 8 * (r >> 2), ir = irl + 4 * hf;
+                const float sc = cp[r] * 0.125f;
+                const bool vis = ir < nrows && 32 * Tp + li <= n_past + i0 + ir;
+                const uint16_t hb = f2h_bits(sc - mrow[r]);
+                uint16_t eb;
+                if constexpr (TAB) eb = exp_tab[hb]; else eb = exp_f16_formula(hb);
+                eb = vis ? eb : (uint16_t) 0;
+                ecol[irl * PH + 32 * Tp] = eb;
+                lsum[r] += (unsigned)(h2f_bits(eb) * 16777216.0f);
+            };
+            if (wid < ntileB) {
+                load_k(wid + 8, kb);
+                FL_WAIT8(8, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                FL_QK(cp, ka);
+                Tp = wid;
+                __builtin_amdgcn_sched_barrier(0);
+                FL_WAIT8(0, kb);
+#pragma unroll
+                for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+                for (int T = wid + 8; T < ntileB; T += 8) {
+                    load_k(T + 8, kb);
+                    FL_WAIT8(8, ka);
+                    __builtin_amdgcn_sched_barrier(0);
+                    v16f c = {0};
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].x, ka[v].x, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].y, ka[v].y, c, 0, 0, 0);
+                        epi(2 * v);
+                        __builtin_amdgcn_sched_barrier(0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].z, ka[v].z, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].w, ka[v].w, c, 0, 0, 0);
+                        epi(2 * v + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    cp = c; Tp = T;
+                    FL_WAIT8(0, kb);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi(r);
+            }
+            FL_WAIT8(0, ka);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double sm = reduce32((double) lsum[r] * (1.0 / 16777216.0), op_add());
+                if (li == 0) rsum[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = sm;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass C: V.P, wave = (dim half, tile parity), waves 0-3 (one per SIMD): four chains is what the association allows. Values two tiles ahead.
+    const int dh = wid & 1, par = (wid >> 1) & 1;
+    v16f c = {0};
+    if (wid < 4) {
+        double sm = rsum[li];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sm += rsum[w * 32 + li];
+        const float inv = (float)(1.0 / sm);
+        const uint16_t * erow = eh + (size_t) li * PH + 16 * hf;
+        const float * const vbase = vc + (int64_t) hk * 64 + 32 * dh + li;
+        auto load_v = [&](int T, float (&v16)[16]) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int j = 32 * T + 16 * hf + s;
+                fl_gload1(v16[s], vbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64);
+            }
+        };
+        auto pv_tile = [&](int T, const float (&v16)[16]) {
+            const uint4 e0 = *(const uint4 *)(erow + 32 * T), e1 = *(const uint4 *)(erow + 32 * T + 8);
+            const unsigned w[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                              // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32)
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(h2f_bits((uint16_t)(w[u] & 0xFFFFu)) * inv, v16[2 * u + 0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(h2f_bits((uint16_t)(w[u] >> 16)) * inv, v16[2 * u + 1], c, 0, 0, 0);
+            }
+        };
+        float va[16], vb[16], vd[16];                                   // tiles T, T + 2, T + 4 of this parity in flight
+        load_v(par, va);
+        load_v(par + 2, vb);
+        int T = par;
+        for (; T + 4 < ntileC; T += 6) {
+            load_v(T + 4, vd); FL_WAIT16(32, va); __builtin_amdgcn_sched_barrier(0); pv_tile(T, va);     __builtin_amdgcn_sched_barrier(0);
+            load_v(T + 6, va); FL_WAIT16(32, vb); __builtin_amdgcn_sched_barrier(0); pv_tile(T + 2, vb); __builtin_amdgcn_sched_barrier(0);
+            load_v(T + 8, vb); FL_WAIT16(32, vd); __builtin_amdgcn_sched_barrier(0); pv_tile(T + 4, vd); __builtin_amdgcn_sched_barrier(0);
+        }
+        FL_WAIT16(0, va); FL_WAIT16(0, vb);
+        if (T < ntileC) pv_tile(T, va);
+        if (T + 2 < ntileC) pv_tile(T + 2, vb);
+        if (par == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(dh * 16 + r) * 64 + lane] = c[r];
+        }
+    }
+    __syncthreads();
+    if (wid < 2) {                                                      // par == 0: E + O
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (ir < nrows) att[(int64_t)(i0 + ir) * H * 64 + (int64_t) h * 64 + 32 * dh + li] = c[r] + xch[(dh * 16 + r) * 64 + lane];
+        }
+    }
+}
+// LDS rows for 16, 32 or 74 key tiles (512, 1024, 2368 keys): the instantiations of the compile-time pitch
+static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 74 ? 74 : 0)); }
+static size_t attn_flash_lds(int nt) { return (size_t) 32 * (size_t)(32 * nt + 8) * 2 + 8 * 32 * 4 + 8 * 32 * 8 + 2 * 16 * 64 * 4; }
+static bool attn_flash_fits(int max_n_kv) { return attn_flash_nt(max_n_kv) != 0; }
+template <bool TAB, int NT, bool PACKED>
+static void launch_attention_flash_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
+                                     const uint16_t * exp_table, float * att, const float * kt, int nt_total, hipStream_t st) {
+    const size_t lds = attn_flash_lds(NT);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
+    static const int dbg = getenv("FQ_ATTN_DBG") ? atoi(getenv("FQ_ATTN_DBG")) : 0;
+    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED>), dim3((unsigned) H, (unsigned)((N + 31) / 32)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg);
+}
+template <bool TAB, bool PACKED>
+static void launch_attention_flash(int nt, const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
+                                   const uint16_t * exp_table, float * att, const float * kt, int nt_total, hipStream_t st) {
+    if (nt == 16)      launch_attention_flash_t<TAB, 16, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+    else if (nt == 32) launch_attention_flash_t<TAB, 32, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+    else               launch_attention_flash_t<TAB, 74, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+}
+// bytes of the packed keys a launch of this size wants (k_attn_pack_k): prompts of FQ_ATTN_PACK_MIN_N (default 256) tokens and more
+static int attn_pack_min_n() { static const int v = getenv("FQ_ATTN_PACK_MIN_N") ? atoi(getenv("FQ_ATTN_PACK_MIN_N")) : 256; return v; }
+static size_t attn_pack_bytes(int N, int HKV, int max_n_kv) { return N >= attn_pack_min_n() ? (size_t) HKV * (size_t)((max_n_kv + 31) >> 5) * 8192 : 0; }
+
 static int g_attn_f64 = 0;
-static int g_attn_form = 0;      // prefill attention on the matrix pipe: 0 = default (32 rows, scores in the global scratch), 16 = k_attention_mfma16, 17 = k_attention_mfma16h
+static int g_attn_form = 0;      // prefill attention on the matrix pipe: 0 = default (k_attention_flash while 32 rows of fp16 probabilities fit LDS, else the scratch form), 32 = k_attention_mfma (scores in the global scratch), 16 = k_attention_mfma16, 17 = k_attention_mfma16h
 void fq_attn_set_form(int form) { g_attn_form = form; }
 void fq_attn_set_f64(int on) { g_attn_f64 = on != 0; }
 int  fq_attn_f64() { return g_attn_f64; }
@@ -602,14 +878,16 @@ static void launch_attention_rows(const float * qkv, int N, int H, int HKV, cons
 // score rows of long-context launches (one slice per workgroup). A model context owns its own buffer, sized once for its
 // (n_batch, n_ctx) at context_create (fq_attention_scratch_need) and passed in; the process-wide one below serves only the
 // op-level API (ggml_hip_attention: synchronous, one stream) and is grown on demand up to FQ_ATTN_SCRATCH_GB (default 4) GiB.
+static bool attn_flash_default() { static const int v = getenv("FQ_ATTN_FLASH") ? atoi(getenv("FQ_ATTN_FLASH")) : 1; return v != 0; }
 static size_t att_scratch_cap() {
     static const size_t cap = (size_t)(getenv("FQ_ATTN_SCRATCH_GB") ? atoi(getenv("FQ_ATTN_SCRATCH_GB")) : 4) << 30;
     return cap;
 }
-size_t fq_attention_scratch_need(int N, int H, int max_n_kv) {
+size_t fq_attention_scratch_need(int N, int H, int max_n_kv, int HKV) {
     if (N < 4) return 0;
+    if (N >= 32 && attn_flash_default() && attn_flash_fits(max_n_kv)) return attn_pack_bytes(N, HKV, max_n_kv);      // k_attention_flash: only the packed keys
     const size_t ps = (size_t)((max_n_kv + 31) & ~31);
-    const size_t a = N >= 32 ? (size_t)((N + 31) / 32) * (size_t) H * 32 * ps * 4 : 0;                 // k_attention_mfma: 32 tokens per workgroup
+    const size_t a = (N >= 32 && !(attn_flash_default() && attn_flash_fits(max_n_kv))) ? (size_t)((N + 31) / 32) * (size_t) H * 32 * ps * 4 : 0;   // k_attention_mfma (32 tokens per workgroup): only contexts too long for k_attention_flash's LDS rows
     const size_t row = (size_t)((max_n_kv + 3) & ~3) * 4;
     const size_t b = (16 * 4 + 16 * 64 * 8) + 4 * row > 56 * 1024 ? (size_t)((N + 3) / 4) * (size_t) H * 4 * row : 0;   // 4 tokens per workgroup, once their rows leave LDS
     const size_t need = a > b ? a : b;
@@ -655,6 +933,20 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
         // the score rows of 16 query tokens in LDS while they fit (~2400 keys); beyond that 32 tokens per workgroup and the global scratch
         static const int env_form = (getenv("FQ_ATTN_MFMA16H") && atoi(getenv("FQ_ATTN_MFMA16H"))) ? 17 : ((getenv("FQ_ATTN_MFMA16") && atoi(getenv("FQ_ATTN_MFMA16"))) ? 16 : 0);
         const int form = g_attn_form ? g_attn_form : env_form;      // (16 and 17: measured slower than the scratch form at 2048 tokens, see k_attention_mfma16h)
+        if ((form == 1 || (form == 0 && attn_flash_default())) && attn_flash_fits(max_n_kv)) {
+            const int nt = attn_flash_nt(max_n_kv), nt_total = (max_n_kv + 31) >> 5;
+            const size_t pk = attn_pack_bytes(N, HKV, max_n_kv);
+            float * kt = pk ? att_scratch(own_scratch, pk, st) : nullptr;
+            if (kt) {
+                hipLaunchKernelGGL(k_attn_pack_k, dim3((unsigned) nt_total, (unsigned) HKV), dim3(256), 0, st, k_cache, N, HKV, n_past_dev, kt, nt_total);
+                if (exp_table) launch_attention_flash<true, true>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+                else           launch_attention_flash<false, true>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+            } else {
+                if (exp_table) launch_attention_flash<true, false>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, nullptr, 0, st);
+                else           launch_attention_flash<false, false>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, nullptr, 0, st);
+            }
+            return;
+        }
         static const int max_kv16 = getenv("FQ_ATTN_MFMA16_MAXKV") ? atoi(getenv("FQ_ATTN_MFMA16_MAXKV")) : 4096;
         const int ps16 = ((max_n_kv + 31) & ~31) + 4;
         const size_t lds16 = ((size_t) 16 * ps16 + 8 * 16 + 16 + 4 * 4 * 64) * 4;
@@ -746,6 +1038,26 @@ __global__ void k_verify_exp_formula(const uint16_t * __restrict__ table, int * 
     if (i >= 65536u) return;
     if ((i & 0x7C00u) == 0x7C00u && (i & 0x03FFu)) return;      // NaN in: NaN out either way, payloads are not compared
     if (exp_f16_formula((uint16_t) i) != table[i]) atomicAdd(mismatches, 1);
+}
+// diagnostic: the inputs exp_f16_fast leaves undecided, with the table's entries: (bits << 16 | entry), ascending; returns their number
+__global__ void k_exp_boundary(const uint16_t * __restrict__ table, unsigned * __restrict__ flags) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536u) return;
+    uint16_t h;
+    const bool nan = (i & 0x7C00u) == 0x7C00u && (i & 0x03FFu);
+    flags[i] = (!nan && !exp_f16_fast((uint16_t) i, h)) ? ((i << 16) | table[i]) : 0xFFFFFFFFu;
+}
+int fq_exp_boundary(const uint16_t * exp_table, unsigned * out_host, int cap, hipStream_t st) {
+    unsigned * d = nullptr;
+    HIP_CHECK(hipMalloc((void **) &d, 65536 * 4));
+    hipLaunchKernelGGL(k_exp_boundary, dim3(256), dim3(256), 0, st, exp_table, d);
+    std::vector<unsigned> f(65536);
+    HIP_CHECK(hipMemcpyAsync(f.data(), d, 65536 * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(d));
+    int n = 0;
+    for (unsigned v : f) if (v != 0xFFFFFFFFu) { if (n < cap) out_host[n] = v; ++n; }
+    return n;
 }
 int fq_verify_exp_formula(const uint16_t * exp_table, hipStream_t st) {
     int * d = nullptr; int h = -1;

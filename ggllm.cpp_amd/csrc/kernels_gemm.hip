@@ -33,13 +33,12 @@
 #ifndef GQ_PACKED
 #define GQ_PACKED 0
 #endif
-// GQ_FMA=1 (round 4: the default order of the legacy formats' K-split sums): acc = fma(dw * dx, (float) c, acc), the form the reference's AVX2
-// builds accumulate in (ggml.c:2415-2438) -- 3 instead of 4 VALU operations per result; measured 3-5 % of a prompt. The sequential sum
+// GQ_FMA (= FQ_SPLIT_FMA of fq_types.h, shared with kernels_gemm_skinny.hip; round 4: the default order of the legacy formats' K-split sums):
+// acc = fma(dw * dx, (float) c, acc) -- FMA form, oracle-pinned (the reference's AVX2 builds also fuse, ggml.c:2415-2438, but on 8 per-lane integer
+// sums, so this is not their bits either) -- 3 instead of 4 VALU operations per result; measured 3-5 % of a prompt. The sequential sum
 // (S == 1, ggml_hip_gemm_sequential / reference order) keeps the scalar build's two roundings per term and its bit-identity with the reference.
-// GQ_FMA=0 at compile time restores the unfused K-split sums (the oracle then needs ORC_SPLIT_FMA=0 too).
-#ifndef GQ_FMA
-#define GQ_FMA 1
-#endif
+// -DFQ_SPLIT_FMA=0 at compile time restores the unfused K-split sums in BOTH files (the oracle then needs ORC_SPLIT_FMA=0 too).
+#define GQ_FMA FQ_SPLIT_FMA
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i  __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));

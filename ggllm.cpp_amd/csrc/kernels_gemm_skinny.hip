@@ -27,9 +27,7 @@
 
 
 #include "fq_skinny_dev.h"
-#ifndef SK_FMA
-#define SK_FMA 1                                                           // the legacy formats' K-split sums in the fused form (kernels_gemm.hip GQ_FMA): must match the tile GEMM
-#endif
+#define SK_FMA FQ_SPLIT_FMA                                                 // the legacy formats' K-split sums in the fused form: ONE macro with the tile GEMM (fq_types.h)
 
 namespace {
 

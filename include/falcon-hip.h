@@ -131,6 +131,9 @@ void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* cap
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
 /* 1 when N == 1 evals of this context run through the persistent engine (mode 4 and a model inside its scope) */
 int   falcon_hip_context_engine_active(falcon_hip_context * c);
+/* 1 when the library was built with the engine (make ENGINE=1; the default build leaves it out -- it is measured slower than mode 2 --
+ * and mode 4 then runs the two-launch path for every model) */
+int   falcon_hip_engine_compiled(void);
 /* tuning aid (FALCON_HIP_ENGINE_DEBUG=1): failure records and phase stamps of the engine, n int64 copied to the host */
 int   falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out_host, int n);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
@@ -154,6 +157,11 @@ falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank,
                                                  int n_groups, int batch, int n_ctx);
 void  falcon_hip_pipeline_free(falcon_hip_pipeline * p);
 int   falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p);           /* ncclCommCount of its communicator (1: one rank, 0: local transport) */
+/* how this rank's hand-offs travel: 0 one stage (none), 1 RCCL ncclSend / ncclRecv, 2 device copies inside one process (local), 3 the local job over
+ * a one-rank RCCL communicator, 4 host shared memory between the processes of one node -- selected for falcon_hip_pipeline_create by the environment,
+ * FALCON_PIPE_TRANSPORT=shm: the multi-process job on a node whose ranks share a GPU (RCCL refuses two ranks on one device); same ranks, same unique-id
+ * hand-out, same slot schedule and stage steps, the exchange blocking on the host */
+int   falcon_hip_pipeline_transport(falcon_hip_pipeline * p);
 int   falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * tokens);
 int   falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0);
 int   falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, int first_round, int n_rounds);

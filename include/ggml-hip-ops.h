@@ -25,8 +25,11 @@ int     ggml_hip_device_count(void);
 /* tuning aid: wall_clock64 phase stamps (8 per workgroup) of the last k_gemv_ln [0,4096) and k_gemv_out [4096,8192) */
 void    ggml_hip_debug_stamps(int enable, long long * out_host);
 void    ggml_hip_debug_force_gemv(int on);        /* tests: N > 4 through column-chunked mat-vec instead of the MFMA GEMM */
-void    ggml_hip_debug_attention_form(int form);  /* tests / tuning: the prefill attention kernel for N >= 32 tokens -- 0 default, 16 / 17: 16-token tiles with the score
-                                                     rows (f32) / the probabilities (fp16, exact) in LDS; all three bit-identical (ggml.c:10911-11102, 12389-12456) */
+void    ggml_hip_debug_attention_form(int form);  /* tests / tuning: the prefill attention kernel for N >= 32 tokens -- 0 default (k_attention_flash: 32-token tiles, K.Q twice,
+                                                     fp16 probabilities in LDS, while they fit; else 32), 1 the same forced, 32 the scratch form (scores through HBM), 16 / 17:
+                                                     16-token tiles with the score rows (f32) / the probabilities (fp16, exact) in LDS; all bit-identical (ggml.c:10911-11102, 12389-12456) */
+int     ggml_hip_debug_exp_boundary(unsigned * out_host, int cap);   /* diagnostic: (input bits << 16 | table entry) of the fp16 inputs whose exp() the in-kernel formula's f32 fast
+                                                     path leaves undecided (they are looked up in csrc/fq_exp_fix.h, generated from this list); returns their number */
 /* Prefill GEMM (N > 4): by default each row's sum over its 32-element blocks is split into S interleaved partial sums,
  * P_s = blocks s, s + S, ... added left to right, result ((P0 + P1) + P2) + P3: S = 4 for matrices with fewer than 4 x #CU
  * 32x32 tiles, S = 2 above (S times the K-parallelism; 1.1-1.5 x faster). on = 1: S = 1 always, the reference's single

@@ -9,4 +9,4 @@ for l in sys.stdin:
         continue
     r = d["roofline"]
     print("%-62s | decode %8.1f tok/s | prefill %9.1f tok/s | launch frac %s | step frac %.3f" % (
-        d["config"]["workload"][:62], d["value"], d.get("prefill_tok_s", 0.0), ("%.3f" % r["frac"]) if r.get("frac") else "-", r.get("step_frac", 0.0)))
+        d["config"]["workload"][:62], d["value"], d.get("prefill_tok_s", 0.0), ("%.3f" % r["launch_frac"]) if r.get("launch_frac") else "-", r.get("step_frac", 0.0)))

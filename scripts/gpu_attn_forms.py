@@ -1,6 +1,7 @@
 """time the prefill attention kernels on a Falcon-7B block's shape (71 heads, MQA): python scripts/gpu_attn_forms.py [N ...]
-form 0 = k_attention_mfma (32-token tiles, scores through the global scratch), 16 = k_attention_mfma16 (f32 scores in LDS), 17 = k_attention_mfma16h (fp16
-probabilities in LDS, K.Q twice, two workgroups per CU); FORMS=0,17 selects; also checks that the three agree bit for bit"""
+form 32 = k_attention_mfma (32-token tiles, scores through the global scratch), 1 = k_attention_flash (round 5: 32-token tiles, K.Q twice, fp16 probabilities in
+LDS, nothing leaves the CU; the default while it fits), 16 = k_attention_mfma16 (f32 scores in LDS), 17 = k_attention_mfma16h (fp16 probabilities in LDS, K.Q twice,
+two workgroups per CU); FORMS=32,1 selects; also checks that they agree bit for bit with the first one"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ggllm_cpp_amd as g
 g.init(0); L = g.load()
 H, HKV, D = 71, 1, 64
-FORMS = [int(f) for f in os.environ.get("FORMS", "0,16,17").split(",")]
+FORMS = [int(f) for f in os.environ.get("FORMS", "32,1,16,17").split(",")]
 for N in [int(a) for a in sys.argv[1:]] or [2048, 512, 128]:
     rng = np.random.default_rng(N)
     qkv = rng.standard_normal((N, H + 2 * HKV, D)).astype(np.float32)
@@ -26,6 +27,6 @@ for N in [int(a) for a in sys.argv[1:]] or [2048, 512, 128]:
         ms = L.ggml_hip_event_elapsed_ms(e0, e1) / 8
         out = ob_.to_host(np.float32, (N, H * D))
         if ref is None: ref = out
-        print("N=%5d form %2d: %8.3f ms per launch   bit-identical to form 0: %s" % (N, form, ms, bool(np.array_equal(out, ref))), flush=True)
+        print("N=%5d form %2d: %8.3f ms per launch   bit-identical to the first form: %s" % (N, form, ms, bool(np.array_equal(out, ref))), flush=True)
     L.ggml_hip_debug_attention_form(0)
     for b in (qb, kb, vb, ob_): b.free()

@@ -169,12 +169,14 @@ def test_softmax_golden_through_attention(oracle, golden):
             assert np.array_equal(got[:min(nk, D)], gb["sm_p"][h, t, :min(nk, D)])
 
 
-@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 32, 0), (8, 2, 45, 5), (3, 1, 100, 37), (2, 2, 33, 64), (5, 1, 700, 0), (2, 1, 17 * 16, 1500)])
+@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 32, 0), (8, 2, 45, 5), (3, 1, 100, 37), (2, 2, 33, 64), (5, 1, 700, 0), (2, 1, 17 * 16, 1500),
+                                            (3, 1, 2048, 0), (16, 8, 513, 1790), (2, 1, 70, 2390)])
 def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
-    """the three prefill attention kernels on the f32 matrix pipe -- k_attention_mfma (32-token tiles, scores in the global scratch: the default, pinned against
-    the oracle's dot_qk_mfma / dot_pv_mfma by the whole-model tests), k_attention_mfma16 (16-token tiles, f32 scores in LDS) and k_attention_mfma16h (16-token
-    tiles, K.Q run twice and the probabilities kept in LDS as the fp16 values the soft_max's exp table yields: two workgroups per CU) -- give the same bits:
-    ragged last tiles, a context that does not start at 0, MQA and GQA (ggml.c:10911-11102 soft_max, 12389-12456 the two dot products)"""
+    """the prefill attention kernels on the f32 matrix pipe -- k_attention_mfma (32-token tiles, scores in the global scratch: pinned against the oracle's
+    dot_qk_mfma / dot_pv_mfma by the whole-model tests; form 32), k_attention_flash (round 5, the default while 32 rows of fp16 probabilities fit LDS: K.Q run
+    twice, nothing leaves the CU; forms 0 and 1 -- beyond ~2370 keys form 0 IS the scratch form), k_attention_mfma16 (16-token tiles, f32 scores in LDS) and
+    k_attention_mfma16h (16-token tiles, K.Q twice, fp16 probabilities in LDS: two workgroups per CU) -- give the same bits: ragged last tiles, a context that
+    does not start at 0, MQA and GQA, a full 2048-token prompt (ggml.c:10911-11102 soft_max, 12389-12456 the two dot products)"""
     L = g.load()
     D = 64
     rng = np.random.default_rng(H * 1000 + N + n_past)
@@ -185,7 +187,7 @@ def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
     qb, kb, vb, ob_ = g.DevBuf(host=qkv), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(N * H * D * 4)
     outs = {}
     try:
-        for form in (0, 16, 17):
+        for form in (32, 0, 1, 16, 17):
             L.ggml_hip_debug_attention_form(form)
             L.ggml_hip_memset(ob_.ptr, 0xFF, N * H * D * 4)
             L.ggml_hip_attention(qb.ptr, N, H, HKV, D, n_past, kb.ptr, vb.ptr, ob_.ptr)
@@ -194,6 +196,6 @@ def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
         L.ggml_hip_debug_attention_form(0)
         for b in (qb, kb, vb, ob_):
             b.free()
-    assert np.isfinite(outs[0]).all()
-    assert np.array_equal(outs[16], outs[0])
-    assert np.array_equal(outs[17], outs[0])
+    assert np.isfinite(outs[32]).all()
+    for form in (0, 1, 16, 17):
+        assert np.array_equal(outs[form], outs[32]), f"form {form}"
