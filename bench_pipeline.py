@@ -267,6 +267,7 @@ def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torc
         uid = box[0]
     pipe = g.Pipeline(model, rank, world, groups, batch, n_ctx, unique_id=uid)
     rccl_ranks = int(L.falcon_hip_pipeline_rccl_ranks(pipe.p))      # ncclCommCount of the communicator the hand-offs use
+    run_cpp.transport = pipe.transport()
     t_setup = time.time() - t0
     pipe.set_tokens(synth.tokens(groups * batch, hp["n_vocab"], seed=42))
     done = _watchdog(600, f"warm-up of the {world}-rank pipeline (RCCL channel set-up)")
@@ -286,6 +287,9 @@ def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torc
     hist = pipe.history(wr, steps)                               # (last rank) also surfaces hand-off time-outs
     if hist is not None and (hist < 0).any():
         raise RuntimeError("pipeline produced invalid tokens")
+    dump = os.environ.get("FALCON_PIPE_DUMP_HISTORY")            # tests: the last rank's sampled tokens [round][sequence] of the timed rounds
+    if dump and hist is not None and world > 1:
+        np.save(dump, hist)
     dt_t = torch.tensor([dt], dtype=torch.float64)
     wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64)
     if world > 1:
@@ -326,9 +330,14 @@ def main(a, rank, world, local):
         raise SystemExit(f"--warmup + --steps must stay below {n_ctx} positions")
     tok_s, wbytes, blocks, t_setup, dt = run_cpp(a, rank, world, local, hp, wtype, a.model, a.quant, dist, torch, groups, batch, n_ctx, a.steps, a.warmup)
     rccl_ranks = getattr(run_cpp, "rccl_ranks", None)
-    if world > 1 and rccl_ranks != world:
+    transport = getattr(run_cpp, "transport", None)
+    shm = os.environ.get("FALCON_PIPE_TRANSPORT") == "shm"       # ranks on one node exchanging through host shared memory (the one-GPU boxes: RCCL refuses two ranks per device)
+    if world > 1 and not shm and rccl_ranks != world:
         raise SystemExit(f"bench_pipeline: RCCL communicator has {rccl_ranks} ranks, launched {world}")
-    extra = {"rccl_ranks": rccl_ranks}
+    if world > 1 and shm and not str(transport).startswith("shm"):
+        raise SystemExit(f"bench_pipeline: FALCON_PIPE_TRANSPORT=shm but the pipeline reports transport {transport!r}")
+    extra = {"rccl_ranks": rccl_ranks, "transport": transport,
+             "ranks_share_device_0": os.environ.get("FALCON_PIPE_SAME_DEVICE") == "1"}
 
     def one_gpu_same_workload(hp1, wt1, mname, qname, steps, warmup):
         # the denominator of the scaling figure: the SAME workload (groups x batch lock-step streams, all blocks) on rank 0's GPU alone,
@@ -356,6 +365,21 @@ def main(a, rank, world, local):
         ns1 = one_gpu_same_workload(hp40, tname["q4_K"], "40b", "q4_k", max(8, a.steps // 4), max(2, a.warmup // 2))
         extra["north_star"]["same_workload_1gpu_tok_s"] = ns1
         extra["north_star"]["scaling_vs_1gpu"] = (ns_tok_s / ns1) if ns1 else None
+    # cpu_baseline: the N = 1 leg's measurement -- the reference itself (oracle/_ref) on this box's host cores, one decode stream of the same model
+    # (the reference has no multi-stream mode); rank 0 synthesizes the whole model on the host for it while the other ranks wait
+    cpu = None
+    if not getattr(a, "no_cpu", False) and not a.layers and a.model != "40b":
+        if rank == 0:
+            try:
+                from bench import cpu_baseline
+                wall = synth.make_model_fast(hp, wtype, seed=1234)
+                cpu = cpu_baseline(wall, hp, wbytes, 32, getattr(a, "cpu_tokens", 12), synth.tokens(40, hp["n_vocab"], seed=42))
+                cpu["sample"] += " -- ONE decode stream (the reference has no lock-step mode); same measurement as the --gpus 1 line's leg, with a 32-token prompt"
+                del wall
+            except Exception as e:                                   # (never lose the line to the baseline leg)
+                cpu = {"error": repr(e)}
+        if world > 1:
+            dist.barrier()
     if rank == 0:
         from bench import kv_bytes_per_token, HBM_PEAK_GBS
         S = groups * batch
@@ -370,12 +394,14 @@ def main(a, rank, world, local):
             "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
             "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPU(s) "
                                    f"({blocks} blocks per stage, balanced by bytes incl. lm_head), {groups} groups x {batch} lock-step greedy decode streams "
-                                   f"in flight, a step = one round (one token per stream); residual rows and sampled tokens by RCCL ncclSend/ncclRecv "
-                                   f"(csrc/falcon_pipeline.hip)",
+                                   f"in flight (MULTI-STREAM: {S} sequences, one weight pass serves {batch} tokens -- NOT the single-stream workload of --gpus 1; "
+                                   f"compare with same_workload_1gpu_tok_s, the same streams on one GPU), a step = one round (one token per stream); residual rows "
+                                   f"and sampled tokens by " + ("host shared memory between the ranks (FALCON_PIPE_TRANSPORT=shm)" if shm else "RCCL ncclSend/ncclRecv")
+                                   + " (csrc/falcon_pipeline.hip)" + ("" if not a.layers else f" [TRUNCATED to {a.layers} blocks: not the benchmark config]"),
                        "streams": S, "groups": groups, "batch": batch, "weight_bytes_per_pass": wbytes, "n_past_timed": [a.warmup, a.warmup + a.steps]},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                          "traffic": None, "note": "whole-job view: (weight bytes / batch + KV bytes) per token x tokens/s over the summed peak of all GPUs"},
-            "cpu_baseline": None, "setup_s": t_setup, **extra,
+            "cpu_baseline": cpu, "setup_s": t_setup, **extra,
         }))
     if world > 1:
         dist.destroy_process_group()
