@@ -394,7 +394,7 @@ int falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p) {
         if (fq_rccl()->ncclCommCount(p->loop->comm, &n) != ncclSuccess) return -1;
         return n;
     }
-    if (!p || p->local) return 0;
+    if (!p || p->local || p->shm) return 0;
     if (!p->comm) return 1;
     int n = -1;
     if (fq_rccl()->ncclCommCount(p->comm, &n) != ncclSuccess) return -1;

@@ -35,6 +35,7 @@ const uint16_t * orc_exp_table(void)  { orc_tables_init(); return g_exp_tab; }
 float orc_gelu(float x)    { orc_tables_init(); return orc_fp16_to_fp32(g_gelu_tab[orc_fp32_to_fp16(x)]); }   /* ggml.c:3477-3484 */
 float orc_exp_f16(float x) { orc_tables_init(); return orc_fp16_to_fp32(g_exp_tab[orc_fp32_to_fp16(x)]); }    /* ggml.c:12436-12442 */
 
+int orc_exact_f64(void);          /* the f64 yardstick (oracle_quants.c, orc_set_sum_order(6)): products formed in f64 as well */
 /* ------------------------------------------------------------------ norm (ggml.c:10540-10594) */
 void orc_norm(const float * x, int64_t n, int64_t rows, float * y) {
     for (int64_t r = 0; r < rows; ++r, x += n, y += n) {
@@ -45,7 +46,7 @@ void orc_norm(const float * x, int64_t n, int64_t rows, float * y) {
         for (int64_t i = 0; i < n; ++i) {
             const float v = x[i] - mean;
             y[i] = v;
-            sum2 += (double)(v * v);
+            sum2 += orc_exact_f64() ? (double) v * (double) v : (double)(v * v);
         }
         const float variance = (float)(sum2 / (double) n);
         const float scale = 1.0f / sqrtf(variance + 1e-5f);
@@ -126,6 +127,7 @@ void orc_softmax_rows(float * x, int64_t nc, int64_t nr) {
  * (The SIMD branches, ggml.c:2270-2294, keep 32 f32 partial sums instead; only the association differs.) */
 static float dot_f32(const float * a, const float * b, int64_t n, int64_t stride_a) {
     double s = 0.0;
+    if (orc_exact_f64()) { for (int64_t i = 0; i < n; ++i) s += (double) a[i * stride_a] * (double) b[i]; return (float) s; }
     for (int64_t i = 0; i < n; ++i) s += (double)(a[i * stride_a] * b[i]);
     return (float) s;
 }

@@ -394,9 +394,14 @@ void orc_set_backend_batch(int n) { g_backend_batch = n > 0 ? n : 0; }
 static int g_kq_min_cols = 5;
 void orc_set_kq_min_cols(int n) { g_kq_min_cols = n >= 1 ? n : 5; }
 int  orc_backend_batch(void) { return g_backend_batch; }
-int orc_attn_backend_order(void) { return g_sum_mode >= 2; }   /* modes 2, 3, 4 = "as the backend" for the attention too */
+int orc_attn_backend_order(void) { return g_sum_mode >= 2 && g_sum_mode <= 5; }   /* modes 2, 3, 4, 5 = "as the backend" for the attention too */
+/* mode 6 (round 5) = the YARDSTICK, not an order any build runs: every reduction of the path -- a row's sum over its blocks, the attention's two dot products,
+ * LayerNorm's and soft_max's sums -- accumulated in f64 from exactly converted terms (the integer dots, table look-ups, activation quantizers and every
+ * elementwise f32 step stay the reference's), rounded to f32 once where the reference stores an f32 tensor. What the different f32 associations (the reference's
+ * scalar and AVX2 builds, the backend's default and reference orders) are measured against: bench.py `parity.err_vs_f64`, tests/test_gpu_parity_f64.py. */
+int orc_exact_f64(void) { return g_sum_mode == 6; }
 void orc_set_sum_order(int mode) {
-    g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4 || mode == 5) ? 2 : 0);
+    g_sum_mode = mode; g_sum_order = (mode == 1) ? 1 : ((mode == 3 || mode == 4 || mode == 5) ? 2 : (mode == 6 ? 3 : 0));
     g_split = (mode == 4) ? 2 : ((mode == 5) ? 1 : 4);
     g_kseg = 0;
 }
@@ -464,6 +469,24 @@ static void kq_decode_sb(int wtype, const uint8_t * w, kq_sb * o) {
 
 /* a = the column's Q8_K blocks (292 bytes each) */
 static float kq_dot_row(int wtype, int64_t nsb, const kq_sb * row, const uint8_t * a) {
+    if (g_sum_order == 3) {                                                   /* the f64 yardstick: sum_i d dy isum_i - dmin dy msum_i, every product and sum in f64 */
+        double acc = 0.0;
+        for (int64_t i = 0; i < nsb; ++i, a += 292) {
+            const kq_sb * sb = &row[i];
+            const double dy = (double) rd_f32(a);
+            const int8_t * q8 = (const int8_t *)(a + 4);
+            long is = 0, ms = 0;
+            for (int b = 0; b < 16; ++b) {
+                int t = 0;
+                for (int j = 0; j < 16; ++j) t += sb->qv[16 * b + j] * q8[16 * b + j];
+                is += (long) sb->sc16[b] * t;
+                ms += (long) sb->mn16[b] * rd_i16(a + 260 + 2 * b);
+            }
+            acc += (double) sb->d * dy * (double) is;
+            if (sb->has_min) acc -= (double) sb->dmin * dy * (double) ms;
+        }
+        return (float) acc;
+    }
     float sumf = 0.0f;
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float lane[64] = {0};
@@ -575,6 +598,19 @@ float orc_vec_dot(int wtype, int64_t n, const void * wv, const void * av) {
     const uint8_t * w = (const uint8_t *) wv;
     const uint8_t * a = (const uint8_t *) av;
     float sumf = 0.0f;
+    if (orc_blck_size(wtype) == 32 && g_sum_order == 3) {                     /* the f64 yardstick: sum_i d_w d_x isum_i (+ m_w s_x), every product and sum in f64 */
+        const int at = orc_vec_dot_type(wtype);
+        double acc = 0.0;
+        for (int64_t i = 0; i < n / 32; ++i) {
+            const uint8_t * wb = w + i * orc_type_size(wtype), * ab = a + i * orc_type_size(at);
+            float dd, ms_m = 0.0f, ms_s = 0.0f; int sumi;
+            orc_legacy_block_parts(wtype, wb, ab, &dd, &sumi, &ms_m, &ms_s);      /* (dd is not used: the two scales are multiplied in f64 below) */
+            const double dw = (double) rd_f16(wb), dx = (at == ORC_Q8_0) ? (double) rd_f16(ab) : (double) rd_f32(ab);
+            acc += dw * dx * (double) sumi;
+            if (wtype == ORC_Q4_1 || wtype == ORC_Q5_1) acc += (double) ms_m * (double) ms_s;
+        }
+        return (float) acc;
+    }
     if (orc_blck_size(wtype) == 32 && g_sum_order == 1 && n > 32) {
         const int at = orc_vec_dot_type(wtype);
         float lane[64] = {0};

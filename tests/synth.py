@@ -21,8 +21,9 @@ def quantized_matrix(oracle, t, rows, k, rng, std=0.02):
     return oracle.quantize(t, w).reshape(rows, ob.row_bytes(t, k))
 
 
-def make_model(oracle, hp, wtype, seed=1234, emb_type=None):
-    """dict of numpy arrays describing a Falcon model with random-init weights (ggml block bytes)."""
+def make_model(oracle, hp, wtype, seed=1234, emb_type=None, out_gain=1.0):
+    """dict of numpy arrays describing a Falcon model with random-init weights (ggml block bytes). out_gain < 1 (legacy formats): wo and down -- the
+    matrices that write the residual stream -- are drawn that much smaller: a residual-dominated, well-conditioned model (ggllm_cpp_amd.synth.make_model_fast)"""
     E, H, HKV, L, FF, V = hp["n_embd"], hp["n_head"], hp["n_head_kv"], hp["n_layer"], hp["n_ff"], hp["n_vocab"]
     D = E // H
     idx = [0]
@@ -31,8 +32,8 @@ def make_model(oracle, hp, wtype, seed=1234, emb_type=None):
         idx[0] += 1
         return np.random.default_rng(seed + idx[0])
 
-    def mat(rows, k):
-        return quantized_matrix(oracle, wtype, rows, k, rng())
+    def mat(rows, k, gain=1.0):
+        return quantized_matrix(oracle, wtype, rows, k, rng(), std=0.02 * gain)
 
     def ln():
         r = rng()
@@ -41,7 +42,7 @@ def make_model(oracle, hp, wtype, seed=1234, emb_type=None):
     m = dict(hparams=dict(hp), wtype=wtype, layers=[])
     m["tok_emb"] = mat(V, E)
     for _ in range(L):
-        lw = dict(qkv=mat((H + 2 * HKV) * D, E), wo=mat(E, E), up=mat(FF, E), down=mat(E, FF))
+        lw = dict(qkv=mat((H + 2 * HKV) * D, E), wo=mat(E, E, out_gain), up=mat(FF, E), down=mat(E, FF, out_gain))
         lw["ln_w"], lw["ln_b"] = ln()
         if hp.get("two_norms"):
             lw["ln2_w"], lw["ln2_b"] = ln()

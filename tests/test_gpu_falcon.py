@@ -43,7 +43,7 @@ CASES = [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0, "tiny_models"), ("gqa_q5_1", s
 #       then flips one 8-bit activation rounding, and one flip moves logits by 1e-3..1e-2. The reference's own AVX2 and
 #       scalar builds differ by up to 2.8e-2 on these fixtures (both are in the golden files). For the legacy formats the
 #       default order is asserted within max(1e-3, 2 x that spread) of the reference, for the k-quants (whose two reference
-#       builds share one association) within 5.6e-2 = twice the largest legacy spread; it is printed for all.
+#       builds share one association) within 3.6e-2 = twice the largest distance measured on MI355X (Q2_K 1.8e-2; round 5: was 5.6e-2); it is printed for all.
 
 
 @pytest.mark.parametrize("name,hp,t,gfile", CASES)
@@ -85,8 +85,9 @@ def test_tiny_falcon_vs_reference_fixture(oracle, golden, name, hp, t, gfile):
         # k-quants: the reference's two builds keep the same eight float lanes, so THEIR spread is ~1e-6 and says nothing about the
         # model's sensitivity; the default order's distance is the backend's own re-association (one term per lane-unit + butterfly for
         # N <= 4, K-split partial sums in the GEMM), amplified by the same activation-rounding flips as on the legacy models, whose
-        # builds differ by up to 2.8e-2 on these fixtures: the stated bound is twice that
-        assert max(e_l, e_d) <= 5.6e-2, (name, e_l, e_d)
+        # builds differ by up to 2.8e-2 on these fixtures. Measured on MI355X: 1.1e-2 (Q4_K) .. 1.8e-2 (Q2_K), one flipped Q8_K rounding in 2 blocks of a
+        # tiny model; the stated bound is twice the largest (round 5; it was 5.6e-2)
+        assert max(e_l, e_d) <= 3.6e-2, (name, e_l, e_d)
 
 
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
