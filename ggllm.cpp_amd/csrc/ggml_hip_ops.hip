@@ -61,10 +61,11 @@ extern "C" int ggml_hip_init(int device) {
         g_ctx.n_cu = prop.multiProcessorCount;
         snprintf(g_ctx.name, sizeof(g_ctx.name), "%s", prop.name);
         build_tables(g_ctx);
-        // the attention kernels recompute the EXP table's entries instead of gathering them -- only if the recomputation
-        // reproduces the host-built table for every input (GGML_HIP_EXP_TABLE=1 forces the gather)
+        // the attention kernels gather exp() from the fp16 table (round 5, measured A/B/A/B on one MI355X: Falcon-7B Q4_0 decode 1 022 tok/s against 1 004 with the
+        // in-kernel recomputation -- rounds 1-4 had it the other way round by ~0.5 %). GGML_HIP_EXP_FORMULA=1 selects the recomputation, and then only if it
+        // reproduces the host-built table for every input (tests/test_gpu_block_ops.py::test_exp_formula_reproduces_table checks that on every run)
         g_ctx.exp_table_attn = g_ctx.exp_table;
-        if (!getenv("GGML_HIP_EXP_TABLE") && fq_verify_exp_formula(g_ctx.exp_table, g_ctx.stream) == 0) g_ctx.exp_table_attn = nullptr;
+        if (getenv("GGML_HIP_EXP_FORMULA") && atoi(getenv("GGML_HIP_EXP_FORMULA")) && !getenv("GGML_HIP_EXP_TABLE") && fq_verify_exp_formula(g_ctx.exp_table, g_ctx.stream) == 0) g_ctx.exp_table_attn = nullptr;
         HIP_CHECK(hipMalloc((void **) &g_ctx.scalar_i32, 256));
         g_ctx.ready = true;
         if (const char * e = getenv("GGML_HIP_REFERENCE_ORDER")) ggml_hip_reference_order(atoi(e));      // (callers that only know ggml-cuda.h)

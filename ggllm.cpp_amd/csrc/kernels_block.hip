@@ -13,6 +13,7 @@
 #include "fq_block_dev.h"
 #include "fq_attn_dev.h"
 #include "kernels.h"
+#include "hip_context.h"
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------ layer norm
@@ -935,6 +936,10 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
         const int form = g_attn_form ? g_attn_form : env_form;      // (16 and 17: measured slower than the scratch form at 2048 tokens, see k_attention_mfma16h)
         if ((form == 1 || (form == 0 && attn_flash_default())) && attn_flash_fits(max_n_kv)) {
             const int nt = attn_flash_nt(max_n_kv), nt_total = (max_n_kv + 31) >> 5;
+            // pass B reads exp() from the fp16 table even when the in-kernel formula is verified: ~25 VALU instructions per score make the pass VALU-bound (measured in
+            // the model: 2048-token prompt 110.6 ms with the formula, the table gather rides on the vector cache under the matrix instructions); FQ_ATTN_FLASH_TAB=0: formula
+            static const int use_tab = getenv("FQ_ATTN_FLASH_TAB") ? atoi(getenv("FQ_ATTN_FLASH_TAB")) : 1;
+            if (!exp_table && use_tab) exp_table = fq_ctx().exp_table;
             const size_t pk = attn_pack_bytes(N, HKV, max_n_kv);
             float * kt = pk ? att_scratch(own_scratch, pk, st) : nullptr;
             if (kt) {

@@ -39,6 +39,13 @@
 // (S == 1, ggml_hip_gemm_sequential / reference order) keeps the scalar build's two roundings per term and its bit-identity with the reference.
 // -DFQ_SPLIT_FMA=0 at compile time restores the unfused K-split sums in BOTH files (the oracle then needs ORC_SPLIT_FMA=0 too).
 #define GQ_FMA FQ_SPLIT_FMA
+#ifndef GQ_OUTER
+#define GQ_OUTER 0        // 1: the scales' products d_w * d_x of the FMA form on the f32 matrix pipe instead of 16 v_mul_f32 per group (see compute()). Round 5, bit-identical
+                          // (tests/test_gpu_mul_mat.py: 332 passed with it) and SLOWER, A/B/A/B of two builds in one gpurun call: 2048-token prompt 110.8 against 99.3 ms,
+                          // 128 tokens 9.0 against 8.7 -- a third fewer vector instructions per result do not help: the 64-cycle f32 matrix instruction sits in front of
+                          // the group's 16 fused multiply-adds, and a wave's group is a dependent chain (LDS -> matrix pipe -> scaling), not a VALU-issue budget. OFF.
+#endif
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i  __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -534,6 +541,21 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         // the K-split partial sums of the legacy formats (the DEFAULT order) accumulate as the reference's AVX2 build does
                         // (acc = _mm256_fmadd_ps(d, q, acc), ggml.c:2415-2438): 3 instead of 4 vector operations per result; the oracle's split orders
                         // restate it with fmaf. S == 1 (ggml_hip_gemm_sequential: the reference ORDER) keeps the scalar build's two roundings per term
+#if GQ_OUTER
+                        // Round 5: the 32 x 32 products d_w[row] * d_x[token] of the group are a rank-1 matrix, and v_mfma_f32_32x32x2_f32 forms it on the
+                        // (idle) matrix pipe: A = the tokens' scales in k slot 0 (lanes 0-31), B = the rows' scales, C = 0 -- one fused multiply-add per
+                        // k step (scripts/microbench/mb_mfma_f32.hip), fma(d_x, d_w, +0) then + 0 * 0: the single rounding of the v_mul_f32 it replaces
+                        // (a zero product's sign cannot reach the sum: acc is never -0). 2 instead of 3 vector operations per result, 16 fewer LDS values.
+                        const float dxl = half == 0 ? ((const float *)(B + LB::DX))[gg * TN + 32 * tt + rot + l31] : 0.0f;
+                        const v16f dd = __builtin_amdgcn_mfma_f32_32x32x2f32(dxl, half == 0 ? dw : 0.0f, v16f{0}, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) {
+                            const float ci = (float) c[i];
+                            float a = __builtin_fmaf(dd[i], ci, ACC(rb, i));
+                            if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
+                            ACC(rb, i) = a;
+                        }
+#else
 #pragma unroll
                         for (int i = 0; i < NR; ++i) {
                             const float ci = (float) c[i];
@@ -541,6 +563,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                             if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
                             ACC(rb, i) = a;
                         }
+#endif
                     } else {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
