@@ -248,6 +248,53 @@ def _watchdog(seconds, what):
     return done
 
 
+_PREFLIGHT = r"""
+import sys
+sys.path.insert(0, %r)
+import ggllm_cpp_amd as g
+rank, world, dev = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[4])
+sys.exit(g.load().falcon_hip_rccl_selftest(rank, world, bytes.fromhex(sys.argv[3]), dev))
+"""
+
+
+def rccl_preflight(g, dist, torch, rank, world, local, timeout_s=None):
+    """RCCL's send / recv between THESE ranks, tried in a child process per rank under a time-out (falcon_hip_rccl_selftest: a ring of one small message over a
+    fresh communicator) before anything is built on it: on the boxes this library is developed on RCCL refuses (two ranks on one device), and it has never run
+    between two GPUs there -- a refusal or a hang must cost the job a fall-back to the host-staged transport, not its life. Returns (ok on EVERY rank, reason)."""
+    import subprocess
+    timeout_s = float(os.environ.get("FALCON_PIPE_PREFLIGHT_S", "120")) if timeout_s is None else timeout_s
+    if timeout_s <= 0:
+        return True, "skipped"
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = g.Pipeline.unique_id().hex()
+        except Exception as e:                                      # noqa: BLE001
+            box[0] = "!" + repr(e)
+    dist.broadcast_object_list(box, src=0)
+    if box[0].startswith("!"):
+        return False, "no RCCL unique id: " + box[0][1:]
+    why, ok = "", 0
+    try:
+        p = subprocess.Popen([sys.executable, "-c", _PREFLIGHT % ROOT, str(rank), str(world), box[0], str(local)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        try:
+            _, err = p.communicate(timeout=timeout_s)
+            ok = 1 if p.returncode == 0 else 0
+            if not ok:
+                why = "rank %d: exit %d: %s" % (rank, p.returncode, err.decode("utf-8", "replace").strip().splitlines()[-1][-160:] if err.strip() else "")
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            why = "rank %d: no answer within %.0f s" % (rank, timeout_s)
+    except Exception as e:                                          # noqa: BLE001
+        why = "rank %d: %r" % (rank, e)
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    reasons = [None] * world
+    dist.all_gather_object(reasons, why)
+    return bool(int(t.item())), "; ".join(r for r in reasons if r) or "a peer failed"
+
+
 def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torch, groups, batch, n_ctx, steps, warmup):
     """one timed run of the C++ pipeline (csrc/falcon_pipeline.hip): returns (tokens/s over the job, weight bytes over all
     ranks, blocks per stage, setup seconds) on every rank"""
@@ -323,6 +370,15 @@ def main(a, rank, world, local):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side control only (id hand-out, barrier, max over ranks); the data path is RCCL inside libggml_hip.so
+    transport_note = None
+    if world > 1 and os.environ.get("FALCON_PIPE_TRANSPORT") != "shm":
+        ok, why = rccl_preflight(g, dist, torch, rank, world, local)
+        if not ok:
+            os.environ["FALCON_PIPE_TRANSPORT"] = "shm"
+            transport_note = ("RCCL pre-flight failed (" + why + "): the job runs with the host-staged transport between the ranks (FALCON_PIPE_TRANSPORT=shm), "
+                              "same ranks, schedule and stage code")
+            if rank == 0:
+                sys.stderr.write("bench_pipeline: " + transport_note + "\n")
     batch = max(1, min(int(getattr(a, "pipe_batch", 4)), 256))
     groups = max(2 * world, 2) if world > 1 else max(1, getattr(a, "streams", 2))
     n_ctx = min(a.n_ctx, 512)
@@ -336,7 +392,7 @@ def main(a, rank, world, local):
         raise SystemExit(f"bench_pipeline: RCCL communicator has {rccl_ranks} ranks, launched {world}")
     if world > 1 and shm and not str(transport).startswith("shm"):
         raise SystemExit(f"bench_pipeline: FALCON_PIPE_TRANSPORT=shm but the pipeline reports transport {transport!r}")
-    extra = {"rccl_ranks": rccl_ranks, "transport": transport,
+    extra = {"rccl_ranks": rccl_ranks, "transport": transport, "transport_note": transport_note,
              "ranks_share_device_0": os.environ.get("FALCON_PIPE_SAME_DEVICE") == "1"}
 
     def one_gpu_same_workload(hp1, wt1, mname, qname, steps, warmup):

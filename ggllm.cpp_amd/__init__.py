@@ -38,7 +38,7 @@ falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_engine_
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
-falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_rccl_ranks falcon_hip_pipeline_transport falcon_hip_pipeline_set_tokens
+falcon_hip_pipeline_unique_id falcon_hip_pipeline_create falcon_hip_pipeline_create_local falcon_hip_pipeline_free falcon_hip_pipeline_rccl_ranks falcon_hip_pipeline_transport falcon_hip_rccl_selftest falcon_hip_pipeline_set_tokens
 falcon_hip_pipeline_run falcon_hip_pipeline_run_local falcon_hip_pipeline_local_attach_rccl falcon_hip_pipeline_get_history falcon_hip_pipeline_schedule""".split()
 
 
@@ -100,7 +100,7 @@ def load():
         "falcon_hip_model_get_hparams": (None, [vp, vp]),
         "falcon_hip_context_create_seqs": (vp, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_n_seq": (C.c_int, [vp]),
         "falcon_hip_pipeline_unique_id": (C.c_int, [vp]), "falcon_hip_pipeline_create": (vp, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
-        "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]), "falcon_hip_pipeline_rccl_ranks": (C.c_int, [vp]), "falcon_hip_pipeline_transport": (C.c_int, [vp]),
+        "falcon_hip_pipeline_create_local": (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_free": (None, [vp]), "falcon_hip_pipeline_rccl_ranks": (C.c_int, [vp]), "falcon_hip_pipeline_transport": (C.c_int, [vp]), "falcon_hip_rccl_selftest": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int]),
         "falcon_hip_pipeline_set_tokens": (C.c_int, [vp, vp]), "falcon_hip_pipeline_run": (C.c_int, [vp, C.c_int, C.c_int]),
         "falcon_hip_pipeline_run_local": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_pipeline_local_attach_rccl": (C.c_int, [vp, C.c_int]),
         "falcon_hip_pipeline_get_history": (C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -401,6 +401,45 @@ int falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p) {
     return n;
 }
 
+// A ring of one small message over a FRESH communicator: rank r sends 256 floats to r + 1 and receives from r - 1 (grouped ncclSend / ncclRecv, the pipeline's
+// own call pattern), checks what arrived, destroys the communicator. The launcher runs it in a CHILD process per rank under a time-out before the job proper
+// (bench_pipeline.py): RCCL between these ranks has never run where this library is developed, and a hung or refused collective must cost the job a
+// fall-back to the host-staged transport, not its life. Returns 0, or a non-zero code with a message on stderr.
+int falcon_hip_rccl_selftest(int rank, int world, const void * unique_id, int device) {
+    if (world < 2 || rank < 0 || rank >= world || !unique_id) return 1;
+    rccl_api * R = fq_rccl();
+    if (!R) return 2;
+    if (hipSetDevice(device) != hipSuccess) { fprintf(stderr, "falcon-hip: rccl selftest: hipSetDevice(%d) failed\n", device); return 3; }
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    ncclResult_t rc = R->ncclCommInitRank(&comm, world, id, rank);
+    if (rc != ncclSuccess) { fprintf(stderr, "falcon-hip: rccl selftest: ncclCommInitRank(rank %d of %d): %s\n", rank, world, R->ncclGetErrorString(rc)); return 4; }
+    const int n = 256, next = (rank + 1) % world, prev = (rank + world - 1) % world;
+    float host[256], * out = nullptr, * in = nullptr;
+    hipStream_t st = nullptr;
+    int bad = 0;
+    if (hipMalloc((void **) &out, n * 4) != hipSuccess || hipMalloc((void **) &in, n * 4) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) bad = 5;
+    if (!bad) {
+        for (int i = 0; i < n; ++i) host[i] = (float)(1000 * rank + i);
+        if (hipMemcpy(out, host, n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(in, 0, n * 4) != hipSuccess) bad = 5;
+    }
+    if (!bad) {
+        if (R->ncclGroupStart() != ncclSuccess) bad = 6;
+        if (!bad && R->ncclSend(out, n, ncclFloat32, next, comm, st) != ncclSuccess) bad = 6;
+        if (!bad && R->ncclRecv(in, n, ncclFloat32, prev, comm, st) != ncclSuccess) bad = 6;
+        if (R->ncclGroupEnd() != ncclSuccess) bad = 6;
+        if (!bad && hipStreamSynchronize(st) != hipSuccess) bad = 7;
+        if (!bad && hipMemcpy(host, in, n * 4, hipMemcpyDeviceToHost) != hipSuccess) bad = 7;
+        if (!bad) for (int i = 0; i < n; ++i) if (host[i] != (float)(1000 * prev + i)) { bad = 8; break; }
+    }
+    if (bad) fprintf(stderr, "falcon-hip: rccl selftest: rank %d of %d failed at step %d\n", rank, world, bad);
+    if (st) (void) hipStreamDestroy(st);
+    if (out) (void) hipFree(out);
+    if (in) (void) hipFree(in);
+    R->ncclCommDestroy(comm);
+    return bad;
+}
+
 // how this rank's hand-offs travel: 0 = nowhere (one stage), 1 = RCCL send / recv, 2 = device copies in one process (local), 3 = the local job
 // over a one-rank RCCL communicator (loop-back), 4 = host shared memory between processes (FALCON_PIPE_TRANSPORT=shm)
 int falcon_hip_pipeline_transport(falcon_hip_pipeline * p) {

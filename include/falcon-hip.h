@@ -162,6 +162,9 @@ int   falcon_hip_pipeline_rccl_ranks(falcon_hip_pipeline * p);           /* nccl
  * FALCON_PIPE_TRANSPORT=shm: the multi-process job on a node whose ranks share a GPU (RCCL refuses two ranks on one device); same ranks, same unique-id
  * hand-out, same slot schedule and stage steps, the exchange blocking on the host */
 int   falcon_hip_pipeline_transport(falcon_hip_pipeline * p);
+/* one small message around the ring of ranks over a fresh RCCL communicator (rank r -> r + 1), checked and torn down: 0 = RCCL's send / recv works between
+ * these ranks. bench_pipeline.py runs it in a child process per rank under a time-out before the job and falls back to FALCON_PIPE_TRANSPORT=shm otherwise. */
+int   falcon_hip_rccl_selftest(int rank, int world, const void * unique_id, int device);
 int   falcon_hip_pipeline_set_tokens(falcon_hip_pipeline * p, const int32_t * tokens);
 int   falcon_hip_pipeline_run(falcon_hip_pipeline * p, int rounds, int n_past0);
 int   falcon_hip_pipeline_get_history(falcon_hip_pipeline * p, int32_t * out, int first_round, int n_rounds);

@@ -72,3 +72,21 @@ def test_a_rank_that_never_comes_ends_the_job_with_a_message(tmp_path):
             "except RuntimeError as e:\n    print('refused:', e)\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=300)
     assert b"refused" in r.stdout and b"every rank to attach" in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_rccl_preflight_refusal_falls_back_to_the_host_staged_transport(tmp_path):
+    """no transport forced: every rank on GPU 0 makes RCCL refuse ("Duplicate GPU detected") in the pre-flight child processes (falcon_hip_rccl_selftest), and the
+    job must run on with the host-staged transport and say so in its line -- the insurance for the first multi-GPU node, where RCCL between these ranks runs for
+    the first time: a refusal or a hang there costs a fall-back, not the SCALE run"""
+    dump = str(tmp_path / "hist.npy")
+    env = dict(os.environ, FALCON_PIPE_SAME_DEVICE="1", FALCON_PIPE_DUMP_HISTORY=dump, FALCON_PIPE_SHM_TIMEOUT_S="120", FALCON_PIPE_PREFLIGHT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FALCON_PIPE_TRANSPORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--quant", "q4_0", "--layers", "4", "--steps", "4", "--warmup", "2",
+                        "--pipe-batch", "2", "--no-north-star", "--no-cpu"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode("utf-8", "replace")[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["transport"].startswith("shm") and "pre-flight failed" in line["transport_note"]
+    hp = dict(synth.HP_TINY_MQA); hp["n_layer"] = 4
+    want = _single_process_tokens(hp, g.Q4_0, 4, 2, 512, 2, 4)
+    assert np.array_equal(np.load(dump), want)
