@@ -261,10 +261,22 @@ static fq_act act_for(uint8_t * buf, const fq_weight & w, int64_t cols) {
     fq_act a{}; a.type = fq_desc(w.type).act_type; a.K = w.K; a.ncols = cols; a.base = buf; return a;
 }
 
+static int g_live_contexts = 0;       // the ring forms' schedule tables are shared by every context of the process and released with the last one
 // the ring forms' per-shape schedules (device tables) must exist before any launch is captured into a graph: legacy formats kernels_ring.hip, k-quants kernels_ringk.hip
+// (one schedule per distinct (format, shape) of the stage's blocks -- not only block 0's: launchers look plans up without creating them, and a block of another format
+// would silently take the register-streaming kernel)
 static bool ring_prepare_any(const falcon_hip_model * m) {
-    const fq_weight & q = m->layers[0].qkv;
-    return fq_ring_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu) || fq_ringk_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu);
+    bool any = false; int seen[32]; int n_seen = 0;
+    for (const layer_weights & L : m->layers) {
+        const fq_weight & q = L.qkv;
+        bool dup = false;
+        for (int i = 0; i < n_seen; ++i) dup = dup || seen[i] == q.type;
+        if (dup) continue;
+        if (n_seen < 32) seen[n_seen++] = q.type;
+        const bool ok = fq_ring_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu) || fq_ringk_prepare(q.type, m->hp.n_embd, m->hp.n_ff, q.M, fq_ctx().n_cu);
+        any = any || ok;
+    }
+    return any;
 }
 
 // the ring form of the unmerged output mat-vec launch (k_ring_out, one wave per row in chunks): measured on Falcon-40B against k_gemv_out with the fast k-quant
@@ -337,6 +349,7 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     if (const char * e = getenv("FALCON_HIP_STAGE_GRAPH")) c->stage_graph = atoi(e) != 0;
     c->ring_ln = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);      // (default on: a context starts in mode 2)
     if (const char * e = getenv("FALCON_HIP_PREFILL_GRAPH")) c->prefill_graph = atoi(e) != 0;
+    ++g_live_contexts;
     if (c->ring_ln && nl > 0) c->ring_ln = ring_prepare_any(m);
     c->ring_out = ring_out_auto(m);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
@@ -355,6 +368,7 @@ extern "C" int falcon_hip_context_n_seq(const falcon_hip_context * c) { return c
 
 extern "C" void falcon_hip_context_free(falcon_hip_context * c) {
     if (!c) return;
+    if (--g_live_contexts == 0) { HIP_CHECK(hipStreamSynchronize(fq_ctx().stream)); fq_ring_free_plans(); fq_ringk_free_plans(); }
     if (c->decode_graph) HIP_CHECK(hipGraphExecDestroy(c->decode_graph));
     if (c->step_graph) HIP_CHECK(hipGraphExecDestroy(c->step_graph));
     if (c->token_graph) HIP_CHECK(hipGraphExecDestroy(c->token_graph));
@@ -912,7 +926,13 @@ extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
     if (c->logits_pending) {                                         // the last falcon_hip_eval_token's row copy (page-locked memory) is in flight behind its launches
         // (polled, not slept on: the caller samples the moment the row is there, and a blocking wait's wake-up costs tens of microseconds of a ~1 ms step)
         hipStream_t st = fq_ctx().stream;
-        for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) break; if (e != hipErrorNotReady) HIP_CHECK(e); }
+        // bounded: ~20 ms of polling (a step is ~1 ms), then a blocking wait -- a stream that hangs must not burn a host core for ever
+        bool done = false;
+        for (int spin = 0; spin < 200000 && !done; ++spin) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) done = true; else if (e != hipErrorNotReady) HIP_CHECK(e); else __builtin_ia32_pause();
+        }
+        if (!done) HIP_CHECK(hipStreamSynchronize(st));
         c->sync_err_host = *(const unsigned *)(c->logits_pinned + c->m->hp.n_vocab);
         c->logits_pending = false;
         (void) report_sync_error(c, "eval");                        // sticky: falcon_hip_context_last_error / the next eval report it (this call cannot)
