@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_last_error falcon_hip_context_set_rope_n_ctx
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_engine_compiled falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
+falcon_hip_eval_debug_timings falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_engine_compiled falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
@@ -118,7 +118,7 @@ def load():
         "falcon_hip_tokenize": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int]),
         "falcon_hip_token_to_bytes": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p)]),
         "falcon_hip_token_bos": (C.c_int32, []), "falcon_hip_token_eos": (C.c_int32, []),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_engine_compiled": (C.c_int, []), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_eval_debug_timings": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_engine_compiled": (C.c_int, []), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_plan_stages": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),

@@ -922,6 +922,17 @@ extern "C" int falcon_hip_eval(falcon_hip_context * c, const int32_t * tokens, i
     return falcon_hip_eval_stage(c, tokens, nullptr, n_tokens, n_past, logits_all, nullptr);
 }
 
+// falcon_hip_eval with the per-launch timing table printed on stderr afterwards (kernels.h fq_tl_*): the resident path's counterpart of the reference's
+// --debug-timings node table (libfalcon.cpp:2506-2520 -> ggml_graph_print_impl, ggml.c:18266-18360). Plain launches (no graph replay), one synchronisation at the end.
+extern "C" int falcon_hip_eval_debug_timings(falcon_hip_context * c, const int32_t * tokens, int n_tokens, int n_past, int logits_all) {
+    fq_tl_begin();
+    const int rc = falcon_hip_eval(c, tokens, n_tokens, n_past, logits_all);
+    char title[160];
+    snprintf(title, sizeof(title), "falcon-hip: launches of this eval (%d token%s at n_past %d; device-resident path, no ggml graph: one line per launch site)", n_tokens, n_tokens == 1 ? "" : "s", n_past);
+    fq_tl_end(stderr, title);
+    return rc;
+}
+
 extern "C" const float * falcon_hip_get_logits(falcon_hip_context * c) {
     if (c->logits_pending) {                                         // the last falcon_hip_eval_token's row copy (page-locked memory) is in flight behind its launches
         // (polled, not slept on: the caller samples the moment the row is there, and a blocking wait's wake-up costs tens of microseconds of a ~1 ms step)

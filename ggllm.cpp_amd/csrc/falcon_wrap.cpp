@@ -148,7 +148,17 @@ int __wrap_falcon_eval(struct falcon_context * ctx, const falcon_token * tokens,
     falcon_hip_context_set_rope_n_ctx(s->c, configuration.n_max_real_ctx ? configuration.n_max_real_ctx : s->n_ctx);
     const int64_t t0 = now_us();
     int rc;
-    if (N == 1 && !s->logits_all) {
+    // --debug-timings (falcon_evaluation_config::debug_timings; the reference's rule, libfalcon.cpp:2506-2516: 1 the first eval, 2 the first eval past the prompt's
+    // first batch -- falcon_main turns it into 3 for its last token --, 3 every eval): the reference prints its ggml graph's nodes; here the eval's launches
+    bool timings = false;
+    if (configuration.debug_timings && (n_past > 0 || configuration.debug_timings != 2)) {
+        static bool first = true;
+        if ((first && configuration.debug_timings <= 2) || configuration.debug_timings > 2) { first = false; timings = true; }
+    }
+    if (timings) {
+        rc = falcon_hip_eval_debug_timings(s->c, (const int32_t *) tokens, N, n_past, s->logits_all ? 1 : 0);
+        s->pending_one = false;
+    } else if (N == 1 && !s->logits_all) {
         // one token: the captured graph, no copy, no wait -- falcon_get_logits fetches the row if (and when) the caller samples from it;
         // the time until then is booked there
         rc = falcon_hip_eval_token(s->c, (int32_t) tokens[0], n_past);

@@ -436,6 +436,53 @@ extern "C" void ggml_hip_mul_mat_q(const ggml_hip_weight * w, const float * x_de
     HIP_CHECK(hipFree(slab));
 }
 
+
+// ------------------------------------------------------------------------------------------------ per-launch timing table (kernels.h)
+namespace {
+struct tl_rec { const char * name; hipEvent_t e0, e1; };
+struct tl_state { bool on = false; int depth = 0; std::vector<tl_rec> recs; std::vector<hipEvent_t> pool; size_t next = 0; } g_tl;
+hipEvent_t tl_event() {
+    if (g_tl.next == g_tl.pool.size()) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); g_tl.pool.push_back(e); }
+    return g_tl.pool[g_tl.next++];
+}
+}
+bool fq_tl_collecting() { return g_tl.on; }
+fq_tl_scope::fq_tl_scope(hipStream_t st_, const char * name) : st(st_), slot(-1) {
+    if (!g_tl.on) return;
+    if (g_tl.depth++ > 0) return;                                  // (a launch site inside another: the outer one carries the bracket)
+    slot = (int) g_tl.recs.size();
+    g_tl.recs.push_back(tl_rec{ name, tl_event(), tl_event() });
+    HIP_CHECK(hipEventRecord(g_tl.recs[(size_t) slot].e0, st));
+}
+fq_tl_scope::~fq_tl_scope() {
+    if (!g_tl.on) return;
+    --g_tl.depth;
+    if (slot >= 0) HIP_CHECK(hipEventRecord(g_tl.recs[(size_t) slot].e1, st));
+}
+void fq_tl_begin() { g_tl.recs.clear(); g_tl.next = 0; g_tl.depth = 0; g_tl.on = true; }
+int fq_tl_end(FILE * out, const char * title) {
+    g_tl.on = false;
+    HIP_CHECK(hipDeviceSynchronize());
+    struct agg { const char * name; int n; double us; };
+    std::vector<agg> a;
+    double total = 0.0;
+    for (const tl_rec & r : g_tl.recs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void) hipGetLastError(); continue; }
+        size_t i = 0;
+        for (; i < a.size(); ++i) if (!strcmp(a[i].name, r.name)) break;
+        if (i == a.size()) a.push_back(agg{ r.name, 0, 0.0 });
+        a[i].n += 1; a[i].us += 1e3 * (double) ms; total += 1e3 * (double) ms;
+    }
+    if (out) {
+        fprintf(out, "%s\n", title ? title : "falcon-hip: launches");
+        fprintf(out, "  %-28s %8s %12s %10s %7s\n", "launch site", "calls", "total us", "avg us", "share");
+        for (const agg & g : a) fprintf(out, "  %-28s %8d %12.1f %10.2f %6.1f%%\n", g.name, g.n, g.us, g.us / g.n, total > 0 ? 100.0 * g.us / total : 0.0);
+        fprintf(out, "  %-28s %8zu %12.1f   (event brackets around each launch site on its stream; sites on the second stream overlap the first)\n", "all", g_tl.recs.size(), total);
+    }
+    return (int) g_tl.recs.size();
+}
+
 // ------------------------------------------------------------------------------------------------ block ops
 extern "C" void ggml_hip_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y) {
     fq_launch_layer_norm(x, n, rows, w, b, y, fq_ctx().stream);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fq_types.h"
+#include <stdio.h>
 
 enum { FQ_EPI_STORE = 0, FQ_EPI_GELU = 1, FQ_EPI_ADD2 = 2 };
 
@@ -166,6 +167,20 @@ struct fq_gemv_out_cols_args {
 bool   fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st);                 // false: outside its scope, nothing launched
 bool   fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st);
 int    fq_gemv_out_cols_width(int type, int64_t K_down, int64_t K_wo);      // columns per launch that fit its LDS: 4, 2 or 0
+
+
+// ---- per-launch timing table (round 5; takes the place of the reference's --debug-timings node table, libfalcon.cpp:2506-2520 / ggml.c:18266-18360, on the
+// resident path, where there is no ggml graph whose nodes could be listed). Every fq_launch_* opens a scope; while a table is being collected (fq_tl_begin ..
+// fq_tl_end) the outermost scope of a launch site brackets its launches with two events on its stream. Inactive: one load and a branch per launch site.
+struct fq_tl_scope {
+    hipStream_t st; int slot;
+    fq_tl_scope(hipStream_t st_, const char * name);
+    ~fq_tl_scope();
+};
+#define FQ_TL(st_, name_) fq_tl_scope fq_tl_scope_((st_), (name_))
+void fq_tl_begin();                                   // start collecting (plain launches only: the caller must not replay a captured graph meanwhile)
+int  fq_tl_end(FILE * out, const char * title);       // synchronises, prints one line per launch site kind (calls, total / average microseconds, share), returns the number of brackets
+bool fq_tl_collecting();
 
 // kernels_engine.hip -- the persistent decode engine: one launch per token
 #include <vector>

@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) k_layer_norm_quant(const float * __restri
     quantize_row_block<ACT>(row, n, act_image_at(col, ACT, n));
 }
 void fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st) {
+    FQ_TL(st, "layer_norm_quant");
     const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
     if (a.type == FQ_Q8_0)      hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_0>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
     else if (a.type == FQ_Q8_1) hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_1>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(256) k_layer_norm_quant2(const float * __restr
 }
 bool fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const float * w0, const float * b0, const fq_act & a0,
                                  const float * w1, const float * b1, const fq_act & a1, hipStream_t st) {
+    FQ_TL(st, "layer_norm_quant2");
     if (a0.type != a1.type) return false;
     const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
     const dim3 grid((unsigned) rows, 2);
@@ -77,6 +79,7 @@ bool fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const
 }
 
 void fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st) {
+    FQ_TL(st, "layer_norm");
     const size_t lds = ((n * 4 + 15) & ~(size_t) 15) + 64;
     hipLaunchKernelGGL(k_layer_norm, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y);
 }
@@ -87,6 +90,7 @@ __global__ void k_gelu(const float * __restrict__ x, float * __restrict__ y, int
         y[i] = h2f_bits(tab[f2h_bits(x[i])]);
 }
 void fq_launch_gelu(const float * x, float * y, int64_t n, const uint16_t * gelu_table, hipStream_t st) {
+    FQ_TL(st, "gelu");
     const int blocks = (int) ((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(k_gelu, dim3(blocks), dim3(256), 0, st, x, y, n, gelu_table);
 }
@@ -95,6 +99,7 @@ __global__ void k_add3(const float * __restrict__ a, const float * __restrict__ 
         y[i] = (a[i] + b[i]) + c[i];
 }
 void fq_launch_add3(const float * a, const float * b, const float * c, float * y, int64_t n, hipStream_t st) {
+    FQ_TL(st, "add3");
     const int blocks = (int) ((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(k_add3, dim3(blocks), dim3(256), 0, st, a, b, c, y, n);
 }
@@ -131,6 +136,7 @@ __global__ void k_rope_kv(float * __restrict__ qkv, int N, int H, int HKV, int D
 }
 void fq_launch_rope_kv(float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, const float * rope_cs, float * k_cache, float * v_cache, hipStream_t st,
                        int64_t seq_stride) {
+    FQ_TL(st, "rope_kv");
     const int64_t total = (int64_t) N * (H + 2 * HKV) * (D / 2);
     const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(k_rope_kv, dim3(blocks), dim3(256), 0, st, qkv, N, H, HKV, D, n_past_dev, rope_cs, k_cache, v_cache, seq_stride);
@@ -913,6 +919,7 @@ static float * att_scratch(fq_att_scratch * own, size_t bytes, hipStream_t st) {
 
 void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const int * n_past_dev, int max_n_kv, const float * k_cache,
                          const float * v_cache, const uint16_t * exp_table, float * att, hipStream_t st, int64_t seq_stride, fq_att_scratch * own_scratch) {
+    FQ_TL(st, "attention");
     if (D != 64) { fprintf(stderr, "ggml-hip: attention: head_dim %d != 64\n", D); exit(1); }
     const int p_stride = (max_n_kv + 3) & ~3;
     const size_t fixed = 16 * 4 + 16 * 64 * 8, row = (size_t) p_stride * 4, budget = 150 * 1024;

@@ -244,6 +244,7 @@ void launch_out_cols_t(const fq_gemv_out_cols_args & a, unsigned blocks, int nw,
 
 // both launchers return false (nothing launched) when the shape is outside their scope; the caller keeps the op list
 bool fq_launch_gemv_cols(fq_gemv_cols_args a, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemv_cols");
     (void) n_cu;
     if (a.ncols < 1 || a.ncols > 4 || a.nseg < 1 || a.nseg > 2) return false;
     const int type = a.seg[0].w.type;
@@ -277,6 +278,7 @@ int fq_gemv_out_cols_width(int type, int64_t K_down, int64_t K_wo) {
     return per * 4 + 16 <= 160 * 1024 ? 4 : (per * 2 + 16 <= 160 * 1024 ? 2 : 0);
 }
 bool fq_launch_gemv_out_cols(const fq_gemv_out_cols_args & a, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemv_out_cols");
     if (a.ncols < 1 || a.ncols > 4 || a.w_down.type != a.w_wo.type || a.w_down.M != a.w_wo.M) return false;
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;

@@ -320,6 +320,7 @@ static void gemv_ln_shape(const fq_gemv_ln_args & a, int n_cu, int & nw_out, int
 }
 
 void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemv_ln");
     int nw = 4, npass = 2;
     gemv_ln_shape(a, n_cu, nw, npass);
     a.npass = npass;
@@ -426,6 +427,7 @@ __global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
 }
 
 void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemv_out");
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
     size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (a.att_image ? 0 : (size_t) a.w_wo.K * 4) + 16;
@@ -469,6 +471,7 @@ size_t fq_attn_decode_lds_bytes(int max_n_kv) { return attn_decode_lds(max_n_kv)
 
 void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                            float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st) {
+    FQ_TL(st, "attn_decode");
     const size_t lds = attn_decode_lds(max_n_kv);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
@@ -511,6 +514,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_seqs(fq_attn_decode_args a,
 void fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                                 float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
                                 int att_act_type, int64_t image_stride, hipStream_t st, const float * qx, int64_t q_ldx, const fq_act * qa) {
+    FQ_TL(st, "attn_decode_seqs");
     const size_t lds = attn_decode_lds(max_n_kv);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
     if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode_seqs, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
@@ -693,6 +697,7 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
                         const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
                         int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st,
                         const fq_gemv_ln_args * ln, unsigned long long * xgran) {
+    FQ_TL(st, "attn_out");
     const int type = g.w_wo.type, act = fq_desc(type).act_type;
     const int nw = 12, hpw = 2;             // 2 heads per attention workgroup: the attention is instruction-issue bound per SIMD
     const int n_attn = (H + hpw - 1) / hpw;

@@ -719,6 +719,7 @@ int fq_gemm_split_for(int64_t M, int64_t N, int n_cu) {
 
 // dst[n*ldd + m], n < N; act holds N quantized columns
 void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemm");
     // The unit of parallelism is a 32-token x 32-row tile (568 of them for a 4544-row matrix and 128 tokens), split S ways
     // over K. Measured on MI355X, Falcon-7B shapes, Q4_0 (scripts/gpu_gemm_prof.sh), us for qkv / wo / up / down:
     //   128 tokens   <S 1, 4 tiles>  44 / 44 /  92 / 163    <S 2, 4 tiles>  34 / 34 /  82 / 119    <S 4, 4 tiles>  31 / 31 /  95 / 106

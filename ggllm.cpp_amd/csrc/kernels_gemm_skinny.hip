@@ -822,12 +822,14 @@ static bool fq_launch_gemm_skinny_res(const fq_weight & w, const fq_weight & w1,
 // two matrices behind the same N <= 16 activation columns in one launch (same format, same K, the same K split S); false: nothing launched
 bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & act, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                                 float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, int S, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny_pair");
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4) || w0.type != w1.type || w0.K != w1.K || w0.nblk != w1.nblk) return false;
     return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
 }
 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use
 bool fq_launch_gemm_skinny(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny");
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4)) return false;
     if (w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q6_K) return fq_launch_gemm_skinny_kq(w, act, N, dst, ldd, ep, S, st);
     if (w.type != FQ_Q4_0 && w.type != FQ_Q4_1 && w.type != FQ_Q5_0 && w.type != FQ_Q5_1 && w.type != FQ_Q8_0) return false;

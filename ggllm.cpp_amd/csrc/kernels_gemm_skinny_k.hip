@@ -857,9 +857,11 @@ static bool q4k_main(const fq_weight & w, const fq_act & act, int64_t N, float *
     return true;
 }
 void fq_launch_skinny_sum4(const float * part, int64_t N, int64_t M, float * dst, int64_t ldd, const fq_gemv_epi & ep, int64_t mstride, int nseg, hipStream_t st) {
+    FQ_TL(st, "skinny_sum4");
     hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((M + 255) / 256), (unsigned) N), dim3(256), 0, st, part, (int) N, M, dst, ldd, ep, mstride, nseg);
 }
 bool fq_launch_gemm_skinny_kq(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny_kq");
     int64_t mstride; int nseg;
     if (S == 1 || !q4k_main(w, act, N, fq_ctx().ks_scratch, mstride, nseg, st)) return false;
     hipLaunchKernelGGL(k_skinny_sum4, dim3((unsigned)((w.M + 255) / 256), (unsigned) N), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, ep, mstride, nseg);
@@ -868,6 +870,7 @@ bool fq_launch_gemm_skinny_kq(const fq_weight & w, const fq_act & act, int64_t N
 // Wup of a block whose Wdown takes Q8_K columns: the sum launch applies GELU and writes the Q8_K image of the result (k_quantize_q8K's code) next to
 // the f32 matrix. false: nothing launched (not this form's shape)
 bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const uint16_t * gelu_table, const fq_act & out, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny_q4k_gelu_q8k");
     if (out.type != FQ_Q8_K || out.K != w.M || w.M % 256 || out.ncols < N) return false;
     int64_t mstride; int nseg;
     if (!q4k_main(w, act, N, fq_ctx().ks_scratch, mstride, nseg, st)) return false;
@@ -877,6 +880,7 @@ bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act,
 }
 // x = (Wdown a_ff + Wo a_att) + x for both matrices in this form: two main launches, ONE sum launch (Wo's result never exists as a matrix)
 bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny_q4k_out2");
     if (wo.M != down.M || !fq_skinny_q4k_shape(wo) || !fq_skinny_q4k_shape(down) || a_att.type != FQ_Q8_K || a_ff.type != FQ_Q8_K || N < 1 || N > SK_TN) return false;
     const int64_t ms = (down.M + 63) & ~(int64_t) 63;
     const int sgd = (down.type == FQ_Q4_K || down.type == FQ_Q5_K) ? KQ_SEG : K2_SEG, sgw = (wo.type == FQ_Q4_K || wo.type == FQ_Q5_K) ? KQ_SEG : K2_SEG;

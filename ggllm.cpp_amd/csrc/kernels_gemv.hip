@@ -142,6 +142,7 @@ static void launch_gemv_n(const fq_weight & w, const fq_act & act, int ncols, fl
 
 // dst[c*ldd + row] for columns [0, ncols); ncols in {1,2,4} (the caller splits other counts)
 void fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float * dst, int64_t ldd, const fq_gemv_epi & ep, int max_blocks, hipStream_t st) {
+    FQ_TL(st, "gemv");
 #define FQ_CASE(T) case T: launch_gemv_n<T>(w, act, ncols, dst, ldd, ep, max_blocks, st); break;
     switch (w.type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)

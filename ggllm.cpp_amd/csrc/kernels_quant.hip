@@ -27,6 +27,7 @@ __global__ void k_retile(const uint8_t * __restrict__ src, fq_weight w, int type
 }
 
 void fq_launch_retile(const uint8_t * src_dev, const fq_weight & w, hipStream_t st) {
+    FQ_TL(st, "retile");
     const int64_t total = w.M * w.nblk;
     const int blocks = (int) ((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(k_retile, dim3(blocks), dim3(256), 0, st, src_dev, w, w.type);
@@ -113,6 +114,7 @@ __global__ void k_dequant_rows(fq_weight w, const int32_t * __restrict__ rows, i
 }
 
 void fq_launch_dequant_rows(const fq_weight & w, const int32_t * rows_dev, int64_t nrows, float * dst, hipStream_t st) {
+    FQ_TL(st, "dequant_rows");
     const int64_t total = nrows * w.K;
     const int blocks = (int) ((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
 #define FQ_CASE(T) case T: hipLaunchKernelGGL(k_dequant_rows<T>, dim3(blocks), dim3(256), 0, st, w, rows_dev, nrows, dst); break;
@@ -160,6 +162,7 @@ __global__ void k_quantize_q8K(const float * __restrict__ x, int64_t ldx, fq_act
 }
 
 void fq_launch_quantize_act(const float * x, int64_t ldx, const fq_act & a, hipStream_t st) {
+    FQ_TL(st, "quantize_act");
     if (a.type == FQ_Q8_K) {
         const int64_t total_sb = (a.K >> 8) * a.ncols;
         const int blocks = (int) ((total_sb + 3) / 4 > 4096 ? 4096 : (total_sb + 3) / 4);
@@ -208,6 +211,7 @@ __global__ void k_act_export(fq_act a, uint8_t * __restrict__ out) {
 }
 
 void fq_launch_act_export(const fq_act & a, uint8_t * out, hipStream_t st) {
+    FQ_TL(st, "act_export");
     const int64_t total = (a.type == FQ_Q8_K ? (a.K >> 8) : (a.K >> 5)) * a.ncols;
     const int blocks = (int) ((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(k_act_export, dim3(blocks), dim3(256), 0, st, a, out);

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_ref(fq_weight w, fq_act act, in
 }
 
 void fq_launch_mul_mat_ref(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
+    FQ_TL(st, "mul_mat_ref");
     const int64_t total = w.M * N;
     const unsigned blocks = (unsigned)((total + 255) / 256);
 #define FQ_CASE(T) case T: hipLaunchKernelGGL((k_mul_mat_ref<T>), dim3(blocks), dim3(256), 0, st, w, act, N, dst, ldd, ep); break;

@@ -433,6 +433,7 @@ bool fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu
 
 // k_gemv_ln's launch through the ring form; false = outside its scope (nothing launched)
 bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st) {
+    FQ_TL(st, "gemv_ln_ring");
     if (g.nseg != 2 || g.seg[1].epi != FQ_LNEPI_GELU_QUANT || g.seg[0].epi != FQ_LNEPI_STORE || g.argmax_val) return false;
     const fq_weight & wq = g.seg[0].w, & wu = g.seg[1].w;
     const int type = wq.type;

@@ -596,6 +596,7 @@ bool fq_ringk_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_c
 
 // k_gemv_ln's launch (k-quants, GELU_STORE epilogue) through the ring form; false = outside its scope or no prepared schedule (nothing launched)
 bool fq_launch_ringk_ln(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st) {
+    FQ_TL(st, "ringk_ln");
     if (g.nseg != 2 || g.seg[1].epi != FQ_LNEPI_GELU_STORE || g.seg[0].epi != FQ_LNEPI_STORE || g.argmax_val) return false;
     const fq_weight & wq = g.seg[0].w, & wu = g.seg[1].w;
     const int type = wq.type;
@@ -630,6 +631,7 @@ bool fq_launch_ringk_ln(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hip
 
 // k_gemv_out's launch through the ring form (all ten formats); false = outside its scope, nothing launched
 bool fq_launch_ring_out(const fq_gemv_out_args & g, unsigned * err, int n_cu, hipStream_t st) {
+    FQ_TL(st, "ring_out");
     const fq_weight & wd = g.w_down, & wo = g.w_wo;
     const int type = wo.type, act = fq_desc(type).act_type;
     if (type != wd.type || wd.M != wo.M || fq_desc(type).blck == 0) return false;

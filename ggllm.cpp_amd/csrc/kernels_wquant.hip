@@ -110,6 +110,7 @@ static void launch_k(const float * x, int64_t nsb, uint8_t * out, hipStream_t st
 
 // n_elems f32 (a whole number of blocks) -> ggml blocks at out; hist: 16 counters (legacy formats only) or nullptr
 bool fq_launch_wquant(int type, const float * x, int64_t n_elems, uint8_t * out, unsigned long long * hist, hipStream_t st) {
+    FQ_TL(st, "wquant");
     if (n_elems <= 0) return true;
     switch (type) {
         case FQ_Q4_0: launch_legacy<FQ_Q4_0>(x, n_elems / 32, out, hist, st); return true;
@@ -126,11 +127,13 @@ bool fq_launch_wquant(int type, const float * x, int64_t n_elems, uint8_t * out,
     return false;
 }
 void fq_launch_f16_to_f32(const uint16_t * src, float * dst, int64_t n, hipStream_t st) {
+    FQ_TL(st, "f16_to_f32");
     if (n <= 0) return;
     const int64_t wgs = (n + 255) / 256;
     hipLaunchKernelGGL(k_f16_to_f32, dim3((unsigned)(wgs > 8192 ? 8192 : wgs)), dim3(256), 0, st, src, dst, n);
 }
 void fq_launch_f32_to_f16(const float * src, uint16_t * dst, int64_t n, hipStream_t st) {
+    FQ_TL(st, "f32_to_f16");
     if (n <= 0) return;
     const int64_t wgs = (n + 255) / 256;
     hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)(wgs > 8192 ? 8192 : wgs)), dim3(256), 0, st, src, dst, n);

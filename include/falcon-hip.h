@@ -112,6 +112,10 @@ int falcon_hip_context_last_error(const falcon_hip_context * c);      /* 0 or 3;
 /* the n_ctx ggml_rope is given may change per call (falcon_evaluation_config::n_max_real_ctx, libfalcon.cpp:2229-2230);
  * the table is rebuilt when the dynamic-NTK bucket n_ctx / 2048 changes (<= 0: the context's n_ctx)                       */
 void falcon_hip_context_set_rope_n_ctx(falcon_hip_context * c, int rope_n_ctx);
+/* falcon_hip_eval, then one line per launch site on stderr (calls, total / average microseconds, share): what the reference's --debug-timings node table
+ * (libfalcon.cpp:2506-2520) becomes on the resident path, where a block is a handful of launches instead of a ggml graph; falcon_wrap.cpp calls it where the
+ * reference would print its table (falcon_evaluation_config::debug_timings, same first / last / every-token rule) */
+int   falcon_hip_eval_debug_timings(falcon_hip_context * c, const int32_t * tokens, int n_tokens, int n_past, int logits_all);
 const float * falcon_hip_get_logits(falcon_hip_context * c);        /* host, n_vocab (or n_tokens*n_vocab) floats */
 /* The reference's perplexity loop (falcon_perplexity.cpp:28-124) over a token stream: chunks of n_ctx tokens evaluated
  * from an empty context in batches of n_batch, NLL of the second half of every chunk (host soft_max as in :12-27).

@@ -204,3 +204,39 @@ def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path):
     r = subprocess.run([exe, "-m", path, "-f", txt, "-t", "2", "-c", "32", "-b", "8", "-s", "1"], capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout == bytes(golden["cli"]["ppl_stdout"])
+
+
+def test_debug_timings_prints_the_launch_table(oracle, golden, tmp_path):
+    """--debug-timings 3 (every eval): where the reference prints its ggml graph's nodes (libfalcon.cpp:2506-2520 -> ggml_graph_print_impl) the resident path
+    prints one line per launch site of the eval (falcon_hip_eval_debug_timings: event brackets around every fq_launch_*) -- and the generated bytes stay the
+    CPU build's (the timed evals run as plain launches, same kernels)"""
+    exe = _need("falcon_main_hip")
+    path = str(tmp_path / "tiny_bpe.ggcc")
+    _cli_model(oracle, path)
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    r = subprocess.run([exe, "-m", path, "-p", "The quick brown fox didn't jump", "-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1", "--debug-timings", "3"],
+                       capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    err = r.stderr.decode("utf-8", "replace")
+    assert err.count("falcon-hip: launches of this eval") >= 8 and "launch site" in err and "attention" in err and "mul_mat_ref" in err
+    assert r.stdout == bytes(golden["cli"]["main_stdout"])
+
+
+def test_eval_debug_timings_through_the_c_abi(oracle, capfd):
+    """falcon_hip_eval_debug_timings == falcon_hip_eval (same logits) + the table on stderr, default order, a prompt batch and a single token"""
+    g.init(0)
+    hp = dict(synth.HP_TINY_GQA)
+    w = synth.make_model(oracle, hp, ob.Q5_1, seed=9)
+    toks = synth.tokens(40, hp["n_vocab"], seed=2)
+    m = g.FalconModel(w, n_ctx=64, n_batch=40)
+    want = [m.eval(toks[:36], 0, logits_all=False).copy(), m.eval(toks[36:37], 36, logits_all=False).copy()]
+    L = g.load()
+    got = []
+    for lo, n, past in ((0, 36, 0), (36, 1, 36)):
+        t = np.ascontiguousarray(toks[lo:lo + n], np.int32)
+        assert L.falcon_hip_eval_debug_timings(m.ctx, t.ctypes.data, n, past, 0) == 0
+        got.append(m.logits().reshape(1, -1).copy())
+    m.free()
+    err = capfd.readouterr().err
+    assert err.count("falcon-hip: launches of this eval") == 2 and "gemm" in err and "attention" in err
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
