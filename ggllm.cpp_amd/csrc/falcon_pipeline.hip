@@ -240,6 +240,7 @@ bool shm_attach(falcon_hip_pipeline * p, const void * unique_id) {
     }
     __atomic_add_fetch(&h->attached, 1u, __ATOMIC_ACQ_REL);
     if (!shm_wait(t, &h->attached, (uint32_t) p->world, "every rank to attach", p->rank, -1)) { munmap(t->base, t->bytes); close(t->fd); if (t->owner) shm_unlink(t->name); delete t; return false; }
+    if (t->owner) { shm_unlink(t->name); t->name[0] = 0; }           // every rank holds its mapping now: the name can go, and a job that dies later leaves nothing in /dev/shm
     HIP_CHECK(hipHostMalloc(&t->stage_out, t->hid_bytes, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc(&t->stage_in, t->hid_bytes, hipHostMallocDefault));
     t->sent_h.assign(G, 0); t->sent_t.assign(G, 0); t->got_h.assign(G, 0); t->got_t.assign(G, 0);
@@ -252,7 +253,7 @@ void shm_detach(falcon_hip_pipeline * p) {
     if (t->stage_out) HIP_CHECK(hipHostFree(t->stage_out));
     if (t->stage_in) HIP_CHECK(hipHostFree(t->stage_in));
     munmap(t->base, t->bytes); close(t->fd);
-    if (t->owner) shm_unlink(t->name);                              // (the others keep their mappings until they detach)
+    if (t->owner && t->name[0]) shm_unlink(t->name);                // (normally gone since every rank attached)
     delete t; p->shm = nullptr;
 }
 // the slot's exchange over the mailboxes, BLOCKING on the host: sends first (they wait for nobody but the mailbox's ack), then the
