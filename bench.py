@@ -509,6 +509,7 @@ def main():
                                    "parity.benchmark_model.default_order_vs_cpu -- one flipped 8-bit activation rounding moves its logits by 1e-2, the reference's own "
                                    "AVX2 and scalar builds differ by parity.benchmark_model.reference_avx2_vs_scalar_spread there -- and the reference-order mode is "
                                    "bit-identical to the scalar reference on both (reference_order_vs_cpu = 0.0); err_vs_f64 places all of them against exact sums") if parity else None,
+        "max_rel_logit_err_vs_cpu_reference_order": max(v["reference_order_vs_cpu"] for v in parity.values()) if parity else None,    # ggml_hip_reference_order(1): bit-identical (0.0) on both models
         "parity": parity, "reference_order": ref_order,
         "setup_s": {"synthesize": t_gen, "upload": t_up},
         "lock_step_streams": lock_step,
