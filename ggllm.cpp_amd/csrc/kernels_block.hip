@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ 
 template <bool TAB, int NT, bool PACKED>
 __global__ void __launch_bounds__(512) k_attention_flash(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                          const float * __restrict__ kc, const float * __restrict__ vc,
-                                                         const uint16_t * __restrict__ exp_tab, float * __restrict__ att, const float * __restrict__ kt, int nt_total, int dbg) {
+                                                         const uint16_t * __restrict__ exp_tab, float * __restrict__ att, const float * __restrict__ kt, int nt_total, int dbg, int * __restrict__ next_item) {
     constexpr int PH = 32 * NT + 8;                                               // halfwords per LDS row (a compile-time pitch: the 16 rows of a lane are immediate offsets)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t * const eh   = (uint16_t *) smem;                                    // [32][PH] fp16 bits of exp()
@@ -660,8 +660,17 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     double   * const rsum = (double *)(rmax + 8 * 32);                            // [8 waves][32 rows]
     float    * const xch  = (float *)(rsum + 8 * 32);                             // [2 dim halves][16][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, hf = lane >> 5;
-    const int h = blockIdx.x, i0 = ((int) gridDim.y - 1 - (int) blockIdx.y) * 32, hk = h / (H / HKV), heads = H + 2 * HKV;
+    // PERSISTENT workgroups (round 5): the grid is one workgroup per CU (a workgroup takes a whole CU: 8 waves x ~210 VGPRs), and each walks the (head, query tile)
+    // items blockIdx.x, blockIdx.x + gridDim.x, ... -- heavy tiles (the last tokens of the prompt) first, so every workgroup gets the same mix. Per-pass timing had
+    // shown 19 % of a launch to be workgroup turnover (dispatch of a 512-thread, 160 KiB workgroup onto a drained CU, kernel arguments, position word).
+    // Items are handed out by a counter (next_item, zeroed by the launcher; nullptr: one item per workgroup): a fixed round-robin gave workgroups 0..70 the heaviest
+    // tile of every round (512 tokens: 0.128 against 0.121 ms). The next index is fetched by one lane during the item's pass A and read by everybody behind barrier 3.
     const int n_past = *n_past_ptr;
+    const int ntq = (N + 31) >> 5, n_items = ntq * H, heads = H + 2 * HKV;
+    int * const nxt = (int *)(xch + 2 * 16 * 64);                     // one LDS word behind xch
+  for (int item = (int) blockIdx.x; item < n_items;) {
+    if (next_item && tid == 64) *nxt = (int) gridDim.x + atomicAdd(next_item, 1);      // (a lane of wave 1: published by the time barrier 3 has been passed)
+    const int h = item % H, i0 = (ntq - 1 - item / H) * 32, hk = h / (H / HKV);
     const int nrows = N - i0 < 32 ? N - i0 : 32;
     const int n_kv_max = n_past + i0 + nrows;                       // keys the tile's last token sees
     const int n_rows_cache = n_past + N;                            // key / value rows that exist
@@ -846,10 +855,15 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
             if (ir < nrows) att[(int64_t)(i0 + ir) * H * 64 + (int64_t) h * 64 + 32 * dh + li] = c[r] + xch[(dh * 16 + r) * 64 + lane];
         }
     }
+    // (no barrier before the next item: its first LDS writes are rmax after its pass A -- a region nobody reads now --, eh / rsum / xch only behind its own barriers;
+    // the next index word is rewritten by wave 1 only after wave 1 itself has read it, and every other wave reads it before its next barrier 1)
+    item = next_item ? *(volatile int *) nxt : n_items;
+    if (next_item) __syncthreads();                                   // (the word is rewritten at the top of the next item: everybody must have read it)
+  }
 }
 // LDS rows for 16, 32 or 74 key tiles (512, 1024, 2368 keys): the instantiations of the compile-time pitch
 static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 74 ? 74 : 0)); }
-static size_t attn_flash_lds(int nt) { return (size_t) 32 * (size_t)(32 * nt + 8) * 2 + 8 * 32 * 4 + 8 * 32 * 8 + 2 * 16 * 64 * 4; }
+static size_t attn_flash_lds(int nt) { return (size_t) 32 * (size_t)(32 * nt + 8) * 2 + 8 * 32 * 4 + 8 * 32 * 8 + 2 * 16 * 64 * 4 + 16; }
 static bool attn_flash_fits(int max_n_kv) { return attn_flash_nt(max_n_kv) != 0; }
 template <bool TAB, int NT, bool PACKED>
 static void launch_attention_flash_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
@@ -858,7 +872,12 @@ static void launch_attention_flash_t(const float * qkv, int N, int H, int HKV, c
     static bool attr = false;
     if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
     static const int dbg = getenv("FQ_ATTN_DBG") ? atoi(getenv("FQ_ATTN_DBG")) : 0;
-    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED>), dim3((unsigned) H, (unsigned)((N + 31) / 32)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg);
+    static const int persist = getenv("FQ_ATTN_PERSIST") ? atoi(getenv("FQ_ATTN_PERSIST")) : 1;      // 0: one workgroup per item (A/B)
+    const int n_items = H * ((N + 31) / 32);
+    const bool per = persist && n_items >= 4 * fq_ctx().n_cu;           // persistent workgroups where there are rounds enough to amortise over
+    int * counter = per ? fq_ctx().scalar_i32 + 32 : nullptr;           // (a word of the library's scalar scratch; zeroed on the launch's own stream)
+    if (per) HIP_CHECK(hipMemsetAsync(counter, 0, 4, st));
+    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED>), dim3((unsigned)(per ? fq_ctx().n_cu : n_items)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg, counter);
 }
 template <bool TAB, bool PACKED>
 static void launch_attention_flash(int nt, const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
