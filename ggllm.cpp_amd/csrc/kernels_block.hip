@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     float    * const rmax = (float *)(smem + (size_t) 32 * PH * 2);               // [8 waves][32 rows]
     double   * const rsum = (double *)(rmax + 8 * 32);                            // [8 waves][32 rows]
     float    * const xch  = (float *)(rsum + 8 * 32);                             // [2 dim halves][16][64]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, hf = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hf = lane >> 5;
     // PERSISTENT workgroups (round 5): the grid is one workgroup per CU (a workgroup takes a whole CU: 8 waves x ~210 VGPRs), and each walks the (head, query tile)
     // items blockIdx.x, blockIdx.x + gridDim.x, ... -- heavy tiles (the last tokens of the prompt) first, so every workgroup gets the same mix. Per-pass timing had
     // shown 19 % of a launch to be workgroup turnover (dispatch of a 512-thread, 160 KiB workgroup onto a drained CU, kernel arguments, position word).
@@ -813,11 +813,15 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
         for (int w = 1; w < 8; ++w) sm += rsum[w * 32 + li];
         const float inv = (float)(1.0 / sm);
         const uint16_t * erow = eh + (size_t) li * PH + 16 * hf;
+        // (opaque zero in the row index: without it the persistent loop lets the compiler hoist the clamped row offsets of the first two value tiles of a wave -- they
+        // do not depend on the item -- out of the ITEM loop into spill slots: 63 spilled VGPRs and +72 MB of scratch traffic per 2048-token launch in the counters)
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
         const float * const vbase = vc + (int64_t) hk * 64 + 32 * dh + li;
         auto load_v = [&](int T, float (&v16)[16]) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int j = 32 * T + 16 * hf + s;
+                const int j = 32 * T + 16 * hf + s + opq;
                 fl_gload1(v16[s], vbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64);
             }
         };
