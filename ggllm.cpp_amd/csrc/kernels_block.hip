@@ -649,7 +649,11 @@ __global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ 
         dst[o] = *(const f32x4 *)(kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hf + 4 * v);
     }
 }
-template <bool TAB, int NT, bool PACKED>
+// KEEP (round 5, the default up to 64 key tiles): a wave keeps the scores of ITS tiles -- T = wid, wid + 8, ...: NT / 8 tiles x 16 registers -- from pass A to pass B instead
+// of running the chains twice: two units of matrix work per launch instead of three (the f32 matrix instruction and the vector ALU do not overlap on a SIMD of this
+// chip, scripts/microbench/mb_mfma_f32_mix.hip: a second run of the chains is 0.18 ms of a 0.91 ms launch at 2048 tokens). The scores are the same chains' results, kept
+// as c * 0.125f with the invisible ones set to -inf (table[f16(-inf)] = 0, the reference's own rule for a masked score: ggml.c:10925); pass B is then vector work only.
+template <bool TAB, int NT, bool PACKED, bool KEEP>
 __global__ void __launch_bounds__(512) k_attention_flash(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                          const float * __restrict__ kc, const float * __restrict__ vc,
                                                          const uint16_t * __restrict__ exp_tab, float * __restrict__ att, const float * __restrict__ kt, int nt_total, int dbg, int * __restrict__ next_item) {
@@ -700,6 +704,83 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
         };
         f32x4 ka[8], kb[8];
         load_k(wid, ka);
+        if constexpr (KEEP) {
+            static_assert(FQ_FLASH_PLAIN && NT % 8 == 0, "the KEEP form uses compiler-managed loads");
+            constexpr int KW = NT / 8;                                 // tiles of a wave
+            v16f S[KW];
+            const int tfull = (n_past + i0 + 1) >> 5;                  // tiles [0, tfull) are visible to every row of the item
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int T = wid + 8 * k;
+                if (T < ntile_real) {                                  // (wave-uniform)
+                    if (k + 1 < KW) load_k(T + 8, kb);
+                    v16f c = {0};
+                    FL_QK(c, ka);
+                    if (T < tfull) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = c[r] * 0.125f;
+                    } else {
+                        const int lim = n_past + i0 - 32 * T - li;     // key 32 T + li is visible to row ir iff ir + lim >= 0
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                            c[r] = (ir + lim >= 0) ? c[r] * 0.125f : -INFINITY;
+                        }
+                    }
+                    S[k] = c;
+                    if (k + 1 < KW) {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+                    }
+                }
+            }
+            float mx[16];                                              // (the maxima only now: the query and key registers are free again)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                if (wid + 8 * k < ntile_real) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx[r] = fq_max_f32(mx[r], S[k][r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = reduce32(mx[r], op_max());
+                if (li == 0) rmax[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = m;
+            }
+            __syncthreads();
+            unsigned lsum[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                float m = rmax[ir];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) m = fq_max_f32(m, rmax[w * 32 + ir]);
+                mx[r] = m; lsum[r] = 0u;
+            }
+            uint16_t * const ecol = eh + (size_t)(4 * hf) * PH + li;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int T = wid + 8 * k;
+                if (T < ntile_real) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int irl = (r & 3) + 8 * (r >> 2);
+                        const uint16_t hb = f2h_bits(S[k][r] - mx[r]);
+                        uint16_t eb;
+                        if constexpr (TAB) eb = exp_tab[hb]; else eb = exp_f16_formula(hb);
+                        ecol[irl * PH + 32 * T] = eb;
+                        lsum[r] += (unsigned)(h2f_bits(eb) * 16777216.0f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double sm = reduce32((double) lsum[r] * (1.0 / 16777216.0), op_add());
+                if (li == 0) rsum[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = sm;
+            }
+        } else {
         {   // pass A: row maxima
             float mx[16];
 #pragma unroll
@@ -802,6 +883,7 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
                 if (li == 0) rsum[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = sm;
             }
         }
+        }   // !KEEP
     }
     __syncthreads();
     // ---- pass C: V.P, wave = (dim half, tile parity), waves 0-3 (one per SIMD): four chains is what the association allows. Values two tiles ahead.
@@ -861,34 +943,40 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     }
     // (no barrier before the next item: its first LDS writes are rmax after its pass A -- a region nobody reads now --, eh / rsum / xch only behind its own barriers;
     // the next index word is rewritten by wave 1 only after wave 1 itself has read it, and every other wave reads it before its next barrier 1)
-    item = next_item ? *(volatile int *) nxt : n_items;
+    item = next_item ? __builtin_amdgcn_readfirstlane(*(volatile int *) nxt) : n_items;      // (wave-uniform, and known to the compiler as such: the item's tile counts and row bases stay scalar)
     if (next_item) __syncthreads();                                   // (the word is rewritten at the top of the next item: everybody must have read it)
   }
 }
 // LDS rows for 16, 32 or 74 key tiles (512, 1024, 2368 keys): the instantiations of the compile-time pitch
-static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 74 ? 74 : 0)); }
+// (64: the KEEP form's largest -- 8 tiles x 16 score registers per wave; 65-74 tiles run the three-pass form)
+static bool attn_flash_keep() { static const int v = getenv("FQ_ATTN_KEEP") ? atoi(getenv("FQ_ATTN_KEEP")) : 1; return v != 0; }
+static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 64 && attn_flash_keep() ? 64 : (nt <= 74 ? 74 : 0))); }
 static size_t attn_flash_lds(int nt) { return (size_t) 32 * (size_t)(32 * nt + 8) * 2 + 8 * 32 * 4 + 8 * 32 * 8 + 2 * 16 * 64 * 4 + 16; }
 static bool attn_flash_fits(int max_n_kv) { return attn_flash_nt(max_n_kv) != 0; }
-template <bool TAB, int NT, bool PACKED>
+template <bool TAB, int NT, bool PACKED, bool KEEP>
 static void launch_attention_flash_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
                                      const uint16_t * exp_table, float * att, const float * kt, int nt_total, hipStream_t st) {
     const size_t lds = attn_flash_lds(NT);
     static bool attr = false;
-    if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
+    if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
     static const int dbg = getenv("FQ_ATTN_DBG") ? atoi(getenv("FQ_ATTN_DBG")) : 0;
     static const int persist = getenv("FQ_ATTN_PERSIST") ? atoi(getenv("FQ_ATTN_PERSIST")) : 1;      // 0: one workgroup per item (A/B)
     const int n_items = H * ((N + 31) / 32);
     const bool per = persist && n_items >= 4 * fq_ctx().n_cu;           // persistent workgroups where there are rounds enough to amortise over
     int * counter = per ? fq_ctx().scalar_i32 + 32 : nullptr;           // (a word of the library's scalar scratch; zeroed on the launch's own stream)
     if (per) HIP_CHECK(hipMemsetAsync(counter, 0, 4, st));
-    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED>), dim3((unsigned)(per ? fq_ctx().n_cu : n_items)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg, counter);
+    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED, KEEP>), dim3((unsigned)(per ? fq_ctx().n_cu : n_items)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg, counter);
 }
 template <bool TAB, bool PACKED>
 static void launch_attention_flash(int nt, const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
                                    const uint16_t * exp_table, float * att, const float * kt, int nt_total, hipStream_t st) {
-    if (nt == 16)      launch_attention_flash_t<TAB, 16, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
-    else if (nt == 32) launch_attention_flash_t<TAB, 32, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
-    else               launch_attention_flash_t<TAB, 74, PACKED>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+    const bool keep = attn_flash_keep();
+    if (nt == 16)      { if (keep) launch_attention_flash_t<TAB, 16, PACKED, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+                         else      launch_attention_flash_t<TAB, 16, PACKED, false>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st); }
+    else if (nt == 32) { if (keep) launch_attention_flash_t<TAB, 32, PACKED, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+                         else      launch_attention_flash_t<TAB, 32, PACKED, false>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st); }
+    else if (nt == 64) launch_attention_flash_t<TAB, 64, PACKED, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+    else               launch_attention_flash_t<TAB, 74, PACKED, false>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
 }
 // bytes of the packed keys a launch of this size wants (k_attn_pack_k): prompts of FQ_ATTN_PACK_MIN_N (default 256) tokens and more
 static int attn_pack_min_n() { static const int v = getenv("FQ_ATTN_PACK_MIN_N") ? atoi(getenv("FQ_ATTN_PACK_MIN_N")) : 256; return v; }

@@ -45,6 +45,19 @@
                           // 128 tokens 9.0 against 8.7 -- a third fewer vector instructions per result do not help: the 64-cycle f32 matrix instruction sits in front of
                           // the group's 16 fused multiply-adds, and a wave's group is a dependent chain (LDS -> matrix pipe -> scaling), not a VALU-issue budget. OFF.
 #endif
+#ifndef GQ_MAGIC
+#define GQ_MAGIC 0        // 1: the matrix instruction's int32 sums come out as the BITS of the float 1.5 * 2^23 + c (its C operand is the constant 0x4B400000; |c| <= 32 * 127 * 127 < 2^22, so
+                          // the sum cannot leave the binade whose ulp is 1) and (float) c is one exact v_sub_f32 instead of v_cvt_f32_i32. Same value, bit for bit. Why: on MI355X
+                          // (scripts/microbench/mb_mfma_i8_mix.hip) 16 v_cvt_f32_i32 cost a SIMD 28.7 ns against 16.9 for 16 v_mul_f32 / v_sub_f32, and the packed forms run at half rate
+                          // (8 v_pk_fma_f32: 17.7 ns for the 16 results 16 v_fma_f32 take 20.5 for) -- the conversion is the dearest of the three operations per result.
+#endif
+#if GQ_MAGIC
+#define GQ_C0 0x4B400000
+#define GQ_CF(v) (__int_as_float(v) - 12582912.0f)
+#else
+#define GQ_C0 0
+#define GQ_CF(v) ((float)(v))
+#endif
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i  __attribute__((ext_vector_type(4)));
@@ -465,6 +478,10 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int rot = 0;
     const int arow = l31;
+    // the matrix instruction's C operand of the legacy formats' groups (GQ_MAGIC): sixteen registers that hold the constant for the whole kernel -- opaque to the compiler, which
+    // otherwise lets the second instruction of a pair accumulate in place and re-creates the constant with eight 64-bit moves per pair
+    v16i cmagic = { GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0, GQ_C0 };
+    if constexpr (GQ_MAGIC && !KINT) asm volatile("" : "+v"(cmagic));
 
     const int dbgm = g_gemm_dbg;
     // ---- software pipeline, prefetch distance TWO stages (a stage's math, ~0.7 us, is shorter than a load round trip):
@@ -519,8 +536,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
                     const float dw = ((const float *)(B + LB::DW))[(gg * SUB + ss) * TM + row];
                     const float mw = HAS_MIN ? ((const float *)(B + LB::MW))[(gg * SUB + ss) * TM + row] : 0.0f;
-                    v16i c = {0};
-                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+                    const v16i c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, cmagic, 0, 0, 0);
                     // f32 epilogue: the reference's scalar per-block expression, added left to right over the groups, so
                     // that for the legacy formats a row of this GEMM is bit-identical to ggml_vec_dot_q*_q8_* (scalar branch)
 #if GQ_PACKED
@@ -528,7 +544,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     const v2f dw2 = { dw, dw }, mw2 = { mw, mw };
 #pragma unroll
                     for (int i = 0; i < NR; i += 2) {
-                        const v2f ci = { (float) c[i], (float) c[i + 1] };
+                        const v2f ci = { GQ_CF(c[i]), GQ_CF(c[i + 1]) };
                         const v2f dx = { dxv[i], dxv[i + 1] };
                         v2f t;
                         if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw2) * dx;                       // ggml.c:2606
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                         const v16f dd = __builtin_amdgcn_mfma_f32_32x32x2f32(dxl, half == 0 ? dw : 0.0f, v16f{0}, 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NR; ++i) {
-                            const float ci = (float) c[i];
+                            const float ci = GQ_CF(c[i]);
                             float a = __builtin_fmaf(dd[i], ci, ACC(rb, i));
                             if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
                             ACC(rb, i) = a;
@@ -558,7 +574,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #else
 #pragma unroll
                         for (int i = 0; i < NR; ++i) {
-                            const float ci = (float) c[i];
+                            const float ci = GQ_CF(c[i]);
                             float a = __builtin_fmaf(dw * dxv[i], ci, ACC(rb, i));
                             if constexpr (HAS_MIN) a = __builtin_fmaf(mw, sxv[i], a);
                             ACC(rb, i) = a;
@@ -567,7 +583,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     } else {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
-                        const float ci = (float) c[i];
+                        const float ci = GQ_CF(c[i]);
                         float t;
                         if constexpr (TYPE == FQ_Q4_0)                          t = (ci * dw) * dxv[i];                    // ggml.c:2606
                         else if constexpr (TYPE == FQ_Q5_0 || TYPE == FQ_Q8_0)  t = (dw * dxv[i]) * ci;                    // ggml.c:2972, 3325
