@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     float    * const rmax = (float *)(smem + (size_t) 32 * PH * 2);               // [8 waves][32 rows]
     double   * const rsum = (double *)(rmax + 8 * 32);                            // [8 waves][32 rows]
     float    * const xch  = (float *)(rsum + 8 * 32);                             // [2 dim halves][16][64]
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hf = lane >> 5;
+    const int tid = threadIdx.x, lane0 = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // PERSISTENT workgroups (round 5): the grid is one workgroup per CU (a workgroup takes a whole CU: 8 waves x ~210 VGPRs), and each walks the (head, query tile)
     // items blockIdx.x, blockIdx.x + gridDim.x, ... -- heavy tiles (the last tokens of the prompt) first, so every workgroup gets the same mix. Per-pass timing had
     // shown 19 % of a launch to be workgroup turnover (dispatch of a 512-thread, 160 KiB workgroup onto a drained CU, kernel arguments, position word).
@@ -673,6 +673,11 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     const int ntq = (N + 31) >> 5, n_items = ntq * H, heads = H + 2 * HKV;
     int * const nxt = (int *)(xch + 2 * 16 * 64);                     // one LDS word behind xch
   for (int item = (int) blockIdx.x; item < n_items;) {
+    // (the lane's coordinates opaque per item: what the compiler derives from them -- row offsets of the output, of the value rows, LDS addresses -- is then formed in
+    // the item instead of once per kernel and kept in spill slots: the registers of pass A are the kernel's peak, 224 of 256 for the scores, the queries and two key tiles)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 31, hf = lane >> 5;
     if (next_item && tid == 64) *nxt = (int) gridDim.x + atomicAdd(next_item, 1);      // (a lane of wave 1: published by the time barrier 3 has been passed)
     const int h = item % H, i0 = (ntq - 1 - item / H) * 32, hk = h / (H / HKV);
     const int nrows = N - i0 < 32 ? N - i0 : 32;
@@ -895,39 +900,48 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
         for (int w = 1; w < 8; ++w) sm += rsum[w * 32 + li];
         const float inv = (float)(1.0 / sm);
         const uint16_t * erow = eh + (size_t) li * PH + 16 * hf;
-        // (opaque zero in the row index: without it the persistent loop lets the compiler hoist the clamped row offsets of the first two value tiles of a wave -- they
-        // do not depend on the item -- out of the ITEM loop into spill slots: 63 spilled VGPRs and +72 MB of scratch traffic per 2048-token launch in the counters)
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
         const float * const vbase = vc + (int64_t) hk * 64 + 32 * dh + li;
         auto load_v = [&](int T, float (&v16)[16]) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int j = 32 * T + 16 * hf + s + opq;
+                const int j = 32 * T + 16 * hf + s;
                 fl_gload1(v16[s], vbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64);
             }
         };
-        auto pv_tile = [&](int T, const float (&v16)[16]) {
+        // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32), formed ONE TILE AHEAD of the matrix instructions that take it: the chain
+        // LDS read -> convert -> multiply -> matrix instruction was exposed twice per tile (ds_read_b128, s_waitcnt lgkmcnt(0), 8 matrix instructions) -- a fifth of the
+        // pass; with the next tile's sixteen values formed between this tile's matrix instructions only their issue slots are left
+        auto form_p = [&](int T, float (&p16)[16]) {
             const uint4 e0 = *(const uint4 *)(erow + 32 * T), e1 = *(const uint4 *)(erow + 32 * T + 8);
             const unsigned w[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                              // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32)
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(h2f_bits((uint16_t)(w[u] & 0xFFFFu)) * inv, v16[2 * u + 0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(h2f_bits((uint16_t)(w[u] >> 16)) * inv, v16[2 * u + 1], c, 0, 0, 0);
-            }
+            for (int u = 0; u < 8; ++u) { p16[2 * u] = h2f_bits((uint16_t)(w[u] & 0xFFFFu)) * inv; p16[2 * u + 1] = h2f_bits((uint16_t)(w[u] >> 16)) * inv; }
         };
-        float va[16], vb[16], vd[16];                                   // tiles T, T + 2, T + 4 of this parity in flight
-        load_v(par, va);
-        load_v(par + 2, vb);
+        auto pv_tile = [&](const float (&p16)[16], const float (&v16)[16]) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c = __builtin_amdgcn_mfma_f32_32x32x2f32(p16[u], v16[u], c, 0, 0, 0);
+        };
+        constexpr int NB = 4;                                           // value tiles T, T + 2, T + 4, T + 6 of this parity in flight (even: the p buffers alternate)
+        float vv[NB][16], pp[2][16];
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) load_v(par + 2 * b, vv[b]);
         int T = par;
-        for (; T + 4 < ntileC; T += 6) {
-            load_v(T + 4, vd); FL_WAIT16(32, va); __builtin_amdgcn_sched_barrier(0); pv_tile(T, va);     __builtin_amdgcn_sched_barrier(0);
-            load_v(T + 6, va); FL_WAIT16(32, vb); __builtin_amdgcn_sched_barrier(0); pv_tile(T + 2, vb); __builtin_amdgcn_sched_barrier(0);
-            load_v(T + 8, vb); FL_WAIT16(32, vd); __builtin_amdgcn_sched_barrier(0); pv_tile(T + 4, vd); __builtin_amdgcn_sched_barrier(0);
+        form_p(T, pp[0]);                                               // (a tile index beyond the item's last reads LDS words behind the row: never used)
+        for (; T + 2 * (NB - 1) < ntileC; T += 2 * NB) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                load_v(T + 2 * b + 2 * (NB - 1), vv[(b + NB - 1) % NB]);
+                form_p(T + 2 * b + 2, pp[(b + 1) & 1]);
+                pv_tile(pp[b & 1], vv[b]);
+            }
         }
-        FL_WAIT16(0, va); FL_WAIT16(0, vb);
-        if (T < ntileC) pv_tile(T, va);
-        if (T + 2 < ntileC) pv_tile(T + 2, vb);
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) {
+            if (T + 2 * b < ntileC) {
+                if (b + 1 < NB - 1) form_p(T + 2 * b + 2, pp[(b + 1) & 1]);
+                pv_tile(pp[b & 1], vv[b]);
+            }
+        }
         if (par == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) xch[(dh * 16 + r) * 64 + lane] = c[r];

@@ -1,10 +1,11 @@
 #!/bin/bash
 # One gpurun call of a round: every -m gpu test, smoke, the bench line the driver reads; optionally rocprofv3 kernel trace + PMC passes.
-# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|b40|lockstep|lockstep40|q4kpmc|all ...]
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc|mfma|prefill2048|prefill128|b40|lockstep|lockstep40|q4kpmc|all ...]
 #   prof         rocprofv3 kernel trace of the decode bench             -> <tag>/decode_7b_q4_0_kernel_stats.{csv,md}
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (HBM traffic per launch)  -> <tag>/pmc_traffic.json
 #   mfma         SQ matrix-pipe / VALU counters (decode + 128- and 2048-token prefill in one run) -> <tag>/pmc_mfma.json
 #   prefill2048  kernel trace of a 2048-token prompt                     -> <tag>/prefill2048_7b_q4_0_kernel_stats.{csv,md}
+#   prefill128   kernel trace of the bench's 128-token prompt            -> <tag>/prefill128_7b_q4_0_kernel_stats.{csv,md}
 #   b40          Falcon-40B Q4_K, all 60 blocks, one GPU: bench line + kernel trace -> <tag>/bench_40b_q4_k.json, <tag>/decode_40b_q4_k_kernel_stats.{csv,md}
 #   lockstep     kernel trace of 16 lock-step streams per weight pass    -> <tag>/lockstep_b16_kernel_stats.{csv,md}
 #   q4kpmc       counters of the Q4_K small-batch launches on Falcon-40B shapes (16 columns): VALU / matrix pipe, HBM fetch / write -> <tag>/q4k_pmc_mfma.json, <tag>/q4k_pmc_traffic.json
@@ -72,6 +73,9 @@ if has mfma; then
 fi
 if has prefill2048; then
   trace prefill2048_7b_q4_0 python $R/bench.py --prompt 2048 --n-ctx 4096 --steps 8 --warmup 2 --repeats 1 --no-cpu --no-ref-order --no-north-star --no-lock-step --no-cli --prefill-long 0
+fi
+if has prefill128; then
+  trace prefill128_7b_q4_0 python $R/bench.py --prompt 128 --steps 8 --warmup 2 --repeats 1 --no-cpu --no-ref-order --no-north-star --no-lock-step --no-cli --prefill-long 0
 fi
 if has b40; then
   timeout 900 python bench.py --model 40b --quant q4_k --no-cpu --no-ref-order --no-cli --no-lock-step --no-north-star --prefill-long 0 --steps 32 --warmup 4 --repeats 1 > $OUT/bench_40b_q4_k.json 2> $OUT/bench_40b.err; echo "bench 40b exit $?" | tee -a $OUT/summary.txt
