@@ -316,6 +316,11 @@ template <bool HAS_MIN, int TN, int SUB, int TM> struct gemm_lds {   // TN = tok
 // owns -- the token bytes a workgroup pulls through the CU's memory pipeline (16 KB per stage, against 2.3 KB of Q4_0
 // weights per row block) are then used twice. A CU keeps ~48 KB of requests in flight whatever the kernel does, so at large
 // N the 32-row form is bound by exactly that: the kernel with its math compiled out runs at 76 % of the full kernel's time.
+#ifndef GQ_PAIR
+#define GQ_PAIR 1
+#endif
+// two K stages per barrier (four LDS stage buffers instead of two): the 16-wave forms, whose workgroup has the CU to itself anyway
+template <int S, int TT, int RB> struct gemm_pair { static constexpr bool value = GQ_PAIR && S * TT >= 16; };
 template <int TYPE, int S, int TT, int RB>
 __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -646,6 +651,37 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     auto g0_of = [&](int st) { return st < nstages ? st * GQ_GROUPS : last_g0; };      // beyond the end: re-read the last stage (unused)
     auto pipeline = [&](auto role) __attribute__((always_inline)) {
         stage_regs R0, R1;
+        if constexpr (gemm_pair<S, TT, RB>::value) {
+            // TWO stages per barrier (round 5; four LDS buffers): phase stamps of the 16-wave form at 128 tokens (scripts/gpu_gemm_stamps.py, a -DGQ_STAMPS build) showed a
+            // stage as 350 ns of arithmetic, 105 ns of LDS writes, 65 ns of load issue -- and 330 ns at the barrier, ALL sixteen waves (the workgroup is the CU's only one: the
+            // SIMDs idle). Same stages, same order of the sums; the registers still hold the next two stages.
+            uint8_t * const b0 = smem, * const b1 = smem + LB::BYTES, * const b2 = smem + 2 * LB::BYTES, * const b3 = smem + 3 * LB::BYTES;
+            issue(0, R0, role);
+            issue(g0_of(1), R1, role);
+            commit(0, R0, b0, role);
+            issue(g0_of(2), R0, role);
+            commit(g0_of(1), R1, b1, role);
+            issue(g0_of(3), R1, role);
+            __syncthreads();
+            for (int st = 0; st < nstages; st += 4) {
+                // stages st, st + 1 out of buffers 0, 1; R0 / R1 hold st + 2 / st + 3 and go into buffers 2, 3
+                compute(b0, false);
+                commit(g0_of(st + 2), R0, b2, role);
+                issue(g0_of(st + 4), R0, role);
+                if (st + 1 < nstages) compute(b1, true);
+                commit(g0_of(st + 3), R1, b3, role);
+                issue(g0_of(st + 5), R1, role);
+                __syncthreads();
+                if (st + 2 < nstages) compute(b2, false);
+                commit(g0_of(st + 4), R0, b0, role);
+                issue(g0_of(st + 6), R0, role);
+                if (st + 3 < nstages) compute(b3, true);
+                commit(g0_of(st + 5), R1, b1, role);
+                issue(g0_of(st + 7), R1, role);
+                __syncthreads();
+            }
+            return;
+        }
         issue(0, R0, role);
         issue(g0_of(1), R1, role);
         commit(0, R0, smem, role);
@@ -718,7 +754,7 @@ template <int TYPE, int S, int TT, int RB = 1>
 static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
     constexpr int TN = 32 * TT, TM = GQ_TM * RB;
-    const size_t lds = 2 * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB, TM>::BYTES;
+    const size_t lds = (gemm_pair<S, TT, RB>::value ? 4 : 2) * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB, TM>::BYTES;
     if (lds > 64 * 1024) {
         static bool set = false;
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_q<TYPE, S, TT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; }
