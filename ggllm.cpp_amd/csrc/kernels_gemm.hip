@@ -294,6 +294,17 @@ template <> struct gemm_kint<FQ_Q6_K> { static constexpr bool value = true; };
 // tuning aid (ggml_hip_debug_gemm_mode): bit 1 = no MFMA / scaling (timing only: what the staging alone costs). Bit 0 (no
 // global loads) went with the role-specialised pipeline, whose loads are unconditional on purpose.
 __device__ int g_gemm_dbg = 0;
+#ifndef GQ_STAMPS
+#define GQ_STAMPS 0      // 1 (a tuning build, never the product's; scripts/gpu_gemm_stamps.py): 10 ns clock stamps of the K pipeline's phases per wave, stages 8..23 of workgroups 0 and 100
+#endif                   // of a launch -> ggml_hip_debug_stamps' buffer. A stamp costs ~200 ns (s_memrealtime + a store): the launch runs at half speed, the proportions hold
+#if GQ_STAMPS
+#include "hip_context.h"
+__device__ long long * g_gemm_stamps = nullptr;
+#define GQ_T(slot) do { if (g_gemm_stamps && lane == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && st >= 8 && st < 24) \
+        g_gemm_stamps[((((blockIdx.x ? 1 : 0) * 16 + wid) * 8 + ((st - 8) >> 1)) * 8) + (slot)] = (long long) wall_clock64(); } while (0)
+#else
+#define GQ_T(slot) do { } while (0)
+#endif
 static int g_gemm_dbg_host = 0;
 void fq_gemm_debug_mode(int m) { g_gemm_dbg_host = m; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &m, sizeof m)); }
 int  fq_gemm_debug_get() { return g_gemm_dbg_host; }
@@ -688,14 +699,22 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         __syncthreads();
         for (int st = 0; st < nstages; st += 2) {
             // even stage st out of buffer 0; R1 holds st + 1; st + 2 goes into R0
+            GQ_T(0);
             issue(g0_of(st + 2), R0, role);
+            GQ_T(1);
             compute(smem, false);
+            GQ_T(2);
             commit(g0_of(st + 1), R1, smem + LB::BYTES, role);
+            GQ_T(3);
             __syncthreads();
             // odd stage st + 1 out of buffer 1; R0 holds st + 2; st + 3 goes into R1
+            GQ_T(4);
             issue(g0_of(st + 3), R1, role);
+            GQ_T(5);
             if (st + 1 < nstages) compute(smem + LB::BYTES, true);
+            GQ_T(6);
             commit(g0_of(st + 2), R0, smem, role);
+            GQ_T(7);
             __syncthreads();
         }
     };
@@ -760,6 +779,9 @@ static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, fl
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_q<TYPE, S, TT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; }
     }
     const dim3 grid((unsigned)((w.M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN));
+#if GQ_STAMPS
+    { long long * p = fq_ctx().dbg_stamps; HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gemm_stamps), &p, sizeof p, 0, hipMemcpyHostToDevice, st)); }
+#endif
     hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT, RB>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
 }
 

@@ -1,4 +1,4 @@
-"""Phase stamps of k_gemm_q's K pipeline (a -DGQ_STAMPS=1 tuning build of kernels_gemm.hip, GGLLM_HIP_LIB=...): per wave of workgroups 0 and 100, stages 8..23 of one
+"""Phase stamps of k_gemm_q's K pipeline (a -DGQ_STAMPS=1 -DGQ_PAIR=0 tuning build of kernels_gemm.hip -- the stamps sit in the one-stage-per-barrier loop --, GGLLM_HIP_LIB=...): per wave of workgroups 0 and 100, stages 8..23 of one
 launch -- when the wave passed the top of a stage, finished issuing its loads, finished the stage's arithmetic, finished writing the next stage into LDS (then: barrier).
 python scripts/gpu_gemm_stamps.py [N] [K] [M]"""
 import sys, os, ctypes as C
