@@ -300,8 +300,12 @@ __device__ int g_gemm_dbg = 0;
 #if GQ_STAMPS
 #include "hip_context.h"
 __device__ long long * g_gemm_stamps = nullptr;
+#if GQ_STAMPS == 2       // 2: only the clock of the K loop (shader cycles against 10 ns ticks, scripts/gpu_gemm_clock.py), no per-stage stamps
+#define GQ_T(slot) do { } while (0)
+#else
 #define GQ_T(slot) do { if (g_gemm_stamps && lane == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && st >= 8 && st < 24) \
         g_gemm_stamps[((((blockIdx.x ? 1 : 0) * 16 + wid) * 8 + ((st - 8) >> 1)) * 8) + (slot)] = (long long) wall_clock64(); } while (0)
+#endif
 #else
 #define GQ_T(slot) do { } while (0)
 #endif
@@ -343,6 +347,9 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     static_assert(NT >= TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tt = wid % TT, sw = wid / TT;                               // token tile, K share (groups sw, sw + S, ... of a stage)
+#if GQ_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int64_t m0 = (int64_t) blockIdx.x * TM, n0 = (int64_t) blockIdx.y * TN;
     const int64_t K = w.K, M = w.M;
     const int ngroups = (int)(K >> 5);
@@ -721,6 +728,12 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     if (wid < 2 * RB)                 pipeline(std::integral_constant<int, 1>{});
     else if (wid < 2 * RB + SC_WAVES) pipeline(std::integral_constant<int, 2>{});
     else                         pipeline(std::integral_constant<int, 0>{});
+#if GQ_STAMPS
+    if (g_gemm_stamps && tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 50)) {      // shader cycles and 10 ns ticks of the K loop: the clock this CU ran at
+        g_gemm_stamps[8000 + 2 * (blockIdx.x ? 1 : 0)] = (long long)(__builtin_amdgcn_s_memtime() - clk0);
+        g_gemm_stamps[8001 + 2 * (blockIdx.x ? 1 : 0)] = (long long)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+#endif
     // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free now)
     if constexpr (S > 1) {
         float * xch = (float *) smem;                                      // [tt][rb][i][lane]
