@@ -603,18 +603,18 @@ __global__ void __launch_bounds__(512, 4) k_attention_mfma16h(const float * __re
 // bit-identical to it and to the oracle's dot_qk_mfma / dot_pv_mfma -- but no score ever leaves the CU: the scratch form moves the N x n_kv score matrix through
 // HBM four times (1.25 GB per Falcon-7B launch at 2048 tokens, 17 x the q / K / V / output bytes). A score must be known in f32 until its row's maximum is, and
 // exp() comes out of a table of fp16 values (ggml.c:10911-10960), so:
-//   pass A   K.Q on the matrix pipe, only the row maxima are kept (registers -> 1 KiB of LDS)
-//   pass B   the same chains again (same operands, same order: the same bits), e = table[f16(s - max)] stored as the 2-byte value it is: 32 rows x n_kv x 2 B
-//            of LDS (128 KiB at 2048 keys); f64 row sums (exact in any order: <= 2^13 fp16-valued terms)
-//   pass C   V.P with p = (float) e16 * inv formed on the way into the matrix instruction
-// 8 waves: passes A and B deal the 32-key tiles round-robin (two waves per SIMD: one wave's exp() arithmetic -- ~25 VALU instructions per score -- runs under the
-// other's 64-cycle matrix instructions; key tiles go from L2 straight to registers one tile ahead, a tile is used by one wave only); pass C is four chains
-// (dim half x tile parity: the association fixes that) on waves 0-3, one per SIMD, loads two tiles ahead. Heavy query tiles (the last tokens of the prompt) are
-// dispatched first. 3 units of matrix work (K.Q twice, V.P once) instead of 2, at the f32 pipe's 157 TFLOP/s: 0.37 ms per Falcon-7B block at 2048 tokens.
+//   pass A   K.Q on the matrix pipe; a wave keeps the f32 scores of ITS tiles in registers (KEEP, <= 2048 keys: 8 tiles x 16 registers; beyond that only the row
+//            maxima are kept and pass B runs the same chains again -- same operands, same order: the same bits); row maxima through 1 KiB of LDS
+//   pass B   e = table[f16(s - max)] stored as the 2-byte value it is: 32 rows x n_kv x 2 B of LDS (128 KiB at 2048 keys); row sums as exact integers, f64 across waves
+//   pass C   V.P with p = (float) e16 * inv, formed one tile ahead of the matrix instructions that take it
+// 8 waves: passes A and B deal the 32-key tiles round-robin (two waves per SIMD; key tiles go from L2 straight to registers one tile ahead, a tile is used by one
+// wave only); pass C is four chains (dim half x tile parity: the association fixes that) on waves 0-3, one per SIMD, value tiles three ahead. Workgroups are
+// PERSISTENT from 4 items per CU on (one per CU, items = (head, query tile) handed out by a counter, heavy query tiles first). Two units of f32 matrix work at the
+// pipe's measured rate (one v_mfma_f32_32x32x2_f32 per 30.5 ns and SIMD, and vector instructions do NOT overlap it: scripts/microbench/mb_mfma_f32_*.hip): 0.28 ms
+// per Falcon-7B block at 2048 tokens; measured 0.75 (NOTEBOOK 9.1: value loads and p-forming in front of pass C's one wave per SIMD, item turnover).
 // pitch_h: halfwords per LDS row = 32 ntile_max + 8 (row pitch 16 bytes off a multiple of 64: conflict-free b128 reads down a column of rows).
-// Loads as inline assembly: hipcc sinks a plain prefetch load down to its first use (it reloads the tile just in time, two requests in flight: measured,
-// the first version of this kernel ran at the scratch form's speed), so the tiles are requested with explicit instructions and awaited with explicit counts.
-// The destination registers are tied through the s_waitcnt statement ("+v"): nothing the compiler schedules can read them before the data has landed.
+// Loads: compiler-managed (FQ_FLASH_PLAIN). The first versions requested the tiles by inline assembly with hand-counted waits tied to the destination registers ("+v")
+// because hipcc sinks a plain prefetch load down to its first use -- measured: the same speed (the passes are not bound by load latency), so the plain form is the default.
 #ifndef FQ_FLASH_PLAIN
 #define FQ_FLASH_PLAIN 1            // 1 (default): compiler-managed loads. 0: the tiles requested by inline-asm loads one / two tiles ahead with hand-counted waits -- measured the SAME speed on MI355X (0.926 against 0.922 ms per 2048-token Falcon-7B launch: the passes are not bound by load latency) and, on one box of the pool, intermittently wrong in tiles whose waves do not all hold keys (scripts/gpu_attn_bisect.py): off
 #endif
