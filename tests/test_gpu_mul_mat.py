@@ -97,7 +97,8 @@ GEMM_TYPES = [ob.Q4_0, ob.Q4_1, ob.Q5_0, ob.Q5_1, ob.Q8_0, ob.Q4_K, ob.Q5_K]
 @pytest.mark.parametrize("t", ob.WEIGHT_TYPES)
 @pytest.mark.parametrize("K,M,N", [(512, 37, 9), (4544, 200, 33), (8192, 129, 128), (1024, 300, 257), (18176, 70, 40),
                                    (4544, 200, 16), (18176, 70, 12), (8192, 129, 5), (4544, 100, 7), (4672, 33, 13),      # (N <= 16: the streaming form, kernels_gemm_skinny.hip)
-                                   (4544, 200, 17), (8192, 129, 32), (18176, 70, 29)])                             # (17..32: two passes of it)
+                                   (4544, 200, 17), (8192, 129, 32), (18176, 70, 29),                              # (17..32: two passes of it)
+                                   (4736, 70, 40), (4992, 70, 130), (4864, 40, 64)])                               # (37 / 39 / 38 K stages: the tails of the two-stages-per-barrier loop)
 def test_prefill_gemm_vs_oracle(oracle, t, K, M, N):
     """N > 4 columns through the int8 MFMA GEMM, three orders, each bit-exact against the oracle's restatement of it:
       * default (4 or 2 interleaved K-split partial sums, picked per shape)      == orc_set_sum_order(2)
