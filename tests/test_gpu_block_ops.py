@@ -199,3 +199,17 @@ def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
     assert np.isfinite(outs[32]).all()
     for form in (0, 1, 16, 17):
         assert np.array_equal(outs[form], outs[32]), f"form {form}"
+
+
+@pytest.mark.parametrize("env", [{"FQ_ATTN_KEEP": "0"}, {"FQ_ATTN_PERSIST": "0"}, {"FQ_ATTN_KEEP": "0", "FQ_ATTN_PERSIST": "0", "FQ_ATTN_PACK_MIN_N": "100000"}])
+def test_flash_attention_switches_keep_the_bits(env):
+    """the prefill attention's A/B switches -- K.Q run twice instead of a wave's score tiles kept in registers, one workgroup per item instead of persistent ones, keys
+    not re-laid in operand order -- select other code, not other results: in a process of their own (the switches are read once) the flash form still equals the
+    scratch form bit for bit at 1536 / 288 / 96 tokens of 71 heads (48 / 9 / 3 key tiles: all three pitch instantiations)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_attn_forms.py"), "1536", "288", "96"], env=dict(os.environ, FORMS="32,1", **env),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "form  1" in l]
+    assert len(lines) == 3 and all(l.rstrip().endswith("True") for l in lines), r.stdout
