@@ -638,7 +638,10 @@ __device__ __forceinline__ void fl_gload1(float & d, const float * p) { asm vola
 // lies, lane (hf, li) of a request touches its own 128-byte line: 64 lines per instruction, 512 tag look-ups per tile, and eight waves of them keep a CU's
 // vector cache busy for as long as the matrix pipe needs for the tile -- the first versions of k_attention_flash ran at the scratch form's speed whatever
 // their inside looked like. 512 KiB per Falcon-7B launch at 2048 keys; rows beyond the cache re-read its last row.
-__global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ kc, int N, int HKV, const int * __restrict__ n_past_ptr, float * __restrict__ kt, int nt_total) {
+#ifndef FQ_ATTN_PACK_V
+#define FQ_ATTN_PACK_V 1
+#endif
+__global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ kc, const float * __restrict__ vc, int N, int HKV, const int * __restrict__ n_past_ptr, float * __restrict__ kt, int nt_total) {
     const int T = blockIdx.x, hk = blockIdx.y, n_rows_cache = *n_past_ptr + N;
     f32x4 * const dst = (f32x4 *) kt + ((size_t) hk * nt_total + T) * 512;
 #pragma unroll
@@ -648,6 +651,23 @@ __global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ 
         const int j = 32 * T + li;
         dst[o] = *(const f32x4 *)(kc + ((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * hf + 4 * v);
     }
+#if FQ_ATTN_PACK_V
+    // ... and the values in pass C's operand order behind all the keys: tile T, dim half dh, register quad q, lane (hf, li): V[32 T + 16 hf + 4 q + e][32 dh + li], e = 0..3 --
+    // four requests of 1 KiB of consecutive bytes per tile and wave instead of sixteen that touch two 128-byte lines each
+    f32x4 * const vdst = (f32x4 *)(kt + (size_t) HKV * nt_total * 2048) + ((size_t) hk * nt_total + T) * 512;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int o = threadIdx.x + 256 * u;                          // (dh, q, lane)
+        const int dh = o >> 8, q = (o >> 6) & 3, hf = (o >> 5) & 1, li = o & 31;
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 32 * T + 16 * hf + 4 * q + e;
+            t[e] = vc[((int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV + hk) * 64 + 32 * dh + li];
+        }
+        vdst[o] = t;
+    }
+#endif
 }
 // KEEP (round 5, the default up to 64 key tiles): a wave keeps the scores of ITS tiles -- T = wid, wid + 8, ...: NT / 8 tiles x 16 registers -- from pass A to pass B instead
 // of running the chains twice: two units of matrix work per launch instead of three (the f32 matrix instruction and the vector ALU do not overlap on a SIMD of this
@@ -901,11 +921,18 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
         const float inv = (float)(1.0 / sm);
         const uint16_t * erow = eh + (size_t) li * PH + 16 * hf;
         const float * const vbase = vc + (int64_t) hk * 64 + 32 * dh + li;
+        const f32x4 * const vpk = (const f32x4 *)(kt + (int64_t) HKV * nt_total * 2048) + ((int64_t) hk * nt_total * 2 + dh) * 256 + lane;      // (PACKED: k_attn_pack_k's value part)
         auto load_v = [&](int T, float (&v16)[16]) {
+            if constexpr (PACKED && FQ_ATTN_PACK_V) {
+                const f32x4 * vp = vpk + (int64_t)(T < nt_total ? T : nt_total - 1) * 512;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const f32x4 t = vp[64 * q]; v16[4 * q] = t.x; v16[4 * q + 1] = t.y; v16[4 * q + 2] = t.z; v16[4 * q + 3] = t.w; }
+            } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int j = 32 * T + 16 * hf + s;
                 fl_gload1(v16[s], vbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64);
+            }
             }
         };
         // p = e * inv, the rounding of the soft_max's own scaling step (ggml_vec_scale_f32), formed ONE TILE AHEAD of the matrix instructions that take it: the chain
@@ -994,7 +1021,7 @@ static void launch_attention_flash(int nt, const float * qkv, int N, int H, int 
 }
 // bytes of the packed keys a launch of this size wants (k_attn_pack_k): prompts of FQ_ATTN_PACK_MIN_N (default 256) tokens and more
 static int attn_pack_min_n() { static const int v = getenv("FQ_ATTN_PACK_MIN_N") ? atoi(getenv("FQ_ATTN_PACK_MIN_N")) : 256; return v; }
-static size_t attn_pack_bytes(int N, int HKV, int max_n_kv) { return N >= attn_pack_min_n() ? (size_t) HKV * (size_t)((max_n_kv + 31) >> 5) * 8192 : 0; }
+static size_t attn_pack_bytes(int N, int HKV, int max_n_kv) { return N >= attn_pack_min_n() ? (size_t) HKV * (size_t)((max_n_kv + 31) >> 5) * 8192 * (FQ_ATTN_PACK_V ? 2 : 1) : 0; }
 
 static int g_attn_f64 = 0;
 static int g_attn_form = 0;      // prefill attention on the matrix pipe: 0 = default (k_attention_flash while 32 rows of fp16 probabilities fit LDS, else the scratch form), 32 = k_attention_mfma (scores in the global scratch), 16 = k_attention_mfma16, 17 = k_attention_mfma16h
@@ -1075,7 +1102,7 @@ void fq_launch_attention(const float * qkv, int N, int H, int HKV, int D, const 
             const size_t pk = attn_pack_bytes(N, HKV, max_n_kv);
             float * kt = pk ? att_scratch(own_scratch, pk, st) : nullptr;
             if (kt) {
-                hipLaunchKernelGGL(k_attn_pack_k, dim3((unsigned) nt_total, (unsigned) HKV), dim3(256), 0, st, k_cache, N, HKV, n_past_dev, kt, nt_total);
+                hipLaunchKernelGGL(k_attn_pack_k, dim3((unsigned) nt_total, (unsigned) HKV), dim3(256), 0, st, k_cache, v_cache, N, HKV, n_past_dev, kt, nt_total);
                 if (exp_table) launch_attention_flash<true, true>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
                 else           launch_attention_flash<false, true>(nt, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
             } else {
