@@ -449,10 +449,21 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                 dx[0] = R.d4.x; dx[1] = R.d4.y; dx[2] = R.d4.z; dx[3] = R.d4.w;
                 if constexpr (ACT == FQ_Q8_1) { sx[0] = R.sa.x; sx[1] = R.sa.y; sx[2] = R.sb.x; sx[3] = R.sb.y; }
             }
+            if (full) {                                                     // (wave-uniform; every stage but a row's last: the four groups are where they belong -- no selects)
+                const bool okt = n0 + sc_tok < N;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    ((float *)(B + LB::DX))[gg * TN + sc_tok] = okt ? dx[gg] : 0.0f;
+                    if constexpr (HAS_MIN && !KINT) {
+                        ((float *)(B + LB::SX))[(gg * SUB) * TN + sc_tok] = okt ? sx[gg] : 0.0f;
+                        if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + sc_tok] = okt ? sx1[gg] : 0.0f;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 // a tail stage (fewer than 4 groups left) re-read the LAST four groups: shift them back into place
-                const int src = full ? gg : gg + (g0 - (ngroups >= 4 ? ngroups - 4 : 0));
+                const int src = gg + (g0 - (ngroups >= 4 ? ngroups - 4 : 0));
                 const bool ok = n0 + sc_tok < N && g0 + gg < ngroups && src < 4;
                 float dv = 0.0f, sv = 0.0f, sv1 = 0.0f;
 #pragma unroll
@@ -462,6 +473,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     ((float *)(B + LB::SX))[(gg * SUB) * TN + sc_tok] = ok ? sv : 0.0f;
                     if constexpr (SUB == 2) ((float *)(B + LB::SX))[(gg * SUB + 1) * TN + sc_tok] = ok ? sv1 : 0.0f;
                 }
+            }
             }
             if constexpr (KINT && HAS_MIN) {
                 // the stage's 4 SUB block sums of a token as int8 MFMA operand bytes: bsum = 64 hi + lo, hi in [-64, 63]
