@@ -643,8 +643,11 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                     int2 bn = {0, 0};
                     if (half == 0) bn = *(const int2 *)(B + LB::MW + (32 * rb + l31) * 8);
                     const v4i bmn = { bn.x, bn.y, 0, 0 };
-                    chi[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[0], am[1], 0, 0 }, bmn, chi[rb], 0, 0, 0);
-                    clo[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[2], am[3], 0, 0 }, bmn, clo[rb], 0, 0, 0);
+                    // (a super-block = an even stage, then an odd one: the even stage STARTS the sums -- C = 0 as an inline operand -- instead of adding to registers that the
+                    // flush zeroed with 32 moves per row block)
+                    const v16i z = {0};
+                    chi[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[0], am[1], 0, 0 }, bmn, sb_end ? chi[rb] : z, 0, 0, 0);
+                    clo[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(v4i{ am[2], am[3], 0, 0 }, bmn, sb_end ? clo[rb] : z, 0, 0, 0);
                 }
             }
         }
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
                             float t = (dd * dxq[e]) * (float) iacc[rb][i];
                             iacc[rb][i] = 0;
                             if constexpr (HAS_MIN) {       // (the oracle's / reference's expression: sumf += d isum - dmin msum)
-                                if (sw == S - 1) { t = t - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]); chi[rb][i] = 0; clo[rb][i] = 0; }
+                                if (sw == S - 1) t = t - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]);
                             }
                             ACC(rb, i) = ACC(rb, i) + t;
                         }
