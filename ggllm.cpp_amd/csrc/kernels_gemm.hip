@@ -522,27 +522,41 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
     // ---- software pipeline, prefetch distance TWO stages (a stage's math, ~0.7 us, is shorter than a load round trip):
     // while stage s is computed out of LDS buffer s & 1, stage s+1 sits in one register set and stage s+2 is in flight
     // into the other
-    auto compute = [&](const uint8_t * B, const bool sb_end) __attribute__((always_inline)) {
-#pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
-        for (int gg = sw; gg < ((dbgm & 2) ? 0 : GQ_GROUPS); gg += S) {
-            const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
-            if constexpr (KINT) {
+    // k-quants: one group of the integer-domain sums. FIRST = the wave's first group of a super-block: its products START the sums (v_mul_i32_i24) instead of being added to
+    // registers that the flush had to zero with 16 moves per row block
+    auto kint_group = [&](const uint8_t * B, int gg, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const int row = 32 * rb + l31;
-                    const v4i b = *(const v4i *)(B + LB::WQ + row * GQ_STRIDE + 32 * gg + 16 * half);
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = 32 * rb + l31;
+            const v4i b = *(const v4i *)(B + LB::WQ + row * GQ_STRIDE + 32 * gg + 16 * half);
 #pragma unroll
-                    for (int ss = 0; ss < SUB; ++ss) {
-                        const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
-                        const int isc = ((const int *)(B + LB::DW))[(gg * SUB + ss) * TM + row];
-                        v16i c = {0};
-                        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
+            for (int ss = 0; ss < SUB; ++ss) {
+                const v4i bm = (SUB == 1 || half == ss) ? b : v4i{0, 0, 0, 0};
+                const int isc = ((const int *)(B + LB::DW))[(gg * SUB + ss) * TM + row];
+                v16i c = {0};
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bm, c, 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NR; ++i) iacc[rb][i] = __mul24(c[i], isc) + iacc[rb][i];       // |c| < 2^17, |isc| <= 128
-                    }
+                for (int i = 0; i < NR; ++i) {                             // |c| < 2^17, |isc| <= 128
+                    if (FIRST && ss == 0) iacc[rb][i] = __mul24(c[i], isc);
+                    else                  iacc[rb][i] = __mul24(c[i], isc) + iacc[rb][i];
                 }
-                continue;
             }
+        }
+    };
+    auto compute = [&](const uint8_t * B, const bool sb_end) __attribute__((always_inline)) {
+        if constexpr (KINT) {
+            if (!(dbgm & 2)) {
+                int gg = sw;
+                if (!sb_end) { kint_group(B, gg, std::true_type{}); gg += S; }      // (a super-block = an even stage, then an odd one)
+#pragma unroll 1
+                for (; gg < GQ_GROUPS; gg += S) kint_group(B, gg, std::false_type{});
+            }
+        }
+#pragma unroll 1                          // (unrolled, the four groups' operands are all hoisted: 212 VGPRs, one wave per SIMD)
+        for (int gg = sw; gg < ((dbgm & 2) || KINT ? 0 : GQ_GROUPS); gg += S) {
+            const v4i a = *(const v4i *)(B + LB::XQ + (32 * tt + arow) * GQ_STRIDE + 32 * gg + 16 * half);
             // the lane's result i  <->  token 32 tt + rot + (i & 3) + 8 (i >> 2) + 4 half: runs of 4 consecutive tokens
             float dxv[NR];
 #pragma unroll
@@ -667,8 +681,7 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int i = 4 * q + e;
-                            float t = (dd * dxq[e]) * (float) iacc[rb][i];
-                            iacc[rb][i] = 0;
+                            float t = (dd * dxq[e]) * (float) iacc[rb][i];       // (iacc is not zeroed: the next super-block's first group overwrites it, kint_group)
                             if constexpr (HAS_MIN) {       // (the oracle's / reference's expression: sumf += d isum - dmin msum)
                                 if (sw == S - 1) t = t - (dm * dxq[e]) * (float)((chi[rb][i] << 6) + clo[rb][i]);
                             }
