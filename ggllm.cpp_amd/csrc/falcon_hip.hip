@@ -425,13 +425,26 @@ static bool stage_uniform(const falcon_hip_model * m) {
 // the pipeline step all ask here, so the sampler reads the per-workgroup argmax candidates exactly when the fused lm_head
 // wrote them. The fused kernels are instantiated per weight format (a model that mixes formats inside a block takes the
 // op list) and implement the default summation order only (ggml_hip_reference_order -> op list).
+// Round 6: the FAST reference order (ggml_hip_reference_order(2)) has the fused launches too, for stages of one legacy format (fq_ref_chain.h).
+static bool stage_legacy(const falcon_hip_model * m) {
+    auto leg = [](int t) { return t == FQ_Q4_0 || t == FQ_Q4_1 || t == FQ_Q5_0 || t == FQ_Q5_1 || t == FQ_Q8_0; };
+    if (m->layers.empty() || m->hp.n_embd % 32 || m->hp.n_ff % 32) return false;
+    const int t = m->layers[0].qkv.type;
+    for (const layer_weights & L : m->layers) if (L.qkv.type != t || L.up.type != t || L.down.type != t || L.wo.type != t) return false;
+    if (m->last_stage() && !leg(m->lm_head.type)) return false;
+    return leg(t);
+}
+static bool stage_fused_ref(const falcon_hip_context * c) {        // N = 1 steps run the fused launches in the reference's association
+    return c->fused_decode && fq_reference_fast() && stage_legacy(c->m) && !c->engine && !c->two_phase && !c->dual_stream;
+}
 static bool stage_fused(const falcon_hip_context * c) {
+    if (stage_fused_ref(c)) return true;
     return c->fused_decode && stage_uniform(c->m) && !fq_reference_order() && !fq_attn_f64();
 }
 // everything a captured graph bakes in besides its pointers: a change invalidates decode_graph / step_graph
 static int graph_signature(const falcon_hip_context * c) {
     return (stage_fused(c) ? 1 : 0) | (fq_reference_order() ? 2 : 0) | (fq_attn_f64() ? 4 : 0) | (c->merged_attn_out ? 8 : 0) |
-           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0) | (c->engine ? 64 : 0);
+           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0) | (c->engine ? 64 : 0) | (stage_fused_ref(c) ? 128 : 0);
 }
 
 // ---- the persistent engine: per-context tables (block pointers, work split, hand-off buffers), built on first use
@@ -596,6 +609,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         //   1 launch    k_attn_out_ln = k_attn_out of block l + k_gemv_ln of block l+1 (or ln_f + lm_head) as a second phase
         const bool prof = fq_prof_active();
         const bool dual = c->dual_stream && !prof;
+        const bool ref = stage_fused_ref(c);                    // the reference's association on the same launches (fq_ref_chain.h)
         auto ln_args = [&](size_t li) {
             const layer_weights & L = m->layers[li];
             const int ff_act = fq_desc(L.down.type).act_type;
@@ -637,9 +651,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             } else if (!ln_done) {
                 if (prof) fq_prof_open(st);
                 bool ring = false;
-                if (c->ring_ln && quant_epi) ring = fq_launch_gemv_ln_ring(ga, c->sync_words + 1, hc.n_cu, st);
-                else if (c->ring_ln)         ring = fq_launch_ringk_ln(ga, c->sync_words + 1, hc.n_cu, st);      // k-quants: GELU stored as f32
-                if (!ring) fq_launch_gemv_ln(ga, hc.n_cu, st);
+                if (c->ring_ln && quant_epi) ring = fq_launch_gemv_ln_ring(ga, c->sync_words + 1, hc.n_cu, st, ref);
+                else if (c->ring_ln && !ref) ring = fq_launch_ringk_ln(ga, c->sync_words + 1, hc.n_cu, st);      // k-quants: GELU stored as f32
+                if (!ring) fq_launch_gemv_ln(ga, hc.n_cu, st, ref);
                 if (prof) fq_prof_close(st, (double)(L.qkv.bytes + L.up.bytes));
             }
             ln_done = false;
@@ -653,9 +667,16 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             // gelu(up) still f32 (k-quant consumers: a Q8_K block spans 256 rows, i.e. several workgroups of the launch above): quantized by its own launch
             // ahead of the merged form, or by extra workgroups of the attention launch (the rider) in the three-launch form
             bool ff_pending = !quant_epi && !dual;
-            const bool will_merge = c->merged_attn_out && !dual && fq_attn_out_fits(go, (int) H, max_n_kv, hc.n_cu);
-            if (ff_pending && will_merge) { fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st); ff_pending = false; }
             bool merged = false;
+            if (ref && c->merged_attn_out) {
+                // the merged launch in the reference's association; where its grid does not fit the chip: attention (f64 dots) + output launch below
+                if (prof) fq_prof_open(st);
+                merged = fq_launch_attn_out_ref(go, c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, (const float *)(c->sync_words + 16),
+                                                kc, vc, hc.exp_table_attn, att_act, c->att_gran, c->sync_words, c->sync_words + 1, hc.n_cu, st);
+                if (prof) { if (merged) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes)); else fq_prof_cancel(); }
+            }
+            const bool will_merge = !ref && c->merged_attn_out && !dual && fq_attn_out_fits(go, (int) H, max_n_kv, hc.n_cu);
+            if (ff_pending && will_merge) { fq_launch_quantize_act(c->up, FF, act_for(c->buf_ff, L.down, 1), st); ff_pending = false; }
             if (will_merge) {
                 // second phase: the next block's k_gemv_ln (its GELU output must be quantized in its epilogue: a separate
                 // quantizer launch cannot sit between the phases), or ln_f + lm_head after the last block
@@ -695,10 +716,11 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 } else {
                     if (ff_pending) { fq_launch_quantize_act(c->up, FF, a_ff1, st); ff_pending = false; }
                     fq_launch_attn_decode(c->qkv, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, hc.exp_table_attn,
-                                          att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, st);
+                                          att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, att_act, st, ref);
                 }
                 if (prof) fq_prof_open(st);
-                if (!(c->ring_out && fq_launch_ring_out(go, c->sync_words + 1, hc.n_cu, st))) fq_launch_gemv_out(go, hc.n_cu, st);
+                if (ref) fq_launch_gemv_out(go, hc.n_cu, st, true);
+                else if (!(c->ring_out && fq_launch_ring_out(go, c->sync_words + 1, hc.n_cu, st))) fq_launch_gemv_out(go, hc.n_cu, st);
                 if (prof) fq_prof_close(st, (double)(L.down.bytes + L.wo.bytes));
             }
         }
@@ -709,7 +731,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         if (m->last_stage() && !head_done) {
             const fq_gemv_ln_args ga = head_args();
             if (prof) fq_prof_open(st);
-            fq_launch_gemv_ln(ga, hc.n_cu, st);
+            fq_launch_gemv_ln(ga, hc.n_cu, st, ref);
             if (prof) fq_prof_close(st, (double) m->lm_head.bytes);
         }
         return;
@@ -880,8 +902,8 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));        // n_past / tokens may live on the caller's stack
     // batches: one hipGraph replay per (size, keys) instead of ~10 launches and 3 cross-stream joins per block from the host
-    if (c->prefill_graph && N > 4 && c->n_seq == 0 && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
-        const int sig = (graph_signature(c) | (c->keep_hidden ? 128 : 0)) + 256 * fq_config_epoch();
+    if (c->prefill_graph && N > 4 && c->n_seq == 0 && !fq_prof_active() && !hc.dbg_stamps && (!fq_reference_order() || fq_reference_fast())) {
+        const int sig = (graph_signature(c) | (c->keep_hidden ? 256 : 0)) + 512 * fq_config_epoch();
         hipGraphExec_t exec = nullptr;
         for (const auto & bg : c->batch_graphs) if (bg.N == N && bg.max_kv == n_past + adv && bg.sig == sig) { exec = bg.exec; break; }
         if (!exec) {
@@ -982,7 +1004,7 @@ extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int 
     hipLaunchKernelGGL(k_set2_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past, (int *) c->tokens_dev, (int) token);
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
-    if (stage_fused(c) && fused_graph_fits(c) && !fq_prof_active() && !hc.dbg_stamps && !fq_reference_order()) {
+    if (stage_fused(c) && fused_graph_fits(c) && !fq_prof_active() && !hc.dbg_stamps && (!fq_reference_order() || fq_reference_fast())) {
         if (!c->token_graph || c->token_sig != graph_signature(c)) {
             if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
             hipGraph_t g;

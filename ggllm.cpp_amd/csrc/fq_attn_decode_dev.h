@@ -27,7 +27,8 @@ template <bool PUBLISH, typename T> __device__ __forceinline__ void out_store(T 
     else base[word] = v;
 }
 // PRE: the first key / value rows were requested by the caller (attn_prefetch with the same arguments) before q was known and sit in P
-template <bool PUBLISH, bool PRE>
+// F64: the two dot products accumulated in f64 (fq_attn_dev.h; the reference's portable ggml_vec_dot_f32, ggml.c:2296-2300): the fast reference order
+template <bool PUBLISH, bool PRE, bool F64 = false>
 __device__ __forceinline__ void attn_decode_group_p(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg,
                                                     const fq_publish pub, attn_pre & P) {
     constexpr int D = 64, HALF = 32;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void attn_decode_group_p(const fq_attn_decode_args & 
     }
     if (append && tid >= 2 * HALF && tid < 2 * HALF + D) a.vc[((int64_t) np * HKV + hk) * D + (tid - 2 * HALF)] = av;
     FQ_STAMP(dbg, 2);
-    const float o = attn_head_block<false, true>(nullptr, a.kc, a.vc, HKV, hk, np, nullptr, nullptr, a.exp_tab, L, tid, P, dbg, &nw);
+    const float o = attn_head_block<F64, true>(nullptr, a.kc, a.vc, HKV, hk, np, nullptr, nullptr, a.exp_tab, L, tid, P, dbg, &nw);
     FQ_STAMP(dbg, 6);
     if (tid < 64) {
         if (a.att && live) out_store<PUBLISH>(a.att, (int64_t) h * D + tid, o, pub);
@@ -101,11 +102,11 @@ __device__ __forceinline__ void attn_decode_group_p(const fq_attn_decode_args & 
     }
 }
 
-template <bool PUBLISH>
+template <bool PUBLISH, bool F64 = false>
 __device__ __forceinline__ void attn_decode_group(const fq_attn_decode_args & a, int h, bool live, int tid, uint8_t * smem, long long * dbg = nullptr,
                                                   const fq_publish pub = fq_publish{ nullptr, 0u }) {
     attn_pre P;
-    attn_decode_group_p<PUBLISH, false>(a, h, live, tid, smem, dbg, pub, P);
+    attn_decode_group_p<PUBLISH, false, F64>(a, h, live, tid, smem, dbg, pub, P);
 }
 
 // the barriers of attn_decode_group (attn_head_block's; the rope in front of it needs none since round 4), for waves of the same workgroup that sit a group out

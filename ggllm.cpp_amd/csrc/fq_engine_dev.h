@@ -4,6 +4,7 @@
 #pragma once
 #include "fq_block_dev.h"
 #include "kernels.h"
+#include "fq_ref_chain.h"
 #include <type_traits>
 
 namespace {
@@ -30,6 +31,10 @@ __device__ __forceinline__ unsigned long long lds_ld64(unsigned addr) {
 }
 __device__ __forceinline__ void lds_st64(unsigned addr, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// one unit's f32 term: into the lane's partial sum (default order) or, REF (fast reference order, fq_ref_chain.h), into the row's LDS strip at the
+// block's index u (sa[r] = LDS byte address of row r's strip) -- an explicit DS store: it stays in the wave's LDS queue ahead of the counter that reports the row
+template <bool REF, int R>
+__device__ __forceinline__ void eng_emit(float (&acc)[R], const unsigned * sa, int r, int u, bool ok, float v) { fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
 
 // ---- LDS-DMA of the loader wave. Source = scalar base (64-bit) + per-lane 32-bit offset (+ immediate), destination = M0 (wave-uniform
 // LDS byte address, the lanes' 16 bytes land side by side: 1 KiB per instruction). No vector ALU work per piece.
@@ -131,8 +136,8 @@ __device__ __forceinline__ fq_unit_regs eng_unit_load_q8(const uint8_t * ring, u
     return r;
 }
 // U passes (of 64 units) of R rows: all loads first, then the dots -- per lane the units are still added in ascending order
-template <int TYPE, int RING, int R, int U>
-__device__ __forceinline__ void eng_pass_group(const uint8_t * ring, const unsigned (&pos)[R], int nblk, int u0, const fq_actcol & col, int lane, float (&acc)[R]) {
+template <int TYPE, int RING, int R, int U, bool REF = false>
+__device__ __forceinline__ void eng_pass_group(const uint8_t * ring, const unsigned (&pos)[R], int nblk, int u0, const fq_actcol & col, int lane, float (&acc)[R], const unsigned * sa = nullptr) {
     fq_unit_regs regs[U][R];
 #pragma unroll
     for (int p = 0; p < U; ++p) {
@@ -159,12 +164,12 @@ __device__ __forceinline__ void eng_pass_group(const uint8_t * ring, const unsig
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
     }
 }
 // the same with the lane's activation slices already in registers (a lane's units are the same in every row: hoisted out of the row loop)
-template <int TYPE, int RING, int R, int U>
-__device__ __forceinline__ void eng_pass_group_pre(const uint8_t * ring, const unsigned (&pos)[R], int nblk, int u0, const fq_act32 * act, int lane, float (&acc)[R]) {
+template <int TYPE, int RING, int R, int U, bool REF = false>
+__device__ __forceinline__ void eng_pass_group_pre(const uint8_t * ring, const unsigned (&pos)[R], int nblk, int u0, const fq_act32 * act, int lane, float (&acc)[R], const unsigned * sa = nullptr) {
     fq_unit_regs regs[U][R];
 #pragma unroll
     for (int p = 0; p < U; ++p) {
@@ -187,7 +192,7 @@ __device__ __forceinline__ void eng_pass_group_pre(const uint8_t * ring, const u
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
     }
 }
 // eng_pass_group_pre in two steps, so that the caller can hand the ring space back between them (kernels_ring.hip): the weight units of U passes of R rows
@@ -213,13 +218,13 @@ __device__ __forceinline__ void eng_pass_load(const uint8_t * ring, const unsign
         }
     }
 }
-template <int TYPE, int R, int U>
-__device__ __forceinline__ void eng_pass_dot_pre(const eng_regs<R, U> & G, int nblk, int u0, const fq_act32 * act, int lane, float (&acc)[R]) {
+template <int TYPE, int R, int U, bool REF = false>
+__device__ __forceinline__ void eng_pass_dot_pre(const eng_regs<R, U> & G, int nblk, int u0, const fq_act32 * act, int lane, float (&acc)[R], const unsigned * sa = nullptr) {
 #pragma unroll
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(G.r[p][r], act[p]); acc[r] += ok ? v : 0.0f; }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(G.r[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
     }
 }
 struct eng_wait {                 // per-wave state of the bounded waits

@@ -272,10 +272,15 @@ extern "C" int ggml_hip_debug_exp_boundary(unsigned * out_host, int cap) { retur
 extern "C" void ggml_hip_gemm_sequential(int on) { ++g_config_epoch; fq_gemm_set_sequential(on); }
 // reference order: every mat-mul through the per-thread scalar restatement (kernels_ref.hip: the reference's own block /
 // lane order for all ten formats and any N), attention with f64 accumulation (the portable ggml_vec_dot_f32)
-static bool g_reference_order = false;
-bool fq_reference_order() { return g_reference_order; }
-extern "C" void ggml_hip_reference_order(int on) { ++g_config_epoch; g_reference_order = on != 0; fq_gemm_set_sequential(on); fq_attn_set_f64(on); }
-extern "C" int  ggml_hip_get_reference_order(void) { return g_reference_order ? 1 : 0; }
+// mode 2 (round 6) = the FAST reference order: the same association -- results bit-identical to mode 1 and to the reference's scalar build -- on the fast kernels
+// where they have it: legacy formats, N = 1 through the fused decode launches (fq_ref_chain.h: per-block terms into an LDS strip, lane = row adds them left to
+// right; f64 attention dots), N > 4 through the int8-MFMA GEMM with one left-to-right sum per row (ggml_hip_gemm_sequential). Everything else as mode 1.
+static int g_reference_order = 0;
+bool fq_reference_order() { return g_reference_order != 0; }
+bool fq_reference_fast() { return g_reference_order == 2; }
+extern "C" void ggml_hip_reference_order(int on) { ++g_config_epoch; g_reference_order = on == 2 ? 2 : (on != 0 ? 1 : 0); fq_gemm_set_sequential(on != 0); fq_attn_set_f64(on != 0); }
+extern "C" int  ggml_hip_get_reference_order(void) { return g_reference_order; }
+static bool legacy_type(int t) { return t == FQ_Q4_0 || t == FQ_Q4_1 || t == FQ_Q5_0 || t == FQ_Q5_1 || t == FQ_Q8_0; }
 
 // ---- optional per-launch timing of the GEMV kernels (bench.py roofline leg): hipEvents on the launch stream
 static bool g_prof_on = false;
@@ -375,7 +380,11 @@ void fq_mul_mat_q_acts_from3(const fq_weight & w, const fq_act & a, int64_t N, f
 void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep0, hipStream_t st) {
     hip_context & c = fq_ctx();
     if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }
-    if (g_reference_order) { fq_launch_mul_mat_ref(w, a, N, dst, ldd, ep0, st); return; }
+    // reference order: one thread per output (mode 1), or -- mode 2, legacy formats, batches -- the GEMM below with S = 1 (fq_gemm_set_sequential: one
+    // left-to-right sum per row, the scalar build's two roundings per term: == the reference, tests/test_gpu_mul_mat.py)
+    if (g_reference_order && !(g_reference_order == 2 && legacy_type(w.type) && N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv)) {
+        fq_launch_mul_mat_ref(w, a, N, dst, ldd, ep0, st); return;
+    }
     if (N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv) {      // prefill: int8 MFMA GEMM
         fq_launch_gemm(w, a, N, dst, ldd, ep0, c.n_cu, st);
         return;

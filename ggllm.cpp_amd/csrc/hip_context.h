@@ -40,6 +40,7 @@ struct ggml_hip_weight;
 ggml_hip_weight * fq_weight_upload_part(int type, const void * host_blocks, int64_t K, int64_t rows, int64_t whole_rows);      // a row range of a larger matrix (split_tp.hip)
 std::vector<float> fq_rope_table_host(int head_dim, int n_pos, int rope_n_ctx);
 bool      fq_reference_order();
+bool      fq_reference_fast();          // ggml_hip_reference_order(2): the reference's association on the fast kernels (legacy formats)
 int       fq_config_epoch();        // bumped by every global switch that changes a launch list (reference order, forced mat-vec, sequential GEMM, debug modes)
 bool      fq_prof_active();
 void      fq_prof_open(hipStream_t st);

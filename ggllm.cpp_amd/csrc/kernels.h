@@ -113,8 +113,10 @@ struct fq_gemv_out_args {
 };
 size_t fq_gemv_ln_lds(int type, int64_t E);
 size_t fq_attn_decode_lds_bytes(int max_n_kv);          // LDS of one decode-attention head group whose score row holds max_n_kv keys (<= 160 KiB to launch)
-void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st);       // fills seg[].block_begin
-void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
+// ref (all the fused decode launchers): the fast reference order (fq_ref_chain.h, legacy formats): each row's block terms added left to right, the decode
+// attention's dots accumulated in f64 -- results bit-identical to the reference's scalar build
+void   fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st, bool ref = false);       // fills seg[].block_begin
+void   fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st, bool ref = false);
 // attention + output mat-vec in one launch (k_attn_out); returns false (nothing launched) when the grid would not be
 // resident at once -- the caller then uses fq_launch_attn_decode + fq_launch_gemv_out. gran: >= n_embd granules (8 bytes
 // each), zero-filled once; epoch_word: incremented by the k_gemv_ln launch (or phase) before it. With ln != nullptr the launch
@@ -127,7 +129,11 @@ bool   fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, 
                           const fq_gemv_ln_args * ln = nullptr, unsigned long long * xgran = nullptr);
 void   fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                              float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image,
-                             int att_act_type, hipStream_t st);
+                             int att_act_type, hipStream_t st, bool f64 = false);
+// k_attn_out in the fast reference order (legacy formats; f64 attention dots, rows summed left to right); false: nothing launched
+bool   fq_launch_attn_out_ref(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
+                              const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
+                              int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st);
 // B lock-step sequences: row t of qkv / att, KV cache t (seq_stride floats apart), image column t (image_stride bytes apart)
 void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
                                   float * k_cache, float * v_cache, int64_t seq_stride, const uint16_t * exp_table, float * att, uint8_t * att_image,
@@ -137,7 +143,8 @@ void   fq_launch_attn_decode_seqs(const float * qkv, int n_seq, int H, int HKV, 
 // kernels_ring.hip -- the ring form of k_gemv_ln's launch (LDS-DMA loader wave + consumers out of an LDS ring, one workgroup per CU);
 // false = outside its scope, nothing launched. fq_ring_prepare: builds the shape's schedule (allocates: not inside a stream capture)
 bool   fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu);
-bool   fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st);
+// ref: the fast reference order (fq_ref_chain.h): every row's block terms added left to right as the reference's scalar build adds them
+bool   fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st, bool ref = false);
 
 // kernels_ringk.hip -- ring forms beyond kernels_ring.hip's scope: k_gemv_ln's launch for the k-quants (GELU_STORE epilogue: the Q8_K image of gelu(up)
 // rides on the attention launch), and k_gemv_out's launch for all ten formats. false = outside the form's scope (or no prepared schedule): nothing launched.

@@ -20,6 +20,7 @@
 #include "fq_kdot.h"
 #include "fq_attn_dev.h"
 #include "fq_attn_decode_dev.h"
+#include "fq_ref_chain.h"
 #include "kernels.h"
 #include "hip_context.h"
 #include <hip/hip_ext.h>
@@ -58,9 +59,11 @@ __device__ __forceinline__ void rows_issue(const fq_wrow (&rows)[R], int units, 
 template <int TYPE> __device__ __forceinline__ bool kq_fast_units(int units) {
     if constexpr (fq_kdot<TYPE>::ok) return (units & 63) == 0; else return false;
 }
-template <int TYPE, int R, int NPRE>
-__device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R]) {
+// REF (both functions; legacy formats): every unit's f32 term goes to the strip of its row, sa[r], at the unit's = block's index (fq_ref_chain.h)
+template <int TYPE, int R, int NPRE, bool REF = false>
+__device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R], const unsigned * sa = nullptr) {
     const int lane = threadIdx.x & 63;
+    static_assert(!REF || !fq_kdot<TYPE>::ok, "the fast reference order covers the legacy formats");
     if constexpr (fq_kdot<TYPE>::ok) {
         if (kq_fast_units<TYPE>(units)) {
             typedef fq_kdot<TYPE> KD;
@@ -79,12 +82,13 @@ __device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R]
     for (int i = 0; i < NPRE; ++i) {
         const int u = i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); acc[r] += ok ? v : 0.0f; }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
     }
 }
-template <int TYPE, int R, int UNROLL>
-__device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int units, int u_begin, const fq_actcol & col, float (&acc)[R]) {
+template <int TYPE, int R, int UNROLL, bool REF = false>
+__device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int units, int u_begin, const fq_actcol & col, float (&acc)[R], const unsigned * sa = nullptr) {
     const int lane = threadIdx.x & 63;
+    static_assert(!REF || !fq_kdot<TYPE>::ok, "the fast reference order covers the legacy formats");
     if constexpr (fq_kdot<TYPE>::ok) {
         if (kq_fast_units<TYPE>(units)) {
             typedef fq_kdot<TYPE> KD;
@@ -119,7 +123,7 @@ __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int unit
         for (int i = 0; i < UNROLL; ++i) {
             const int u = u0 + i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); acc[r] += ok ? v : 0.0f; }
+            for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
         }
     }
 }
@@ -146,7 +150,9 @@ __device__ __forceinline__ fq_actcol actcol_at(const uint8_t * base, int act_typ
 // xs.gran != nullptr: the residual row arrives through a hand-off buffer of the same launch (k_attn_out_ln), see fq_block_dev.h
 struct fq_xsrc { const unsigned long long * gran; unsigned epoch; unsigned * err; };
 
-template <int TYPE, int MAXT>
+// REF = the fast reference order (fq_ref_chain.h; legacy formats): a wave leaves the unit terms of two passes (8 rows) in its own LDS strip and adds them with
+// lanes 0..7 = rows, left to right as the reference's scalar build does (ggml.c:2591-2609) -- no other wave is involved, no barrier is added
+template <int TYPE, int MAXT, bool REF = false>
 __device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const int bid, uint8_t * smem, const fq_xsrc xs) {
     constexpr int ACT = act_of<TYPE>::value;
     const int64_t E = a.E;
@@ -164,6 +170,20 @@ __device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const in
 
     constexpr int R = 4, NPRE = MAXT > 256 ? decode_cfg<TYPE>::LN_NPRE_BIG : decode_cfg<TYPE>::LN_NPRE;              // 8 rows per wave = two passes of 4
     const int units = (int)(E / fq_unit<TYPE>::ELEMS);
+    // REF: this wave's strip, 8 row slots (slot = 4 (pass & 1) + row of the pass) of SW floats, behind the reduction scratch
+    const unsigned SW = REF ? fq_ref_strip_stride(units) : 0u;
+    float * const strip_w = (float *)(red + 32) + (size_t) wid * 8 * SW;
+    unsigned sa[R];
+    auto strip_pass = [&](int p) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sa[r] = (unsigned)(uintptr_t)(strip_w + (size_t)(4 * (p & 1) + r) * SW);
+    };
+    // the rows of passes p - 1 and p, summed in the reference's order by lanes 0..7 (the stores above are ahead of these reads in the wave's LDS queue)
+    auto strip_sum = [&](int p) {
+        const int sl = lane & 7;
+        const float v = fq_ref_chain(strip_w + (size_t) sl * SW, units, 0.0f);
+        if (lane < 8) out32[RW * wid + R * (p - 1 + (sl >> 2)) + (sl & 3)] = v;
+    };
     // 1. the residual row's loads, 2. pass-0 weight loads, 3. LayerNorm + Q8 image while those stream, 4. dots of pass 0,
     //    5. pass 1 (its loads overlap other workgroups' dots)
     // the hand-off tag of the launch that follows (in the two-phase kernel: after the row has been read with the current one)
@@ -218,13 +238,16 @@ __device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const in
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-        rows_consume<TYPE, R, NPRE>(pre0, units, col, acc);
-        rows_dot_from<TYPE, R, 2>(rows0, units, 64 * NPRE, col, acc);
+        if constexpr (REF) strip_pass(0);
+        rows_consume<TYPE, R, NPRE, REF>(pre0, units, col, acc, sa);
+        rows_dot_from<TYPE, R, 2, REF>(rows0, units, 64 * NPRE, col, acc, sa);
+        if constexpr (!REF) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
+            for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) out32[RW * wid + r] = acc[r];
+                for (int r = 0; r < R; ++r) out32[RW * wid + r] = acc[r];
+            }
         }
         FQ_STAMP(a.dbg, 4);
     }
@@ -236,13 +259,17 @@ __device__ __forceinline__ void gemv_ln_body(const fq_gemv_ln_args & a, const in
         for (int r = 0; r < R; ++r) acc[r] = 0.0f;
         // (rows of <= 192 units -- Falcon-7B: 142 -- in one trip of LN_NPRE columns; longer rows two columns at a time, so
         // that the last trip does not re-request clamped columns)
-        if (units <= 64 * decode_cfg<TYPE>::LN_NPRE) rows_dot_from<TYPE, R, decode_cfg<TYPE>::LN_NPRE>(rowsp, units, 0, col, acc);
-        else                                         rows_dot_from<TYPE, R, 2>(rowsp, units, 0, col, acc);
+        if constexpr (REF) strip_pass(p);
+        if (units <= 64 * decode_cfg<TYPE>::LN_NPRE) rows_dot_from<TYPE, R, decode_cfg<TYPE>::LN_NPRE, REF>(rowsp, units, 0, col, acc, sa);
+        else                                         rows_dot_from<TYPE, R, 2, REF>(rowsp, units, 0, col, acc, sa);
+        if constexpr (REF) { if (p & 1) strip_sum(p); }
+        else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
+            for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) out32[RW * wid + R * p + r] = acc[r];
+                for (int r = 0; r < R; ++r) out32[RW * wid + R * p + r] = acc[r];
+            }
         }
     }
     FQ_STAMP(a.dbg, 5);
@@ -291,11 +318,17 @@ __global__ void __launch_bounds__(MAXT) k_gemv_ln(fq_gemv_ln_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     gemv_ln_body<TYPE, MAXT>(a, (int) blockIdx.x, smem, fq_xsrc{ nullptr, 0u, nullptr });
 }
+template <int TYPE, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_gemv_ln_ref(fq_gemv_ln_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    gemv_ln_body<TYPE, MAXT, true>(a, (int) blockIdx.x, smem, fq_xsrc{ nullptr, 0u, nullptr });
+}
 
 size_t fq_gemv_ln_lds(int type, int64_t E) {
     const int act = fq_desc(type).act_type;
     return (((size_t) E * 4 + 15) & ~(size_t) 15) + fq_act_col_bytes(act, E) + 384 * 4 + 32 * 8;
 }
+static bool fq_legacy_type(int t) { return t == FQ_Q4_0 || t == FQ_Q4_1 || t == FQ_Q5_0 || t == FQ_Q5_1 || t == FQ_Q8_0; }
 
 // workgroup shape: nw waves (4, 8 or 12) x 4*npass rows per wave (npass even, so that a workgroup is whole 32-row groups;
 // at most 8 passes = 384 rows).
@@ -319,8 +352,8 @@ static void gemv_ln_shape(const fq_gemv_ln_args & a, int n_cu, int & nw_out, int
         while (npass_out < 8 && (a.seg[0].w.M + 4 * npass_out * nw_out - 1) / (4 * npass_out * nw_out) > n_cu) npass_out += 2;
 }
 
-void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
-    FQ_TL(st, "gemv_ln");
+void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st, bool ref) {
+    FQ_TL(st, ref ? "gemv_ln_ref" : "gemv_ln");
     int nw = 4, npass = 2;
     gemv_ln_shape(a, n_cu, nw, npass);
     a.npass = npass;
@@ -330,9 +363,28 @@ void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st) {
     a.n_blocks = blocks;
     const int type = a.seg[0].w.type;
     size_t lds = fq_gemv_ln_lds(type, a.E);
+    if (ref) {
+        // the fast reference order: + 8 strip rows per wave (fq_ref_chain.h); legacy formats, one format per launch
+        for (int s = 0; s < a.nseg; ++s) if (!fq_legacy_type(a.seg[s].w.type) || a.seg[s].w.type != type) { fprintf(stderr, "ggml-hip: gemv_ln: the fast reference order covers launches of one legacy format\n"); exit(1); }
+        lds += (size_t) nw * 8 * fq_ref_strip_stride((int)(a.E / 32)) * 4;
+        if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: gemv_ln: the term strips of a %lld-wide row do not fit the LDS\n", (long long) a.E); exit(1); }
+    }
     // a grid that fits the chip gets one workgroup per CU: claim more than half of the 160 KiB LDS so that the dispatcher
     // cannot co-locate two of them while other CUs stay empty
     if (blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;
+#define FQ_LAUNCH_R(T, MAXT) { \
+        static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ref<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
+        FQ_LAUNCH_PROF((k_gemv_ln_ref<T, MAXT>), dim3((unsigned) blocks), dim3(64 * nw), lds, st, a); }
+#define FQ_CASE_R(T) case T: if (nw <= 4) FQ_LAUNCH_R(T, 256) else FQ_LAUNCH_R(T, 768) break;
+    if (ref) {
+        switch (type) {
+            FQ_CASE_R(FQ_Q4_0) FQ_CASE_R(FQ_Q4_1) FQ_CASE_R(FQ_Q5_0) FQ_CASE_R(FQ_Q5_1) FQ_CASE_R(FQ_Q8_0)
+            default: break;
+        }
+        return;
+    }
+#undef FQ_CASE_R
+#undef FQ_LAUNCH_R
 #define FQ_LAUNCH(T, MAXT) { \
         static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
         FQ_LAUNCH_PROF((k_gemv_ln<T, MAXT>), dim3((unsigned) blocks), dim3(64 * nw), lds, st, a); }
@@ -426,8 +478,10 @@ __global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
     FQ_STAMP(a.dbg, 7);
 }
 
-void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
-    FQ_TL(st, "gemv_out");
+static void gemv_out_ref_launch(const fq_gemv_out_args & a, int n_cu, hipStream_t st);
+void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st, bool ref) {
+    FQ_TL(st, ref ? "gemv_out_ref" : "gemv_out");
+    if (ref) { gemv_out_ref_launch(a, n_cu, st); return; }
     const int type = a.w_wo.type;
     const int act = fq_desc(type).act_type;
     size_t lds = fq_act_col_bytes(act, a.w_down.K) + fq_act_col_bytes(act, a.w_wo.K) + (a.att_image ? 0 : (size_t) a.w_wo.K * 4) + 16;
@@ -465,17 +519,26 @@ __global__ void __launch_bounds__(256) k_attn_decode(fq_attn_decode_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     attn_decode_group<false>(a, (int) blockIdx.x, true, (int) threadIdx.x, smem);
 }
+__global__ void __launch_bounds__(256) k_attn_decode_f64(fq_attn_decode_args a) {      // the fast reference order: dots accumulated in f64
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    attn_decode_group<false, true>(a, (int) blockIdx.x, true, (int) threadIdx.x, smem);
+}
 
 
 size_t fq_attn_decode_lds_bytes(int max_n_kv) { return attn_decode_lds(max_n_kv); }
 
 void fq_launch_attn_decode(const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv, const float * rope_cs,
-                           float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st) {
-    FQ_TL(st, "attn_decode");
+                           float * k_cache, float * v_cache, const uint16_t * exp_table, float * att, uint8_t * att_image, int att_act_type, hipStream_t st, bool f64) {
+    FQ_TL(st, f64 ? "attn_decode_f64" : "attn_decode");
     const size_t lds = attn_decode_lds(max_n_kv);
     if (lds > 160 * 1024) { fprintf(stderr, "ggml-hip: attention: %d keys do not fit the score buffer in LDS\n", max_n_kv); exit(1); }
-    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     const fq_attn_decode_args a{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, att, att_image, att_act_type, max_n_kv, nullptr, nullptr, nullptr, nullptr };
+    if (f64) {
+        if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
+        hipLaunchKernelGGL(k_attn_decode_f64, dim3((unsigned) H), dim3(256), lds, st, a);
+        return;
+    }
+    if (lds > 64 * 1024) { static size_t g = 0; if (lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } }
     hipLaunchKernelGGL(k_attn_decode, dim3((unsigned) H), dim3(256), lds, st, a);
 }
 
@@ -673,6 +736,199 @@ __global__ void __launch_bounds__(768) k_attn_out_ln(fq_attn_out_args a, fq_gemv
     attn_out_body<TYPE>(a, smem, epoch, fq_publish{ xgran, epoch });
     __syncthreads();
     if ((int) blockIdx.x < b.n_blocks) gemv_ln_body<TYPE, 768>(b, (int) blockIdx.x, smem, fq_xsrc{ xgran, epoch, a.err });
+}
+
+// =============================================================================================== the fast reference order of the output launches
+// k_gemv_out_ref / k_attn_out_ref (ggml_hip_reference_order(2), fq_ref_chain.h; legacy formats): the same weight stream, integer dots and per-block f32
+// terms as k_gemv_out / k_attn_out, but each row's terms are added LEFT TO RIGHT, as the reference's scalar build adds them (ggml.c:2591-2609 and the other
+// legacy vec_dots), and the decode attention accumulates its dots in f64 (ggml.c:2296-2300). A workgroup of nw waves = nw - 1 consumer waves with two rows
+// each + ONE summing wave whose lanes are the workgroup's rows: the consumers leave the unit terms in an LDS strip [row][Wdown blocks | Wo blocks], the
+// summing wave follows them -- the pre-issued Wdown columns while the rest of Wdown streams, the rest while the attention output is awaited, Wo's at the end:
+// only Wo's chain (n_embd / 32 dependent adds) trails the stream. x[row] = (down + wo) + x[row] as libfalcon.cpp:2399-2400.
+struct fq_out_ref_geom { unsigned swd, swt; };           // floats: offset of the Wo terms inside a row's strip, stride of the rows
+__host__ __device__ inline fq_out_ref_geom fq_out_ref_strip(int units_d, int units_o) {
+    fq_out_ref_geom g; g.swd = ((unsigned) units_d + 3u) & ~3u; g.swt = fq_ref_strip_stride((int) g.swd + units_o); return g;
+}
+static size_t fq_out_ref_lds(int act, int64_t FF, int64_t E, int nw) {
+    const fq_out_ref_geom sg = fq_out_ref_strip((int)(FF / 32), (int)(E / 32));
+    return fq_act_col_bytes(act, FF) + fq_act_col_bytes(act, E) + 16 + (size_t) 2 * (nw - 1) * sg.swt * 4;
+}
+__device__ __forceinline__ void ref_wait(unsigned addr, unsigned target, unsigned * err) {      // LDS counter (monotonic) >= target; bounded
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+        if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
+        if (spins > (1u << 22)) { if (err && (threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void ref_count(unsigned addr) { if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory"); }
+
+// wg = index among the mat-vec workgroups; gran != nullptr: the attention image arrives through the granules of the same launch (k_attn_out_ref),
+// else it is in memory (k_gemv_out_ref)
+template <int TYPE>
+__device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, uint8_t * smem, const int wg, const unsigned long long * gran, const unsigned epoch, unsigned * err) {
+    constexpr int ACT = act_of<TYPE>::value;
+    static_assert(ACT == FQ_Q8_0 || ACT == FQ_Q8_1, "legacy formats");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x, ncw = (nt >> 6) - 1;      // ncw consumer waves + the summing wave
+    const int64_t E = g.w_wo.K, FF = g.w_down.K;
+    uint8_t * img_ff  = smem;
+    uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
+    uint8_t * ctlp    = img_att + fq_act_col_bytes(ACT, E);
+    float   * strip   = (float *)(ctlp + 16);
+    const unsigned ctl = (unsigned)(uintptr_t) ctlp, DCNT_A = ctl, DCNT_B = ctl + 4, OCNT = ctl + 8;      // consumer waves done with: the pre-issued Wdown columns, all of Wdown, Wo
+    constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
+    const int units_d = (int)(FF / 32), units_o = (int)(E / 32);
+    const fq_out_ref_geom sg = fq_out_ref_strip(units_d, units_o);
+    const int64_t wg_row0 = (int64_t) wg * (2 * ncw);
+    const bool summing = wid == ncw;
+    const int64_t row0 = wg_row0 + 2 * (summing ? 0 : wid);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t nvec_ff = (int64_t)(fq_act_col_bytes(ACT, FF) >> 4);
+    const int64_t nvec_at = gran ? 0 : (int64_t)(fq_act_col_bytes(ACT, E) >> 4);       // (img_att directly follows img_ff in LDS: one flat copy of 16-byte vectors)
+    const u32x4 * src_ff = (const u32x4 *) g.act_ff_image;
+    const u32x4 * src_at = (const u32x4 *) g.att_image;
+    constexpr int NTF = 4;
+    u32x4 tf[NTF];
+#pragma unroll
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
+    if (tid < 4) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 4u * (unsigned) tid), "v"(0u) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the summing wave: lane = row of the workgroup; its residual values now (a dependent load at the very end would add a memory round trip to the tail)
+    const int64_t srow = wg_row0 + lane;
+    const bool slive = summing && lane < 2 * ncw && srow < g.w_wo.M;
+    const float sres = summing ? g.resid[slive ? srow : 0] : 0.0f;
+    fq_wrow rd[2], ro[2];
+    rows_ptrs<TYPE, 2>(g.w_down, row0, rd);
+    rows_ptrs<TYPE, 2>(g.w_wo, row0, ro);
+    fq_unit_regs pd[NPD][2], po[NPO][2];
+    if (!summing) {
+        rows_issue<TYPE, 2, NPD>(rd, units_d, pd);
+        rows_issue<TYPE, 2, NPO>(ro, units_o, po);
+    }
+#pragma unroll
+    for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; if (i < nvec_ff) ((u32x4 *) img_ff)[i] = tf[k]; }
+    for (int64_t i = (int64_t) NTF * nt + tid; i < nvec_ff; i += nt) ((u32x4 *) img_ff)[i] = src_ff[i];
+    for (int64_t i = tid; i < nvec_at; i += nt) ((u32x4 *) img_att)[i] = src_at[i];
+    __syncthreads();
+    const fq_actcol col_d = actcol_at(img_ff, ACT, FF), col_o = actcol_at(img_att, ACT, E);
+    float acc[2] = { 0.0f, 0.0f };
+    unsigned sa_d[2], sa_o[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { sa_d[r] = (unsigned)(uintptr_t)(strip + (size_t)(2 * (summing ? 0 : wid) + r) * sg.swt); sa_o[r] = sa_d[r] + 4u * sg.swd; }
+    const float * srow_strip = strip + (size_t)(lane < 2 * ncw ? lane : 0) * sg.swt;
+    const int n_pre = 64 * NPD < units_d ? 64 * NPD : units_d;
+    float sd = 0.0f;
+    if (!summing) {
+        rows_consume<TYPE, 2, NPD, true>(pd, units_d, col_d, acc, sa_d);
+        ref_count(DCNT_A);
+        rows_dot_from<TYPE, 2, (decode_cfg<TYPE>::four_bit ? 5 : 2), true>(rd, units_d, 64 * NPD, col_d, acc, sa_d);
+        ref_count(DCNT_B);
+    } else {
+        ref_wait(DCNT_A, (unsigned) ncw, err);
+        sd = fq_ref_chain(srow_strip, n_pre, sd);
+        ref_wait(DCNT_B, (unsigned) ncw, err);
+        sd = fq_ref_chain(srow_strip + n_pre, units_d - n_pre, sd);
+    }
+    if (gran) {
+        // the attention output (k_attn_out's sweep): every wave re-reads its share of the granules until all of them carry this launch's tag
+        const int64_t nwords = (E >> 2) + 2 * (E >> 5);
+        unsigned * dstw = (unsigned *) img_att;
+        constexpr int NG = 3;
+        for (int64_t base = 0; base < nwords; base += (int64_t) NG * nt) {
+            unsigned v[NG];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const int64_t i = base + (int64_t) k * nt + tid;
+                    const unsigned long long x = __hip_atomic_load(gran + (i < nwords ? i : nwords - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[k] = (unsigned) x; ok = ok && (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if (spins > (1u << 20)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { const int64_t i = base + (int64_t) k * nt + tid; if (i < nwords) dstw[i] = v[k]; }
+        }
+        __syncthreads();
+    }
+    if (!summing) {
+        rows_consume<TYPE, 2, NPO, true>(po, units_o, col_o, acc, sa_o);
+        rows_dot_from<TYPE, 2, 2, true>(ro, units_o, 64 * NPO, col_o, acc, sa_o);
+        ref_count(OCNT);
+    } else {
+        ref_wait(OCNT, (unsigned) ncw, err);
+        const float so = fq_ref_chain(srow_strip + sg.swd, units_o, 0.0f);
+        if (slive) g.dst[srow] = (sd + so) + sres;                                               // libfalcon.cpp:2399-2400
+    }
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(768) k_gemv_out_ref(fq_gemv_out_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    gemv_out_ref_body<TYPE>(a, smem, (int) blockIdx.x, nullptr, 0u, nullptr);
+}
+template <int TYPE>
+__global__ void __launch_bounds__(768) k_attn_out_ref(fq_attn_out_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned epoch = *a.epoch_word;
+    if ((int) blockIdx.x < a.n_attn) {
+        const int tid = threadIdx.x, grp = tid >> 8, gtid = tid & 255;
+        if (grp >= a.heads_per_wg) return;
+        int h = (int) blockIdx.x * a.heads_per_wg + grp;
+        const bool live = h < a.at.H;
+        if (!live) h = a.at.H - 1;
+        attn_decode_group<true, true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, nullptr, fq_publish{ a.gran, epoch });
+        return;
+    }
+    gemv_out_ref_body<TYPE>(a.g, smem, (int) blockIdx.x - a.n_attn, a.gran, epoch, a.err);
+}
+// waves per workgroup of the reference-order output launches: the most (<= 12) whose strip fits the LDS next to the two images
+static int fq_out_ref_waves(int act, int64_t FF, int64_t E) {
+    for (int nw = 12; nw >= 3; --nw) if (fq_out_ref_lds(act, FF, E, nw) <= 160 * 1024) return nw;
+    return 0;
+}
+static void gemv_out_ref_launch(const fq_gemv_out_args & a, int n_cu, hipStream_t st) {
+    const int type = a.w_wo.type, act = fq_desc(type).act_type;
+    if (!fq_legacy_type(type) || a.w_down.type != type || !a.att_image || a.w_wo.K % 32 || a.w_down.K % 32) { fprintf(stderr, "ggml-hip: gemv_out: the fast reference order covers blocks of one legacy format\n"); exit(1); }
+    const int nw = fq_out_ref_waves(act, a.w_down.K, a.w_wo.K);
+    if (!nw) { fprintf(stderr, "ggml-hip: gemv_out: the term strips do not fit the LDS\n"); exit(1); }
+    size_t lds = fq_out_ref_lds(act, a.w_down.K, a.w_wo.K, nw);
+    const unsigned blocks = (unsigned)((a.w_wo.M + 2 * (nw - 1) - 1) / (2 * (nw - 1)));
+    if ((int) blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;
+#define FQ_CASE(T) case T: { static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
+        FQ_LAUNCH_PROF((k_gemv_out_ref<T>), dim3(blocks), dim3(64 * nw), lds, st, a); } break;
+    switch (type) { FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) default: break; }
+#undef FQ_CASE
+}
+// the merged attention + output launch in the fast reference order; false: the grid would not be resident at once (nothing launched)
+bool fq_launch_attn_out_ref(const fq_gemv_out_args & g, const float * qkv, int H, int HKV, const int * n_past_dev, int max_n_kv,
+                            const float * rope_cs, const float * rope_cur, float * k_cache, float * v_cache, const uint16_t * exp_table,
+                            int att_act_type, unsigned long long * gran, const unsigned * epoch_word, unsigned * err, int n_cu, hipStream_t st) {
+    FQ_TL(st, "attn_out_ref");
+    const int type = g.w_wo.type, act = fq_desc(type).act_type;
+    if (!fq_legacy_type(type) || g.w_down.type != type || !g.att_image || g.w_wo.K % 32 || g.w_down.K % 32) return false;
+    const int nw = 12, hpw = 2;
+    if (fq_out_ref_lds(act, g.w_down.K, g.w_wo.K, nw) > 160 * 1024) return false;
+    const int n_attn = (H + hpw - 1) / hpw;
+    const int n_mv = (int)((g.w_wo.M + 2 * (nw - 1) - 1) / (2 * (nw - 1)));
+    if (n_attn + n_mv > n_cu) return false;
+    const size_t lds_group = (attn_decode_lds(max_n_kv) + 15) & ~(size_t) 15;
+    const size_t lds_mv = fq_out_ref_lds(act, g.w_down.K, g.w_wo.K, nw);
+    size_t lds = lds_group * hpw > lds_mv ? lds_group * hpw : lds_mv;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    if (lds > 160 * 1024) return false;
+    fq_attn_out_args a{};
+    a.g = g;
+    a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, nullptr, const_cast<uint8_t *>(g.att_image), att_act_type, max_n_kv, rope_cur, nullptr, nullptr, nullptr };
+    a.gran = gran; a.epoch_word = epoch_word; a.err = err; a.n_attn = n_attn; a.n_mv = n_mv; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
+    const int grid = n_attn + n_mv;
+#define FQ_CASE(T) case T: { static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
+        FQ_LAUNCH_PROF((k_attn_out_ref<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a); } break;
+    switch (type) { FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) default: return false; }
+#undef FQ_CASE
+    return true;
 }
 
 // the merged form's own conditions (fq_launch_attn_out with ln == nullptr launches exactly when this is true)

@@ -17,12 +17,16 @@
 #include <hip/hip_ext.h>
 #include <vector>
 #include "fq_engine_dev.h"
+#include "fq_ref_chain.h"
 
 namespace {
 
 // control words of this kernel beyond eng_ctl's (which it shares: PSUM, STAT, OUT, CNT, LANDED, LOW, XG_DONE, LN_STAT, IMG_DONE, LN_MEAN, S2_DONE, PSQ)
 constexpr unsigned RING_XISSUED = eng_ctl::A_DONE;    // helper waves that have issued their loads of the residual row
 constexpr unsigned RING_CTL_BYTES = eng_ctl::PTRS + 64;
+constexpr unsigned RING_CTL_BYTES16 = (RING_CTL_BYTES + 15u) & ~15u;
+// REF (fast reference order, fq_ref_chain.h): 32-row groups the epilogue wave has summed -- their strip slots may be written again
+constexpr unsigned RING_SUMMED = eng_ctl::FG_DONE;
 // waves of a workgroup: the loader, the epilogue wave, RNC consumers. (12 consumers instead of 10 were measured SLOWER, 959 against 988 tok/s: their
 // working set leaves the loader less of the ring and the stream ends 1.2 us later -- the consumers' time is latency, not issue slots.)
 constexpr int RNH = 11, RNC = RNH - 1, RNT = 64 * (RNH + 1), RHT = 64 * RNH;
@@ -41,9 +45,14 @@ struct fq_ring_ln_args {
     const fq_engine_sched * sched;                     // per workgroup: rows [qg0, qg1) of Wqkv, 32-row groups [ug0, ug1) of Wup
     unsigned * epoch_word; const int * n_past_ptr; const float * rope_cs; float * rope_cur;
     unsigned * err; int debug_mode; long long * dbg;
+    int strip_slots; unsigned strip_stride;            // REF: the term strip holds strip_slots (32 or 64) rows of strip_stride floats
 };
 
-template <int TYPE, int NSLOT, bool TWO>
+// REF = the fast reference order (ggml_hip_reference_order(2), fq_ref_chain.h): the consumers leave every unit's f32 term -- the reference's per-block term --
+// in an LDS strip [row slot][block] instead of adding them per lane and across the wave, and the epilogue wave, lane = row, adds each row's terms left to
+// right (ggml.c:2591-2609): bit-identical to the reference's scalar build. The strip takes the place of the f32 residual row (dead once the image exists)
+// plus the workgroup's unused LDS; the loader, the ring and the LayerNorm prologue are the default form's.
+template <int TYPE, int NSLOT, bool TWO, bool REF>
 __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = eng_act<TYPE>::value;
@@ -53,10 +62,11 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     const int E = a.E, FF = a.FF;
     const fq_engine_sched sc = a.sched[blockIdx.x];
     uint8_t * ring  = smem;
-    float   * xrow  = (float *)(smem + RING + ENG_MIRROR);
-    uint8_t * img_e = (uint8_t *) xrow + (((size_t) E * 4 + 15) & ~(size_t) 15);          // LN image feeding Wup (and Wqkv with one norm)
+    // default: [ring][mirror][f32 row][image(s)][control]; REF: [ring][mirror][image(s)][control][f32 row, later the term strip, to the end of the LDS]
+    uint8_t * img_e = REF ? smem + RING + ENG_MIRROR : smem + RING + ENG_MIRROR + (((size_t) E * 4 + 15) & ~(size_t) 15);      // LN image feeding Wup (and Wqkv with one norm)
     uint8_t * img_e2 = img_e + fq_act_col_bytes(ACT, E);                                   // attention-norm image of a two-norm block
     uint8_t * ctlp  = img_e + (a.two_norms ? 2 : 1) * fq_act_col_bytes(ACT, E);
+    float   * xrow  = REF ? (float *)(ctlp + RING_CTL_BYTES16) : (float *)(smem + RING + ENG_MIRROR);
     const unsigned ctl = (unsigned)(uintptr_t) ctlp;
     auto ldsf_st = [&](unsigned off, float v) { lds_st(ctl + off, __builtin_bit_cast(unsigned, v)); };
     auto ldsf_ld = [&](unsigned off) { return __builtin_bit_cast(float, lds_ld(ctl + off)); };
@@ -283,7 +293,46 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     const fq_actcol col_e2 = { (const int8_t *) img_e2, (const float *)(img_e2 + fq_act_d_off(ACT, E)), (const void *)(img_e2 + fq_act_aux_off(ACT, E)) };
     const int gA = nA2 / 32;
 
-    if (isG) {
+    if constexpr (REF) if (isG) {
+        // ---- REF: the row sums in the reference's order, lane = row, then the default epilogues. Groups of 32 workgroup-local rows: the Wup groups first
+        // (their rows stream first), then the Wqkv rows; a group's terms are complete when its counter has reached its row count.
+        const float * strip = xrow;                                        // (every helper is past IMG_DONE: the f32 row is dead)
+        const int T = nA2 + nA1, nG = (T + 31) >> 5;
+        const unsigned SW = a.strip_stride; const int SM = a.strip_slots - 1;
+        const act_image_ptr o = act_image_at(a.ff_image, ACT, FF);
+        auto full = [&](int g_) { const int left = T - 32 * g_; return (unsigned)(left < 32 ? left : 32); };
+        for (int gl = 0; gl < nG;) {
+            for (unsigned spins = 0; (int)(lds_ld_u(ctl + eng_ctl::CNT + 4 * gl) - full(gl)) < 0;) { if (!w.spin(spins, ENG_W_GROUP, (unsigned) gl, 0)) break; __builtin_amdgcn_s_sleep(1); }
+            const bool two = gl + 1 < nG && (int)(lds_ld_u(ctl + eng_ctl::CNT + 4 * (gl + 1)) - full(gl + 1)) >= 0;
+            const int j = lane & 31, half = lane >> 5;
+            const int myg = gl + (two ? half : 0);
+            const bool st = two || half == 0;
+            const int row = 32 * myg + j, rc = row < T ? row : T - 1;
+            float v = fq_ref_chain(strip + (size_t)(rc & SM) * SW, nblkE, 0.0f);      // ggml.c:2594-2609: sumf = 0; sumf += term_i, i ascending
+            if (myg >= gA) {
+                if (st && row < T) a.qkv_dst[sc.qg0 + (row - nA2)] = v;
+            }
+            {
+                const int g = sc.ug0 + (myg < gA ? myg : 0);               // block index in the FF-long image
+                v = h2f_bits(a.gelu_tab[f2h_bits(v)]);                     // ggml.c:3477-3484
+                const float amax = reduce32(fabsf(v), op_max());
+                const float d  = amax / 127.0f;
+                const float id = d ? 1.0f / d : 0.0f;
+                const int q = round_half_away(v * id);
+                const int s = reduce32(q, op_add());
+                if (st && myg < gA) o.qs[32 * g + j] = (int8_t) q;
+                if (st && myg < gA && j == 0) {
+                    if (ACT == FQ_Q8_0) { o.d[g] = h2f_bits(f2h_bits(d)); ((int32_t *) o.aux)[g] = s; }
+                    else                { o.d[g] = d; ((float *) o.aux)[g] = (float) s * d; }
+                }
+            }
+            gl += two ? 2 : 1;
+            if (lane == 0) lds_st(ctl + RING_SUMMED, (unsigned) gl);       // (behind the chain's reads in this wave's LDS queue)
+        }
+        RING_T(1, 3);
+        return;
+    }
+    if (!REF && isG) {
         // ---- the Wup epilogues of this workgroup's groups as they complete (k_gemv_ln's epilogue: GELU table, Q8 block of 32) -> the image in memory
         const act_image_ptr o = act_image_at(a.ff_image, ACT, FF);
         for (int gl = 0; gl < gA;) {
@@ -312,7 +361,8 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     }
 
     // ---- consumers: rows out of the ring, runs of R consecutive rows round-robin (kernels_engine.hip `rows`)
-    auto rows = [&](auto rtag, auto ptag, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink) {
+    const unsigned strip_lds = (unsigned)(uintptr_t) xrow;
+    auto rows = [&](auto rtag, auto ptag, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink, const int jbase) {
         constexpr int R = decltype(rtag)::value;
         constexpr bool PRE = decltype(ptag)::value;                        // (compile-time: a run-time choice between the arrays would put them into scratch memory)
         const unsigned row_bytes = (unsigned)(nblkE * TS);
@@ -327,6 +377,13 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
             for (int r = 0; r < R; ++r) { const unsigned q = p0 + (unsigned)(i + r <= last ? r : last - i) * rsE; pr[r] = q >= (unsigned) RING ? q - (unsigned) RING : q; acc[r] = 0.0f; }
             const int nx_ = i + R * RNC;
             const unsigned next_low = nx_ < nrows ? seg_pos + (unsigned) nx_ * rsE : seg_pos + padded;
+            unsigned sa[R];                                            // REF: LDS addresses of the rows' term strips (slot = workgroup-local row mod slots)
+            if constexpr (REF) {
+                const int need = ((jbase + last) >> 5) - (a.strip_slots >> 5) + 1;      // groups that must have been summed before these slots are written again
+                if (need > 0) w.until(ctl + RING_SUMMED, (unsigned) need, ENG_W_GROUP);
+#pragma unroll
+                for (int r = 0; r < R; ++r) sa[r] = strip_lds + (unsigned)((jbase + (i + r <= last ? i + r : last)) & (a.strip_slots - 1)) * a.strip_stride * 4u;
+            }
             for (int ps = 0; ps < npass; ps += 3) {
                 const int np = npass - ps < 3 ? npass - ps : 3;
                 const unsigned upto = (unsigned)((ps + np) * 64 * TS);
@@ -337,22 +394,28 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
                     // rows of <= 3 passes with the lane's activation slices resident: the run's weight units into registers, the ring space handed back
                     // BEFORE the arithmetic (the LDS serves a wave's requests in order: the reads are ahead of the LOW store) -- the loader's look-ahead is
                     // the part of the ring beyond the oldest bytes still needed, and rows held through dots + butterflies kept the stream 1 us longer
-                    if (np == 3)      { eng_regs<R, 3> G; eng_pass_load<TYPE, RING, R, 3>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 3>(G, nblkE, 0, pre, lane, acc); }
-                    else if (np == 2) { eng_regs<R, 2> G; eng_pass_load<TYPE, RING, R, 2>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 2>(G, nblkE, 0, pre, lane, acc); }
-                    else              { eng_regs<R, 1> G; eng_pass_load<TYPE, RING, R, 1>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 1>(G, nblkE, 0, pre, lane, acc); }
+                    if (np == 3)      { eng_regs<R, 3> G; eng_pass_load<TYPE, RING, R, 3>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 3, REF>(G, nblkE, 0, pre, lane, acc, sa); }
+                    else if (np == 2) { eng_regs<R, 2> G; eng_pass_load<TYPE, RING, R, 2>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 2, REF>(G, nblkE, 0, pre, lane, acc, sa); }
+                    else              { eng_regs<R, 1> G; eng_pass_load<TYPE, RING, R, 1>(ring, pr, nblkE, 0, lane, G); if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after); eng_pass_dot_pre<TYPE, R, 1, REF>(G, nblkE, 0, pre, lane, acc, sa); }
                     continue;
                 }
                 if (!nodots) {
                     if (PRE) {                                  // rows of <= 3 passes: the lane's activation slices were loaded once, before the row loop
-                        if (np == 3)      eng_pass_group_pre<TYPE, RING, R, 3>(ring, pr, nblkE, 0, pre, lane, acc);
-                        else if (np == 2) eng_pass_group_pre<TYPE, RING, R, 2>(ring, pr, nblkE, 0, pre, lane, acc);
-                        else              eng_pass_group_pre<TYPE, RING, R, 1>(ring, pr, nblkE, 0, pre, lane, acc);
+                        if (np == 3)      eng_pass_group_pre<TYPE, RING, R, 3, REF>(ring, pr, nblkE, 0, pre, lane, acc, sa);
+                        else if (np == 2) eng_pass_group_pre<TYPE, RING, R, 2, REF>(ring, pr, nblkE, 0, pre, lane, acc, sa);
+                        else              eng_pass_group_pre<TYPE, RING, R, 1, REF>(ring, pr, nblkE, 0, pre, lane, acc, sa);
                     }
-                    else if (np == 3) eng_pass_group<TYPE, RING, R, 3>(ring, pr, nblkE, 64 * ps, col, lane, acc);
-                    else if (np == 2) eng_pass_group<TYPE, RING, R, 2>(ring, pr, nblkE, 64 * ps, col, lane, acc);
-                    else              eng_pass_group<TYPE, RING, R, 1>(ring, pr, nblkE, 64 * ps, col, lane, acc);
+                    else if (np == 3) eng_pass_group<TYPE, RING, R, 3, REF>(ring, pr, nblkE, 64 * ps, col, lane, acc, sa);
+                    else if (np == 2) eng_pass_group<TYPE, RING, R, 2, REF>(ring, pr, nblkE, 64 * ps, col, lane, acc, sa);
+                    else              eng_pass_group<TYPE, RING, R, 1, REF>(ring, pr, nblkE, 64 * ps, col, lane, acc, sa);
                 }
                 if (lane == 0) lds_st(ctl + eng_ctl::LOW + 4 * c, low_after);
+            }
+            if constexpr (REF) {
+                // the rows' terms are in the strip: report them (the counter add follows the term stores in this wave's LDS queue)
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (i + r <= last && lane == 0) lds_add(ctl + eng_ctl::CNT + 4 * ((jbase + i + r) >> 5), 1u);
+                continue;
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[r]);
@@ -362,10 +425,10 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
     };
     std::integral_constant<int, 1> R1; std::integral_constant<int, 2> R2;
     std::integral_constant<bool, true> PT; std::integral_constant<bool, false> PF;
-    auto rows_e = [&](bool prefit_, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink) {
+    auto rows_e = [&](bool prefit_, unsigned seg_pos, unsigned padded, int nrows, const fq_actcol & col, const fq_act32 (&pre)[3], auto && sink, const int jbase) {
         const bool r2 = !(a.debug_mode & 16) && (unsigned)(2 * RNC) * rsE * 2u <= (unsigned) RING;
-        if (prefit_) { if (r2) rows(R2, PT, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PT, seg_pos, padded, nrows, col, pre, sink); }
-        else         { if (r2) rows(R2, PF, seg_pos, padded, nrows, col, pre, sink); else rows(R1, PF, seg_pos, padded, nrows, col, pre, sink); }
+        if (prefit_) { if (r2) rows(R2, PT, seg_pos, padded, nrows, col, pre, sink, jbase); else rows(R1, PT, seg_pos, padded, nrows, col, pre, sink, jbase); }
+        else         { if (r2) rows(R2, PF, seg_pos, padded, nrows, col, pre, sink, jbase); else rows(R1, PF, seg_pos, padded, nrows, col, pre, sink, jbase); }
     };
     // a lane's units are lane, lane + 64, lane + 128 of EVERY row: their activation slices stay in registers when a row is <= 3 passes long
     const bool prefit = ((nblkE + 63) >> 6) <= 3 && !(a.debug_mode & 32);
@@ -378,10 +441,10 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
             if constexpr (TWO) preB[p] = fq_act32_load(col_e2, uc);
         }
     }
-    rows_e(prefit, 0u, pA2, nA2, col_e, preA, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } });
+    rows_e(prefit, 0u, pA2, nA2, col_e, preA, [&](int i, float v) { if (lane == 0) { ldsf_st(eng_ctl::OUT + 4 * i, v); lds_add(ctl + eng_ctl::CNT + 4 * (i >> 5), 1u); } }, 0);
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 3);
-    if constexpr (TWO) rows_e(prefit, pA2, pA1, nA1, col_e2, preB, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
-    else rows_e(prefit, pA2, pA1, nA1, col_e, preA, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; });
+    if constexpr (TWO) rows_e(prefit, pA2, pA1, nA1, col_e2, preB, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; }, nA2);
+    else rows_e(prefit, pA2, pA1, nA1, col_e, preA, [&](int i, float v) { if (lane == 0) a.qkv_dst[sc.qg0 + i] = v; }, nA2);
     if (c == 0 || c == 9) RING_T(c == 0 ? 2 : 3, 4);
 }
 
@@ -432,8 +495,8 @@ bool fq_ring_prepare(int type, int64_t E, int64_t FF, int64_t qkv_rows, int n_cu
 }
 
 // k_gemv_ln's launch through the ring form; false = outside its scope (nothing launched)
-bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st) {
-    FQ_TL(st, "gemv_ln_ring");
+bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hipStream_t st, bool ref) {
+    FQ_TL(st, ref ? "gemv_ln_ring_ref" : "gemv_ln_ring");
     if (g.nseg != 2 || g.seg[1].epi != FQ_LNEPI_GELU_QUANT || g.seg[0].epi != FQ_LNEPI_STORE || g.argmax_val) return false;
     const fq_weight & wq = g.seg[0].w, & wu = g.seg[1].w;
     const int type = wq.type;
@@ -455,19 +518,34 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
     a.err = err; a.dbg = g.dbg;
     static const int dbg = getenv("FQ_RING_DEBUG") ? atoi(getenv("FQ_RING_DEBUG")) : 0;
     a.debug_mode = dbg;
-    const size_t fixed = (size_t) ENG_MIRROR + (((size_t) a.E * 4 + 15) & ~(size_t) 15) + (two_norms ? 2 : 1) * fq_act_col_bytes(act, a.E) + RING_CTL_BYTES;
+    const size_t xrow_bytes = ((size_t) a.E * 4 + 15) & ~(size_t) 15;
+    const size_t fixed = (size_t) ENG_MIRROR + xrow_bytes + (two_norms ? 2 : 1) * fq_act_col_bytes(act, a.E) + (ref ? RING_CTL_BYTES16 : RING_CTL_BYTES);
     int nslot = 0;
-    for (int n : { 7, 6, 4 }) if ((size_t) n * ENG_SLOT + fixed <= 160 * 1024) { nslot = n; break; }
+    size_t lds = 0;
+    a.strip_stride = fq_ref_strip_stride(a.nblkE); a.strip_slots = 0;
+    for (int n : { 7, 6, 4 }) {
+        if ((size_t) n * ENG_SLOT + fixed > 160 * 1024) continue;
+        if (ref) {
+            // the term strip: the f32 row's bytes (the last region of the REF layout) and whatever the workgroup leaves unused behind them; 64 row slots, or 32
+            const size_t room = 160 * 1024 - ((size_t) n * ENG_SLOT + fixed - xrow_bytes), row_b = (size_t) a.strip_stride * 4;
+            const int slots = room >= 64 * row_b ? 64 : (room >= 32 * row_b ? 32 : 0);
+            if (!slots) continue;
+            a.strip_slots = slots;
+            const size_t strip_b = (size_t) slots * row_b;
+            lds = (size_t) n * ENG_SLOT + fixed - xrow_bytes + (strip_b > xrow_bytes ? strip_b : xrow_bytes);
+        } else lds = (size_t) n * ENG_SLOT + fixed;
+        nslot = n; break;
+    }
     if (!nslot) return false;
     // a row (<= 3 passes of it) must fit the ring next to the loader's restart slot
     if ((size_t) 2 * 2 * a.rsE + ENG_SLOT > (size_t) nslot * ENG_SLOT) return false;
-    const size_t lds = (size_t) nslot * ENG_SLOT + fixed;
-#define FQ_RING_LAUNCH2(T, NS, TW) { \
+#define FQ_RING_LAUNCH3(T, NS, TW, RF) { \
         static bool set = false; \
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ring<T, NS, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ring<T, NS, TW, RF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_);      /* (the open profile bracket's events, if any, go to the dispatch) */ \
-        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW>), dim3((unsigned) n_cu), dim3(RNT), lds, st, e0_, e1_, 0, a); \
-        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW>), dim3((unsigned) n_cu), dim3(RNT), lds, st, a); }
+        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, e0_, e1_, 0, a); \
+        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, a); }
+#define FQ_RING_LAUNCH2(T, NS, TW) { if (ref) FQ_RING_LAUNCH3(T, NS, TW, true) else FQ_RING_LAUNCH3(T, NS, TW, false) }
 #define FQ_RING_LAUNCH(T, NS) { if (two_norms) FQ_RING_LAUNCH2(T, NS, true) else FQ_RING_LAUNCH2(T, NS, false) }
 #define FQ_RING_CASE(T) case T: if (nslot == 7) FQ_RING_LAUNCH(T, 7) else if (nslot == 6) FQ_RING_LAUNCH(T, 6) else FQ_RING_LAUNCH(T, 4) break;
     switch (type) {
@@ -477,5 +555,6 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
 #undef FQ_RING_CASE
 #undef FQ_RING_LAUNCH
 #undef FQ_RING_LAUNCH2
+#undef FQ_RING_LAUNCH3
     return true;
 }
