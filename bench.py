@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=0, help="debug: truncate the model to this many blocks (marks the line invalid)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-tokens", type=int, default=12, help="timed CPU decode steps after the CPU prompt (cpu_baseline leg)")
+    ap.add_argument("--cpu-tokens", type=int, default=32, help="timed CPU decode steps after the CPU prompt (cpu_baseline leg)")
     ap.add_argument("--prefill-long", type=int, default=2048, help="also time one prompt of this many tokens (0 = skip)")
     ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     ap.add_argument("--no-ref-order", action="store_true", help="skip the reference_order key (prompt + 16 decode steps in the reference's scalar summation order)")
     ap.add_argument("--no-cli", action="store_true", help="skip the reference_cli key (the reference's own falcon_main, linked against libggml_hip.so, on a written GGCC file)")
+    ap.add_argument("--order", type=int, default=-1, choices=[-1, 0, 2],
+                    help="summation order of the TIMED region: 2 = the fast reference order (ggml_hip_reference_order(2): logits bit-identical to the reference's scalar build; "
+                         "legacy formats), 0 = the default order; -1 (default) = 2 where the format has it, else 0. The other order is timed beside it (key other_order)")
     return ap.parse_args()
 
 
@@ -234,7 +237,7 @@ def reference_cli(g, weights, hp, n_prompt, n_predict, n_ctx):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def parity_sample(model, weights, toks, L):
+def parity_sample(model, weights, toks, L, timed_order=0):
     """logits of two decode steps (n_past 0 and 1) of `model` on the device, in both summation orders, against the reference on the host -- its scalar build
     (what parity is pinned to) and its AVX2 build (what a user runs) -- and all four against the f64 YARDSTICK (oracle order 6: every reduction of the path
     accumulated in f64, same integer dots, quantizers and table look-ups): who is how far from the sums an exact evaluation would give.
@@ -268,7 +271,15 @@ def parity_sample(model, weights, toks, L):
         exact = [model.eval(toks[i:i + 1], i, logits_all=False)[0].copy() for i in range(2)]
     finally:
         L.ggml_hip_reference_order(0)
-    return dict(default_order_vs_cpu=rel(fast, ref), reference_order_vs_cpu=rel(exact, ref),
+    timed = fast
+    if timed_order:
+        L.ggml_hip_reference_order(timed_order)
+        try:
+            timed = [model.eval(toks[i:i + 1], i, logits_all=False)[0].copy() for i in range(2)]
+        finally:
+            L.ggml_hip_reference_order(0)
+    return dict(timed_order=timed_order, timed_order_vs_cpu=rel(timed, ref), timed_order_bit_identical=all(bool(np.array_equal(timed[i], ref[i])) for i in range(2)),
+                default_order_vs_cpu=rel(fast, ref), reference_order_vs_cpu=rel(exact, ref),
                 reference_avx2_vs_scalar_spread=(rel(simd, ref) if simd else None),
                 default_order_vs_reference_avx2=(rel(fast, simd) if simd else None),
                 err_vs_f64=dict(default_order=rel(fast, f64), reference_order=rel(exact, f64), reference_scalar_build=rel(ref, f64),
@@ -278,7 +289,7 @@ def parity_sample(model, weights, toks, L):
                 cpu=kind)
 
 
-def pmc_decode_traffic():
+def pmc_decode_traffic(order=0):
     """(HBM bytes per launch of the decode's fused mat-vec launches, source) from the NEWEST committed profiles/*pmc_traffic.json that
     holds those kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, scripts/gpu_round.sh <tag> pmc, corrected by
     scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes), or None. Files of other workloads (small-batch launches ...) are skipped."""
@@ -291,6 +302,8 @@ def pmc_decode_traffic():
         except (OSError, ValueError):
             continue
         if not (any(k.startswith("k_gemv_ln") for k in d) and any(k.startswith("k_attn_out") for k in d)):      # (the merged attention + output launch: only the headline workload has it)
+            continue
+        if (order == 2) != any(k.startswith("k_attn_out_ref") for k in d):                                      # the timed order's own launches
             continue
         ks = [v for k, v in d.items() if k.startswith(("k_gemv_ln", "k_attn_out"))]
         n = sum(v["launches"] for v in ks)
@@ -336,24 +349,31 @@ def main():
     wbytes = model.weight_bytes()
 
     toks = synth.tokens(max(a.prompt, a.prefill_long) + 8, hp["n_vocab"], seed=42)
-    # ---- parity: (1) THE TIMED ORDER (default) against the CPU reference on a well-conditioned model (north_star: within 1e-3): the same shapes, the two
-    # matrices that write the residual stream (wo, down) drawn 2^-12 times smaller, so that the stream is residual-dominated as in a trained model instead of
-    # being re-drawn by every block; (2) on the benchmark's own N(0, 0.02^2) model, where ONE flipped 8-bit activation rounding moves logits by 1e-2: the
-    # reference-order mode (bit-identical to the scalar reference, expected 0.0), the default order, the reference's own AVX2 build -- all of them also
-    # against the f64 yardstick
+    legacy = a.quant in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0")
+    # THE TIMED ORDER. 2 = the fast reference order (round 6, csrc/fq_ref_chain.h): the fused decode launches and the prefill GEMM add every row's per-block
+    # terms left to right as the reference's scalar build does -- logits bit-identical to the CPU reference (north_star: within 1e-3; measured below on THIS
+    # model: 0.0). The k-quants have no fast form of that association: their timed order is the default one (0).
+    order = a.order if a.order >= 0 else (2 if legacy else 0)
+    if order == 2 and not legacy:
+        sys.stderr.write("bench.py: --order 2 needs a legacy format (q4_0 / q4_1 / q5_0 / q5_1 / q8_0): timing the default order\n")
+        order = 0
+    other = 0 if order == 2 else (2 if legacy else None)
+    # ---- parity, measured on the benchmark's own N(0, 0.02^2) model: the timed order, the default order, the one-thread-per-output instrument (mode 1) and
+    # the reference's AVX2 build against the reference's scalar build on the host, all of them also against the f64 yardstick. (A residual-dominated variant
+    # -- wo / down drawn 2^-4 times smaller, block scales still normal fp16 numbers -- is reported under its own key, never as the headline.)
     parity = None
     if not a.no_cpu:
-        parity = {"benchmark_model": parity_sample(model, weights, toks, L)}
-        if a.quant in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0"):
-            w2 = synth.make_model_fast(hp, wtype, seed=1234, out_gain=2.0 ** -12)
+        parity = {"benchmark_model": parity_sample(model, weights, toks, L, order)}
+        if legacy:
+            w2 = synth.make_model_fast(hp, wtype, seed=1234, out_gain=2.0 ** -4)
             m2 = g.FalconModel(w2, n_ctx=8, n_batch=1)
-            parity["well_conditioned_model"] = parity_sample(m2, w2, toks, L)
-            parity["well_conditioned_model"]["model"] = "same shapes and seeds, wo and down drawn 2^-12 times smaller (synth.make_model_fast(out_gain=2**-12)): residual-dominated"
+            parity["residual_dominated_model"] = parity_sample(m2, w2, toks, L, order)
+            parity["residual_dominated_model"]["model"] = "same shapes and seeds, wo and down drawn 2^-4 times smaller (synth.make_model_fast(out_gain=2**-4)); not the headline"
             m2.free()
             del w2, m2
 
     e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
-    # ---- what bit-identity with the reference's scalar build costs: the same prompt and decode steps in reference order (op list, k_mul_mat_ref)
+    # ---- the one-thread-per-output parity instrument (mode 1) timed on the same prompt and decode steps: what the reference's association cost before round 6
     ref_order = None
     if not a.no_ref_order:
         L.ggml_hip_reference_order(1)
@@ -364,7 +384,7 @@ def main():
             L.ggml_hip_event_record(e1)
             r_prefill_ms = L.ggml_hip_event_elapsed_ms(e0, e1)
             cur = int(lg_r[0].argmax())
-            K_r = min(a.steps, 16)
+            K_r = min(a.steps, 8)
             cur = int(model.eval(np.array([cur], np.int32), a.prompt, logits_all=False)[0].argmax())       # warm
             L.ggml_hip_synchronize()
             t0 = time.perf_counter()
@@ -373,69 +393,95 @@ def main():
             L.ggml_hip_synchronize()
             r_dt = time.perf_counter() - t0
             ref_order = {"mode": "ggml_hip_reference_order(1): every mat-mul one thread per output in the reference's scalar association (csrc/fq_ref_dot.h), f64 attention dots, "
-                                 "op-by-op launches, one logits row D2H + host argmax per step; logits bit-identical to the reference's scalar build (parity.max_rel_logit_err_vs_cpu)",
+                                 "op-by-op launches, one logits row D2H + host argmax per step -- the parity instrument the fast reference order (mode 2) is tested against",
                          "decode_tok_s": K_r / r_dt, "decode_ms_per_token": r_dt / K_r * 1e3, "decode_steps": K_r,
                          "prefill_tok_s": a.prompt / (r_prefill_ms * 1e-3), "prefill_ms": r_prefill_ms, "prompt": a.prompt}
         finally:
             L.ggml_hip_reference_order(0)
-    # ---- one long prompt (BASELINE config 3's size), timed with hipEvents
-    long_ms = None
-    if a.prefill_long:
-        model.eval(toks[:a.prefill_long], 0, logits_all=False)
-        L.ggml_hip_event_record(e0)
-        model.eval(toks[:a.prefill_long], 0, logits_all=False)
-        L.ggml_hip_event_record(e1)
-        long_ms = L.ggml_hip_event_elapsed_ms(e0, e1)
-
-    # ---- prefill of the prompt (timed with hipEvents, reported beside the decode number)
-    model.eval(toks[:a.prompt], 0, logits_all=False)                   # warm (allocations, code load)
-    L.ggml_hip_event_record(e0)
-    lg = model.eval(toks[:a.prompt], 0, logits_all=False)
-    L.ggml_hip_event_record(e1)
-    prefill_ms = L.ggml_hip_event_elapsed_ms(e0, e1)
-    first = int(lg[0].argmax())
 
     use_graph = not a.no_graph
-    n_past = a.prompt
-    # ---- warm-up decode steps (also captures the graph)
-    out_w = model.decode_greedy(first, n_past, max(a.warmup, 1), use_graph=use_graph)
-    n_past += max(a.warmup, 1)
-    # ---- timed region: exactly K decode steps between device synchronisations; run `repeats` times over the SAME positions
-    # (the KV entries are rewritten with the same values) and report the median run, all runs listed beside it
-    runs = []
-    for _ in range(max(1, a.repeats)):
-        L.ggml_hip_synchronize()
-        t0 = time.perf_counter()
-        out = model.decode_greedy(int(out_w[-1]), n_past, a.steps, use_graph=use_graph)
-        L.ggml_hip_synchronize()
-        runs.append(time.perf_counter() - t0)
-    dt = sorted(runs)[len(runs) // 2]
-    tok_s = a.steps / dt
+
+    def timed_run(mode, repeats, with_long, with_profile):
+        """the whole measured workload in summation order `mode`: long prompt, the prompt (hipEvents), W warm-up + K timed decode steps (x repeats), and -- with_profile --
+        the instrumented plain-launch repeat for the kernel-level roofline"""
+        L.ggml_hip_reference_order(mode)
+        try:
+            r = {"order": mode}
+            if with_long and a.prefill_long:
+                model.eval(toks[:a.prefill_long], 0, logits_all=False)
+                L.ggml_hip_event_record(e0)
+                model.eval(toks[:a.prefill_long], 0, logits_all=False)
+                L.ggml_hip_event_record(e1)
+                r["long_ms"] = L.ggml_hip_event_elapsed_ms(e0, e1)
+            model.eval(toks[:a.prompt], 0, logits_all=False)                   # warm (allocations, code load)
+            L.ggml_hip_event_record(e0)
+            lg = model.eval(toks[:a.prompt], 0, logits_all=False)
+            L.ggml_hip_event_record(e1)
+            r["prefill_ms"] = L.ggml_hip_event_elapsed_ms(e0, e1)
+            first = int(lg[0].argmax())
+            n_past = a.prompt
+            # ---- warm-up decode steps (also captures the graph)
+            out_w = model.decode_greedy(first, n_past, max(a.warmup, 1), use_graph=use_graph)
+            n_past += max(a.warmup, 1)
+            # ---- timed region: exactly K decode steps between device synchronisations; run `repeats` times over the SAME positions
+            # (the KV entries are rewritten with the same values) and report the median run, all runs listed beside it
+            runs = []
+            for _ in range(max(1, repeats)):
+                L.ggml_hip_synchronize()
+                t0 = time.perf_counter()
+                out = model.decode_greedy(int(out_w[-1]), n_past, a.steps, use_graph=use_graph)
+                L.ggml_hip_synchronize()
+                runs.append(time.perf_counter() - t0)
+            r["runs"] = runs
+            r["dt"] = sorted(runs)[len(runs) // 2]
+            r["tok_s"] = a.steps / r["dt"]
+            r["n_past"] = n_past
+            r["tokens"] = [int(t) for t in out[:8]]
+            if with_profile and hasattr(L, "ggml_hip_profile_begin"):
+                import ctypes as C
+                L.ggml_hip_profile_begin()
+                model.decode_greedy(int(out[-1]), n_past + a.steps, min(a.steps, 32), use_graph=False)
+                nl, us, by = C.c_int64(), C.c_double(), C.c_double()
+                L.ggml_hip_profile_end(C.byref(nl), C.byref(us), C.byref(by))
+                r["profile"] = (nl.value, us.value, by.value)
+            return r
+        finally:
+            L.ggml_hip_reference_order(0)
+
+    # the other order first (its numbers are reported beside the timed one), the timed order last. The long prompt runs in the default order only: the
+    # prefill numbers that are priced against the MFMA roof are the default order's (int8 MFMA tiles with a K split, f32 attention on the matrix pipe);
+    # the reference association's prompt (one left-to-right sum per row: ggml_hip_gemm_sequential, f64 attention dots) is reported next to it
+    other_run = timed_run(other, 1, other == 0, True) if other is not None else None
+    tr = timed_run(order, a.repeats, order == 0, True)
+    runs, dt, tok_s, n_past = tr["runs"], tr["dt"], tr["tok_s"], tr["n_past"]
+    run0 = tr if order == 0 else other_run                              # the default order's run: prefill_* keys
+    run2 = tr if order == 2 else other_run                              # the fast reference order's run (None for the k-quants)
+    long_ms, prefill_ms = run0.get("long_ms"), run0["prefill_ms"]
     n_mid = n_past + a.steps // 2
     b_tok = wbytes + kv_bytes_per_token(hp, n_mid)
+    kname = ("k_gemv_ln_ring<.., REF> (lm_head: k_gemv_ln_ref) + k_attn_out_ref (the fused quantized mat-vec launches in the reference's association; lm_head included)" if order == 2 else
+             "k_gemv_ln_ring (lm_head: k_gemv_ln) + k_attn_out (fused quantized mat-vec launches; lm_head included)")
 
-    # ---- instrumented repeat for the kernel-level roofline (hipEvents around every GEMV launch)
+    # ---- kernel-level roofline from the instrumented repeat (hipEvents stamped by every fused mat-vec dispatch)
     roof = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
-    if hasattr(L, "ggml_hip_profile_begin"):
-        import ctypes as C
-        L.ggml_hip_profile_begin()
-        model.decode_greedy(int(out[-1]), n_past + a.steps, min(a.steps, 32), use_graph=False)
-        nl, us, by = C.c_int64(), C.c_double(), C.c_double()
-        L.ggml_hip_profile_end(C.byref(nl), C.byref(us), C.byref(by))
-        if nl.value:
-            # the two events of a launch are handed to hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's own
-            # begin / end (the clock rocprofv3's kernel trace reads) -- no marker packets, nothing to subtract
-            ovh = L.ggml_hip_profile_bracket_overhead_us()
-            avg_us = us.value / nl.value
-            ach = (by.value / nl.value) / (avg_us * 1e-6) / 1e9
-            roof.update(launch_achieved=ach, launch_frac=ach / HBM_PEAK_GBS, kernel="k_gemv_ln_ring (lm_head: k_gemv_ln) + k_attn_out (fused quantized mat-vec launches; lm_head included)",
-                        launches=nl.value, avg_launch_us=avg_us, empty_event_pair_us=ovh, bytes_per_launch=by.value / nl.value)
+
+    def launch_roof(prof):
+        nl, us, by = prof
+        if not nl:
+            return {}
+        avg_us = us / nl
+        ach = (by / nl) / (avg_us * 1e-6) / 1e9
+        return dict(launch_achieved=ach, launch_frac=ach / HBM_PEAK_GBS, launches=nl, avg_launch_us=avg_us, bytes_per_launch=by / nl)
+    if tr.get("profile"):
+        # the two events of a launch are handed to hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's own
+        # begin / end (the clock rocprofv3's kernel trace reads) -- no marker packets, nothing to subtract
+        roof.update(launch_roof(tr["profile"]), kernel=kname, empty_event_pair_us=L.ggml_hip_profile_bracket_overhead_us())
     # HBM traffic per launch from the PMC counters: collected off-line (scripts/gpu_pmc.sh: one rocprofv3 --pmc pass per
     # counter over this same command, corrected by scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes) and committed
     if a.model == "7b" and a.quant == "q4_0" and a.layers == 0:
-        tr = pmc_decode_traffic()
-        if tr:
-            roof["traffic"], roof["traffic_source"] = tr
+        tr_pmc = pmc_decode_traffic(order)
+        if tr_pmc:
+            roof["traffic"], roof["traffic_source"] = tr_pmc
         else:                                                           # loud, but the line survives: the driver reads it
             roof["traffic_error"] = "no profiles/*pmc_traffic.json holds the decode launches (k_gemv_ln* + k_attn_out*): run scripts/gpu_round.sh <tag> pmc and commit its summary"
             sys.stderr.write("bench.py: ERROR: roofline.traffic is null -- " + roof["traffic_error"] + "\n")
@@ -445,6 +491,11 @@ def main():
     # instrumented plain-launch repeat; agrees with profiles/*decode_7b_q4_0_kernel_stats.md)
     roof.update(achieved=step_gbs, frac=step_gbs / HBM_PEAK_GBS, step_achieved=step_gbs, step_frac=step_gbs / HBM_PEAK_GBS, bytes_per_token=b_tok,
                 note="frac = whole timed step (B_tok x tok/s over 8 TB/s); launch_frac = the two fused mat-vec launches + lm_head alone")
+    # what this chip streams at the same launch size: the pure-read micro-benchmark's rate (scripts/microbench/mb_stream.hip: a 58 MB launch back to back,
+    # 10.0-10.5 us = 5.6-5.8 TB/s; NOTEBOOK section 4), so that the line states both the fraction of the spec sheet and of what the part can stream
+    roof["measured_stream_GBs"] = 5700.0
+    roof["frac_of_measured_stream"] = step_gbs / 5700.0
+    roof["measured_stream_source"] = "scripts/microbench/mb_stream.hip on MI355X: pure 58 MB read launches back to back, 10.0-10.5 us (NOTEBOOK section 4); MI355X_MICROARCH.md float4 copy: 6.29 TB/s"
 
     # ---- prefill: flops / time against the matrix pipe (2 N sum(ne00 ne01) + attention 4 64 n_head n_layer N(N+1)/2)
     def prefill_roof(N, ms):
@@ -491,6 +542,20 @@ def main():
         cpu = cpu_baseline(weights, hp, wbytes, a.prompt, a.cpu_tokens, toks)
 
     valid = (a.layers == 0)
+    order_name = {0: "default order (per-lane partial sums + wave butterfly, K-split GEMM, f32 attention chains)",
+                  2: "fast reference order (ggml_hip_reference_order(2): every row's block terms added left to right, f64 attention dots -- logits bit-identical to the reference's scalar build)"}
+
+    def order_keys(r):
+        """the numbers of one order's run, for the key that sits beside the timed one"""
+        if r is None:
+            return None
+        k = {"order": r["order"], "order_name": order_name[r["order"]], "decode_tok_s": r["tok_s"], "ms_per_step": r["dt"] / a.steps * 1e3,
+             "step_frac_of_hbm_peak": (wbytes + kv_bytes_per_token(hp, r["n_past"] + a.steps // 2)) * r["tok_s"] / 1e9 / HBM_PEAK_GBS,
+             "prefill_ms": r["prefill_ms"], "prefill_tok_s": a.prompt / (r["prefill_ms"] * 1e-3), "first_tokens": r["tokens"]}
+        if r.get("profile"):
+            k.update(launch_roof(r["profile"]))
+        return k
+    pb = parity["benchmark_model"] if parity else None
     line = {
         "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
                   else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
@@ -499,18 +564,27 @@ def main():
         "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
         "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} full offload, {a.prompt}-token prompt + greedy decode, n_ctx {a.n_ctx}"
                                + ("" if valid else f" [TRUNCATED to {a.layers} blocks: not the benchmark config]"),
+                   "summation_order": order, "summation_order_name": order_name[order],
                    "n_past_timed": [n_past, n_past + a.steps], "hipgraph": use_graph, "weight_bytes_per_token": wbytes},
-        "prefill_tok_s": a.prompt / (prefill_ms * 1e-3), "prefill_ms": prefill_ms,
+        # prefill: the default order's prompt (what the MFMA roofline prices); the reference association's prompt (the one in front of the timed decode steps
+        # when summation_order is 2) beside it
+        "prefill_tok_s": a.prompt / (prefill_ms * 1e-3), "prefill_ms": prefill_ms, "prefill_order": 0,
+        "prefill_reference_order": ({"order": 2, "prefill_ms": run2["prefill_ms"], "prefill_tok_s": a.prompt / (run2["prefill_ms"] * 1e-3),
+                                     "form": "int8-MFMA GEMM with ONE left-to-right sum per row (ggml_hip_gemm_sequential) + f64 attention dots: logits == the reference's scalar build"}
+                                    if run2 else None),
         "prefill_roofline": prefill,
         "roofline": roof, "cpu_baseline": cpu,
-        "max_rel_logit_err_vs_cpu": (parity.get("well_conditioned_model") or parity["benchmark_model"])["default_order_vs_cpu"] if parity else None,
-        "max_rel_logit_err_mode": ("DEFAULT ORDER (the order the timed region runs) against the reference's scalar build on the host, two decode steps, on the "
-                                   "well-conditioned synthetic model (parity.well_conditioned_model); on the benchmark's N(0, 0.02^2) model the same comparison is "
-                                   "parity.benchmark_model.default_order_vs_cpu -- one flipped 8-bit activation rounding moves its logits by 1e-2, the reference's own "
-                                   "AVX2 and scalar builds differ by parity.benchmark_model.reference_avx2_vs_scalar_spread there -- and the reference-order mode is "
-                                   "bit-identical to the scalar reference on both (reference_order_vs_cpu = 0.0); err_vs_f64 places all of them against exact sums") if parity else None,
-        "max_rel_logit_err_vs_cpu_reference_order": max(v["reference_order_vs_cpu"] for v in parity.values()) if parity else None,    # ggml_hip_reference_order(1): bit-identical (0.0) on both models
+        # north_star: logits within 1e-3 of the CPU reference -- measured on THE TIMED CONFIGURATION: the benchmark's own model, the timed summation order,
+        # two decode steps against the reference's scalar build run on the host in this process (max |diff| / rms over the vocabulary)
+        "max_rel_logit_err_vs_cpu": pb["timed_order_vs_cpu"] if pb else None,
+        "max_rel_logit_err_mode": (f"the TIMED order ({order}: {order_name[order]}) on the benchmark's own N(0, 0.02^2) model against the reference's scalar build on the host "
+                                   "(parity.benchmark_model.timed_order_vs_cpu; timed_order_bit_identical says whether every logit has the same bits). The default order's "
+                                   "distance on the same model is parity.benchmark_model.default_order_vs_cpu (one flipped 8-bit activation rounding moves logits by 1e-2; "
+                                   "the reference's own AVX2 and scalar builds differ by reference_avx2_vs_scalar_spread); err_vs_f64 places all of them against exact sums") if pb else None,
+        "max_rel_logit_err_vs_cpu_default_order": pb["default_order_vs_cpu"] if pb else None,
+        "max_rel_logit_err_vs_cpu_reference_order": max(v["reference_order_vs_cpu"] for v in parity.values()) if parity else None,    # ggml_hip_reference_order(1), the instrument: 0.0
         "parity": parity, "reference_order": ref_order,
+        "other_order": order_keys(other_run),                           # the same prompt + decode steps in the other summation order, timed in this run
         "setup_s": {"synthesize": t_gen, "upload": t_up},
         "lock_step_streams": lock_step,
     }

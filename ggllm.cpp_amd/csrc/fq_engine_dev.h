@@ -34,7 +34,7 @@ __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)
 // one unit's f32 term: into the lane's partial sum (default order) or, REF (fast reference order, fq_ref_chain.h), into the row's LDS strip at the
 // block's index u (sa[r] = LDS byte address of row r's strip) -- an explicit DS store: it stays in the wave's LDS queue ahead of the counter that reports the row
 template <bool REF, int R>
-__device__ __forceinline__ void eng_emit(float (&acc)[R], const unsigned * sa, int r, int u, bool ok, float v) { fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
+__device__ __forceinline__ void eng_emit(float (&acc)[R], const unsigned * sa, int r, int uc, bool ok, float v) { fq_emit_term<REF, R>(acc, sa, r, uc, ok, v); }
 
 // ---- LDS-DMA of the loader wave. Source = scalar base (64-bit) + per-lane 32-bit offset (+ immediate), destination = M0 (wave-uniform
 // LDS byte address, the lanes' 16 bytes land side by side: 1 KiB per instruction). No vector ALU work per piece.
@@ -164,7 +164,7 @@ __device__ __forceinline__ void eng_pass_group(const uint8_t * ring, const unsig
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, ok ? u0 + 64 * p + lane : nblk - 1, ok, v); }
     }
 }
 // the same with the lane's activation slices already in registers (a lane's units are the same in every row: hoisted out of the row loop)
@@ -192,7 +192,7 @@ __device__ __forceinline__ void eng_pass_group_pre(const uint8_t * ring, const u
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(regs[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, ok ? u0 + 64 * p + lane : nblk - 1, ok, v); }
     }
 }
 // eng_pass_group_pre in two steps, so that the caller can hand the ring space back between them (kernels_ring.hip): the weight units of U passes of R rows
@@ -224,7 +224,7 @@ __device__ __forceinline__ void eng_pass_dot_pre(const eng_regs<R, U> & G, int n
     for (int p = 0; p < U; ++p) {
         const bool ok = u0 + 64 * p + lane < nblk;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(G.r[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, u0 + 64 * p + lane, ok, v); }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot_x(G.r[p][r], act[p]); eng_emit<REF, R>(acc, sa, r, ok ? u0 + 64 * p + lane : nblk - 1, ok, v); }
     }
 }
 struct eng_wait {                 // per-wave state of the bounded waits

@@ -15,11 +15,14 @@
 __host__ __device__ inline unsigned fq_ref_strip_stride(int nblk) { unsigned q = ((unsigned) nblk + 3u) >> 2; q |= 1u; return 4u * q; }
 
 #if defined(__HIPCC__)
-// one unit's f32 term: into the lane's partial sum (default order) or, REF, into the row's strip at the block's index u (sa[r] = LDS byte address of row r's
-// strip). An explicit DS store: it stays in the wave's LDS queue ahead of the counter add that reports the row to the summing wave.
+// one unit's f32 term: into the lane's partial sum (default order) or, REF, into the row's strip at the block's index (sa[r] = LDS byte address of row r's
+// strip). A DS store: it stays in the wave's LDS queue ahead of the counter add that reports the row to the summing wave.
+// uc = the unit's index CLAMPED to the row's last unit: a lane beyond the row's end (ok == false) holds the clamped re-read of the last unit and has computed
+// exactly that unit's term, so in REF it stores unconditionally (the same value to the same word: no branch around every store); default order: adds 0
 template <bool REF, int R>
-__device__ __forceinline__ void fq_emit_term(float (&acc)[R], const unsigned * sa, int r, int u, bool ok, float v) {
-    if constexpr (REF) { if (ok) asm volatile("ds_write_b32 %0, %1" :: "v"(sa[r] + 4u * (unsigned) u), "v"(v) : "memory"); }
+__device__ __forceinline__ void fq_emit_term(float (&acc)[R], const unsigned * sa, int r, int uc, bool ok, float v) {
+    // (an LDS-address-space store: a ds_write the compiler may schedule among the dots, never a flat store -- a flat access would leave the LDS queue's order)
+    if constexpr (REF) *(__attribute__((address_space(3))) float *)(uintptr_t)(sa[r] + 4u * (unsigned) uc) = v;
     else acc[r] += ok ? v : 0.0f;
 }
 // s + row[0] + row[1] + ... + row[n - 1], strictly in this order (-ffp-contract=off, no reassociation). row: LDS, 16-byte aligned. The next 16 terms are

@@ -82,7 +82,7 @@ __device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R]
     for (int i = 0; i < NPRE; ++i) {
         const int u = i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
+        for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, uc, ok, v); }
     }
 }
 template <int TYPE, int R, int UNROLL, bool REF = false>
@@ -123,7 +123,7 @@ __device__ __forceinline__ void rows_dot_from(const fq_wrow (&rows)[R], int unit
         for (int i = 0; i < UNROLL; ++i) {
             const int u = u0 + i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, u, ok, v); }
+            for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, uc, ok, v); }
         }
     }
 }
@@ -610,6 +610,7 @@ struct fq_attn_out_args {
     const unsigned * epoch_word;    // this launch's tag (incremented by the preceding k_gemv_ln launch, never 0)
     unsigned * err;                 // set to 1 if a sweep gave up
     int n_attn, n_mv, heads_per_wg, attn_lds_group;
+    int ref_debug;                  // tuning aid of the reference-order form (FQ_REF_DBG; results are then garbage): 2 / 4 = no Wdown / Wo chain
 };
 
 // xpub.gran != nullptr: the new residual values are ALSO published as granules for the LayerNorm phase of the same launch
@@ -766,7 +767,7 @@ __device__ __forceinline__ void ref_count(unsigned addr) { if ((threadIdx.x & 63
 // wg = index among the mat-vec workgroups; gran != nullptr: the attention image arrives through the granules of the same launch (k_attn_out_ref),
 // else it is in memory (k_gemv_out_ref)
 template <int TYPE>
-__device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, uint8_t * smem, const int wg, const unsigned long long * gran, const unsigned epoch, unsigned * err) {
+__device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, uint8_t * smem, const int wg, const unsigned long long * gran, const unsigned epoch, unsigned * err, const int dbgm = 0) {
     constexpr int ACT = act_of<TYPE>::value;
     static_assert(ACT == FQ_Q8_0 || ACT == FQ_Q8_1, "legacy formats");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x, ncw = (nt >> 6) - 1;      // ncw consumer waves + the summing wave
@@ -775,7 +776,7 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
     uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
     uint8_t * ctlp    = img_att + fq_act_col_bytes(ACT, E);
     float   * strip   = (float *)(ctlp + 16);
-    const unsigned ctl = (unsigned)(uintptr_t) ctlp, DCNT_A = ctl, DCNT_B = ctl + 4, OCNT = ctl + 8;      // consumer waves done with: the pre-issued Wdown columns, all of Wdown, Wo
+    const unsigned ctl = (unsigned)(uintptr_t) ctlp, DCNT_A = ctl, DCNT_B = ctl + 4, OCNT = ctl + 8, SWEPT = ctl + 12;      // consumer waves done with: the pre-issued Wdown columns, all of Wdown, Wo, their share of the attention image
     constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
     const int units_d = (int)(FF / 32), units_o = (int)(E / 32);
     const fq_out_ref_geom sg = fq_out_ref_strip(units_d, units_o);
@@ -825,22 +826,25 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
         ref_count(DCNT_B);
     } else {
         ref_wait(DCNT_A, (unsigned) ncw, err);
-        sd = fq_ref_chain(srow_strip, n_pre, sd);
+        if (!(dbgm & 2)) sd = fq_ref_chain(srow_strip, n_pre, sd);
         ref_wait(DCNT_B, (unsigned) ncw, err);
-        sd = fq_ref_chain(srow_strip + n_pre, units_d - n_pre, sd);
+        if (!(dbgm & 2)) sd = fq_ref_chain(srow_strip + n_pre, units_d - n_pre, sd);
     }
-    if (gran) {
-        // the attention output (k_attn_out's sweep): every wave re-reads its share of the granules until all of them carry this launch's tag
+    if (gran && !summing) {
+        // the attention output (k_attn_out's sweep) by the consumer waves: each re-reads its share of the granules until all of them carry this launch's tag.
+        // No workgroup barrier behind it: the summing wave is still adding Wdown's terms and must not hold the consumers up -- they count themselves in
+        // (the counter add follows the image stores in the wave's LDS queue) and go on when all have
         const int64_t nwords = (E >> 2) + 2 * (E >> 5);
         unsigned * dstw = (unsigned *) img_att;
         constexpr int NG = 3;
-        for (int64_t base = 0; base < nwords; base += (int64_t) NG * nt) {
+        const int ntc = nt - 64;                                         // consumer threads: tid < ntc
+        for (int64_t base = 0; base < nwords; base += (int64_t) NG * ntc) {
             unsigned v[NG];
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
                 for (int k = 0; k < NG; ++k) {
-                    const int64_t i = base + (int64_t) k * nt + tid;
+                    const int64_t i = base + (int64_t) k * ntc + tid;
                     const unsigned long long x = __hip_atomic_load(gran + (i < nwords ? i : nwords - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v[k] = (unsigned) x; ok = ok && (unsigned)(x >> 32) == epoch;
                 }
@@ -849,9 +853,13 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
                 __builtin_amdgcn_s_sleep(4);
             }
 #pragma unroll
-            for (int k = 0; k < NG; ++k) { const int64_t i = base + (int64_t) k * nt + tid; if (i < nwords) dstw[i] = v[k]; }
+            for (int k = 0; k < NG; ++k) {
+                const int64_t i = base + (int64_t) k * ntc + tid;
+                if (i < nwords) asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(uintptr_t)(dstw + i)), "v"(v[k]) : "memory");
+            }
         }
-        __syncthreads();
+        ref_count(SWEPT);
+        ref_wait(SWEPT, (unsigned) ncw, err);
     }
     if (!summing) {
         rows_consume<TYPE, 2, NPO, true>(po, units_o, col_o, acc, sa_o);
@@ -859,7 +867,7 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
         ref_count(OCNT);
     } else {
         ref_wait(OCNT, (unsigned) ncw, err);
-        const float so = fq_ref_chain(srow_strip + sg.swd, units_o, 0.0f);
+        const float so = (dbgm & 4) ? 0.0f : fq_ref_chain(srow_strip + sg.swd, units_o, 0.0f);
         if (slive) g.dst[srow] = (sd + so) + sres;                                               // libfalcon.cpp:2399-2400
     }
 }
@@ -882,7 +890,7 @@ __global__ void __launch_bounds__(768) k_attn_out_ref(fq_attn_out_args a) {
         attn_decode_group<true, true>(a.at, h, live, gtid, smem + (size_t) grp * a.attn_lds_group, nullptr, fq_publish{ a.gran, epoch });
         return;
     }
-    gemv_out_ref_body<TYPE>(a.g, smem, (int) blockIdx.x - a.n_attn, a.gran, epoch, a.err);
+    gemv_out_ref_body<TYPE>(a.g, smem, (int) blockIdx.x - a.n_attn, a.gran, epoch, a.err, a.ref_debug);
 }
 // waves per workgroup of the reference-order output launches: the most (<= 12) whose strip fits the LDS next to the two images
 static int fq_out_ref_waves(int act, int64_t FF, int64_t E) {
@@ -923,6 +931,8 @@ bool fq_launch_attn_out_ref(const fq_gemv_out_args & g, const float * qkv, int H
     a.g = g;
     a.at = fq_attn_decode_args{ qkv, H, HKV, n_past_dev, rope_cs, k_cache, v_cache, exp_table, nullptr, const_cast<uint8_t *>(g.att_image), att_act_type, max_n_kv, rope_cur, nullptr, nullptr, nullptr };
     a.gran = gran; a.epoch_word = epoch_word; a.err = err; a.n_attn = n_attn; a.n_mv = n_mv; a.heads_per_wg = hpw; a.attn_lds_group = (int) lds_group;
+    static const int dbgm = getenv("FQ_REF_DBG") ? atoi(getenv("FQ_REF_DBG")) : 0;
+    a.ref_debug = dbgm;
     const int grid = n_attn + n_mv;
 #define FQ_CASE(T) case T: { static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
         FQ_LAUNCH_PROF((k_attn_out_ref<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a); } break;

@@ -308,11 +308,11 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
             const int myg = gl + (two ? half : 0);
             const bool st = two || half == 0;
             const int row = 32 * myg + j, rc = row < T ? row : T - 1;
-            float v = fq_ref_chain(strip + (size_t)(rc & SM) * SW, nblkE, 0.0f);      // ggml.c:2594-2609: sumf = 0; sumf += term_i, i ascending
+            float v = (a.debug_mode & 128) ? 0.0f : fq_ref_chain(strip + (size_t)(rc & SM) * SW, nblkE, 0.0f);      // ggml.c:2594-2609: sumf = 0; sumf += term_i, i ascending
             if (myg >= gA) {
                 if (st && row < T) a.qkv_dst[sc.qg0 + (row - nA2)] = v;
             }
-            {
+            if (gl < gA) {                                                 // (wave-uniform: at least one of the two groups is a Wup group)
                 const int g = sc.ug0 + (myg < gA ? myg : 0);               // block index in the FF-long image
                 v = h2f_bits(a.gelu_tab[f2h_bits(v)]);                     // ggml.c:3477-3484
                 const float amax = reduce32(fabsf(v), op_max());
