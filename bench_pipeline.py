@@ -156,29 +156,6 @@ class PipelineRunner:
 
 
 # ------------------------------------------------------------------------------------------------ GPU backend
-class HipEngine:
-    def __init__(self, g, model, n_streams, n_ctx, torch, device):
-        self.g, self.L, self.model, self.torch = g, g.load(), model, torch
-        E = model.hp["n_embd"]
-        self.ctx = [model.ctx] + [model.new_context(n_ctx) for _ in range(n_streams - 1)]
-        z = dict(device=device)
-        self.hidden_in = [torch.zeros(E, dtype=torch.float32, **z) for _ in range(n_streams)]
-        self.hidden_out = [torch.zeros(E, dtype=torch.float32, **z) for _ in range(n_streams)]
-        self.tok_in = [torch.zeros(1, dtype=torch.int32, **z) for _ in range(n_streams)]
-        self.tok_out = [torch.zeros(1, dtype=torch.int32, **z) for _ in range(n_streams)]
-
-    def set_initial_tokens(self, toks):
-        for s, t in enumerate(toks):
-            self.tok_in[s].fill_(int(t))
-
-    def step(self, s, n_past):
-        self.L.falcon_hip_stage_step(self.ctx[s], self.tok_in[s].data_ptr(), self.hidden_in[s].data_ptr(), n_past,
-                                     self.hidden_out[s].data_ptr(), self.tok_out[s].data_ptr())
-
-    def feed_back_token(self, s):
-        self.tok_in[s].copy_(self.tok_out[s], non_blocking=True)
-
-
 class TorchComm:
     """torch.distributed P2P (backend nccl = RCCL on ROCm, or gloo on CPU) on the engine's buffers; one grouped
     batch_isend_irecv per slot"""
@@ -197,37 +174,6 @@ class TorchComm:
     def finish(self, works):
         for w in works:                  # nccl: the current stream waits (not the host); gloo: the host waits
             w.wait()
-
-    def exchange(self, sends, recvs):
-        self.finish(self.post(sends, recvs))
-
-
-class HostStagedComm:
-    """debug transport (FALCON_PIPE_DEBUG_SHARED_GPU=1): the same exchange through host buffers and gloo, so that the
-    whole multi-process path (partition, schedule, stage API, stream ordering) can be exercised with every rank on ONE GPU
-    (RCCL refuses two ranks on one device)"""
-
-    def __init__(self, dist, engine, torch):
-        self.dist, self.e, self.torch = dist, engine, torch
-
-    def post(self, sends, recvs):
-        works, pend = [], []
-        for kind, s, peer in sends:
-            t = (self.e.tok_out[s] if kind == "token" else self.e.hidden_out[s]).cpu()
-            works.append(self.dist.isend(t, peer))
-        for kind, s, peer in recvs:
-            dst = self.e.tok_in[s] if kind == "token" else self.e.hidden_in[s]
-            buf = self.torch.empty(dst.shape, dtype=dst.dtype)
-            works.append(self.dist.irecv(buf, peer))
-            pend.append((dst, buf))
-        return works, pend
-
-    def finish(self, posted):
-        works, pend = posted
-        for w in works:
-            w.wait()
-        for dst, buf in pend:
-            dst.copy_(buf)
 
     def exchange(self, sends, recvs):
         self.finish(self.post(sends, recvs))
@@ -307,12 +253,26 @@ def run_cpp(a, rank, world, local, hp, wtype, model_name, quant_name, dist, torc
     weights = synth.make_model_fast(hp, wtype, seed=1234, layers=range(lb, le))
     model = g.FalconModel(weights, n_ctx=8, n_batch=1, layer_begin=lb, layer_end=le)
     del weights
-    uid = None
-    if world > 1:
-        box = [g.Pipeline.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)                   # 128 bytes over the launcher's (gloo) store
-        uid = box[0]
-    pipe = g.Pipeline(model, rank, world, groups, batch, n_ctx, unique_id=uid)
+    def make_pipe():
+        uid = None
+        if world > 1:
+            box = [g.Pipeline.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)               # 128 bytes over the launcher's (gloo) store
+            uid = box[0]
+        return g.Pipeline(model, rank, world, groups, batch, n_ctx, unique_id=uid)
+    try:
+        pipe = make_pipe()
+    except RuntimeError:
+        # the device-to-device fall-back (ipc) gives itself up on EVERY rank together when one rank cannot export / open a mailbox (csrc/falcon_pipeline.hip):
+        # the job goes on with the host-staged form, under a fresh id
+        if world > 1 and os.environ.get("FALCON_PIPE_TRANSPORT") == "ipc":
+            os.environ["FALCON_PIPE_TRANSPORT"] = "shm"
+            run_cpp.ipc_refused = True
+            if rank == 0:
+                sys.stderr.write("bench_pipeline: the device-to-device (ipc) transport is not available between these ranks: host-staged transport (shm)\n")
+            pipe = make_pipe()
+        else:
+            raise
     rccl_ranks = int(L.falcon_hip_pipeline_rccl_ranks(pipe.p))      # ncclCommCount of the communicator the hand-offs use
     run_cpp.transport = pipe.transport()
     t_setup = time.time() - t0
@@ -354,8 +314,6 @@ def main(a, rank, world, local):
     import ggllm_cpp_amd as g
     from ggllm_cpp_amd import synth
 
-    if os.environ.get("FALCON_PIPE_TORCH") == "1" or os.environ.get("FALCON_PIPE_DEBUG_SHARED_GPU") == "1":
-        return main_torch(a, rank, world, local)                 # the Python driver over torch.distributed P2P (kept for A/B and the shared-GPU debug transport)
     tname = {v: k for k, v in g.TYPE_NAME.items()}
     wtype = tname[a.quant if a.quant in tname else a.quant.replace("_k", "_K")]
     hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B, "tiny": synth.HP_TINY_MQA}[a.model])
@@ -371,14 +329,19 @@ def main(a, rank, world, local):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side control only (id hand-out, barrier, max over ranks); the data path is RCCL inside libggml_hip.so
     transport_note = None
-    if world > 1 and os.environ.get("FALCON_PIPE_TRANSPORT") != "shm":
+    forced = os.environ.get("FALCON_PIPE_TRANSPORT")              # shm / ipc forced by the caller (the one-GPU boxes' tests): not a fall-back
+    fallback = False
+    if world > 1 and forced not in ("shm", "ipc"):
         ok, why = rccl_preflight(g, dist, torch, rank, world, local)
         if not ok:
-            os.environ["FALCON_PIPE_TRANSPORT"] = "shm"
-            transport_note = ("RCCL pre-flight failed (" + why + "): the job runs with the host-staged transport between the ranks (FALCON_PIPE_TRANSPORT=shm), "
-                              "same ranks, schedule and stage code")
+            # LOUD: a multi-GPU number that never touched RCCL must not look like one that did. First choice: device-to-device copies into the peer's
+            # IPC-exported mailboxes (over xGMI between two GPUs); if a rank cannot export / open them, host shared memory.
+            fallback = True
+            os.environ["FALCON_PIPE_TRANSPORT"] = "ipc"
+            transport_note = ("RCCL pre-flight FAILED (" + why + "): the hand-offs do NOT run over RCCL in this job -- FALL-BACK to device-to-device copies into the "
+                              "peer's IPC-exported mailboxes (FALCON_PIPE_TRANSPORT=ipc; host shared memory if a rank cannot open them), same ranks, schedule and stage code")
             if rank == 0:
-                sys.stderr.write("bench_pipeline: " + transport_note + "\n")
+                sys.stderr.write("bench_pipeline: WARNING: " + transport_note + "\n")
     batch = max(1, min(int(getattr(a, "pipe_batch", 4)), 256))
     groups = max(2 * world, 2) if world > 1 else max(1, getattr(a, "streams", 2))
     n_ctx = min(a.n_ctx, 512)
@@ -387,12 +350,15 @@ def main(a, rank, world, local):
     tok_s, wbytes, blocks, t_setup, dt = run_cpp(a, rank, world, local, hp, wtype, a.model, a.quant, dist, torch, groups, batch, n_ctx, a.steps, a.warmup)
     rccl_ranks = getattr(run_cpp, "rccl_ranks", None)
     transport = getattr(run_cpp, "transport", None)
-    shm = os.environ.get("FALCON_PIPE_TRANSPORT") == "shm"       # ranks on one node exchanging through host shared memory (the one-GPU boxes: RCCL refuses two ranks per device)
+    env_tr = os.environ.get("FALCON_PIPE_TRANSPORT")
+    shm = env_tr in ("shm", "ipc")                               # ranks on one node exchanging through mailboxes (host shared memory, or the peer's device memory)
     if world > 1 and not shm and rccl_ranks != world:
         raise SystemExit(f"bench_pipeline: RCCL communicator has {rccl_ranks} ranks, launched {world}")
-    if world > 1 and shm and not str(transport).startswith("shm"):
-        raise SystemExit(f"bench_pipeline: FALCON_PIPE_TRANSPORT=shm but the pipeline reports transport {transport!r}")
-    extra = {"rccl_ranks": rccl_ranks, "transport": transport, "transport_note": transport_note,
+    if world > 1 and shm and not str(transport).startswith(env_tr):
+        raise SystemExit(f"bench_pipeline: FALCON_PIPE_TRANSPORT={env_tr} but the pipeline reports transport {transport!r}")
+    if getattr(run_cpp, "ipc_refused", False) and transport_note:
+        transport_note += " -- the ipc transport was refused as well: host shared memory"
+    extra = {"rccl_ranks": rccl_ranks, "transport": transport, "transport_fallback": bool(fallback), "transport_note": transport_note,
              "ranks_share_device_0": os.environ.get("FALCON_PIPE_SAME_DEVICE") == "1"}
 
     def one_gpu_same_workload(hp1, wt1, mname, qname, steps, warmup):
@@ -410,6 +376,8 @@ def main(a, rank, world, local):
         return val
     if world > 1 and not a.layers:
         extra["same_workload_1gpu_tok_s"] = one_gpu_same_workload(hp, wtype, a.model, a.quant, max(8, a.steps // 2), max(2, a.warmup // 2))
+        # THE scaling figure of this line: the same streams on one GPU of this job, measured in this job (`value` of the --gpus 1 line is ONE stream: another workload)
+        extra["scaling_vs_1gpu"] = (tok_s / extra["same_workload_1gpu_tok_s"]) if extra["same_workload_1gpu_tok_s"] else None
     if not getattr(a, "no_north_star", False) and world > 1 and a.model == "7b" and not a.layers:
         # the north-star configuration next to the headline line: Falcon-40B Q4_K, all 60 blocks, over the same GPUs
         hp40 = dict(synth.HP_40B)
@@ -429,7 +397,7 @@ def main(a, rank, world, local):
             try:
                 from bench import cpu_baseline
                 wall = synth.make_model_fast(hp, wtype, seed=1234)
-                cpu = cpu_baseline(wall, hp, wbytes, 32, getattr(a, "cpu_tokens", 12), synth.tokens(40, hp["n_vocab"], seed=42))
+                cpu = cpu_baseline(wall, hp, wbytes, 32, getattr(a, "cpu_tokens", 32), synth.tokens(40, hp["n_vocab"], seed=42))
                 cpu["sample"] += " -- ONE decode stream (the reference has no lock-step mode); same measurement as the --gpus 1 line's leg, with a 32-token prompt"
                 del wall
             except Exception as e:                                   # (never lose the line to the baseline leg)
@@ -443,8 +411,8 @@ def main(a, rank, world, local):
         b_tok = wbytes / batch + kv_bytes_per_token(hp, a.warmup + a.steps // 2)
         gbs = b_tok * tok_s / 1e9
         print(json.dumps({
-            "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
-                      else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
+            "metric": f"decode tokens/sec, Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPU(s), {groups * batch} lock-step decode streams in flight "
+                      f"(MULTI-STREAM; the --gpus 1 line times ONE stream -- scale with scaling_vs_1gpu = value / same_workload_1gpu_tok_s); % of the summed HBM roofline",
             "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
@@ -452,101 +420,13 @@ def main(a, rank, world, local):
                                    f"({blocks} blocks per stage, balanced by bytes incl. lm_head), {groups} groups x {batch} lock-step greedy decode streams "
                                    f"in flight (MULTI-STREAM: {S} sequences, one weight pass serves {batch} tokens -- NOT the single-stream workload of --gpus 1; "
                                    f"compare with same_workload_1gpu_tok_s, the same streams on one GPU), a step = one round (one token per stream); residual rows "
-                                   f"and sampled tokens by " + ("host shared memory between the ranks (FALCON_PIPE_TRANSPORT=shm)" if shm else "RCCL ncclSend/ncclRecv")
+                                   f"and sampled tokens by " + ({"shm": "host shared memory between the ranks (FALCON_PIPE_TRANSPORT=shm)",
+                                                                 "ipc": "device-to-device copies into the peer's IPC-exported mailboxes (FALCON_PIPE_TRANSPORT=ipc)"}[env_tr] if shm else "RCCL ncclSend/ncclRecv")
                                    + " (csrc/falcon_pipeline.hip)" + ("" if not a.layers else f" [TRUNCATED to {a.layers} blocks: not the benchmark config]"),
                        "streams": S, "groups": groups, "batch": batch, "weight_bytes_per_pass": wbytes, "n_past_timed": [a.warmup, a.warmup + a.steps]},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                          "traffic": None, "note": "whole-job view: (weight bytes / batch + KV bytes) per token x tokens/s over the summed peak of all GPUs"},
             "cpu_baseline": cpu, "setup_s": t_setup, **extra,
         }))
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def main_torch(a, rank, world, local):
-    import torch
-    import torch.distributed as dist
-    import ggllm_cpp_amd as g
-    from ggllm_cpp_amd import synth
-
-    tname = {v: k for k, v in g.TYPE_NAME.items()}
-    wtype = tname[a.quant if a.quant in tname else a.quant.replace("_k", "_K")]
-    hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B, "tiny": synth.HP_TINY_MQA}[a.model])
-    if a.layers:
-        hp["n_layer"] = a.layers
-    if not os.path.exists(g.LIB_PATH):
-        g.build()
-    shared = os.environ.get("FALCON_PIPE_DEBUG_SHARED_GPU") == "1"
-    if shared:
-        local = 0
-    torch.cuda.set_device(local)
-    g.init(local)
-    L = g.load()
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    parts = partition(hp["n_layer"], world, head_units(hp))
-    lb, le = parts[rank]
-    S = max(2 * world, 2) if world > 1 else getattr(a, "streams", 1)
-    n_ctx = min(a.n_ctx, 512)
-
-    t0 = time.time()
-    weights = synth.make_model_fast(hp, wtype, seed=1234, layers=range(lb, le))
-    model = g.FalconModel(weights, n_ctx=n_ctx, n_batch=1, layer_begin=lb, layer_end=le)
-    del weights
-    t_setup = time.time() - t0
-
-    ext = torch.cuda.ExternalStream(L.ggml_hip_stream(), device=torch.device("cuda", local))
-    with torch.cuda.stream(ext):                     # torch allocations / P2P ops are ordered with the library's kernels
-        engine = HipEngine(g, model, S, n_ctx, torch, torch.device("cuda", local))
-        comm = HostStagedComm(dist, engine, torch) if shared else TorchComm(dist, engine)
-        runner = PipelineRunner(rank, world, S, engine, comm)
-        engine.set_initial_tokens(synth.tokens(S, hp["n_vocab"], seed=42))
-        n_past = 0
-        wr = max(a.warmup, 1)
-        runner.run(wr, n_past)                       # warm-up rounds (also build the RCCL P2P channels)
-        n_past += wr
-        L.ggml_hip_synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        runner.run(a.steps, n_past)                  # K rounds = K * S tokens, including pipeline fill and drain
-        n_past += a.steps
-        L.ggml_hip_synchronize()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    red_dev = torch.device("cpu") if shared else torch.device("cuda", local)
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    wb_t = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(wb_t, op=dist.ReduceOp.SUM)
-    dt = float(dt_t.item())
-    if rank == 0:
-        tok_s = a.steps * S / dt
-        wbytes = float(wb_t.item())
-        from bench import kv_bytes_per_token, HBM_PEAK_GBS
-        b_tok = wbytes + kv_bytes_per_token(hp, n_past - a.steps // 2)
-        gbs = b_tok * tok_s / 1e9
-        print(json.dumps({
-            "metric": "decode tokens/sec (+ prefill tok/s), Falcon-7B Q4_0 @1 GPU; % HBM roofline" if a.model == "7b" and a.quant == "q4_0"
-                      else f"decode tokens/sec, Falcon-{a.model} {a.quant}",
-            "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8", "data": "synthetic (random-init blocks, seeds 1234+i; tokens mt(42))",
-            "config": {"workload": f"Falcon-{a.model.upper()} {a.quant.upper()} layer-pipelined over {world} GPUs "
-                                   f"({[e - b for b, e in parts]} blocks per stage, balanced by bytes incl. lm_head), {S} greedy decode streams in flight, "
-                                   f"a step = one round (one token per stream); hidden-state hand-off by RCCL send/recv",
-                       "streams": S, "weight_bytes_per_token": wbytes, "n_past_timed": [n_past - a.steps, n_past]},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
-                         "traffic": None, "note": "whole-job view: bytes per token x tokens/s over the summed peak of all GPUs"},
-            "cpu_baseline": None, "setup_s": t_setup,
-        }))
-    model.free()
     if world > 1:
         dist.destroy_process_group()

@@ -496,7 +496,8 @@ class Pipeline:
     def rccl_ranks(self):
         return load().falcon_hip_pipeline_rccl_ranks(self.p)
 
-    TRANSPORTS = {0: "none (one stage)", 1: "rccl", 2: "local (device copies in one process)", 3: "local over a one-rank RCCL communicator", 4: "shm (host shared memory between processes)"}
+    TRANSPORTS = {0: "none (one stage)", 1: "rccl", 2: "local (device copies in one process)", 3: "local over a one-rank RCCL communicator", 4: "shm (host shared memory between processes)",
+                  5: "ipc (device-to-device copies into the peer's IPC-exported mailboxes)"}
 
     def transport(self):
         return self.TRANSPORTS.get(load().falcon_hip_pipeline_transport(self.p), "?")

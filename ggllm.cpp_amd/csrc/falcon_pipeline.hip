@@ -133,15 +133,25 @@ struct falcon_hip_pipeline {
 // (FALCON_PIPE_SHM_TIMEOUT_S, default 300): a dead peer ends the job with a message instead of hanging it.
 struct shm_box { volatile uint32_t seq, ack; uint32_t pad[14]; };
 static_assert(sizeof(shm_box) == 64, "mailbox header");
-struct shm_header { volatile uint32_t ready, attached; uint32_t world, G, B, E; uint32_t pad[10]; };
+// The DEVICE-TO-DEVICE variant (FALCON_PIPE_TRANSPORT=ipc, round 6): the same segment, mailboxes and { seq, ack } protocol, but a mailbox's payload lives in
+// the RECEIVING rank's device memory -- every rank exports one allocation by hipIpcGetMemHandle (the handle table sits behind the header), opens its
+// successor's, and a send is ONE device-to-device copy into the peer's mailbox (hipMemcpyAsync over xGMI between two GPUs; an on-device copy when the ranks
+// share GPU 0); a receive copies out of this rank's own mailbox. Nothing is staged through the host. The fall-back of a job whose RCCL pre-flight fails,
+// tried before the host-staged form.
+struct shm_header { volatile uint32_t ready, attached; uint32_t world, G, B, E; volatile uint32_t ipc_ok, ipc_bad; uint32_t pad[8]; };
 static_assert(sizeof(shm_header) == 64, "segment header");
 struct shm_transport {
     int fd = -1; uint8_t * base = nullptr; size_t bytes = 0; char name[64] = {0}; bool owner = false;
+    bool ipc = false; size_t table_bytes = 0;                       // ipc: world x 64-byte hipIpcMemHandle_t behind the header
+    uint8_t * dev_box = nullptr, * peer_box = nullptr;              // ipc: this rank's device mailboxes [G][hid | tok]; the successor's, opened through its handle
+    size_t dev_stride = 0; bool ipc_failed = false;
     size_t hid_bytes = 0, tok_bytes = 0, box_stride = 0;            // payload sizes (rounded to 64), bytes per (rank, group)
     void * stage_out = nullptr, * stage_in = nullptr;               // pinned staging rows
     std::vector<uint32_t> sent_h, sent_t, got_h, got_t;             // per group: messages this rank has sent to / taken from a mailbox
     double timeout_s = 300.0;
-    shm_box * box(int rank, int G, int g, bool token) const { return (shm_box *)(base + 64 + ((size_t) rank * G + g) * box_stride + (token ? 64 + hid_bytes : 0)); }
+    size_t tok_hdr_off = 0;                                         // offset of a mailbox's token header behind its residual-row header
+    shm_box * box(int rank, int G, int g, bool token) const { return (shm_box *)(base + 64 + table_bytes + ((size_t) rank * G + g) * box_stride + (token ? tok_hdr_off : 0)); }
+    size_t dev_off(int g, bool token) const { return (size_t) g * dev_stride + (token ? hid_bytes : 0); }
 };
 
 namespace {
@@ -201,20 +211,29 @@ bool shm_wait(const shm_transport * t, const volatile uint32_t * word, uint32_t 
 uint64_t fnv64(const void * data, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= ((const uint8_t *) data)[i]; h *= 1099511628211ull; } return h; }
 
 // every rank of the job calls this with the same unique id: rank 0 creates the segment, the others attach; returns when all have
-bool shm_attach(falcon_hip_pipeline * p, const void * unique_id) {
+bool shm_attach(falcon_hip_pipeline * p, const void * unique_id, bool ipc) {
     shm_transport * t = new shm_transport();
     if (const char * e = getenv("FALCON_PIPE_SHM_TIMEOUT_S")) t->timeout_s = atof(e) > 0 ? atof(e) : t->timeout_s;
     const size_t E = (size_t) p->hp.n_embd, G = (size_t) p->G, B = (size_t) p->B;
     t->hid_bytes = (B * E * 4 + 63) & ~(size_t) 63; t->tok_bytes = (B * 4 + 63) & ~(size_t) 63;
-    t->box_stride = 64 + t->hid_bytes + 64 + t->tok_bytes;
-    t->bytes = 64 + (size_t) p->world * G * t->box_stride;
+    t->ipc = ipc;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle table entry");
+    t->table_bytes = ipc ? (size_t) p->world * 64 : 0;
+    t->tok_hdr_off = ipc ? 64 : 64 + t->hid_bytes;                           // (ipc: the two { seq, ack } headers only; the payloads are in device memory)
+    t->box_stride = t->tok_hdr_off + 64 + (ipc ? 0 : t->tok_bytes);
+    t->dev_stride = t->hid_bytes + t->tok_bytes;
+    t->bytes = 64 + t->table_bytes + (size_t) p->world * G * t->box_stride;
     snprintf(t->name, sizeof(t->name), "/falcon_pipe_%016llx", (unsigned long long) fnv64(unique_id, FALCON_HIP_PIPELINE_ID_BYTES));
     t->owner = p->rank == 0;
     const double t0 = now_s();
     if (t->owner) {
         shm_unlink(t->name);                                        // (a stale segment of a job that died under this very id)
         t->fd = shm_open(t->name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (t->fd < 0 || ftruncate(t->fd, (off_t) t->bytes) != 0) { fprintf(stderr, "falcon-hip: pipeline: shm_open / ftruncate(%s, %zu): %s\n", t->name, t->bytes, strerror(errno)); delete t; return false; }
+        if (t->fd < 0 || ftruncate(t->fd, (off_t) t->bytes) != 0) {
+            fprintf(stderr, "falcon-hip: pipeline: shm_open / ftruncate(%s, %zu): %s\n", t->name, t->bytes, strerror(errno));
+            if (t->fd >= 0) { close(t->fd); shm_unlink(t->name); }
+            delete t; return false;
+        }
     } else {
         for (;;) {
             t->fd = shm_open(t->name, O_RDWR, 0600);
@@ -238,11 +257,43 @@ bool shm_attach(falcon_hip_pipeline * p, const void * unique_id) {
                 p->rank, h->world, h->G, h->B, h->E, p->world, G, B, E);
         munmap(t->base, t->bytes); close(t->fd); delete t; return false;
     }
+    if (ipc) {
+        // this rank's device mailboxes, exported BEFORE it counts itself in: when every rank has attached, every handle is in the table
+        hipIpcMemHandle_t hnd;
+        bool ok = hipMalloc((void **) &t->dev_box, G * t->dev_stride) == hipSuccess && hipMemset(t->dev_box, 0, G * t->dev_stride) == hipSuccess &&
+                  hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(&hnd, t->dev_box) == hipSuccess;
+        if (ok) memcpy(t->base + 64 + (size_t) p->rank * 64, &hnd, 64);
+        else { (void) hipGetLastError(); t->ipc_failed = true; }
+    }
     __atomic_add_fetch(&h->attached, 1u, __ATOMIC_ACQ_REL);
-    if (!shm_wait(t, &h->attached, (uint32_t) p->world, "every rank to attach", p->rank, -1)) { munmap(t->base, t->bytes); close(t->fd); if (t->owner) shm_unlink(t->name); delete t; return false; }
+    if (!shm_wait(t, &h->attached, (uint32_t) p->world, "every rank to attach", p->rank, -1)) { if (t->dev_box) (void) hipFree(t->dev_box); munmap(t->base, t->bytes); close(t->fd); if (t->owner) shm_unlink(t->name); delete t; return false; }
+    if (ipc) {
+        // open the successor's mailboxes (the only rank this one sends to: stage r -> r + 1, the last stage's tokens -> stage 0); every rank reports, and ALL
+        // of them give the transport up together if one could not (the caller falls back to the host-staged form as one job)
+        const int next = (p->rank + 1) % p->world;
+        bool ok = !t->ipc_failed;
+        if (ok) {
+            hipIpcMemHandle_t hnd;
+            memcpy(&hnd, t->base + 64 + (size_t) next * 64, 64);
+            const hipError_t e = hipIpcOpenMemHandle((void **) &t->peer_box, hnd, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { fprintf(stderr, "falcon-hip: pipeline (ipc transport): rank %d could not open rank %d's mailboxes: %s\n", p->rank, next, hipGetErrorString(e)); (void) hipGetLastError(); t->peer_box = nullptr; ok = false; }
+        }
+        __atomic_add_fetch(ok ? &h->ipc_ok : &h->ipc_bad, 1u, __ATOMIC_ACQ_REL);
+        const double t1 = now_s();
+        while (__atomic_load_n(&h->ipc_ok, __ATOMIC_ACQUIRE) + __atomic_load_n(&h->ipc_bad, __ATOMIC_ACQUIRE) < (uint32_t) p->world && now_s() - t1 < t->timeout_s) usleep(200);
+        if (__atomic_load_n(&h->ipc_ok, __ATOMIC_ACQUIRE) != (uint32_t) p->world) {
+            if (p->rank == 0) fprintf(stderr, "falcon-hip: pipeline (ipc transport): %u of %d ranks could not export / open device mailboxes -- the transport is not available to this job\n",
+                                      (unsigned) __atomic_load_n(&h->ipc_bad, __ATOMIC_ACQUIRE), p->world);
+            if (t->peer_box) (void) hipIpcCloseMemHandle(t->peer_box);
+            if (t->dev_box) (void) hipFree(t->dev_box);
+            munmap(t->base, t->bytes); close(t->fd); if (t->owner) shm_unlink(t->name); delete t; return false;
+        }
+    }
     if (t->owner) { shm_unlink(t->name); t->name[0] = 0; }           // every rank holds its mapping now: the name can go, and a job that dies later leaves nothing in /dev/shm
-    HIP_CHECK(hipHostMalloc(&t->stage_out, t->hid_bytes, hipHostMallocDefault));
-    HIP_CHECK(hipHostMalloc(&t->stage_in, t->hid_bytes, hipHostMallocDefault));
+    if (!ipc) {
+        HIP_CHECK(hipHostMalloc(&t->stage_out, t->hid_bytes, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(&t->stage_in, t->hid_bytes, hipHostMallocDefault));
+    }
     t->sent_h.assign(G, 0); t->sent_t.assign(G, 0); t->got_h.assign(G, 0); t->got_t.assign(G, 0);
     p->shm = t;
     return true;
@@ -252,6 +303,8 @@ void shm_detach(falcon_hip_pipeline * p) {
     if (!t) return;
     if (t->stage_out) HIP_CHECK(hipHostFree(t->stage_out));
     if (t->stage_in) HIP_CHECK(hipHostFree(t->stage_in));
+    if (t->peer_box) (void) hipIpcCloseMemHandle(t->peer_box);
+    if (t->dev_box) (void) hipFree(t->dev_box);
     munmap(t->base, t->bytes); close(t->fd);
     if (t->owner && t->name[0]) shm_unlink(t->name);                // (normally gone since every rank attached)
     delete t; p->shm = nullptr;
@@ -267,6 +320,14 @@ bool exchange_shm(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st) 
         const bool tok = o.kind == OP_SEND_TOKEN; const size_t g = (size_t) o.group, n = tok ? nt : nh;
         shm_box * b = t->box(o.peer, p->G, o.group, tok);
         uint32_t & cnt = tok ? t->sent_t[g] : t->sent_h[g];
+        if (t->ipc) {
+            // device to device: wait until the receiver has taken the mailbox's previous message, copy straight into ITS device memory, publish
+            if (!shm_wait(t, &b->ack, cnt, tok ? "the receiver to take the previous tokens" : "the receiver to take the previous residual rows", p->rank, o.group)) return false;
+            HIP_CHECK(hipMemcpyAsync(t->peer_box + t->dev_off(o.group, tok), tok ? (const void *) p->tok_out[g] : (const void *) p->hidden_out[g], n, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            __atomic_store_n(&b->seq, ++cnt, __ATOMIC_RELEASE);
+            continue;
+        }
         HIP_CHECK(hipMemcpyAsync(t->stage_out, tok ? (const void *) p->tok_out[g] : (const void *) p->hidden_out[g], n, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (!shm_wait(t, &b->ack, cnt, tok ? "the receiver to take the previous tokens" : "the receiver to take the previous residual rows", p->rank, o.group)) return false;
@@ -280,6 +341,12 @@ bool exchange_shm(falcon_hip_pipeline * p, const pipe_slot & s, hipStream_t st) 
         shm_box * b = t->box(p->rank, p->G, o.group, tok);
         uint32_t & cnt = tok ? t->got_t[g] : t->got_h[g];
         if (!shm_wait(t, &b->seq, cnt + 1, tok ? "the sampled tokens" : "the residual rows", p->rank, o.group)) return false;
+        if (t->ipc) {
+            HIP_CHECK(hipMemcpyAsync(tok ? (void *) p->tok_in[g] : (void *) p->hidden_in[g], t->dev_box + t->dev_off(o.group, tok), n, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            __atomic_store_n(&b->ack, ++cnt, __ATOMIC_RELEASE);
+            continue;
+        }
         memcpy(t->stage_in, (const uint8_t *) b + 64, n);
         HIP_CHECK(hipMemcpyAsync(tok ? (void *) p->tok_in[g] : (void *) p->hidden_in[g], t->stage_in, n, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -327,7 +394,8 @@ falcon_hip_pipeline * create(falcon_hip_model * m, int rank, int world, int n_gr
 
 extern "C" {
 
-static bool shm_transport_selected() { const char * e = getenv("FALCON_PIPE_TRANSPORT"); return e && !strcmp(e, "shm"); }
+static bool ipc_transport_selected() { const char * e = getenv("FALCON_PIPE_TRANSPORT"); return e && !strcmp(e, "ipc"); }
+static bool shm_transport_selected() { const char * e = getenv("FALCON_PIPE_TRANSPORT"); return e && (!strcmp(e, "shm") || !strcmp(e, "ipc")); }      // (both ride on the segment)
 
 int falcon_hip_pipeline_unique_id(void * id_out) {
     rccl_api * R = fq_rccl();
@@ -349,7 +417,7 @@ falcon_hip_pipeline * falcon_hip_pipeline_create(falcon_hip_model * m, int rank,
     falcon_hip_pipeline * p = create(m, rank, world, n_groups, batch, n_ctx);
     if (!p || world == 1) return p;
     if (shm_transport_selected()) {                                 // ranks = processes of one node, hand-offs through host shared memory
-        if (!unique_id || !shm_attach(p, unique_id)) { fprintf(stderr, "falcon-hip: pipeline: the shm transport could not be set up (rank %d of %d)\n", rank, world); falcon_hip_pipeline_free(p); return nullptr; }
+        if (!unique_id || !shm_attach(p, unique_id, ipc_transport_selected())) { fprintf(stderr, "falcon-hip: pipeline: the %s transport could not be set up (rank %d of %d)\n", ipc_transport_selected() ? "ipc" : "shm", rank, world); falcon_hip_pipeline_free(p); return nullptr; }
         return p;
     }
     rccl_api * R = fq_rccl();
@@ -442,11 +510,12 @@ int falcon_hip_rccl_selftest(int rank, int world, const void * unique_id, int de
 }
 
 // how this rank's hand-offs travel: 0 = nowhere (one stage), 1 = RCCL send / recv, 2 = device copies in one process (local), 3 = the local job
-// over a one-rank RCCL communicator (loop-back), 4 = host shared memory between processes (FALCON_PIPE_TRANSPORT=shm)
+// over a one-rank RCCL communicator (loop-back), 4 = host shared memory between processes (FALCON_PIPE_TRANSPORT=shm), 5 = device-to-device copies into
+// the peer's IPC-exported mailboxes (FALCON_PIPE_TRANSPORT=ipc)
 int falcon_hip_pipeline_transport(falcon_hip_pipeline * p) {
     if (!p) return -1;
     if (p->local) return p->loop ? 3 : 2;
-    if (p->shm) return 4;
+    if (p->shm) return p->shm->ipc ? 5 : 4;
     return p->comm ? 1 : 0;
 }
 

@@ -35,11 +35,15 @@ def _single_process_tokens(hp, wtype, groups, batch, n_ctx, warmup, steps):
     return hist
 
 
-@pytest.mark.parametrize("world,batch,quant", [(2, 2, "q4_0"), (3, 2, "q4_0"), (2, 16, "q5_1"), (3, 1, "q4_0")])
-def test_bench_gpus_n_as_processes_on_one_gpu(tmp_path, world, batch, quant):
+# transport "ipc" (round 6): the same mailbox protocol with the payloads in the RECEIVING rank's device memory, exported by hipIpcGetMemHandle -- a send is one
+# device-to-device copy into the peer's mailbox (over xGMI between two GPUs; on-device here, every rank sharing GPU 0): the first fall-back of a job whose RCCL
+# pre-flight fails, ahead of the host-staged form
+@pytest.mark.parametrize("world,batch,quant,transport", [(2, 2, "q4_0", "shm"), (3, 2, "q4_0", "shm"), (2, 16, "q5_1", "shm"), (3, 1, "q4_0", "shm"),
+                                                         (2, 2, "q4_0", "ipc"), (3, 2, "q4_0", "ipc"), (2, 16, "q5_1", "ipc")])
+def test_bench_gpus_n_as_processes_on_one_gpu(tmp_path, world, batch, quant, transport):
     layers, steps, warmup = 5, 6, 2
     dump = str(tmp_path / "hist.npy")
-    env = dict(os.environ, FALCON_PIPE_TRANSPORT="shm", FALCON_PIPE_SAME_DEVICE="1", FALCON_PIPE_DUMP_HISTORY=dump, FALCON_PIPE_SHM_TIMEOUT_S="120",
+    env = dict(os.environ, FALCON_PIPE_TRANSPORT=transport, FALCON_PIPE_SAME_DEVICE="1", FALCON_PIPE_DUMP_HISTORY=dump, FALCON_PIPE_SHM_TIMEOUT_S="120",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -48,7 +52,9 @@ def test_bench_gpus_n_as_processes_on_one_gpu(tmp_path, world, batch, quant):
                        env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode("utf-8", "replace")[-3000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == world and line["transport"].startswith("shm") and line["ranks_share_device_0"] is True
+    assert line["n_gpus"] == world and line["transport"].startswith(transport) and line["ranks_share_device_0"] is True
+    assert line["transport_fallback"] is False                      # (the transport was asked for, not fallen back to)
+    assert f"over {world} GPU" in line["metric"] and "MULTI-STREAM" in line["metric"]
     assert line["config"]["groups"] == 2 * world and line["config"]["batch"] == batch and line["value"] > 0
     assert "MULTI-STREAM" in line["config"]["workload"]
     got = np.load(dump)
@@ -74,7 +80,7 @@ def test_a_rank_that_never_comes_ends_the_job_with_a_message(tmp_path):
     assert b"refused" in r.stdout and b"every rank to attach" in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
 
 
-def test_rccl_preflight_refusal_falls_back_to_the_host_staged_transport(tmp_path):
+def test_rccl_preflight_refusal_falls_back_loudly(tmp_path):
     """no transport forced: every rank on GPU 0 makes RCCL refuse ("Duplicate GPU detected") in the pre-flight child processes (falcon_hip_rccl_selftest), and the
     job must run on with the host-staged transport and say so in its line -- the insurance for the first multi-GPU node, where RCCL between these ranks runs for
     the first time: a refusal or a hang there costs a fall-back, not the SCALE run"""
@@ -86,7 +92,9 @@ def test_rccl_preflight_refusal_falls_back_to_the_host_staged_transport(tmp_path
                         "--pipe-batch", "2", "--no-north-star", "--no-cpu"], env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode("utf-8", "replace")[-3000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert line["transport"].startswith("shm") and "pre-flight failed" in line["transport_note"]
+    # loud: the line says the hand-offs did not run over RCCL, and which transport carried them (device-to-device mailboxes first, host shared memory behind them)
+    assert line["transport_fallback"] is True and "pre-flight FAILED" in line["transport_note"]
+    assert line["transport"].startswith(("ipc", "shm"))
     hp = dict(synth.HP_TINY_MQA); hp["n_layer"] = 4
     want = _single_process_tokens(hp, g.Q4_0, 4, 2, 512, 2, 4)
     assert np.array_equal(np.load(dump), want)
