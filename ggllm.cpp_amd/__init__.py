@@ -34,7 +34,7 @@ ggml_hip_add3 ggml_hip_rope_table_create ggml_hip_rope_kv_store ggml_hip_attenti
 EXPORTS_FALCON = """falcon_hip_model_create falcon_hip_model_free falcon_hip_model_set_tensor falcon_hip_model_weight_bytes
 falcon_hip_context_create falcon_hip_context_free falcon_hip_eval falcon_hip_eval_stage falcon_hip_stage_step falcon_hip_decode_greedy falcon_hip_eval_token falcon_hip_context_last_error falcon_hip_context_set_rope_n_ctx
 falcon_hip_get_logits falcon_hip_context_keep_hidden falcon_hip_get_hidden falcon_hip_context_use_graph
-falcon_hip_eval_debug_timings falcon_hip_context_set_fused falcon_hip_context_engine_active falcon_hip_engine_compiled falcon_hip_context_engine_debug falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
+falcon_hip_eval_debug_timings falcon_hip_context_set_fused falcon_hip_context_sync_error falcon_hip_model_load_ggcc falcon_hip_ggcc_scan falcon_hip_plan_stages falcon_hip_model_quantize falcon_hip_perplexity
 falcon_hip_vocab_load_ggcc falcon_hip_vocab_error falcon_hip_vocab_free falcon_hip_vocab_size falcon_hip_vocab_merges falcon_hip_tokenize
 falcon_hip_token_to_bytes falcon_hip_token_bos falcon_hip_token_eos
 falcon_hip_model_get_hparams falcon_hip_context_create_seqs falcon_hip_context_n_seq
@@ -47,7 +47,7 @@ def build(verbose=False):
     cmd = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-j", str(min(16, os.cpu_count() or 4))]
     if not verbose:
         cmd.insert(1, "-s")
-    subprocess.check_call(cmd + ["all", "check_engine"])            # (check_engine: the opt-in mode-4 source still compiles; linked only with ENGINE=1)
+    subprocess.check_call(cmd + ["all"])
     return LIB_PATH
 
 
@@ -118,7 +118,7 @@ def load():
         "falcon_hip_tokenize": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int]),
         "falcon_hip_token_to_bytes": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p)]),
         "falcon_hip_token_bos": (C.c_int32, []), "falcon_hip_token_eos": (C.c_int32, []),
-        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_context_engine_active": (C.c_int, [vp]), "falcon_hip_eval_debug_timings": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_engine_compiled": (C.c_int, []), "falcon_hip_context_engine_debug": (C.c_int, [vp, vp, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
+        "falcon_hip_context_use_graph": (None, [vp, C.c_int]), "falcon_hip_context_set_fused": (None, [vp, C.c_int]), "falcon_hip_eval_debug_timings": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]), "falcon_hip_context_sync_error": (C.c_int, [vp]),
         "falcon_hip_model_load_ggcc": (vp, [C.c_char_p, C.c_int, C.c_int, vp]), "falcon_hip_ggcc_scan": (C.c_int, [C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]),
         "falcon_hip_model_quantize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]),
         "falcon_hip_plan_stages": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
@@ -392,26 +392,8 @@ class FalconModel:
         return nll.value, n
 
     def set_fused(self, mode):
-        """0 = op list, 1 = three launches per block, 2 (True) = two (default), 3 = one launch per block, 4 = persistent engine, 5 = two launches, ring form"""
+        """0 = op list, 1 = three launches per block, 2 (True) = two (default), 3 = one launch per block, 5 = two launches, ring form forced (4, the removed persistent engine, selects 2)"""
         load().falcon_hip_context_set_fused(self.ctx, 2 if mode is True else int(mode))
-
-    def engine_active(self):
-        return bool(load().falcon_hip_context_engine_active(self.ctx))
-
-    def engine_debug(self):
-        """(failure records [k, 8], phase stamps of consumer 0 / the attention workgroups [256 workgroups, 4 blocks, 8 slots]) of the engine
-        (FALCON_HIP_ENGINE_DEBUG=1); also sets engine_gstamps (the gatherer wave's stamps) and engine_counters [256, 16]
-        (kernels.h FQ_ENG_DBG_*: loader total / blocked / report-wait cycles, refills, bytes; consumer 0: wait-landed, dot cycles, rows,
-        waits for statistics / image / GELU image / attention image, gather; gatherer: gather, epilogues, wait for statistics)"""
-        S, NS = 4096, 256 * 4 * 8
-        buf = np.zeros(S + 2 * NS + 256 * 16, np.int64)
-        n = load().falcon_hip_context_engine_debug(self.ctx, buf.ctypes.data, buf.size)
-        if n == 0:
-            return None, None
-        k = int(min(buf[0], 500))
-        self.engine_gstamps = buf[S + NS:S + 2 * NS].reshape(256, 4, 8)
-        self.engine_counters = buf[S + 2 * NS:].reshape(256, 16)
-        return buf[16:16 + 8 * k].reshape(k, 8), buf[S:S + NS].reshape(256, 4, 8)
 
     def sync_error(self):
         return load().falcon_hip_context_sync_error(self.ctx)

@@ -33,7 +33,7 @@ struct falcon_hip_model {
     std::vector<layer_weights> layers;        // local layers only
     std::vector<void *> allocs;
     // Weight ARENA: every matrix of the stage is carved out of a few very large allocations instead of one hipMalloc per
-    // tensor. Measured on MI355X (Falcon-7B Q4_0, the persistent engine's loader alone, scripts/gpu_engine_debug.py): 131
+    // tensor. Measured on MI355X (Falcon-7B Q4_0, the persistent engine's loader alone, round 3): 131
     // separate allocations 2680 us per token (1.45 TB/s), one arena 695 us (5.6 TB/s) -- the driver maps a large allocation
     // with large page fragments, and a wave that streams 1 KiB pieces lives or dies by the translation reach.
     uint8_t * arena_cur = nullptr; size_t arena_left = 0;
@@ -109,11 +109,6 @@ struct falcon_hip_context {
     int  graph_base = -1;                      // n_past the captured graph was built for
     int  decode_sig = -1, step_sig = -1;       // graph_signature() at capture time
     unsigned sync_err_host = 0;                // copy of sync_words[1], fetched wherever the host synchronises anyway
-    // the persistent decode engine (kernels_engine.hip): one launch per token. Prepared lazily on the first N = 1 step.
-    bool engine = false;                       // FALCON_HIP_ENGINE=1 / set_fused(4)
-    int  eng_state = 0;                        // 0 not prepared, 1 ready, -1 not supported for this model
-    fq_engine_args eng{};
-    int  eng_nslot = 0; size_t eng_lds = 0;
 };
 
 // k_attn_out hands the attention output from workgroup to workgroup with a BOUNDED spin; a time-out sets sync_words[1] and
@@ -353,7 +348,6 @@ static falcon_hip_context * context_create(falcon_hip_model * m, int n_ctx, int 
     if (c->ring_ln && nl > 0) c->ring_ln = ring_prepare_any(m);
     c->ring_out = ring_out_auto(m);
     if (const char * e = getenv("FALCON_HIP_MERGED")) c->merged_attn_out = atoi(e) != 0;
-    if (const char * e = getenv("FALCON_HIP_ENGINE")) c->engine = atoi(e) != 0;
     return c;
 }
 
@@ -398,7 +392,7 @@ extern "C" int falcon_hip_context_sync_error(falcon_hip_context * c) {      // 1
     HIP_CHECK(hipMemcpy(w, c->sync_words, sizeof w, hipMemcpyDeviceToHost));
     return (int) w[1];
 }
-extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one, 4 the persistent engine (one per token)
+extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {      // 0 op list, 1 three launches per block, 2 two (default), 3 one (two-phase), 5 two with the ring form forced; 4 was the persistent engine (removed in round 6, NOTEBOOK section 4): now the default form
     if (c->decode_graph) { HIP_CHECK(hipGraphExecDestroy(c->decode_graph)); c->decode_graph = nullptr; }
     if (c->step_graph) { HIP_CHECK(hipGraphExecDestroy(c->step_graph)); c->step_graph = nullptr; }
     if (c->token_graph) { HIP_CHECK(hipGraphExecDestroy(c->token_graph)); c->token_graph = nullptr; }
@@ -406,16 +400,14 @@ extern "C" void falcon_hip_context_set_fused(falcon_hip_context * c, int mode) {
     c->batch_graphs.clear();
     c->fused_decode = mode != 0;
     c->merged_attn_out = mode >= 2;
+    if (mode == 4) mode = 2;
     c->two_phase = mode == 3;
-    c->engine = mode == 4;
     // the LayerNorm mat-vec launch in the ring form (kernels_ring.hip): mode 5 always, mode 2 unless FALCON_HIP_RING=0 (measured +1.6 % on
     // Falcon-7B Q4_0; legacy formats only, other models keep k_gemv_ln)
     static const bool ring_default = !(getenv("FALCON_HIP_RING") && atoi(getenv("FALCON_HIP_RING")) == 0);
     c->ring_ln = (mode == 5 || (mode == 2 && ring_default)) && !c->m->layers.empty() && ring_prepare_any(c->m);
     c->ring_out = mode == 5 || (mode == 2 && ring_out_auto(c->m));
 }
-// 1 when N = 1 steps of this context run through the persistent engine, 0 when the model is outside its scope (the two-launch path runs)
-extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c);
 
 static bool stage_uniform(const falcon_hip_model * m) {
     for (const layer_weights & L : m->layers) if (L.qkv.type != L.up.type || L.down.type != L.wo.type) return false;
@@ -435,7 +427,7 @@ static bool stage_legacy(const falcon_hip_model * m) {
     return leg(t);
 }
 static bool stage_fused_ref(const falcon_hip_context * c) {        // N = 1 steps run the fused launches in the reference's association
-    return c->fused_decode && fq_reference_fast() && stage_legacy(c->m) && !c->engine && !c->two_phase && !c->dual_stream;
+    return c->fused_decode && fq_reference_fast() && stage_legacy(c->m) && !c->two_phase && !c->dual_stream;
 }
 static bool stage_fused(const falcon_hip_context * c) {
     if (stage_fused_ref(c)) return true;
@@ -444,115 +436,7 @@ static bool stage_fused(const falcon_hip_context * c) {
 // everything a captured graph bakes in besides its pointers: a change invalidates decode_graph / step_graph
 static int graph_signature(const falcon_hip_context * c) {
     return (stage_fused(c) ? 1 : 0) | (fq_reference_order() ? 2 : 0) | (fq_attn_f64() ? 4 : 0) | (c->merged_attn_out ? 8 : 0) |
-           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0) | (c->engine ? 64 : 0) | (stage_fused_ref(c) ? 128 : 0);
-}
-
-// ---- the persistent engine: per-context tables (block pointers, work split, hand-off buffers), built on first use
-// (round 5: the engine is measured 36 % slower than the two-launch form and is compiled only with `make ENGINE=1` (-DFQ_WITH_ENGINE=1); without it
-// mode 4 is "outside the engine's scope" for every model and the two-launch path runs)
-extern "C" int falcon_hip_engine_compiled(void) {
-#if FQ_WITH_ENGINE
-    return 1;
-#else
-    return 0;
-#endif
-}
-static bool engine_prepare(falcon_hip_context * c) {
-    if (c->eng_state) return c->eng_state > 0;
-    c->eng_state = -1;
-#if !FQ_WITH_ENGINE
-    return false;
-#else
-    falcon_hip_model * m = c->m;
-    const falcon_hip_hparams & hp = m->hp;
-    hip_context & hc = fq_ctx();
-    if (m->layers.empty()) return false;
-    const int type = m->layers[0].qkv.type;
-    for (const layer_weights & L : m->layers) if (L.qkv.type != type || L.up.type != type || L.down.type != type || L.wo.type != type) return false;
-    if (m->last_stage() && m->lm_head.type != type) return false;
-    if (type != FQ_Q4_0 && type != FQ_Q4_1 && type != FQ_Q5_0 && type != FQ_Q5_1 && type != FQ_Q8_0) return false;
-    const int E = hp.n_embd, FF = hp.n_ff, H = hp.n_head, HKV = hp.n_head_kv, QKVR = (H + 2 * HKV) * 64, V = hp.n_vocab;
-    if (E > 4 * 3 * 64 * 11) return false;                                  // the LayerNorm weights of the row must fit the helper waves' registers
-    int hpw = 2;
-    if (const char * e = getenv("FALCON_HIP_ENGINE_HPW")) hpw = atoi(e) >= 3 ? 3 : (atoi(e) <= 1 ? 1 : 2);
-    const int n_attn = (H + hpw - 1) / hpw, n_stream = hc.n_cu - n_attn;
-    if (n_stream < 8) return false;
-    std::vector<fq_engine_sched> sched;
-    int mg = 0, mr = 0;
-    if (!fq_engine_plan(type, E, FF, QKVR, V, m->last_stage(), n_stream, sched, &mg, &mr)) return false;
-    const size_t attn_group = (768 + 3 * 64 * 4 + 16 * 4 + 16 * 64 * 8 + (((size_t) c->n_ctx * 4 + 15) & ~(size_t) 15) + 15) & ~(size_t) 15;
-    int nslot = 0; size_t lds = 0;
-    for (int ns : { 8, 7, 6, 4 }) {
-        const size_t need = fq_engine_lds_bytes(type, ns, E, FF, (int) m->layers.size(), hp.two_norms ? 1 : 0);
-        if (need <= 160 * 1024) { nslot = ns; lds = need; break; }
-    }
-    if (!nslot) return false;
-    if (attn_group * hpw > lds) lds = attn_group * hpw;
-    if (lds > 160 * 1024) return false;
-    // device tables
-    std::vector<fq_engine_layer> lay(m->layers.size());
-    for (size_t i = 0; i < m->layers.size(); ++i) {
-        const layer_weights & L = m->layers[i];
-        lay[i] = { L.qkv.plane[0], L.up.plane[0], L.down.plane[0], L.wo.plane[0], L.ln_w, L.ln_b, L.ln2_w, L.ln2_b,
-                   c->k_cache + i * (size_t) c->n_ctx * HKV * 64, c->v_cache + i * (size_t) c->n_ctx * HKV * 64 };
-    }
-    if (getenv("FALCON_HIP_ENGINE_ONEBUF")) {           // tuning aid: every matrix inside ONE allocation (timing of the loader only; results are garbage)
-        size_t tot = 0;
-        for (const layer_weights & L : m->layers) tot += (size_t) L.qkv.M * L.qkv.row_stride + (size_t) L.up.M * L.up.row_stride + (size_t) L.down.M * L.down.row_stride + (size_t) L.wo.M * L.wo.row_stride;
-        uint8_t * big = (uint8_t *) dev_alloc(c->allocs, tot + 4096);
-        HIP_CHECK(hipMemset(big, 1, tot + 4096));
-        size_t off = 0;
-        for (size_t i = 0; i < m->layers.size(); ++i) {
-            const layer_weights & L = m->layers[i];
-            lay[i].qkv = big + off; off += (size_t) L.qkv.M * L.qkv.row_stride;
-            lay[i].up = big + off; off += (size_t) L.up.M * L.up.row_stride;
-            lay[i].down = big + off; off += (size_t) L.down.M * L.down.row_stride;
-            lay[i].wo = big + off; off += (size_t) L.wo.M * L.wo.row_stride;
-        }
-    }
-    fq_engine_layer * lay_dev = (fq_engine_layer *) dev_alloc(c->allocs, lay.size() * sizeof(fq_engine_layer));
-    HIP_CHECK(hipMemcpy(lay_dev, lay.data(), lay.size() * sizeof(fq_engine_layer), hipMemcpyHostToDevice));
-    fq_engine_sched * sched_dev = (fq_engine_sched *) dev_alloc(c->allocs, sched.size() * sizeof(fq_engine_sched));
-    HIP_CHECK(hipMemcpy(sched_dev, sched.data(), sched.size() * sizeof(fq_engine_sched), hipMemcpyHostToDevice));
-    auto gran = [&](size_t n) {
-        unsigned long long * p = (unsigned long long *) dev_alloc(c->allocs, n * 8 + 64);
-        HIP_CHECK(hipMemset(p, 0, n * 8 + 64));
-        return p;
-    };
-    fq_engine_args & a = c->eng;
-    a = fq_engine_args{};
-    a.type = type; a.n_layers = (int) m->layers.size(); a.layers = lay_dev; a.sched = sched_dev;
-    a.E = E; a.FF = FF; a.H = H; a.HKV = HKV; a.V = V; a.two_norms = hp.two_norms ? 1 : 0;
-    a.rsE = (unsigned) m->layers[0].qkv.row_stride; a.rsF = (unsigned) m->layers[0].down.row_stride;
-    a.n_attn = n_attn; a.hpw = hpw; a.n_stream = n_stream; a.attn_lds_group = (int) attn_group;
-    if (m->last_stage()) { a.lm_head = m->lm_head.plane[0]; a.lnf_w = m->out_norm_w; a.lnf_b = m->out_norm_b; a.logits = c->logits_dev; a.argmax_val = c->argmax_val; a.argmax_idx = c->argmax_idx; }
-    a.x = c->x;
-    a.xg = gran((size_t) E); a.qkvg = gran((size_t) QKVR); a.ffg = gran((size_t)(FF / 4 + FF / 16)); a.attg = gran((size_t)(E / 4 + E / 16));
-    unsigned one = 1u;
-    HIP_CHECK(hipMemcpy(c->sync_words + 2, &one, 4, hipMemcpyHostToDevice));
-    a.epoch_word = c->sync_words + 2; a.err = c->sync_words + 1;
-    a.n_past = c->n_past_dev; a.max_n_kv = c->n_ctx; a.rope_cs = c->rope_cs; a.exp_tab = hc.exp_table_attn; a.gelu_tab = hc.gelu_table;
-    if (const char * e = getenv("FALCON_HIP_ENGINE_DEBUG_MODE")) a.debug_mode = atoi(e);
-    a.thin_loader = 1;
-    if (const char * e = getenv("FALCON_HIP_ENGINE_THIN")) a.thin_loader = atoi(e) != 0;
-    if (getenv("FALCON_HIP_ENGINE_DEBUG")) {
-        a.dbg = (long long *) dev_alloc(c->allocs, (size_t) FQ_ENG_DBG_WORDS * sizeof(long long));
-        HIP_CHECK(hipMemset(a.dbg, 0, (size_t) FQ_ENG_DBG_WORDS * sizeof(long long)));
-    }
-    c->eng_nslot = nslot; c->eng_lds = lds;
-    c->eng_state = 1;
-    return true;
-#endif
-}
-extern "C" int falcon_hip_context_engine_active(falcon_hip_context * c) { return c->engine && stage_fused(c) && engine_prepare(c) ? 1 : 0; }
-// tuning aid: the engine's debug buffer (FALCON_HIP_ENGINE_DEBUG=1 at context creation): n int64 to the host; returns the number copied
-extern "C" int falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out, int n) {
-    if (c->eng_state <= 0 || !c->eng.dbg) return 0;
-    const int total = FQ_ENG_DBG_WORDS;
-    if (n > total) n = total;
-    HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemcpy(out, c->eng.dbg, (size_t) n * sizeof(long long), hipMemcpyDeviceToHost));
-    return n;
+           (c->two_phase ? 16 : 0) | (c->dual_stream ? 32 : 0) | (stage_fused_ref(c) ? 128 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ one eval
@@ -583,25 +467,6 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     const int64_t seq_stride = c->n_seq > 0 ? (int64_t) c->n_ctx * HKV * D : 0;             // lock-step sequences: one KV cache per row
     const int64_t n_caches = c->n_seq > 0 ? c->n_seq : 1;
     if (c->n_seq > 0 && N != c->n_seq) { fprintf(stderr, "falcon-hip: a context of %d lock-step sequences evaluates %d rows per step, not %d\n", c->n_seq, c->n_seq, N); exit(1); }
-    if (N == 1 && stage_fused(c) && c->engine && !c->dual_stream && engine_prepare(c)) {
-        // ---- the persistent engine: every block of the stage (+ ln_f, lm_head) in ONE launch (kernels_engine.hip)
-        fq_engine_args a = c->eng;
-        a.hidden = nullptr;
-        HIP_CHECK(hipMemcpyAsync(c->ln, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));     // the engine reads the row from a buffer it never writes
-        a.x_in = c->ln;
-        if (c->keep_hidden) {
-            HIP_CHECK(hipMemcpyAsync(c->hidden_dev, c->x, (size_t) E * 4, hipMemcpyDeviceToDevice, st));
-            a.hidden = c->hidden_dev;
-            c->hidden_tokens = 1;
-        }
-        const bool prof = fq_prof_active();
-        if (prof) fq_prof_open(st);
-#if FQ_WITH_ENGINE
-        if (!fq_launch_decode_engine(a, c->eng_nslot, c->eng_lds, st)) { fprintf(stderr, "falcon-hip: the decode engine refused a configuration it had accepted\n"); exit(1); }
-#endif
-        if (prof) fq_prof_close(st, (double) m->weight_bytes);
-        return;
-    }
     if (N == 1 && stage_fused(c)) {
         // ---- fused single-token path (kernels_decode.hip), bit-identical to the op list below. Per block, by mode:
         //   3 launches  k_gemv_ln | k_attn_decode | k_gemv_out
@@ -999,7 +864,6 @@ extern "C" int falcon_hip_eval_token(falcon_hip_context * c, int32_t token, int 
         c->logits_pending = false;
         if (report_sync_error(c, "eval")) return 3;
     }
-    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
     if (!c->logits_pinned) HIP_CHECK(hipHostMalloc((void **) &c->logits_pinned, (size_t) m->hp.n_vocab * 4 + 64, hipHostMallocDefault));      // (+ the hand-off error word: a copy into pageable memory would make this call wait for the whole step)
     hipLaunchKernelGGL(k_set2_i32, dim3(1), dim3(1), 0, st, c->n_past_dev, n_past, (int *) c->tokens_dev, (int) token);
     const bool was_keep = c->keep_hidden;
@@ -1150,7 +1014,6 @@ extern "C" int falcon_hip_stage_step(falcon_hip_context * c, const int32_t * tok
     falcon_hip_model * m = c->m;
     hipStream_t st = hc.stream;
     if (n_past < 0 || n_past + 1 > c->n_ctx) { fprintf(stderr, "falcon-hip: stage step at n_past %d exceeds n_ctx %d\n", n_past, c->n_ctx); exit(1); }
-    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
     // body of one step; n_past_base >= 0: position baked into the launch arguments (plain launches), < 0: the position is
@@ -1213,7 +1076,6 @@ extern "C" int falcon_hip_decode_greedy(falcon_hip_context * c, int32_t first_to
     HIP_CHECK(hipMemcpyAsync(c->n_past_dev, &n_past, 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->tokens_dev, &first_token, 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    if (c->engine && stage_fused(c)) engine_prepare(c);              // (allocates: must not happen inside a stream capture)
     const bool was_keep = c->keep_hidden;
     c->keep_hidden = false;
     auto one_step = [&](hipStream_t s, int max_kv) {

@@ -1,5 +1,5 @@
-// fq_engine_dev.h -- device pieces shared by the persistent decode engine (kernels_engine.hip) and the ring form of the fused
-// decode launches (kernels_ring.hip): the LDS-DMA loader primitives, LDS control words, row dots out of the ring, bounded waits,
+// fq_engine_dev.h -- device pieces of the ring forms of the fused decode launches (kernels_ring.hip, kernels_ringk.hip; first written for the persistent
+// decode engine of rounds 2-3, which was measured slower and removed in round 6 -- NOTEBOOK section 4): the LDS-DMA loader primitives, LDS control words, row dots out of the ring, bounded waits,
 // chunked gathers. Included once per translation unit (anonymous namespace).
 #pragma once
 #include "fq_block_dev.h"
@@ -254,69 +254,5 @@ struct eng_wait {                 // per-wave state of the bounded waits
 // failure / wait codes
 enum { ENG_W_RING = 1, ENG_W_LAND = 2, ENG_W_QKV = 4, ENG_W_XG = 5, ENG_W_GROUP = 6, ENG_W_FG = 7, ENG_W_AG = 8,
        ENG_W_STAT = 12, ENG_W_IMG = 13, ENG_W_ADONE = 14, ENG_W_B1 = 15, ENG_W_B2 = 16, ENG_W_FGD = 17, ENG_W_AGD = 18 };
-
-// one helper's chunks of a granule buffer: chunk k (k = h, h + stride, ..) = words [1024 k, 1024 k + 1024) -> dst (LDS words) once
-// every granule of the chunk carries `tag`. All 16 loads of a lane are in flight together: an attempt costs ONE memory round trip.
-// SUM: the chunk's values are floats; their f64 sum goes to psum[k] (lane order, then the wave butterfly).
-// Returns the number of chunks this helper owned.
-template <bool SUM>
-__device__ __forceinline__ unsigned eng_gather(const unsigned long long * gran, unsigned tag, int nwords, unsigned * dst, int h, int lane, eng_wait & w,
-                                               unsigned code, bool nowait, unsigned psum_addr, int stride = ENG_NH) {
-    const int nchunks = (nwords + ENG_CHUNK - 1) / ENG_CHUNK;
-    unsigned own = 0;
-    for (int k = h; k < nchunks; k += stride) {
-        const int base = k * ENG_CHUNK;
-        unsigned v[16];
-        for (unsigned spins = 0;;) {
-            unsigned long long x[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; x[j] = gran_ld(gran + (i < nwords ? i : nwords - 1)); }
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { v[j] = (unsigned) x[j]; ok = ok && (unsigned)(x[j] >> 32) == tag; }
-            if (nowait || __all(ok)) break;
-            if (!w.spin(spins, code, (unsigned) base, tag)) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) dst[i] = v[j]; }
-        if constexpr (SUM) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) s += (double) __builtin_bit_cast(float, v[j]); }
-            s = wave_sum(s);
-            if (lane == 0) lds_st64(psum_addr + 8u * (unsigned) k, (unsigned long long) __builtin_bit_cast(long long, s));
-        }
-        ++own;
-    }
-    return own;
-}
-// the same chunks of a plain f32 row in memory (the residual row entering the stage)
-__device__ __forceinline__ unsigned eng_gather_mem(const float * x, int nwords, unsigned * dst, int h, int lane, unsigned psum_addr) {
-    const int nchunks = (nwords + ENG_CHUNK - 1) / ENG_CHUNK;
-    unsigned own = 0;
-    for (int k = h; k < nchunks; k += ENG_NH) {
-        const int base = k * ENG_CHUNK;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; v[j] = x[i < nwords ? i : nwords - 1]; }
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int i = base + 64 * j + lane; if (i < nwords) { dst[i] = __builtin_bit_cast(unsigned, v[j]); s += (double) v[j]; } }
-        s = wave_sum(s);
-        if (lane == 0) lds_st64(psum_addr + 8u * (unsigned) k, (unsigned long long) __builtin_bit_cast(long long, s));
-        ++own;
-    }
-    return own;
-}
-
-// LDS of a streaming workgroup: [ring][mirror][R][S][control block + pointer table].
-//   R: the f32 residual row while it is gathered and normalised, then the GELU image (phase B1)
-//   S: the LayerNorm image(s) during phase A, then the attention output image (phase B2)
-__host__ __device__ inline size_t eng_region_r(int act, int64_t E, int64_t FF) {
-    const size_t ff = fq_act_col_bytes(act, FF), x = ((size_t) E * 4 + 15) & ~(size_t) 15;
-    return ff > x ? ff : x;
-}
-__host__ __device__ inline size_t eng_region_s(int act, int64_t E, int two_norms) { return (two_norms ? 2 : 1) * fq_act_col_bytes(act, E); }
 
 }   // namespace

@@ -189,37 +189,6 @@ void fq_tl_begin();                                   // start collecting (plain
 int  fq_tl_end(FILE * out, const char * title);       // synchronises, prints one line per launch site kind (calls, total / average microseconds, share), returns the number of brackets
 bool fq_tl_collecting();
 
-// kernels_engine.hip -- the persistent decode engine: one launch per token
+// one streaming workgroup of the ring forms (kernels_ring.hip / kernels_ringk.hip): rows [qg0, qg1) of Wqkv, 32-row groups [ug0, ug1) of Wup (r*, hg*: rows of the output form)
 #include <vector>
-struct fq_engine_layer {
-    const uint8_t * qkv, * up, * down, * wo;          // row 0 of each matrix (device layout)
-    const float * ln_w, * ln_b, * ln2_w, * ln2_b;     // ln: the norm that feeds the MLP (and Wqkv of a one-norm block); ln2: the attention norm of a two-norm block
-    float * kc, * vc;                                 // this block's KV cache
-};
-struct fq_engine_sched { int qg0, qg1, ug0, ug1, r0, r1, hg0, hg1; };   // one streaming workgroup: 32-row groups of Wqkv / Wup / lm_head, rows of Wdown + Wo
-struct fq_engine_args {
-    int type, n_layers; const fq_engine_layer * layers; const fq_engine_sched * sched;     // device arrays
-    int E, FF, H, HKV, V, two_norms;
-    unsigned rsE, rsF;                                // row strides of the K = E and K = FF matrices
-    int n_attn, hpw, n_stream, attn_lds_group;        // roles: attention workgroups first (hpw heads each), then the streaming ones
-    const uint8_t * lm_head; const float * lnf_w, * lnf_b; float * logits, * argmax_val; int * argmax_idx;     // lm_head == nullptr: no head phase
-    const float * x_in;                               // residual row entering the stage (must not alias x: workgroups without phase-A work may still read it when the first rows of x are written)
-    float * x;                                        // residual row leaving every block (the last block's is the stage's output)
-    float * hidden;                                   // optional: rows 1 .. n_layers of [(n_layers + 1)][E]
-    unsigned long long * xg, * qkvg, * ffg, * attg;   // hand-off granules: E, (H + 2 HKV) 64, FF/4 + FF/16, E/4 + E/16 entries (zero-filled once)
-    const unsigned * epoch_word; unsigned * err;      // err: 0, or the code of the first wait that gave up
-    int thin_loader;                                  // 1 (default; FALCON_HIP_ENGINE_THIN=0 clears): the loader keeps 16 instead of 48 pieces in flight while its workgroup gathers a hand-off
-    int debug_mode;                                   // tuning aid (FALCON_HIP_ENGINE_DEBUG_MODE; results are garbage): 1 = the loader alone; bits: 2 = no row dots, 4 / 8 / 16 / 32 = do not wait for the x / qkv / GELU-image / attention-image hand-off
-    long long * dbg;                                  // optional (FALCON_HIP_ENGINE_DEBUG=1), FQ_ENG_DBG_WORDS int64: [0] failure count, records of 8 from [16], then the regions below
-    const int * n_past; int max_n_kv; const float * rope_cs; const uint16_t * exp_tab, * gelu_tab;
-};
-// debug buffer regions (int64 indices): phase stamps of consumer 0 / the attention workgroups [256 workgroups][4 blocks][8 slots], the
-// same of the gatherer wave, per-workgroup counters [256][16]
-#define FQ_ENG_DBG_STAMPS   4096
-#define FQ_ENG_DBG_GSTAMPS  (FQ_ENG_DBG_STAMPS + 256 * 4 * 8)
-#define FQ_ENG_DBG_COUNTERS (FQ_ENG_DBG_GSTAMPS + 256 * 4 * 8)
-#define FQ_ENG_DBG_WORDS    (FQ_ENG_DBG_COUNTERS + 256 * 16)
-bool   fq_engine_plan(int type, int E, int FF, int qkv_rows, int V, bool with_head, int n_stream, std::vector<fq_engine_sched> & out, int * max_groups, int * max_rows);
-size_t fq_engine_lds_bytes(int type, int nslot, int64_t E, int64_t FF, int n_layers, int two_norms);
-int    fq_engine_threads();
-bool   fq_launch_decode_engine(const fq_engine_args & a, int nslot, size_t lds_bytes, hipStream_t st);
+struct fq_engine_sched { int qg0, qg1, ug0, ug1, r0, r1, hg0, hg1; };

@@ -126,20 +126,12 @@ int   falcon_hip_perplexity(falcon_hip_context * c, const int32_t * tokens, int6
 void  falcon_hip_context_keep_hidden(falcon_hip_context * c, int keep);
 void  falcon_hip_get_hidden(falcon_hip_context * c, float * dst_host);
 void  falcon_hip_context_use_graph(falcon_hip_context * c, int enable);   /* capture decode steps into a hipGraph */
-/* N == 1 evals: 2 (default) = fused decode kernels, two launches per block (LayerNorm mat-vec | attention + output mat-vec,
- * when the grid fits the chip), 3 = one launch per block (the next block's LayerNorm mat-vec as a second phase of the same
- * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests), 4 = the persistent decode
- * engine: ONE launch per token for all blocks of the stage + lm_head (csrc/kernels_engine.hip; legacy formats, one format
- * per stage -- other models keep mode 2), 5 = mode 2 with the LayerNorm mat-vec launch in the ring form (csrc/kernels_ring.hip: an LDS-DMA
- * loader wave + consumers out of an LDS ring; legacy formats). All produce the same bits; 3, 4 and 5 are measured no faster than 2. */
+/* N == 1 evals: 2 (default) = fused decode kernels, two launches per block (LayerNorm mat-vec in the ring form, csrc/kernels_ring.hip, where the format has it |
+ * attention + output mat-vec, when the grid fits the chip), 3 = one launch per block (the next block's LayerNorm mat-vec as a second phase of the same
+ * launch; measured slower, kept for A/B), 1 = three launches, 0 = one launch per graph op (tests), 5 = mode 2 with the ring form forced. All produce the
+ * same bits. (4 was the persistent decode engine of rounds 2-3 -- one launch per token, measured 36 % slower, removed in round 6: it now selects mode 2.)
+ * With ggml_hip_reference_order(2) (ggml-hip-ops.h) modes 1, 2 and 5 run the same launches in the reference's own association (csrc/fq_ref_chain.h). */
 void  falcon_hip_context_set_fused(falcon_hip_context * c, int mode);
-/* 1 when N == 1 evals of this context run through the persistent engine (mode 4 and a model inside its scope) */
-int   falcon_hip_context_engine_active(falcon_hip_context * c);
-/* 1 when the library was built with the engine (make ENGINE=1; the default build leaves it out -- it is measured slower than mode 2 --
- * and mode 4 then runs the two-launch path for every model) */
-int   falcon_hip_engine_compiled(void);
-/* tuning aid (FALCON_HIP_ENGINE_DEBUG=1): failure records and phase stamps of the engine, n int64 copied to the host */
-int   falcon_hip_context_engine_debug(falcon_hip_context * c, long long * out_host, int n);
 /* 1 if an in-launch wait of the 2-launch form ever timed out (results invalid; never expected). Synchronises the device. */
 int   falcon_hip_context_sync_error(falcon_hip_context * c);
 
