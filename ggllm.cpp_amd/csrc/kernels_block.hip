@@ -673,7 +673,13 @@ __global__ void __launch_bounds__(256) k_attn_pack_k(const float * __restrict__ 
 // of running the chains twice: two units of matrix work per launch instead of three (the f32 matrix instruction and the vector ALU do not overlap on a SIMD of this
 // chip, scripts/microbench/mb_mfma_f32_mix.hip: a second run of the chains is 0.18 ms of a 0.91 ms launch at 2048 tokens). The scores are the same chains' results, kept
 // as c * 0.125f with the invisible ones set to -inf (table[f16(-inf)] = 0, the reference's own rule for a masked score: ggml.c:10925); pass B is then vector work only.
-template <bool TAB, int NT, bool PACKED, bool KEEP>
+// LONG (round 6): contexts whose 32 rows of fp16 probabilities do NOT fit the LDS (beyond 74 key tiles = 2368 keys; the reference's 8k / 16k contexts, BASELINE
+// config 5). The LDS rows hold a CHUNK of NT key tiles; the row maxima (pass A) and the row sums (pass B without stores) come from two runs of the K.Q chains over
+// all tiles, then chunk after chunk: K.Q a third time -> the chunk's exp() values into LDS -> V.P of the chunk's tiles into accumulators that live across the
+// chunks. Four units of f32 matrix work instead of two -- the same chains on the same operands in the same order, so the same bits as every other form
+// (tests/test_gpu_block_ops.py::test_prefill_attention_forms_are_bit_identical at 4096 / 8192 / 16384 keys) -- and still no score in HBM: the scratch form
+// moves N x n_kv x H x 16 bytes per launch (4.8 GB for a 512-token batch at 8192 keys) and needs a 1.2 GB scratch allocation.
+template <bool TAB, int NT, bool PACKED, bool KEEP, bool LONG = false>
 __global__ void __launch_bounds__(512) k_attention_flash(const float * __restrict__ qkv, int N, int H, int HKV, const int * __restrict__ n_past_ptr,
                                                          const float * __restrict__ kc, const float * __restrict__ vc,
                                                          const uint16_t * __restrict__ exp_tab, float * __restrict__ att, const float * __restrict__ kt, int nt_total, int dbg, int * __restrict__ next_item) {
@@ -706,6 +712,9 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     const int ntile_real = (n_kv_max + 31) >> 5;
     // (tuning aid, FQ_ATTN_DBG: bits 1 / 2 / 4 run pass A / B / C over no tiles -- results are garbage, the time is what the other passes cost)
     const int ntileA = (dbg & 1) ? 0 : ntile_real, ntileB = (dbg & 2) ? 0 : ntile_real, ntileC = (dbg & 4) ? 0 : ntile_real;
+    // (pass C's accumulators and roles, declared here: the LONG form runs pass C inside the scope of passes A and B, chunk by chunk)
+    const int dh = wid & 1, par = (wid >> 1) & 1;
+    v16f c = {0};
     // ---- passes A and B: K.Q, tiles wid, wid + 8, ...; the next tile is requested before a tile's matrix instructions start (rows beyond the cache
     // re-read its last row: every request is unconditional, the counts in the waits are exact)
     {
@@ -846,6 +855,138 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
             for (int w = 1; w < 8; ++w) m = fq_max_f32(m, rmax[w * 32 + ir]);
             mrow[r] = m;
         }
+        if constexpr (LONG) {
+            static_assert(!KEEP && FQ_FLASH_PLAIN && NT % 2 == 0, "the LONG form: compiler-managed loads, whole tile pairs per chunk");
+            unsigned lsum[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum[r] = 0u;
+            v16f cp = {0}; int Tp = 0, toff = 0;
+            uint16_t * const ecol = eh + (size_t)(4 * hf) * PH + li;
+            // one score of the previous tile: STORE = its exp() value into the chunk's LDS rows (tile Tp - toff of the chunk), else into the row's integer sum
+            auto epiL = [&](int r, auto store_tag) {
+                constexpr bool STORE = decltype(store_tag)::value;
+                const int irl = (r & 3) + 8 * (r >> 2), ir = irl + 4 * hf;
+                const float sc = cp[r] * 0.125f;
+                const bool vis = ir < nrows && 32 * Tp + li <= n_past + i0 + ir;
+                const uint16_t hb = f2h_bits(sc - mrow[r]);
+                uint16_t eb;
+                if constexpr (TAB) eb = exp_tab[hb]; else eb = exp_f16_formula(hb);
+                eb = vis ? eb : (uint16_t) 0;
+                if constexpr (STORE) ecol[irl * PH + 32 * (Tp - toff)] = eb;
+                else lsum[r] += (unsigned)(h2f_bits(eb) * 16777216.0f);
+            };
+            // the K.Q chains of tiles Tb + wid, Tb + wid + 8, ... < Te (ka holds the first of them), pass B's software pipeline: the exp() work of a tile between the
+            // matrix instructions of the next
+            auto pass_b = [&](int Tb, int Te, auto store_tag) {
+                if (Tb + wid < Te) {
+                    load_k(Tb + wid + 8, kb);
+                    v16f c0_ = {0};
+                    FL_QK(c0_, ka);
+                    cp = c0_; Tp = Tb + wid;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+                    for (int T = Tb + wid + 8; T < Te; T += 8) {
+                        load_k(T + 8, kb);
+                        v16f c1_ = {0};
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            c1_ = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].x, ka[v].x, c1_, 0, 0, 0);
+                            c1_ = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].y, ka[v].y, c1_, 0, 0, 0);
+                            epiL(2 * v, store_tag);
+                            __builtin_amdgcn_sched_barrier(0);
+                            c1_ = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].z, ka[v].z, c1_, 0, 0, 0);
+                            c1_ = __builtin_amdgcn_mfma_f32_32x32x2f32(q8[v].w, ka[v].w, c1_, 0, 0, 0);
+                            epiL(2 * v + 1, store_tag);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        cp = c1_; Tp = T;
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) ka[v] = kb[v];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) epiL(r, store_tag);
+                }
+            };
+            std::integral_constant<bool, true> STORE_T; std::integral_constant<bool, false> SUM_T;
+            // ---- the row sums: every tile once more, nothing stored (a lane adds <= 64 values <= 2^24 per row at 16384 keys: exact in 32 bits)
+            pass_b(0, ntileB, SUM_T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double sm = reduce32((double) lsum[r] * (1.0 / 16777216.0), op_add());
+                if (li == 0) rsum[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = sm;
+            }
+            __syncthreads();
+            float inv = 0.0f;
+            if (wid < 4) {
+                double sm = rsum[li];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) sm += rsum[w * 32 + li];
+                inv = (float)(1.0 / sm);
+            }
+            // ---- pass C's pieces (k_attention_flash's own, with the LDS column relative to the chunk)
+            const uint16_t * erow = eh + (size_t) li * PH + 16 * hf;
+            const float * const vbase = vc + (int64_t) hk * 64 + 32 * dh + li;
+            const f32x4 * const vpk = (const f32x4 *)(kt + (int64_t) HKV * nt_total * 2048) + ((int64_t) hk * nt_total * 2 + dh) * 256 + lane;
+            auto load_v = [&](int T, float (&v16)[16]) {
+                if constexpr (PACKED && FQ_ATTN_PACK_V) {
+                    const f32x4 * vp = vpk + (int64_t)(T < nt_total ? T : nt_total - 1) * 512;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const f32x4 t = vp[64 * q]; v16[4 * q] = t.x; v16[4 * q + 1] = t.y; v16[4 * q + 2] = t.z; v16[4 * q + 3] = t.w; }
+                } else {
+#pragma unroll
+                    for (int s_ = 0; s_ < 16; ++s_) {
+                        const int j = 32 * T + 16 * hf + s_;
+                        fl_gload1(v16[s_], vbase + (int64_t)(j < n_rows_cache ? j : n_rows_cache - 1) * HKV * 64);
+                    }
+                }
+            };
+            auto form_p = [&](int Tl, float (&p16)[16]) {                 // Tl: the tile's index inside the chunk (one beyond the chunk reads words behind the row: never used)
+                const uint4 e0 = *(const uint4 *)(erow + 32 * Tl), e1 = *(const uint4 *)(erow + 32 * Tl + 8);
+                const unsigned w[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { p16[2 * u] = h2f_bits((uint16_t)(w[u] & 0xFFFFu)) * inv; p16[2 * u + 1] = h2f_bits((uint16_t)(w[u] >> 16)) * inv; }
+            };
+            auto pv_tile = [&](const float (&p16)[16], const float (&v16)[16]) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) c = __builtin_amdgcn_mfma_f32_32x32x2f32(p16[u], v16[u], c, 0, 0, 0);
+            };
+            // ---- chunk after chunk: exp() values of NT tiles into LDS, their V.P into the accumulators (tile order of a chain = ascending: the association of every form)
+            for (int c0 = 0; c0 < ntile_real; c0 += NT) {
+                const int c1 = c0 + NT < ntile_real ? c0 + NT : ntile_real;
+                load_k(c0 + wid, ka);
+                if (c0) __syncthreads();                              // (the previous chunk's pass C has read its rows)
+                toff = c0;
+                if (!(dbg & 2)) pass_b(c0, c1, STORE_T);
+                __syncthreads();
+                if (wid < 4 && !(dbg & 4)) {
+                    constexpr int NB = 4;
+                    float vv[NB][16], pp[2][16];
+#pragma unroll
+                    for (int b = 0; b < NB - 1; ++b) load_v(c0 + par + 2 * b, vv[b]);
+                    int T = c0 + par;
+                    form_p(T - c0, pp[0]);
+                    for (; T + 2 * (NB - 1) < c1; T += 2 * NB) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            load_v(T + 2 * b + 2 * (NB - 1), vv[(b + NB - 1) % NB]);
+                            form_p(T - c0 + 2 * b + 2, pp[(b + 1) & 1]);
+                            pv_tile(pp[b & 1], vv[b]);
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB - 1; ++b) {
+                        if (T + 2 * b < c1) {
+                            if (b + 1 < NB - 1) form_p(T - c0 + 2 * b + 2, pp[(b + 1) & 1]);
+                            pv_tile(pp[b & 1], vv[b]);
+                        }
+                    }
+                }
+            }
+            if (wid < 4 && par == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(dh * 16 + r) * 64 + lane] = c[r];
+            }
+        } else
         {   // pass B: exp() values into LDS, row sums. Software-pipelined by hand: the exp() arithmetic of the wave's previous tile (~25 VALU instructions per
             // score, 16 scores per lane) is issued BETWEEN the matrix instructions of the current one -- a 64-cycle v_mfma_f32_32x32x2_f32 leaves ~14 issue
             // slots, and a wave that ran its 32 dependent matrix instructions back to back and its 400 VALU instructions after them would keep the pipe idle
@@ -912,9 +1053,7 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
     }
     __syncthreads();
     // ---- pass C: V.P, wave = (dim half, tile parity), waves 0-3 (one per SIMD): four chains is what the association allows. Values two tiles ahead.
-    const int dh = wid & 1, par = (wid >> 1) & 1;
-    v16f c = {0};
-    if (wid < 4) {
+    if (!LONG && wid < 4) {
         double sm = rsum[li];
 #pragma unroll
         for (int w = 1; w < 8; ++w) sm += rsum[w * 32 + li];
@@ -991,22 +1130,24 @@ __global__ void __launch_bounds__(512) k_attention_flash(const float * __restric
 // LDS rows for 16, 32 or 74 key tiles (512, 1024, 2368 keys): the instantiations of the compile-time pitch
 // (64: the KEEP form's largest -- 8 tiles x 16 score registers per wave; 65-74 tiles run the three-pass form)
 static bool attn_flash_keep() { static const int v = getenv("FQ_ATTN_KEEP") ? atoi(getenv("FQ_ATTN_KEEP")) : 1; return v != 0; }
-static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 64 && attn_flash_keep() ? 64 : (nt <= 74 ? 74 : 0))); }
+// (beyond 74 tiles: the LONG form, chunks of 64 tiles -- returned as 1064; FQ_ATTN_FLASH_LONG=0: the scratch form there, as before round 6)
+static bool attn_flash_long_on() { static const int v = getenv("FQ_ATTN_FLASH_LONG") ? atoi(getenv("FQ_ATTN_FLASH_LONG")) : 1; return v != 0; }
+static int attn_flash_nt(int max_n_kv) { const int nt = (max_n_kv + 31) >> 5; return nt <= 16 ? 16 : (nt <= 32 ? 32 : (nt <= 64 && attn_flash_keep() ? 64 : (nt <= 74 ? 74 : (attn_flash_long_on() ? 1064 : 0)))); }
 static size_t attn_flash_lds(int nt) { return (size_t) 32 * (size_t)(32 * nt + 8) * 2 + 8 * 32 * 4 + 8 * 32 * 8 + 2 * 16 * 64 * 4 + 16; }
 static bool attn_flash_fits(int max_n_kv) { return attn_flash_nt(max_n_kv) != 0; }
-template <bool TAB, int NT, bool PACKED, bool KEEP>
+template <bool TAB, int NT, bool PACKED, bool KEEP, bool LONG = false>
 static void launch_attention_flash_t(const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
                                      const uint16_t * exp_table, float * att, const float * kt, int nt_total, hipStream_t st) {
     const size_t lds = attn_flash_lds(NT);
     static bool attr = false;
-    if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
+    if (!attr && lds > 64 * 1024) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attention_flash<TAB, NT, PACKED, KEEP, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); attr = true; }
     static const int dbg = getenv("FQ_ATTN_DBG") ? atoi(getenv("FQ_ATTN_DBG")) : 0;
     static const int persist = getenv("FQ_ATTN_PERSIST") ? atoi(getenv("FQ_ATTN_PERSIST")) : 1;      // 0: one workgroup per item (A/B)
     const int n_items = H * ((N + 31) / 32);
     const bool per = persist && n_items >= 4 * fq_ctx().n_cu;           // persistent workgroups where there are rounds enough to amortise over
     int * counter = per ? fq_ctx().scalar_i32 + 32 : nullptr;           // (a word of the library's scalar scratch; zeroed on the launch's own stream)
     if (per) HIP_CHECK(hipMemsetAsync(counter, 0, 4, st));
-    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED, KEEP>), dim3((unsigned)(per ? fq_ctx().n_cu : n_items)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg, counter);
+    hipLaunchKernelGGL((k_attention_flash<TAB, NT, PACKED, KEEP, LONG>), dim3((unsigned)(per ? fq_ctx().n_cu : n_items)), dim3(512), lds, st, qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, dbg, counter);
 }
 template <bool TAB, bool PACKED>
 static void launch_attention_flash(int nt, const float * qkv, int N, int H, int HKV, const int * n_past_dev, const float * k_cache, const float * v_cache,
@@ -1017,6 +1158,7 @@ static void launch_attention_flash(int nt, const float * qkv, int N, int H, int 
     else if (nt == 32) { if (keep) launch_attention_flash_t<TAB, 32, PACKED, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
                          else      launch_attention_flash_t<TAB, 32, PACKED, false>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st); }
     else if (nt == 64) launch_attention_flash_t<TAB, 64, PACKED, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
+    else if (nt == 1064) launch_attention_flash_t<TAB, 64, PACKED, false, true>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
     else               launch_attention_flash_t<TAB, 74, PACKED, false>(qkv, N, H, HKV, n_past_dev, k_cache, v_cache, exp_table, att, kt, nt_total, st);
 }
 // bytes of the packed keys a launch of this size wants (k_attn_pack_k): prompts of FQ_ATTN_PACK_MIN_N (default 256) tokens and more

@@ -201,6 +201,36 @@ def test_prefill_attention_forms_are_bit_identical(H, HKV, N, n_past):
         assert np.array_equal(outs[form], outs[32]), f"form {form}"
 
 
+@pytest.mark.parametrize("H,HKV,N,n_past", [(4, 1, 512, 3584), (3, 1, 512, 7680), (4, 2, 512, 15872), (2, 1, 513, 5000), (8, 8, 33, 2400), (2, 1, 512, 2048), (2, 1, 96, 8000)])
+def test_prefill_attention_long_contexts_keep_the_flash_form(H, HKV, N, n_past):
+    """round 6: beyond 2368 keys (74 tiles) k_attention_flash runs its LONG form -- the LDS rows hold a chunk of 64 key tiles, K.Q is run for the row maxima, again
+    for the row sums and a third time chunk by chunk in front of V.P, whose accumulators live across the chunks -- instead of handing the launch to the scratch
+    form (k_attention_mfma: the N x n_kv score matrix through HBM four times). Same chains, same operands, same order: bit-identical to the scratch form (32) at
+    4096 / 8192 / 16384 keys with 512-token batches (BASELINE config 5's batches; the reference's 8k-16k range, README.md:9; semantics ggml.c:12389-12456,
+    libfalcon.cpp:2285-2366), ragged last tiles, a chunk boundary inside the batch's causal triangle, MQA and GQA"""
+    L = g.load()
+    D = 64
+    rng = np.random.default_rng(H * 1000 + N + n_past)
+    n_kv = n_past + N
+    qkv = rng.standard_normal((N, H + 2 * HKV, D)).astype(np.float32)
+    kc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    vc = rng.standard_normal((n_kv, HKV, D)).astype(np.float32)
+    qb, kb, vb, ob_ = g.DevBuf(host=qkv), g.DevBuf(host=kc), g.DevBuf(host=vc), g.DevBuf(N * H * D * 4)
+    outs = {}
+    try:
+        for form in (32, 0):
+            L.ggml_hip_debug_attention_form(form)
+            L.ggml_hip_memset(ob_.ptr, 0xFF, N * H * D * 4)
+            L.ggml_hip_attention(qb.ptr, N, H, HKV, D, n_past, kb.ptr, vb.ptr, ob_.ptr)
+            outs[form] = ob_.to_host(np.float32, (N, H * D))
+    finally:
+        L.ggml_hip_debug_attention_form(0)
+        for b in (qb, kb, vb, ob_):
+            b.free()
+    assert np.isfinite(outs[32]).all()
+    assert np.array_equal(outs[0], outs[32])
+
+
 @pytest.mark.parametrize("env", [{"FQ_ATTN_KEEP": "0"}, {"FQ_ATTN_PERSIST": "0"}, {"FQ_ATTN_KEEP": "0", "FQ_ATTN_PERSIST": "0", "FQ_ATTN_PACK_MIN_N": "100000"}])
 def test_flash_attention_switches_keep_the_bits(env):
     """the prefill attention's A/B switches -- K.Q run twice instead of a wave's score tiles kept in registers, one workgroup per item instead of persistent ones, keys
