@@ -20,6 +20,7 @@
 #include <string>
 #include <string.h>
 #include <vector>
+#include <atomic>
 
 struct layer_weights {
     fq_weight qkv{}, wo{}, up{}, down{};
@@ -256,7 +257,7 @@ static fq_act act_for(uint8_t * buf, const fq_weight & w, int64_t cols) {
     fq_act a{}; a.type = fq_desc(w.type).act_type; a.K = w.K; a.ncols = cols; a.base = buf; return a;
 }
 
-static int g_live_contexts = 0;       // the ring forms' schedule tables are shared by every context of the process and released with the last one
+static std::atomic<int> g_live_contexts{0};       // the ring forms' schedule tables are shared by every context of the process and released with the last one
 // the ring forms' per-shape schedules (device tables) must exist before any launch is captured into a graph: legacy formats kernels_ring.hip, k-quants kernels_ringk.hip
 // (one schedule per distinct (format, shape) of the stage's blocks -- not only block 0's: launchers look plans up without creating them, and a block of another format
 // would silently take the register-streaming kernel)
@@ -767,7 +768,7 @@ extern "C" int falcon_hip_eval_stage(falcon_hip_context * c, const int32_t * tok
     else                  HIP_CHECK(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) N * m->hp.n_embd * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));        // n_past / tokens may live on the caller's stack
     // batches: one hipGraph replay per (size, keys) instead of ~10 launches and 3 cross-stream joins per block from the host
-    if (c->prefill_graph && N > 4 && c->n_seq == 0 && !fq_prof_active() && !hc.dbg_stamps && (!fq_reference_order() || fq_reference_fast())) {
+    if (c->prefill_graph && N > 4 && c->n_seq == 0 && !fq_prof_active() && !fq_tl_collecting() && !hc.dbg_stamps && (!fq_reference_order() || fq_reference_fast())) {
         const int sig = (graph_signature(c) | (c->keep_hidden ? 256 : 0)) + 512 * fq_config_epoch();
         hipGraphExec_t exec = nullptr;
         for (const auto & bg : c->batch_graphs) if (bg.N == N && bg.max_kv == n_past + adv && bg.sig == sig) { exec = bg.exec; break; }

@@ -92,6 +92,7 @@ void attach(falcon_context * ctx, falcon_hip_model * hm, const falcon_context_pa
         const int nb = s.n_batch < s.n_ctx ? s.n_batch : s.n_ctx - 1;
         std::vector<int32_t> zeros((size_t)(nb > 0 ? nb : 1), 0);
         if (nb > 1) falcon_hip_eval(s.c, zeros.data(), nb, 0, 0);
+        else if (s.n_ctx > 2) falcon_hip_eval(s.c, zeros.data(), 1, 0, 0);      // (n_batch 1: position 0's KV rows exist before the step at position 1 attends over them)
         if (s.n_ctx > 2) { falcon_hip_eval_token(s.c, 0, 1); (void) falcon_hip_get_logits(s.c); falcon_hip_eval_token(s.c, 0, 2); (void) falcon_hip_get_logits(s.c); }
     }
     s.t_start_us = now_us();

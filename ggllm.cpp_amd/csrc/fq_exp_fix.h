@@ -1,5 +1,5 @@
 // fq_exp_fix.h -- (input bits << 16 | table entry) of the fp16 inputs whose exp() the f32 fast path of exp_f16_formula (fq_device.h) cannot decide.
-// GENERATED on an MI355X by scripts/gpu_exp_boundary.py from ggml_hip_debug_exp_boundary (48 of 63488 inputs); an input missing here takes the f64 path.
+// GENERATED on an MI355X by scripts/gpu_exp_boundary.py from ggml_hip_debug_exp_boundary (48 of 63488 inputs); an input missing here keeps the fast path's value -- which is why the formula is used only on request (GGML_HIP_EXP_FORMULA=1; the table gather is the default since round 5) and only after ggml_hip_init has compared formula and table for EVERY input (fq_verify_exp_formula == 0): on any mismatch (another chip's v_exp_f32) the kernels keep the table.
 #pragma once
 #define FQ_EXP_FIX_N 48
 static __device__ const unsigned fq_exp_fix[48] = {

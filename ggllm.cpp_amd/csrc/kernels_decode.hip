@@ -60,8 +60,9 @@ template <int TYPE> __device__ __forceinline__ bool kq_fast_units(int units) {
     if constexpr (fq_kdot<TYPE>::ok) return (units & 63) == 0; else return false;
 }
 // REF (both functions; legacy formats): every unit's f32 term goes to the strip of its row, sa[r], at the unit's = block's index (fq_ref_chain.h)
+// col0: regs[i] holds unit column col0 + i of the rows (a caller that consumes the pre-issued columns one by one)
 template <int TYPE, int R, int NPRE, bool REF = false>
-__device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R], const unsigned * sa = nullptr) {
+__device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R], int units, const fq_actcol & col, float (&acc)[R], const unsigned * sa = nullptr, const int col0 = 0) {
     const int lane = threadIdx.x & 63;
     static_assert(!REF || !fq_kdot<TYPE>::ok, "the fast reference order covers the legacy formats");
     if constexpr (fq_kdot<TYPE>::ok) {
@@ -80,7 +81,7 @@ __device__ __forceinline__ void rows_consume(const fq_unit_regs (&regs)[NPRE][R]
     }
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-        const int u = i * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
+        const int u = (col0 + i) * 64 + lane; const bool ok = u < units; const int uc = ok ? u : units - 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) { const float v = fq_unit<TYPE>::dot(regs[i][r], col, uc); fq_emit_term<REF, R>(acc, sa, r, uc, ok, v); }
     }
@@ -752,7 +753,7 @@ __host__ __device__ inline fq_out_ref_geom fq_out_ref_strip(int units_d, int uni
 }
 static size_t fq_out_ref_lds(int act, int64_t FF, int64_t E, int nw) {
     const fq_out_ref_geom sg = fq_out_ref_strip((int)(FF / 32), (int)(E / 32));
-    return fq_act_col_bytes(act, FF) + fq_act_col_bytes(act, E) + 16 + (size_t) 2 * (nw - 1) * sg.swt * 4;
+    return fq_act_col_bytes(act, FF) + fq_act_col_bytes(act, E) + 32 + (size_t) 2 * (nw - 1) * sg.swt * 4;
 }
 __device__ __forceinline__ void ref_wait(unsigned addr, unsigned target, unsigned * err) {      // LDS counter (monotonic) >= target; bounded
     for (unsigned spins = 0;; ++spins) {
@@ -775,8 +776,8 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
     uint8_t * img_ff  = smem;
     uint8_t * img_att = smem + fq_act_col_bytes(ACT, FF);
     uint8_t * ctlp    = img_att + fq_act_col_bytes(ACT, E);
-    float   * strip   = (float *)(ctlp + 16);
-    const unsigned ctl = (unsigned)(uintptr_t) ctlp, DCNT_A = ctl, DCNT_B = ctl + 4, OCNT = ctl + 8, SWEPT = ctl + 12;      // consumer waves done with: the pre-issued Wdown columns, all of Wdown, Wo, their share of the attention image
+    float   * strip   = (float *)(ctlp + 32);
+    const unsigned ctl = (unsigned)(uintptr_t) ctlp, DCNT_A = ctl, DCNT_B = ctl + 4, OCNT = ctl + 8, SWEPT = ctl + 12, OCOL = ctl + 16;      // consumer waves done with: the pre-issued Wdown columns, all of Wdown, Wo, their share of the attention image
     constexpr int NPD = decode_cfg<TYPE>::OUT_NPRE_D, NPO = decode_cfg<TYPE>::OUT_NPRE_O;
     const int units_d = (int)(FF / 32), units_o = (int)(E / 32);
     const fq_out_ref_geom sg = fq_out_ref_strip(units_d, units_o);
@@ -792,7 +793,7 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
     u32x4 tf[NTF];
 #pragma unroll
     for (int k = 0; k < NTF; ++k) { const int64_t i = (int64_t) k * nt + tid; tf[k] = src_ff[i < nvec_ff ? i : nvec_ff - 1]; }
-    if (tid < 4) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 4u * (unsigned) tid), "v"(0u) : "memory");
+    if (tid < 8) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 4u * (unsigned) tid), "v"(0u) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     // the summing wave: lane = row of the workgroup; its residual values now (a dependent load at the very end would add a memory round trip to the tail)
     const int64_t srow = wg_row0 + lane;
@@ -861,13 +862,36 @@ __device__ __forceinline__ void gemv_out_ref_body(const fq_gemv_out_args & g, ui
         ref_count(SWEPT);
         ref_wait(SWEPT, (unsigned) ncw, err);
     }
+    // Wo: one chain behind the workgroup's last dot. (-DFQ_REF_WO_PIPE=1: the pre-issued columns consumed and reported one by one, the summing wave adding a
+    // column's 64 terms while the consumers are in the dots of the next -- built and measured SLOWER, 912 against 925 tok/s A/B/A/B on one box
+    // (profiles/r06i_ab_wo_pipe.txt): three more polled waits and three chain start-ups cost more than the ~100 adds they take off the tail)
+#ifndef FQ_REF_WO_PIPE
+#define FQ_REF_WO_PIPE 0
+#endif
+    constexpr int NOC = !FQ_REF_WO_PIPE ? 0 : (NPO < 3 ? NPO : 3);   // columns reported singly (counters OCOL + 4 i); 0: one chain behind the last dot (A/B)
     if (!summing) {
-        rows_consume<TYPE, 2, NPO, true>(po, units_o, col_o, acc, sa_o);
+#pragma unroll
+        for (int i = 0; i < NPO; ++i) {
+            const fq_unit_regs (&one)[1][2] = *(const fq_unit_regs (*)[1][2]) &po[i];
+            rows_consume<TYPE, 2, 1, true>(one, units_o, col_o, acc, sa_o, i);
+            if (i < NOC) ref_count(OCOL + 4u * (unsigned) i);
+        }
         rows_dot_from<TYPE, 2, 2, true>(ro, units_o, 64 * NPO, col_o, acc, sa_o);
         ref_count(OCNT);
     } else {
+        float so = 0.0f;
+        int done = 0;
+        if (!(dbgm & 4)) {
+#pragma unroll
+            for (int i = 0; i < NOC; ++i) {
+                const int n = 64 * (i + 1) < units_o ? 64 : (units_o - 64 * i > 0 ? units_o - 64 * i : 0);
+                ref_wait(OCOL + 4u * (unsigned) i, (unsigned) ncw, err);
+                so = fq_ref_chain(srow_strip + sg.swd + 64 * i, n, so);
+                done += n;
+            }
+        }
         ref_wait(OCNT, (unsigned) ncw, err);
-        const float so = (dbgm & 4) ? 0.0f : fq_ref_chain(srow_strip + sg.swd, units_o, 0.0f);
+        if (!(dbgm & 4)) so = fq_ref_chain(srow_strip + sg.swd + done, units_o - done, so);
         if (slive) g.dst[srow] = (sd + so) + sres;                                               // libfalcon.cpp:2399-2400
     }
 }

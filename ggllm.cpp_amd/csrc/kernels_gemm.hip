@@ -870,6 +870,10 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // or four (<4,4,2>: 16 waves) for the formats whose 64-row kernel stays within 128 VGPRs
     static const int64_t rb_min = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : 32;      // x #CU tiles; 0 = never
     if (cfg == 3 && rb_min > 0 && tiles >= rb_min * (int64_t) n_cu) cfg = 6;
+    // few columns (round 6): token tiles of 32 / 64 instead of 128 -- the same four-way K split (S = 4: the same association, the same bits), a quarter /
+    // half of the matrix work on padding columns gone and 4 / 8 waves per workgroup instead of 16 (FQ_GEMM_SMALL_TT=0: the 128-token tiles, as before)
+    static const bool small_tt = !(getenv("FQ_GEMM_SMALL_TT") && atoi(getenv("FQ_GEMM_SMALL_TT")) == 0);
+    if (small_tt && cfg == 2 && N <= 32) cfg = 1; else if (small_tt && cfg == 2 && N <= 64) cfg = 4;
     if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>, 6 = <2,4,2>, 7 = <4,4,2>
 #define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
