@@ -290,26 +290,31 @@ def parity_sample(model, weights, toks, L, timed_order=0):
 
 
 def pmc_decode_traffic(order=0):
-    """(HBM bytes per launch of the decode's fused mat-vec launches, source) from the NEWEST committed profiles/*pmc_traffic.json that
+    """(HBM bytes per launch of the decode's fused mat-vec launches IN SUMMATION ORDER `order`, source) from the NEWEST committed profiles/*pmc_traffic.json that
     holds those kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, scripts/gpu_round.sh <tag> pmc, corrected by
     scripts/pmc_summary.py as MI355X_MICROARCH.md prescribes), or None. Files of other workloads (small-batch launches ...) are skipped."""
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
         return None
+
+    def mine(k):
+        # the launches of this order: default = k_gemv_ln_ring<T, NS, TWO, false> / k_gemv_ln<..> / k_attn_out<T>; fast reference order = the <.., true> ring form,
+        # k_gemv_ln_ref, k_attn_out_ref
+        if order == 2:
+            return k.startswith(("k_attn_out_ref", "k_gemv_ln_ref")) or (k.startswith("k_gemv_ln_ring") and k.rstrip().endswith("true>"))
+        return k.startswith(("k_attn_out<", "k_gemv_ln<")) or (k.startswith("k_gemv_ln_ring") and not k.rstrip().endswith("true>"))
     for f in sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(os.path.join(pdir, f)))
         except (OSError, ValueError):
             continue
-        if not (any(k.startswith("k_gemv_ln") for k in d) and any(k.startswith("k_attn_out") for k in d)):      # (the merged attention + output launch: only the headline workload has it)
+        ks = {k: v for k, v in d.items() if mine(k)}
+        if not (any(k.startswith("k_gemv_ln") for k in ks) and any(k.startswith("k_attn_out") for k in ks)):      # (the merged attention + output launch: only the headline workload has it)
             continue
-        if (order == 2) != any(k.startswith("k_attn_out_ref") for k in d):                                      # the timed order's own launches
-            continue
-        ks = [v for k, v in d.items() if k.startswith(("k_gemv_ln", "k_attn_out"))]
-        n = sum(v["launches"] for v in ks)
+        n = sum(v["launches"] for v in ks.values())
         if n:
-            return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n,
-                    "profiles/" + f + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH_SIZE per the gfx950 note; bytes per launch, same launch mix)")
+            return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks.values()) / n,
+                    "profiles/" + f + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH_SIZE per the gfx950 note; bytes per launch over " + ", ".join(sorted(ks)) + ")")
     return None
 
 
