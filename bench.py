@@ -214,24 +214,37 @@ def reference_cli(g, weights, hp, n_prompt, n_predict, n_ctx):
         prompt = text[:lo]
         n_tok = len(voc.tokenize(prompt))
         voc.free() if hasattr(voc, "free") else None
-        env = dict(os.environ)
-        env.pop("GGML_HIP_REFERENCE_ORDER", None)
-        t0 = time.time()
-        r = subprocess.run([exe, "-m", path, "-p", prompt, "-n", str(n_predict), "--temp", "0", "-t", "4", "-c", str(n_ctx), "-b", "128", "--ignore-eos", "-s", "1"],
-                           capture_output=True, env=env, timeout=600)
-        wall = time.time() - t0
-        err = r.stderr.decode("utf-8", "replace")
-        if r.returncode != 0:
-            return {"error": "falcon_main_hip exited %d" % r.returncode, "stderr_tail": err[-600:]}
-        out = {"workload": f"oracle/_ref/falcon_main_hip -m <this model as GGCC v10> -p <{n_tok} tokens> -n {n_predict} --temp 0 -t 4 -c {n_ctx} -b 128 --ignore-eos "
-                           f"(the reference's falcon_main.cpp + libfalcon.cpp + ggml.c, unchanged, with falcon_eval on the device; default order)",
-               "prompt_tokens": n_tok, "wall_s": wall, "ggcc_write_s": t_write, "on_device": "resident on the device" in err}
-        m = re.search(r"batch eval time\s*=\s*([0-9.]+) ms /\s*(\d+) tokens \(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
-        if m:
-            out.update(batch_eval_ms=float(m.group(1)), batch_eval_tokens=int(m.group(2)), batch_eval_tok_s=float(m.group(4)))
-        m = re.search(r"[^h] eval time\s*=\s*([0-9.]+) ms /\s*(\d+) runs\s*\(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
-        if m:
-            out.update(eval_ms=float(m.group(1)), eval_runs=int(m.group(2)), eval_ms_per_token=float(m.group(3)), eval_tok_s=float(m.group(4)))
+        def run(order):
+            env = dict(os.environ)
+            env.pop("GGML_HIP_REFERENCE_ORDER", None)
+            if order:
+                env["GGML_HIP_REFERENCE_ORDER"] = str(order)
+            t0 = time.time()
+            r = subprocess.run([exe, "-m", path, "-p", prompt, "-n", str(n_predict), "--temp", "0", "-t", "4", "-c", str(n_ctx), "-b", "128", "--ignore-eos", "-s", "1"],
+                               capture_output=True, env=env, timeout=600)
+            wall = time.time() - t0
+            err = r.stderr.decode("utf-8", "replace")
+            if r.returncode != 0:
+                return {"error": "falcon_main_hip exited %d" % r.returncode, "stderr_tail": err[-600:]}, None
+            out = {"summation_order": order, "wall_s": wall, "on_device": "resident on the device" in err}
+            m = re.search(r"batch eval time\s*=\s*([0-9.]+) ms /\s*(\d+) tokens \(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
+            if m:
+                out.update(batch_eval_ms=float(m.group(1)), batch_eval_tokens=int(m.group(2)), batch_eval_tok_s=float(m.group(4)))
+            m = re.search(r"[^h] eval time\s*=\s*([0-9.]+) ms /\s*(\d+) runs\s*\(\s*([0-9.]+) ms per token,\s*([0-9.]+) tokens per second", err)
+            if m:
+                out.update(eval_ms=float(m.group(1)), eval_runs=int(m.group(2)), eval_ms_per_token=float(m.group(3)), eval_tok_s=float(m.group(4)))
+            return out, r.stdout
+        out, text0 = run(0)
+        out["workload"] = (f"oracle/_ref/falcon_main_hip -m <this model as GGCC v10> -p <{n_tok} tokens> -n {n_predict} --temp 0 -t 4 -c {n_ctx} -b 128 --ignore-eos "
+                           f"(the reference's falcon_main.cpp + libfalcon.cpp + ggml.c, unchanged, with falcon_eval on the device; default order)")
+        out["prompt_tokens"] = n_tok
+        out["ggcc_write_s"] = t_write
+        # the same command with GGML_HIP_REFERENCE_ORDER=2: the reference's own CLI at the fast reference order's speed (its logits are then the CPU build's, bit for bit:
+        # tests/test_gpu_dropin.py compares the bytes it prints with the pure-CPU build's on the small fixture)
+        o2, text2 = run(2)
+        if text0 is not None and text2 is not None:
+            o2["same_text_as_default_order"] = text0 == text2
+        out["fast_reference_order"] = o2
         return out
     finally:
         shutil.rmtree(td, ignore_errors=True)

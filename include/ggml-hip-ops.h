@@ -41,7 +41,12 @@ void    ggml_hip_gemm_sequential(int on);
  * sums for the legacy formats, the eight float lanes of k_quants.c:1684-1746 ... for Q3_K .. Q6_K), f64 accumulation of the
  * attention's two dot products (ggml.c:2296-2300; the default is f32 fused multiply-add chains like the reference's SIMD
  * builds), N = 1 steps through the op-by-op launch list. Prefill AND decode logits of all ten formats are then
- * bit-identical with that reference build's (tests/test_gpu_falcon.py). A parity instrument: 10-100 x slower.             */
+ * bit-identical with that reference build's (tests/test_gpu_falcon.py). A parity instrument: 10-100 x slower.
+ * on = 2 (round 6): the SAME association -- the same bits as on = 1 and as the reference's scalar build -- on the fast kernels wherever they have it, i.e. the legacy
+ * formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0): N = 1 steps through the fused decode launches, whose lanes leave every unit's f32 term (the reference's per-block term,
+ * ggml.c:2591-2609 ...) in an LDS strip [row][block] that a wave with lane = row adds left to right (csrc/fq_ref_chain.h); batches of N > 4 through the int8-MFMA GEMM
+ * with one left-to-right sum per row (ggml_hip_gemm_sequential); attention dots in f64. Everything else (k-quants, N = 2..4) runs mode 1's kernels. Falcon-7B Q4_0
+ * decode: 925-930 tok/s (default order 1 005-1 020, mode 1: 40). tests/test_gpu_ref_fast.py.                                                                      */
 void    ggml_hip_reference_order(int on);
 int     ggml_hip_get_reference_order(void);
 /* ---- row-split tensor parallelism, one process per GPU (csrc/split_tp.hip): the reference's `-ts` / GGML_BACKEND_GPU_SPLIT.

@@ -57,10 +57,13 @@ L.reff_free(ctx)
 """
 
 
+# order: GGML_HIP_REFERENCE_ORDER = 1 (the one-thread-per-output parity instrument) or 2 (round 6, the FAST reference order: the fused decode launches and the
+# sequential-sum GEMM in the reference's association, csrc/fq_ref_chain.h; formats without a fast form -- the k-quants -- run mode 1's kernels under it)
+@pytest.mark.parametrize("order", ["1", "2"])
 @pytest.mark.parametrize("so", ["libfalcon_ref_shim.so", "libfalcon_ref_hip.so"])
 @pytest.mark.parametrize("name,hp,t", [("mqa_q4_0", synth.HP_TINY_MQA, ob.Q4_0), ("gqa_q5_1", synth.HP_TINY_GQA, ob.Q5_1),
                                        ("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K)])
-def test_reference_code_on_libggml_hip_reproduces_reference_logits(oracle, golden, tmp_path, so, name, hp, t):
+def test_reference_code_on_libggml_hip_reproduces_reference_logits(oracle, golden, tmp_path, so, name, hp, t, order):
     """the reference's falcon_init_from_file / falcon_eval / falcon_get_logits, with the offload (shim) or the device-resident
     evaluation (wrap) underneath: prefill and decode logits == the pure-CPU reference's (run in a child process: the
     reference's ggml_init starts its own CUDA-init thread and owns process-wide state)"""
@@ -75,7 +78,7 @@ def test_reference_code_on_libggml_hip_reproduces_reference_logits(oracle, golde
     out = str(tmp_path / "out.npz")
     script = str(tmp_path / "run.py")
     open(script, "w").write(_LOGITS_SCRIPT)
-    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER=order)
     r = subprocess.run([sys.executable, script, lib, path, str(hp["n_vocab"]), "100", out, toks, g.LIB_PATH], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     if so.endswith("_hip.so"):
@@ -103,13 +106,14 @@ def _cli_model(oracle, path):
     return bpe_fixture
 
 
-def test_falcon_main_unchanged_on_the_fast_path(oracle, golden, tmp_path):
+@pytest.mark.parametrize("order", ["1", "2"])
+def test_falcon_main_unchanged_on_the_fast_path(oracle, golden, tmp_path, order):
     """the reference's falcon_main (examples/falcon/falcon_main.cpp, unchanged: its argument parser, tokenizer, repetition
     penalty, greedy sampler, detokenizer) with falcon_eval on the device prints the same bytes as the pure-CPU build"""
     exe = _need("falcon_main_hip")
     path = str(tmp_path / "tiny_bpe.ggcc")
     _cli_model(oracle, path)
-    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER=order)
     r = subprocess.run([exe, "-m", path, "-p", "The quick brown fox didn't jump", "-n", "8", "--temp", "0", "-t", "2", "-c", "64", "-b", "8", "--ignore-eos", "-s", "1"],
                        capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -193,14 +197,15 @@ def test_lora_fails_loudly_on_a_device_context(oracle, tmp_path):
     assert "llama_apply_lora_from_file is not supported for a context evaluated on the device" in r.stderr
 
 
-def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path):
+@pytest.mark.parametrize("order", ["1", "2"])
+def test_falcon_perplexity_unchanged_on_the_fast_path(oracle, golden, tmp_path, order):
     """the reference's falcon_perplexity tool, unchanged, with falcon_eval on the device: the chunk perplexities it prints"""
     exe = _need("falcon_perplexity_hip")
     path = str(tmp_path / "tiny_bpe.ggcc")
     bf = _cli_model(oracle, path)
     txt = str(tmp_path / "corpus.txt")
     open(txt, "wb").write((bf.CORPUS * 2).encode("utf-8"))
-    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER="1")
+    env = dict(os.environ, GGML_HIP_REFERENCE_ORDER=order)
     r = subprocess.run([exe, "-m", path, "-f", txt, "-t", "2", "-c", "32", "-b", "8", "-s", "1"], capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout == bytes(golden["cli"]["ppl_stdout"])
