@@ -313,9 +313,13 @@ def pmc_decode_traffic(order=0):
     def mine(k):
         # the launches of this order: default = k_gemv_ln_ring<T, NS, TWO, false> / k_gemv_ln<..> / k_attn_out<T>; fast reference order = the <.., true> ring form,
         # k_gemv_ln_ref, k_attn_out_ref
+        ring_ref = False
+        if k.startswith("k_gemv_ln_ring<"):                       # <TYPE, NSLOT, TWO, REF> since round 6 (three arguments before)
+            targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            ring_ref = len(targs) == 4 and targs[3] == "true"
         if order == 2:
-            return k.startswith(("k_attn_out_ref", "k_gemv_ln_ref")) or (k.startswith("k_gemv_ln_ring") and k.rstrip().endswith("true>"))
-        return k.startswith(("k_attn_out<", "k_gemv_ln<")) or (k.startswith("k_gemv_ln_ring") and not k.rstrip().endswith("true>"))
+            return k.startswith(("k_attn_out_ref", "k_gemv_ln_ref")) or ring_ref
+        return k.startswith(("k_attn_out<", "k_gemv_ln<")) or (k.startswith("k_gemv_ln_ring") and not ring_ref)
     for f in sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(os.path.join(pdir, f)))

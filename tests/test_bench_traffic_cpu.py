@@ -30,3 +30,25 @@ def test_no_decode_file_means_none(tmp_path, monkeypatch):
     assert bench.pmc_decode_traffic() is None
     monkeypatch.setattr(bench, "ROOT", str(tmp_path / "nowhere"))
     assert bench.pmc_decode_traffic() is None
+
+
+def test_traffic_of_the_timed_order_only(tmp_path, monkeypatch):
+    """round 6: one profile run holds the decode launches of BOTH summation orders (bench.py times the fast reference order and the default one beside it):
+    `roofline.traffic` of an order averages that order's launches only, and a file without the order's launches is passed over for an older one that has them"""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    both = {"k_gemv_ln_ring<2, 7, false, true>": {"launches": 10, "hbm_bytes_per_launch": 61e6}, "k_attn_out_ref<2>": {"launches": 10, "hbm_bytes_per_launch": 59e6},
+            "k_gemv_ln_ref<2, 768>": {"launches": 1, "hbm_bytes_per_launch": 167e6},
+            "k_gemv_ln_ring<2, 7, false, false>": {"launches": 10, "hbm_bytes_per_launch": 60e6}, "k_attn_out<2>": {"launches": 10, "hbm_bytes_per_launch": 58e6},
+            "k_gemv_ln<2, 768>": {"launches": 1, "hbm_bytes_per_launch": 166e6}}
+    (prof / "r06a_pmc_traffic.json").write_text(json.dumps(both))
+    (prof / "r06b_pmc_traffic.json").write_text(json.dumps({k: v for k, v in both.items() if "ref" not in k and "true>" not in k}))      # newer, default order only
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    v2, s2 = bench.pmc_decode_traffic(2)
+    assert "r06a_pmc_traffic.json" in s2 and abs(v2 - (10 * 61e6 + 10 * 59e6 + 167e6) / 21) < 1.0
+    v0, s0 = bench.pmc_decode_traffic(0)
+    assert "r06b_pmc_traffic.json" in s0 and abs(v0 - (10 * 60e6 + 10 * 58e6 + 166e6) / 21) < 1.0
+    # round-5 files name the ring form without the REF parameter: still the default order's launches
+    os.remove(prof / "r06b_pmc_traffic.json"); os.remove(prof / "r06a_pmc_traffic.json")
+    (prof / "r05h_pmc_traffic.json").write_text(json.dumps({"k_gemv_ln_ring<2, 7, false>": {"launches": 4, "hbm_bytes_per_launch": 60e6}, "k_attn_out<2>": {"launches": 4, "hbm_bytes_per_launch": 58e6}}))
+    assert bench.pmc_decode_traffic(0)[0] == 59e6 and bench.pmc_decode_traffic(2) is None
