@@ -52,8 +52,21 @@ struct fq_ring_ln_args {
 // in an LDS strip [row slot][block] instead of adding them per lane and across the wave, and the epilogue wave, lane = row, adds each row's terms left to
 // right (ggml.c:2591-2609): bit-identical to the reference's scalar build. The strip takes the place of the f32 residual row (dead once the image exists)
 // plus the workgroup's unused LDS; the loader, the ring and the LayerNorm prologue are the default form's.
+// Kernel arguments (round 6): the words the launch needs FIRST -- the residual row, the schedule entry, the two matrices' first rows, the shape -- are leading scalar
+// arguments, which the command processor preloads into SGPRs before the first wave starts (-mllvm -amdgpu-kernarg-preload-count, gfx940+: the Makefile sets it for
+// this file); the struct behind them is fetched by scalar loads as before, under the prologue's first requests. FQ_RING_PRELOAD=0 at compile time: the struct only.
+#ifndef FQ_RING_PRELOAD
+#define FQ_RING_PRELOAD 1
+#endif
 template <int TYPE, int NSLOT, bool TWO, bool REF>
-__global__ void __launch_bounds__(RNT) k_gemv_ln_ring(fq_ring_ln_args a) {
+__global__ void __launch_bounds__(RNT) k_gemv_ln_ring(
+#if FQ_RING_PRELOAD
+                                                      const float * p_x, const fq_engine_sched * p_sched, const uint8_t * p_qkv, const uint8_t * p_up, int p_E, int p_FF, int p_nblkE, unsigned p_rsE,
+#endif
+                                                      fq_ring_ln_args a) {
+#if FQ_RING_PRELOAD
+    a.x = p_x; a.sched = p_sched; a.qkv = p_qkv; a.up = p_up; a.E = p_E; a.FF = p_FF; a.nblkE = p_nblkE; a.rsE = p_rsE;
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = eng_act<TYPE>::value;
     constexpr int RING = NSLOT * ENG_SLOT;
@@ -539,12 +552,17 @@ bool fq_launch_gemv_ln_ring(const fq_gemv_ln_args & g, unsigned * err, int n_cu,
     if (!nslot) return false;
     // a row (<= 3 passes of it) must fit the ring next to the loader's restart slot
     if ((size_t) 2 * 2 * a.rsE + ENG_SLOT > (size_t) nslot * ENG_SLOT) return false;
+#if FQ_RING_PRELOAD
+#define FQ_RING_LEAD a.x, a.sched, a.qkv, a.up, a.E, a.FF, a.nblkE, a.rsE,
+#else
+#define FQ_RING_LEAD
+#endif
 #define FQ_RING_LAUNCH3(T, NS, TW, RF) { \
         static bool set = false; \
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_ln_ring<T, NS, TW, RF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_);      /* (the open profile bracket's events, if any, go to the dispatch) */ \
-        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, e0_, e1_, 0, a); \
-        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, a); }
+        if (e0_) hipExtLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, e0_, e1_, 0, FQ_RING_LEAD a); \
+        else     hipLaunchKernelGGL((k_gemv_ln_ring<T, NS, TW, RF>), dim3((unsigned) n_cu), dim3(RNT), lds, st, FQ_RING_LEAD a); }
 #define FQ_RING_LAUNCH2(T, NS, TW) { if (ref) FQ_RING_LAUNCH3(T, NS, TW, true) else FQ_RING_LAUNCH3(T, NS, TW, false) }
 #define FQ_RING_LAUNCH(T, NS) { if (two_norms) FQ_RING_LAUNCH2(T, NS, true) else FQ_RING_LAUNCH2(T, NS, false) }
 #define FQ_RING_CASE(T) case T: if (nslot == 7) FQ_RING_LAUNCH(T, 7) else if (nslot == 6) FQ_RING_LAUNCH(T, 6) else FQ_RING_LAUNCH(T, 4) break;
