@@ -719,8 +719,23 @@ __device__ __forceinline__ void attn_out_body(const fq_attn_out_args & a, uint8_
     FQ_STAMP(dbg, 7);
 }
 
+// Kernel arguments (round 6, as k_gemv_ln_ring): the words both roles need first are leading scalar arguments, preloaded into SGPRs by the command processor
+// (-mllvm -amdgpu-kernarg-preload-count=14 for this file); the ~300-byte struct behind them is fetched by scalar loads as before. FQ_ATTN_OUT_PRELOAD=0: struct only.
+#ifndef FQ_ATTN_OUT_PRELOAD
+#define FQ_ATTN_OUT_PRELOAD 1
+#endif
+#if FQ_ATTN_OUT_PRELOAD
+#define FQ_AO_PARAMS const uint8_t * p_ff, uint8_t * p_down, uint8_t * p_wo, const float * p_qkv, const int * p_np, const unsigned * p_epoch, int p_n_attn, int p_n_mv,
+#define FQ_AO_TAKE   a.g.act_ff_image = p_ff; a.g.w_down.plane[0] = p_down; a.g.w_wo.plane[0] = p_wo; a.at.qkv = p_qkv; a.at.n_past_ptr = p_np; a.epoch_word = p_epoch; a.n_attn = p_n_attn; a.n_mv = p_n_mv;
+#define FQ_AO_LEAD   a.g.act_ff_image, a.g.w_down.plane[0], a.g.w_wo.plane[0], a.at.qkv, a.at.n_past_ptr, a.epoch_word, a.n_attn, a.n_mv,
+#else
+#define FQ_AO_PARAMS
+#define FQ_AO_TAKE
+#define FQ_AO_LEAD
+#endif
 template <int TYPE>
-__global__ void __launch_bounds__(768) k_attn_out(fq_attn_out_args a) {
+__global__ void __launch_bounds__(768) k_attn_out(FQ_AO_PARAMS fq_attn_out_args a) {
+    FQ_AO_TAKE
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     attn_out_body<TYPE>(a, smem, *a.epoch_word, fq_publish{ nullptr, 0u });
 }
@@ -902,7 +917,8 @@ __global__ void __launch_bounds__(768) k_gemv_out_ref(fq_gemv_out_args a) {
     gemv_out_ref_body<TYPE>(a, smem, (int) blockIdx.x, nullptr, 0u, nullptr);
 }
 template <int TYPE>
-__global__ void __launch_bounds__(768) k_attn_out_ref(fq_attn_out_args a) {
+__global__ void __launch_bounds__(768) k_attn_out_ref(FQ_AO_PARAMS fq_attn_out_args a) {
+    FQ_AO_TAKE
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const unsigned epoch = *a.epoch_word;
     if ((int) blockIdx.x < a.n_attn) {
@@ -959,7 +975,7 @@ bool fq_launch_attn_out_ref(const fq_gemv_out_args & g, const float * qkv, int H
     a.ref_debug = dbgm;
     const int grid = n_attn + n_mv;
 #define FQ_CASE(T) case T: { static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
-        FQ_LAUNCH_PROF((k_attn_out_ref<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a); } break;
+        FQ_LAUNCH_PROF((k_attn_out_ref<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, FQ_AO_LEAD a); } break;
     switch (type) { FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) default: return false; }
 #undef FQ_CASE
     return true;
@@ -1033,7 +1049,7 @@ bool fq_launch_attn_out(const fq_gemv_out_args & g, const float * qkv, int H, in
         FQ_LAUNCH_PROF((k_attn_out_ln<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a, b, xgran); \
     } else { \
         static size_t gmax = 0; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_out<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
-        FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, a); } break;
+        FQ_LAUNCH_PROF((k_attn_out<T>), dim3((unsigned) grid), dim3(64 * nw), lds, st, FQ_AO_LEAD a); } break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)
         FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K)
