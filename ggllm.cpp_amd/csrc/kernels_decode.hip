@@ -402,8 +402,10 @@ void fq_launch_gemv_ln(fq_gemv_ln_args a, int n_cu, hipStream_t st, bool ref) {
 // =============================================================================================== k_gemv_out
 // one workgroup = NW waves = 2*NW consecutive output rows (wave w: rows 2w, 2w+1), NW chosen by the launcher for about
 // one workgroup per CU; x[row] = (down + wo) + x[row]
+// (round 6: the first-needed arguments as leading scalars, preloaded into SGPRs -- see k_attn_out)
 template <int TYPE, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_gemv_out(fq_gemv_out_args a) {
+__global__ void __launch_bounds__(MAXT) k_gemv_out(const uint8_t * p_ff, const uint8_t * p_att_image, uint8_t * p_down, uint8_t * p_wo, const float * p_resid, float * p_dst, fq_gemv_out_args a) {
+    a.act_ff_image = p_ff; a.att_image = p_att_image; a.w_down.plane[0] = p_down; a.w_wo.plane[0] = p_wo; a.resid = p_resid; a.dst = p_dst;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = act_of<TYPE>::value;
     const int64_t E = a.w_wo.K, FF = a.w_down.K;
@@ -497,7 +499,7 @@ void fq_launch_gemv_out(const fq_gemv_out_args & a, int n_cu, hipStream_t st, bo
     if ((int) blocks <= n_cu && lds < 84 * 1024) lds = 84 * 1024;       // one workgroup per CU (see fq_launch_gemv_ln)
 #define FQ_LAUNCH(T, MAXT) { \
         static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_out<T, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
-        FQ_LAUNCH_PROF((k_gemv_out<T, MAXT>), dim3(blocks), dim3(64 * nw), lds, st, a); }
+        FQ_LAUNCH_PROF((k_gemv_out<T, MAXT>), dim3(blocks), dim3(64 * nw), lds, st, a.act_ff_image, a.att_image, a.w_down.plane[0], a.w_wo.plane[0], a.resid, a.dst, a); }
 #define FQ_CASE(T) case T: if (nw <= 4) FQ_LAUNCH(T, 256) else FQ_LAUNCH(T, 768) break;
     switch (type) {
         FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0)

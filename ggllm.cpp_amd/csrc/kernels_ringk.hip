@@ -40,8 +40,11 @@ struct fq_ringk_ln_args {
     unsigned * err; int debug_mode; long long * dbg;
 };
 
+// (round 6, as k_gemv_ln_ring: the first-needed arguments as leading scalars, preloaded into SGPRs by the command processor -- -amdgpu-kernarg-preload-count=12 for this file)
 template <int TYPE>
-__global__ void __launch_bounds__(KNT) k_ring_ln_k(fq_ringk_ln_args a) {
+__global__ void __launch_bounds__(KNT) k_ring_ln_k(const float * p_x, const fq_engine_sched * p_sched, const uint8_t * p_qkv, const uint8_t * p_up, int p_E, int p_FF, int p_nblkE, unsigned p_rsE,
+                                                   fq_ringk_ln_args a) {
+    a.x = p_x; a.sched = p_sched; a.qkv = p_qkv; a.up = p_up; a.E = p_E; a.FF = p_FF; a.nblkE = p_nblkE; a.rsE = p_rsE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = FQ_Q8_K;
     constexpr int RING = KNSLOT * ENG_SLOT;
@@ -619,8 +622,8 @@ bool fq_launch_ringk_ln(const fq_gemv_ln_args & g, unsigned * err, int n_cu, hip
         static bool set = false; \
         if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_ring_ln_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipEvent_t e0_ = nullptr, e1_ = nullptr; fq_prof_events(&e0_, &e1_); \
-        if (e0_) hipExtLaunchKernelGGL((k_ring_ln_k<T>), dim3((unsigned) n_cu), dim3(KNT), lds, st, e0_, e1_, 0, a); \
-        else     hipLaunchKernelGGL((k_ring_ln_k<T>), dim3((unsigned) n_cu), dim3(KNT), lds, st, a); } break;
+        if (e0_) hipExtLaunchKernelGGL((k_ring_ln_k<T>), dim3((unsigned) n_cu), dim3(KNT), lds, st, e0_, e1_, 0, a.x, a.sched, a.qkv, a.up, a.E, a.FF, a.nblkE, a.rsE, a); \
+        else     hipLaunchKernelGGL((k_ring_ln_k<T>), dim3((unsigned) n_cu), dim3(KNT), lds, st, a.x, a.sched, a.qkv, a.up, a.E, a.FF, a.nblkE, a.rsE, a); } break;
     switch (type) {
         FQ_RK_CASE(FQ_Q2_K) FQ_RK_CASE(FQ_Q3_K) FQ_RK_CASE(FQ_Q4_K) FQ_RK_CASE(FQ_Q5_K) FQ_RK_CASE(FQ_Q6_K)
         default: return false;
