@@ -372,14 +372,15 @@ def main():
 
     toks = synth.tokens(max(a.prompt, a.prefill_long) + 8, hp["n_vocab"], seed=42)
     legacy = a.quant in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0")
+    kq_fast = a.quant.lower() in ("q2_k", "q4_k", "q5_k")         # k-quants with a wave-speed form of the reference's association (csrc/kernels_kqref.hip: ~0.5-0.7 x the default order's decode)
     # THE TIMED ORDER. 2 = the fast reference order (round 6, csrc/fq_ref_chain.h): the fused decode launches and the prefill GEMM add every row's per-block
     # terms left to right as the reference's scalar build does -- logits bit-identical to the CPU reference (north_star: within 1e-3; measured below on THIS
     # model: 0.0). The k-quants have no fast form of that association: their timed order is the default one (0).
     order = a.order if a.order >= 0 else (2 if legacy else 0)
-    if order == 2 and not legacy:
-        sys.stderr.write("bench.py: --order 2 needs a legacy format (q4_0 / q4_1 / q5_0 / q5_1 / q8_0): timing the default order\n")
+    if order == 2 and not (legacy or kq_fast):
+        sys.stderr.write("bench.py: --order 2 needs a format with a fast form of the reference's association (legacy formats, q2_k / q4_k / q5_k): timing the default order\n")
         order = 0
-    other = 0 if order == 2 else (2 if legacy else None)
+    other = 0 if order == 2 else (2 if (legacy or kq_fast) else None)
     # ---- parity, measured on the benchmark's own N(0, 0.02^2) model: the timed order, the default order, the one-thread-per-output instrument (mode 1) and
     # the reference's AVX2 build against the reference's scalar build on the host, all of them also against the f64 yardstick. (A residual-dominated variant
     # -- wo / down drawn 2^-4 times smaller, block scales still normal fp16 numbers -- is reported under its own key, never as the headline.)
@@ -674,10 +675,39 @@ def north_star_1gpu(g, synth, L, tname, a):
         dl = time.perf_counter() - t1
         pipe.free()
         ls[str(B)] = {"tok_s": 6 * B / dl, "ms_per_weight_pass": dl / 6 * 1e3}
+    # the same model in the reference's own association (round 6, csrc/kernels_kqref.hip: Q4_K's eight float lanes per super-block at wave speed; op-by-op launches):
+    # decode steps after the same prompt, the first tokens against the one-thread-per-output instrument's (mode 1; bit-identity of the logits: tests/test_gpu_kqref.py)
+    ref2 = None
+    try:
+        L.ggml_hip_reference_order(2)
+        lg2 = model.eval(toks[:128], 0, logits_all=False)
+        ow2 = model.decode_greedy(int(lg2[0].argmax()), 128, 2, use_graph=not a.no_graph)
+        L.ggml_hip_synchronize()
+        t2 = time.perf_counter()
+        o2 = model.decode_greedy(int(ow2[-1]), 130, 16, use_graph=not a.no_graph)
+        L.ggml_hip_synchronize()
+        d2 = time.perf_counter() - t2
+        L.ggml_hip_reference_order(1)
+        cur = int(ow2[-1])
+        t1 = time.perf_counter()
+        o1 = []
+        for i in range(2):
+            cur = int(model.eval(np.array([cur], np.int32), 130 + i, logits_all=False)[0].argmax()); o1.append(cur)
+        L.ggml_hip_synchronize()
+        d1 = time.perf_counter() - t1
+        ref2 = {"order": 2, "decode_tok_s": 16 / d2, "ms_per_step": d2 / 16 * 1e3, "mode1_decode_tok_s": 2 / d1,
+                "first_tokens_equal_mode1": [int(t) for t in o2[:2]] == o1,
+                "form": "ggml_hip_reference_order(2): single-token mat-vecs through k_gemv_kq_ref (the reference's scalar association: eight float lanes + the mins' chain per row), "
+                        "f64 attention dots, op-by-op launches; the prompt column by column through the same kernel"}
+    except Exception as e:                                              # (never lose the line to the extra key)
+        ref2 = {"error": repr(e)}
+    finally:
+        L.ggml_hip_reference_order(0)
     model.free()
     tok_s = K / dt
     b_tok = wbytes + kv_bytes_per_token(hp, 132 + K // 2)
     return {"workload": "Falcon-40B Q4_K (60 blocks, GQA 128/8, 8192 wide) fully resident on ONE GPU, 128-token prompt + 32 greedy decode steps",
+            "fast_reference_order": ref2,
             "value": tok_s, "unit": "tokens/s", "ms_per_step": dt / K * 1e3, "prefill_tok_s": 128 / (prefill_ms * 1e-3),
             "weight_bytes_per_token": wbytes, "step_achieved_GBs": b_tok * tok_s / 1e9, "step_frac": b_tok * tok_s / 1e9 / HBM_PEAK_GBS, "setup_s": t_setup,
             "roofline": kroof,

@@ -20,8 +20,8 @@ m = g.FalconModel(w, n_ctx=2048, n_batch=128)
 toks = synth.tokens(136, hp["n_vocab"], seed=42)
 K = 64
 out = {}
-LEGACY = quant in ('q4_0', 'q4_1', 'q5_0', 'q5_1', 'q8_0')
-MODES = (0, 2) if LEGACY else (0,)          # the k-quants have no fast reference form: only the default order is timed
+LEGACY = quant in ('q4_0', 'q4_1', 'q5_0', 'q5_1', 'q8_0', 'q2_k', 'q4_k', 'q5_k')      # formats with a fast form of the reference's association (k-quants: single-token mat-vecs, kernels_kqref.hip)
+MODES = (0, 2) if LEGACY else (0,)
 e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
 for rep in range(2):
     for mode in MODES:
@@ -52,6 +52,15 @@ for mode in ((1, 2) if LEGACY else ()):
     res[mode] = (a, b, c)
     L.ggml_hip_reference_order(0)
 eq = [bool(np.array_equal(x, y)) for x, y in zip(res[1], res[2])] if LEGACY else None
+# the one-thread-per-output instrument's decode speed, for scale
+L.ggml_hip_reference_order(1)
+cur = 5
+L.ggml_hip_synchronize(); t0 = time.perf_counter()
+for i in range(4):
+    cur = int(m.eval(np.array([cur], np.int32), 130 + i, logits_all=False)[0].argmax())
+L.ggml_hip_synchronize(); out["mode1_decode_tok_s"] = 4 / (time.perf_counter() - t0)
+L.ggml_hip_reference_order(0)
+print("mode 1 decode: %.1f tok/s" % out["mode1_decode_tok_s"], flush=True)
 print("mode 2 == mode 1 (prefill, step 128, step 129):", eq, flush=True)
 out["mode2_equals_mode1"] = eq
 # per-launch timing table of one decode step in each mode
