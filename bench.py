@@ -372,13 +372,13 @@ def main():
 
     toks = synth.tokens(max(a.prompt, a.prefill_long) + 8, hp["n_vocab"], seed=42)
     legacy = a.quant in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0")
-    kq_fast = a.quant.lower() in ("q2_k", "q4_k", "q5_k")         # k-quants with a wave-speed form of the reference's association (csrc/kernels_kqref.hip: ~0.5-0.7 x the default order's decode)
+    kq_fast = a.quant.lower() in ("q2_k", "q3_k", "q4_k", "q5_k", "q6_k")         # k-quants with a wave-speed form of the reference's association (csrc/kernels_kqref.hip: ~0.5-0.7 x the default order's decode)
     # THE TIMED ORDER. 2 = the fast reference order (round 6, csrc/fq_ref_chain.h): the fused decode launches and the prefill GEMM add every row's per-block
     # terms left to right as the reference's scalar build does -- logits bit-identical to the CPU reference (north_star: within 1e-3; measured below on THIS
     # model: 0.0). The k-quants have no fast form of that association: their timed order is the default one (0).
     order = a.order if a.order >= 0 else (2 if legacy else 0)
     if order == 2 and not (legacy or kq_fast):
-        sys.stderr.write("bench.py: --order 2 needs a format with a fast form of the reference's association (legacy formats, q2_k / q4_k / q5_k): timing the default order\n")
+        sys.stderr.write("bench.py: --order 2 needs a format with a fast form of the reference's association (every format has one since round 6): timing the default order\n")
         order = 0
     other = 0 if order == 2 else (2 if (legacy or kq_fast) else None)
     # ---- parity, measured on the benchmark's own N(0, 0.02^2) model: the timed order, the default order, the one-thread-per-output instrument (mode 1) and

@@ -383,7 +383,7 @@ void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float *
     // reference order: one thread per output (mode 1), or -- mode 2, legacy formats, batches -- the GEMM below with S = 1 (fq_gemm_set_sequential: one
     // left-to-right sum per row, the scalar build's two roundings per term: == the reference, tests/test_gpu_mul_mat.py)
     if (g_reference_order && !(g_reference_order == 2 && legacy_type(w.type) && N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv)) {
-        // mode 2, Q2_K / Q4_K / Q5_K: the wave-speed mat-vec in the reference's association (kernels_kqref.hip), column by column. A prompt re-reads the matrix per
+        // mode 2, the k-quants: the wave-speed mat-vec in the reference's association (kernels_kqref.hip), column by column. A prompt re-reads the matrix per
         // token (out of L2 / the Infinity Cache) and is still 4.5 x faster than mode 1's one thread per output (Falcon-40B Q4_K, 128 tokens, 16 blocks: 268 against
         // 1 217 ms). FQ_KQREF_MAX_N=n: mode 1's kernel beyond n columns (A/B)
         static const int64_t kq_max_n = getenv("FQ_KQREF_MAX_N") ? atoll(getenv("FQ_KQREF_MAX_N")) : INT64_MAX;

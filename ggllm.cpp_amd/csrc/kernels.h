@@ -32,7 +32,7 @@ void   fq_launch_gemv(const fq_weight & w, const fq_act & act, int ncols, float 
 // kernels_ref.hip -- any N, the reference's scalar summation order (ggml_hip_reference_order)
 void   fq_launch_mul_mat_ref(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st);
 
-// kernels_kqref.hip -- Q2_K / Q4_K / Q5_K mat-vec (per column) in the reference's scalar association at wave speed (ggml_hip_reference_order(2)); false: outside its scope
+// kernels_kqref.hip -- the k-quants' mat-vec (per column) in the reference's scalar association at wave speed (ggml_hip_reference_order(2)); false: outside its scope
 bool   fq_gemv_kq_ref_supported(const fq_weight & w);
 bool   fq_launch_gemv_kq_ref(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st);
 

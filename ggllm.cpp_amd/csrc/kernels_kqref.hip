@@ -1,4 +1,4 @@
-// kernels_kqref.hip -- the k-quant mat-vec in the REFERENCE'S OWN association at wave speed (round 6; ggml_hip_reference_order(2) for Q2_K, Q4_K, Q5_K).
+// kernels_kqref.hip -- the k-quant mat-vec in the REFERENCE'S OWN association at wave speed (round 6; ggml_hip_reference_order(2) for the five k-quants).
 //
 // The scalar branches of ggml_vec_dot_q{2,4,5}_K_q8_K (k_quants.c:1267-1306, 1999-2055, 2340-2400; caller ggml.c:11484-11516) do not add one term per
 // 32-element group the way the legacy formats do:
@@ -16,7 +16,8 @@
 //     eight lane sums in order.
 // Every f32 operation is the reference's, in the reference's order: the results are bit-identical to k_mul_mat_ref (mode 1) and to the reference's scalar build
 // (tests/test_gpu_kqref.py). The integer work is ~2 x the default kernels' per unit (perms, sixteen half-filled dot4, the exchange), so this form runs at roughly half
-// their speed -- against one thread per output in mode 1. Q3_K / Q6_K (16-element scale blocks) keep mode 1.
+// their speed -- against one thread per output in mode 1. Q6_K (k_quants.c:2748-2789: int8 scales per 16 elements) has Q4_K's unit shape; Q3_K (k_quants.c:1684-1746) has
+// units of four 16-element scale blocks and super-blocks of four lanes, which end the exchange with two residues each.
 #include "fq_block_dev.h"
 #include "fq_units.h"
 #include "fq_ref_chain.h"
@@ -28,8 +29,10 @@ namespace {
 constexpr int KQ_R = 2;                                                     // rows of a run (per wave)
 
 template <int TYPE> struct kq_ref_fmt {
-    static constexpr bool LANES8 = (TYPE == FQ_Q4_K || TYPE == FQ_Q5_K);
-    static constexpr int  NCH = LANES8 ? 9 : 1;                             // chains per row: eight float lanes + the mins, or the one sum
+    static constexpr bool LANES8 = (TYPE == FQ_Q4_K || TYPE == FQ_Q5_K || TYPE == FQ_Q6_K);
+    static constexpr bool MINS = (TYPE == FQ_Q4_K || TYPE == FQ_Q5_K);      // the ninth chain, sumf -= dmin * sumi
+    static constexpr bool Q3 = (TYPE == FQ_Q3_K);                           // eight float lanes too, but a unit = four 16-element scale blocks and a super-block = four lanes
+    static constexpr int  NCH = (LANES8 || Q3) ? (MINS ? 9 : 8) : 1;        // chains per row: eight float lanes (+ the mins), or the one sum
     static constexpr int  UPS = LANES8 ? 8 : 4;                             // units (lanes) per super-block
 };
 
@@ -39,9 +42,9 @@ __device__ __forceinline__ int xor2(int v) { return dpp_mov<0x4E>(v); }     // q
 
 // LDS bytes: the activation column (Q4_K / Q5_K: four planes of K / 32 uint4 = 2 K bytes, the residue pairs zero-padded; Q2_K: the K int8 as they are),
 // the column's d (K / 256 floats) and bsums (K / 16 int16), and per wave a strip of KQ_R rows x NCH chains
-__host__ __device__ inline size_t kq_ref_act_bytes(int type, int64_t K) { return (size_t)((type == FQ_Q2_K) ? K : 2 * K); }
+__host__ __device__ inline size_t kq_ref_act_bytes(int type, int64_t K) { return (size_t)((type == FQ_Q2_K) ? K : 2 * K); }      // (Q3_K: eight planes of K / 64 uint4 = 2 K bytes as well)
 __host__ __device__ inline size_t kq_ref_lds(int type, int64_t K, int nw) {
-    const int nsb = (int)(K / 256), nch = (type == FQ_Q2_K) ? 1 : 9;
+    const int nsb = (int)(K / 256), nch = (type == FQ_Q2_K) ? 1 : ((type == FQ_Q6_K || type == FQ_Q3_K) ? 8 : 9);
     return kq_ref_act_bytes(type, K) + (((size_t) nsb * 36 + 15) & ~(size_t) 15) + (size_t) nw * KQ_R * nch * fq_ref_strip_stride(nsb) * 4;
 }
 
@@ -75,7 +78,9 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
             for (int i = tid; i < 2 * U; i += nt) {
                 const int u = i >> 1, h = i & 1;
                 const int sb = u >> 3, c = (u >> 1) & 3, g = u & 1;
-                const uint4 x = *(const uint4 *)(img + 256 * (size_t) sb + 64 * c + 32 * h + 16 * g);
+                // (Q6_K: unit = (sb, 128-half c >> 1, quarter c & 1, g); its low nibbles are quarter (c & 1), its high nibbles quarter (c & 1) + 2: 64 elements on)
+                const size_t e0 = (TYPE == FQ_Q6_K) ? 256 * (size_t) sb + 128 * (c >> 1) + 32 * (c & 1) + 64 * h + 16 * g : 256 * (size_t) sb + 64 * c + 32 * h + 16 * g;
+                const uint4 x = *(const uint4 *)(img + e0);
                 const unsigned xw[4] = { x.x, x.y, x.z, x.w };
                 auto xb = [&](int e) { return (xw[e >> 2] >> (8 * (e & 3))) & 0xFFu; };
                 unsigned o[8];
@@ -83,6 +88,22 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
                 for (int r = 0; r < 8; ++r) { const unsigned p = xb(r) | (xb(r + 8) << 8); o[r] = (r & 1) ? p << 16 : p; }
                 xa[(size_t)(0 + h) * U + u] = make_uint4(o[0], o[1], o[2], o[3]);
                 xa[(size_t)(2 + h) * U + u] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+        } else if constexpr (F::Q3) {
+            // unit u = (sb, hf, g), block j = 0..3 (the unit's 2-bit field j): the 16 elements at 256 sb + 128 hf + 32 j + 16 g -> plane 2 j + k4 as above
+            const int U = units;
+            uint4 * xa = (uint4 *) actx;
+            for (int i = tid; i < 4 * U; i += nt) {
+                const int u = i >> 2, j = i & 3;
+                const int sb = u >> 2, hf = (u >> 1) & 1, g = u & 1;
+                const uint4 x = *(const uint4 *)(img + 256 * (size_t) sb + 128 * hf + 32 * j + 16 * g);
+                const unsigned xw[4] = { x.x, x.y, x.z, x.w };
+                auto xb = [&](int e) { return (xw[e >> 2] >> (8 * (e & 3))) & 0xFFu; };
+                unsigned o[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const unsigned p = xb(r) | (xb(r + 8) << 8); o[r] = (r & 1) ? p << 16 : p; }
+                xa[(size_t)(2 * j + 0) * U + u] = make_uint4(o[0], o[1], o[2], o[3]);
+                xa[(size_t)(2 * j + 1) * U + u] = make_uint4(o[4], o[5], o[6], o[7]);
             }
         } else {
             for (int64_t i = tid; i < (K >> 4); i += nt) ((uint4 *) actx)[i] = ((const uint4 *) img)[i];
@@ -106,17 +127,31 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
                 const int sb = uc >> 3, c = (uc >> 1) & 3, g = uc & 1, t = lane & 7;
                 const uint4 * xa = (const uint4 *) actx;
                 const uint4 xl0 = xa[(size_t) 0 * units + uc], xh0 = xa[(size_t) 1 * units + uc], xl1 = xa[(size_t) 2 * units + uc], xh1 = xa[(size_t) 3 * units + uc];
-                const int bs0 = bss[16 * sb + 4 * c + g], bs1 = bss[16 * sb + 4 * c + g + 2];
+                const int bs0 = F::MINS ? bss[16 * sb + 4 * c + g] : 0, bs1 = F::MINS ? bss[16 * sb + 4 * c + g + 2] : 0;
                 const float dy = dxs[sb];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const fq_unit_regs & q = regs[r];
-                    int sc0, mn0, sc1, mn1;
-                    k4_scale_min(q.s0, q.s1, q.s2, 2 * c, sc0, mn0); k4_scale_min(q.s0, q.s1, q.s2, 2 * c + 1, sc1, mn1);
-                    fq_u4 lo = and4(q.q, 0x0F0F0F0Fu), hi = and4(shr4(q.q, 4), 0x0F0F0F0Fu);
-                    if constexpr (TYPE == FQ_Q5_K) {                        // the 5th bits: bit 2c / 2c + 1 of the unit's qh bytes (k_quants.c:2369-2378)
-                        lo = or4(lo, shl4(and4(shr4(q.q2, 2 * c),     0x01010101u), 4));
-                        hi = or4(hi, shl4(and4(shr4(q.q2, 2 * c + 1), 0x01010101u), 4));
+                    int sc0, mn0 = 0, sc1, mn1 = 0;
+                    fq_u4 lo, hi;
+                    if constexpr (TYPE == FQ_Q6_K) {                        // k_quants.c:2756-2771: q = (low 4 | high 2 << 4) - 32, int8 scales per 16 elements
+                        const int t01 = c & 1;
+                        const uint64_t sc8 = (uint64_t) q.s0 | ((uint64_t) q.s1 << 32);
+                        sc0 = (int)(int8_t)(sc8 >> (8 * (2 * t01 + g)));
+                        sc1 = (int)(int8_t)(sc8 >> (8 * (2 * (t01 + 2) + g)));
+                        const fq_u4 l6 = or4(and4(q.q, 0x0F0F0F0Fu),          shl4(and4(shr4(q.q2, 2 * t01),     0x03030303u), 4));
+                        const fq_u4 h6 = or4(and4(shr4(q.q, 4), 0x0F0F0F0Fu), shl4(and4(shr4(q.q2, 2 * t01 + 4), 0x03030303u), 4));
+                        // per byte v - 32 as int8, borrow-free: ((v | 0x80) - 0x20) ^ 0x80
+                        auto m32 = [](uint32_t v) { return ((v | 0x80808080u) - 0x20202020u) ^ 0x80808080u; };
+                        lo = fq_u4{ m32(l6.x), m32(l6.y), m32(l6.z), m32(l6.w) };
+                        hi = fq_u4{ m32(h6.x), m32(h6.y), m32(h6.z), m32(h6.w) };
+                    } else {
+                        k4_scale_min(q.s0, q.s1, q.s2, 2 * c, sc0, mn0); k4_scale_min(q.s0, q.s1, q.s2, 2 * c + 1, sc1, mn1);
+                        lo = and4(q.q, 0x0F0F0F0Fu); hi = and4(shr4(q.q, 4), 0x0F0F0F0Fu);
+                        if constexpr (TYPE == FQ_Q5_K) {                    // the 5th bits: bit 2c / 2c + 1 of the unit's qh bytes (k_quants.c:2369-2378)
+                            lo = or4(lo, shl4(and4(shr4(q.q2, 2 * c),     0x01010101u), 4));
+                            hi = or4(hi, shl4(and4(shr4(q.q2, 2 * c + 1), 0x01010101u), 4));
+                        }
                     }
                     // [a.b0, b.b0, a.b1, b.b1] and [a.b2, b.b2, a.b3, b.b3] of the dword pairs (0, 2) and (1, 3): one residue class per dot4 half
                     auto p01 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05010400u); };
@@ -130,7 +165,7 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
                     lanes8(lo, xl0, xl1, Al); lanes8(hi, xh0, xh1, Ah);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) a[k] = ok ? sc0 * Al[k] + sc1 * Ah[k] : 0;      // aux32[l] += scale * aux16[l] (k_quants.c:2036-2043): integers
-                    int ms = ok ? mn0 * bs0 + mn1 * bs1 : 0;                                      // sumi's share (k_quants.c:2026-2027)
+                    int ms = (F::MINS && ok) ? mn0 * bs0 + mn1 * bs1 : 0;                         // sumi's share (k_quants.c:2026-2027)
                     // the super-block's eight lanes add their shares: lane t ends with residue t
                     const bool b2 = t & 4, b1 = t & 2, b0 = t & 1;
                     int a1[4], a2[2];
@@ -139,11 +174,54 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
 #pragma unroll
                     for (int k = 0; k < 2; ++k) { const int keep = b1 ? a1[2 + k] : a1[k], send = b1 ? a1[k] : a1[2 + k]; a2[k] = keep + xor2(send); }
                     const int tot = (b0 ? a2[1] : a2[0]) + xor1(b0 ? a2[0] : a2[1]);
-                    ms += swz_xor4(ms); ms += xor2(ms); ms += xor1(ms);
+                    if constexpr (F::MINS) { ms += swz_xor4(ms); ms += xor2(ms); ms += xor1(ms); }
                     if (ok) {
-                        const float d = fq_h2f((uint16_t) q.dm) * dy;                            // k_quants.c:2045: d = fp16(x.d) * y.d
+                        const float d = fq_h2f((uint16_t) q.dm) * dy;                            // k_quants.c:2045 / 2781: d = fp16(x.d) * y.d
                         strip_w[(size_t)(r * NCH + t) * SW + sb] = d * (float) tot;              // sums[l] += d * aux32[l]
-                        if (t == 0) strip_w[(size_t)(r * NCH + 8) * SW + sb] = -((fq_h2f((uint16_t)(q.dm >> 16)) * dy) * (float) ms);      // sumf -= dmin * sumi
+                        if constexpr (F::MINS) { if (t == 0) strip_w[(size_t)(r * NCH + 8) * SW + sb] = -((fq_h2f((uint16_t)(q.dm >> 16)) * dy) * (float) ms); }      // sumf -= dmin * sumi
+                    }
+                }
+            } else if constexpr (F::Q3) {                                  // Q3_K (k_quants.c:1684-1746)
+                const int sb = uc >> 2, hf = (uc >> 1) & 1, g = uc & 1, t = lane & 3;
+                const uint4 * xa = (const uint4 *) actx;
+                const float dy = dxs[sb];
+                auto p01 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05010400u); };
+                auto p23 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07030602u); };
+                auto m4 = [](uint32_t v) { return ((v | 0x80808080u) - 0x04040404u) ^ 0x80808080u; };      // per byte v - 4 as int8, borrow-free
+                int a[R][8];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[r][k] = 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint4 x0 = xa[(size_t)(2 * j) * units + uc], x1 = xa[(size_t)(2 * j + 1) * units + uc];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const fq_unit_regs & q = regs[r];
+                        const fq_u4 l2 = and4(shr4(q.q, 2 * j), 0x03030303u);
+                        const fq_u4 hb = shl4(and4(shr4(q.q2, 4 * hf + j), 0x01010101u), 2);                 // high bit set -> + 4, then - 4 for all (k_quants.c:1701-1716)
+                        const fq_u4 v = { m4(l2.x | hb.x), m4(l2.y | hb.y), m4(l2.z | hb.z), m4(l2.w | hb.w) };
+                        const int sc = q3_scale(q.s0, q.s1, q.s2, 8 * hf + 2 * j + g) - 32;
+                        const unsigned e01 = p01(v.x, v.z), e23 = p23(v.x, v.z), o01 = p01(v.y, v.w), o23 = p23(v.y, v.w);
+                        a[r][0] += sc * fq_dot4(e01, x0.x, 0); a[r][1] += sc * fq_dot4(e01, x0.y, 0); a[r][2] += sc * fq_dot4(e23, x0.z, 0); a[r][3] += sc * fq_dot4(e23, x0.w, 0);
+                        a[r][4] += sc * fq_dot4(o01, x1.x, 0); a[r][5] += sc * fq_dot4(o01, x1.y, 0); a[r][6] += sc * fq_dot4(o23, x1.z, 0); a[r][7] += sc * fq_dot4(o23, x1.w, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    // the super-block's four lanes add their shares: lane t ends with residues 2 t and 2 t + 1
+                    const bool b1 = t & 2, b0 = t & 1;
+                    int a1[4], a2[2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int own = ok ? a[r][(b1 ? 4 : 0) + k] : 0, oth = ok ? a[r][(b1 ? 0 : 4) + k] : 0; a1[k] = own + xor2(oth); }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) { const int own = b0 ? a1[2 + k] : a1[k], oth = b0 ? a1[k] : a1[2 + k]; a2[k] = own + xor1(oth); }
+                    if (ok) {
+                        const float d = fq_h2f((uint16_t) regs[r].dm) * dy;                       // k_quants.c:1739: d = fp16(x.d) * y.d
+                        strip_w[(size_t)(r * NCH + 2 * t) * SW + sb] = d * (float) a2[0];          // sums[l] += d * aux32[l]
+                        strip_w[(size_t)(r * NCH + 2 * t + 1) * SW + sb] = d * (float) a2[1];
                     }
                 }
             } else {                                                       // Q2_K (k_quants.c:1267-1306)
@@ -175,10 +253,10 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
         // ---- the chains: lane = (row of the run, chain), left to right over the super-blocks (the term stores above are ahead in this wave's LDS queue)
         const int cl = lane < R * NCH ? lane : 0;
         float v = fq_ref_chain(strip_w + (size_t) cl * SW, nsb, 0.0f);
-        if constexpr (F::LANES8) {
+        if constexpr (F::LANES8 || F::Q3) {
             // sumf (the mins' chain, lane 9 r + 8) += sums[0], .., sums[7] in this order (k_quants.c:2052-2053)
             const int rr = cl / NCH;
-            float s = __shfl(v, rr * NCH + 8);
+            float s = F::MINS ? __shfl(v, rr * NCH + 8) : 0.0f;
 #pragma unroll
             for (int l = 0; l < 8; ++l) s += __shfl(v, rr * NCH + l);
             v = s;
@@ -193,7 +271,7 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
 }
 
 bool fq_gemv_kq_ref_supported(const fq_weight & w) {
-    return (w.type == FQ_Q2_K || w.type == FQ_Q4_K || w.type == FQ_Q5_K) && w.K % 256 == 0 && w.K >= 256 && kq_ref_lds(w.type, w.K, 4) <= 160 * 1024;
+    return (w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q6_K) && w.K % 256 == 0 && w.K >= 256 && kq_ref_lds(w.type, w.K, 4) <= 160 * 1024;
 }
 
 // dst[col * ldd + row], col < N: the mat-vec per column (N > 1: the columns one after the other over the same weights -- short batches; a prompt re-reads the matrix per token)
@@ -211,7 +289,7 @@ bool fq_launch_gemv_kq_ref(const fq_weight & w, const fq_act & act, int64_t N, f
     const unsigned blocks = (unsigned)((w.M + rpw * nw - 1) / (rpw * nw));
 #define FQ_CASE(T) case T: { static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_kq_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
         hipLaunchKernelGGL((k_gemv_kq_ref<T>), dim3(blocks, (unsigned) N), dim3(64 * nw), lds, st, w, act, dst, ldd, ep, (int) rpw); } break;
-    switch (w.type) { FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) default: return false; }
+    switch (w.type) { FQ_CASE(FQ_Q2_K) FQ_CASE(FQ_Q3_K) FQ_CASE(FQ_Q4_K) FQ_CASE(FQ_Q5_K) FQ_CASE(FQ_Q6_K) default: return false; }
 #undef FQ_CASE
     return true;
 }

@@ -45,9 +45,9 @@ void    ggml_hip_gemm_sequential(int on);
  * on = 2 (round 6): the SAME association -- the same bits as on = 1 and as the reference's scalar build -- on the fast kernels wherever they have it, i.e. the legacy
  * formats (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0): N = 1 steps through the fused decode launches, whose lanes leave every unit's f32 term (the reference's per-block term,
  * ggml.c:2591-2609 ...) in an LDS strip [row][block] that a wave with lane = row adds left to right (csrc/fq_ref_chain.h); batches of N > 4 through the int8-MFMA GEMM
- * with one left-to-right sum per row (ggml_hip_gemm_sequential); attention dots in f64. Q2_K / Q4_K / Q5_K: every mat-mul column by column through k_gemv_kq_ref
- * (csrc/kernels_kqref.hip: the scalar branches' eight float lanes per super-block at wave speed: ~0.5-0.7 x the default order's decode). Everything else (Q3_K, Q6_K,
- * legacy N = 2..4) runs mode 1's kernels. Falcon-7B Q4_0
+ * with one left-to-right sum per row (ggml_hip_gemm_sequential); attention dots in f64. The k-quants: every mat-mul column by column through k_gemv_kq_ref
+ * (csrc/kernels_kqref.hip: the scalar branches' eight float lanes per super-block at wave speed: ~0.5-0.7 x the default order's decode). Legacy N = 2..4 runs
+ * mode 1's kernel. Falcon-7B Q4_0
  * decode: 925-930 tok/s (default order 1 005-1 020, mode 1: 40). tests/test_gpu_ref_fast.py.                                                                      */
 void    ggml_hip_reference_order(int on);
 int     ggml_hip_get_reference_order(void);

@@ -20,7 +20,7 @@ m = g.FalconModel(w, n_ctx=2048, n_batch=128)
 toks = synth.tokens(136, hp["n_vocab"], seed=42)
 K = 64
 out = {}
-LEGACY = quant in ('q4_0', 'q4_1', 'q5_0', 'q5_1', 'q8_0', 'q2_k', 'q4_k', 'q5_k')      # formats with a fast form of the reference's association (k-quants: single-token mat-vecs, kernels_kqref.hip)
+LEGACY = quant in ('q4_0', 'q4_1', 'q5_0', 'q5_1', 'q8_0', 'q2_k', 'q3_k', 'q4_k', 'q5_k', 'q6_k')      # formats with a fast form of the reference's association (k-quants: single-token mat-vecs, kernels_kqref.hip)
 MODES = (0, 2) if LEGACY else (0,)
 e0, e1 = L.ggml_hip_event_create(), L.ggml_hip_event_create()
 for rep in range(2):

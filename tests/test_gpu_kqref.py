@@ -1,4 +1,4 @@
-"""GPU: the k-quant mat-vec in the reference's OWN association at wave speed (csrc/kernels_kqref.hip, ggml_hip_reference_order(2) for Q2_K / Q4_K / Q5_K):
+"""GPU: the k-quant mat-vec in the reference's OWN association at wave speed (csrc/kernels_kqref.hip, ggml_hip_reference_order(2) for all five k-quants):
 one term per super-block (Q2_K, k_quants.c:1267-1306) / eight float lanes of the elements e = l (mod 8) plus the mins' chain (Q4_K, Q5_K: k_quants.c:1999-2055,
 2340-2400), every f32 operation the reference's in the reference's order. Bit-identical (==) with the oracle's order 0 (the restatement pinned to the reference's
 scalar build), with the one-thread-per-output instrument (mode 1) and -- whole tiny models -- with the logits captured from the real reference."""
@@ -10,7 +10,7 @@ from oracle import binding as ob
 import synth
 
 pytestmark = pytest.mark.gpu
-KQ = [ob.Q2_K, ob.Q4_K, ob.Q5_K]
+KQ = [ob.Q2_K, ob.Q3_K, ob.Q4_K, ob.Q5_K, ob.Q6_K]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -41,7 +41,7 @@ def test_kq_mat_vec_in_reference_order_vs_oracle_order0(oracle, t, K, M, N):
 
 
 @pytest.mark.parametrize("name,hp,t,gfile", [("gqa_q4_K", synth.HP_TINY_GQA, ob.Q4_K, "tiny_models"), ("gqa_q2_K", synth.HP_TINY_GQA, ob.Q2_K, "tiny_models_all"),
-                                             ("gqa_q5_K", synth.HP_TINY_GQA, ob.Q5_K, "tiny_models_all")])
+                                             ("gqa_q5_K", synth.HP_TINY_GQA, ob.Q5_K, "tiny_models_all"), ("gqa_q6_K", synth.HP_TINY_GQA, ob.Q6_K, "tiny_models_all"), ("gqa_q3_K", synth.HP_TINY_GQA, ob.Q3_K, "tiny_models_all")])
 def test_kq_models_in_fast_reference_order_equal_the_real_reference(oracle, golden, name, hp, t, gfile):
     """tiny Falcon models: prefill (8 tokens: the column-by-column form of the same kernel) and four decode steps under mode 2 == the reference's scalar build"""
     gt = golden[gfile]
