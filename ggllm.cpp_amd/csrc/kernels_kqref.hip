@@ -116,10 +116,18 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
         fq_wrow rows[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { const int64_t row = row0 + r; rows[r] = fq_row<TYPE>(w, row < M ? row : M - 1); }
+        // (the next unit column is requested before the current one's arithmetic: two columns of R rows in flight per wave)
+        fq_unit_regs nxt[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) nxt[r] = fq_unit_load_col<TYPE>(rows[r], 0, lane, units);
         for (int c0 = 0; c0 < ncolu; ++c0) {
             fq_unit_regs regs[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) regs[r] = fq_unit_load_col<TYPE>(rows[r], c0, lane, units);
+            for (int r = 0; r < R; ++r) regs[r] = nxt[r];
+            if (c0 + 1 < ncolu) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) nxt[r] = fq_unit_load_col<TYPE>(rows[r], c0 + 1, lane, units);
+            }
             const int u = 64 * c0 + lane;
             const bool ok = u < units;                                      // (K % 256 == 0: a super-block's lanes are in or out together)
             const int uc = ok ? u : units - 1;
