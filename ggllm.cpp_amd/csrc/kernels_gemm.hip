@@ -874,6 +874,11 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // half of the matrix work on padding columns gone and 4 / 8 waves per workgroup instead of 16 (FQ_GEMM_SMALL_TT=0: the 128-token tiles, as before)
     static const bool small_tt = !(getenv("FQ_GEMM_SMALL_TT") && atoi(getenv("FQ_GEMM_SMALL_TT")) == 0);
     if (small_tt && cfg == 2 && N <= 32) cfg = 1; else if (small_tt && cfg == 2 && N <= 64) cfg = 4;
+    // (tuning aid, FQ_GEMM_FILL=1: a launch of 128-token workgroups that leaves CUs empty -- 142 workgroups for a 4544-row matrix and 128 tokens -- as 64-token
+    // workgroups, 284 of them: measured SLOWER, 128-token prompt 9.46 against 8.30-8.34 ms A/B/A/B on one box (round 6): the 16-wave workgroup hides its own latencies better
+    // than two 8-wave ones fill the chip)
+    static const bool fill = getenv("FQ_GEMM_FILL") && atoi(getenv("FQ_GEMM_FILL")) != 0;
+    if (fill && cfg == 2 && N > 64 && ((fq_form_rows(w) + GQ_TM - 1) / GQ_TM) * ((N + 127) / 128) < n_cu) cfg = 4;
     if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>, 6 = <2,4,2>, 7 = <4,4,2>
 #define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
