@@ -8,9 +8,9 @@ from ggllm_cpp_amd import synth
 mode = int(sys.argv[1]); layers = int(sys.argv[2]) if len(sys.argv) > 2 else 32; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 g.init(0)
 L = g.load()
-hp = dict(synth.HP_7B); hp["n_layer"] = layers
+hp = dict({"7b": synth.HP_7B, "40b": synth.HP_40B}[os.environ.get("MODEL", "7b")]); hp["n_layer"] = layers
 tname = {v: k for k, v in g.TYPE_NAME.items()}
-w = synth.make_model_fast(hp, tname["q4_0"], seed=1234)
+w = synth.make_model_fast(hp, tname[os.environ.get("QUANT", "q4_0")], seed=1234)      # MODEL=40b QUANT=q4_K: the k-quant forms
 m = g.FalconModel(w, n_ctx=2048, n_batch=128)
 if len(sys.argv) > 4:
     m.set_fused(int(sys.argv[4]))          # 1 = three launches per block (k_gemv_ln | k_attn_decode | k_gemv_out)
