@@ -382,7 +382,8 @@ void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float *
     if (fq_desc(w.type).act_type != a.type || a.K != w.K) { fprintf(stderr, "ggml-hip: mul_mat: activation format/length mismatch\n"); exit(1); }
     // reference order: one thread per output (mode 1), or -- mode 2, legacy formats, batches -- the GEMM below with S = 1 (fq_gemm_set_sequential: one
     // left-to-right sum per row, the scalar build's two roundings per term: == the reference, tests/test_gpu_mul_mat.py)
-    if (g_reference_order && !(g_reference_order == 2 && legacy_type(w.type) && N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv)) {
+    // (mode 2, legacy formats: from TWO columns on -- a lock-step context of 2-4 sequences is a 128-token tile of padding, still far ahead of one thread per output)
+    if (g_reference_order && !(g_reference_order == 2 && legacy_type(w.type) && N >= 2 && fq_gemm_supported(w.type) && !g_force_gemv)) {
         // mode 2, the k-quants: the wave-speed mat-vec in the reference's association (kernels_kqref.hip), column by column. A prompt re-reads the matrix per
         // token (out of L2 / the Infinity Cache) and is still 4.5 x faster than mode 1's one thread per output (Falcon-40B Q4_K, 128 tokens, 16 blocks: 268 against
         // 1 217 ms). FQ_KQREF_MAX_N=n: mode 1's kernel beyond n columns (A/B)
@@ -390,7 +391,7 @@ void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float *
         if (g_reference_order == 2 && N <= kq_max_n && fq_launch_gemv_kq_ref(w, a, N, dst, ldd, ep0, st)) return;
         fq_launch_mul_mat_ref(w, a, N, dst, ldd, ep0, st); return;
     }
-    if (N > FQ_GEMV_MAX_COLS && fq_gemm_supported(w.type) && !g_force_gemv) {      // prefill: int8 MFMA GEMM
+    if ((N > FQ_GEMV_MAX_COLS || (g_reference_order == 2 && N >= 2)) && fq_gemm_supported(w.type) && !g_force_gemv) {      // prefill: int8 MFMA GEMM
         fq_launch_gemm(w, a, N, dst, ldd, ep0, c.n_cu, st);
         return;
     }

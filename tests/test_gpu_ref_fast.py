@@ -100,3 +100,19 @@ def test_fast_reference_order_vs_oracle_order0(oracle):
     want = [mo.eval(toks[:3], 0, 8), mo.eval(toks[3:4], 3, 8), mo.eval(toks[4:5], 4, 8), mo.eval(toks[5:6], 5, 8)]
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("t", [ob.Q4_0, ob.Q4_1, ob.Q5_0, ob.Q5_1, ob.Q8_0])
+@pytest.mark.parametrize("K,M", [(512, 37), (4544, 70), (18176, 33)])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 17, 40])
+def test_fast_reference_order_mul_mat_vs_oracle_order0(oracle, t, K, M, N):
+    """op level, every column count: N = 1 the one-thread-per-output kernel (the fused launches are the model-level path), N >= 2 the int8-MFMA GEMM / the streaming
+    small-batch forms with ONE left-to-right sum per row -- == the oracle's order 0 (the reference's scalar build)"""
+    rng = np.random.default_rng(K * 31 + M + N + t)
+    w = synth.quantized_matrix(oracle, t, M, K, rng)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    dw = g.Weight(t, w, K, M)
+    with order(2):
+        got = dw.mul_mat(x)
+    dw.free()
+    assert np.array_equal(got, oracle.mul_mat(t, w, K, M, x, 4))
