@@ -388,6 +388,7 @@ void fq_mul_mat_q_acts(const fq_weight & w, const fq_act & a, int64_t N, float *
         // token (out of L2 / the Infinity Cache) and is still 4.5 x faster than mode 1's one thread per output (Falcon-40B Q4_K, 128 tokens, 16 blocks: 268 against
         // 1 217 ms). FQ_KQREF_MAX_N=n: mode 1's kernel beyond n columns (A/B)
         static const int64_t kq_max_n = getenv("FQ_KQREF_MAX_N") ? atoll(getenv("FQ_KQREF_MAX_N")) : INT64_MAX;
+        // (and the legacy formats' single columns: the op-level API and the ggml-cuda.h shim; batches took the GEMM above)
         if (g_reference_order == 2 && N <= kq_max_n && fq_launch_gemv_kq_ref(w, a, N, dst, ldd, ep0, st)) return;
         fq_launch_mul_mat_ref(w, a, N, dst, ldd, ep0, st); return;
     }

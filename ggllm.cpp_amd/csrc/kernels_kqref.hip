@@ -1,4 +1,5 @@
-// kernels_kqref.hip -- the k-quant mat-vec in the REFERENCE'S OWN association at wave speed (round 6; ggml_hip_reference_order(2) for the five k-quants).
+// kernels_kqref.hip -- the stand-alone mat-vec in the REFERENCE'S OWN association at wave speed (round 6; ggml_hip_reference_order(2)): the five k-quants (k_gemv_kq_ref,
+// below) and, at the end of the file, the legacy formats' op-level form (k_gemv_legacy_ref).
 //
 // The scalar branches of ggml_vec_dot_q{2,4,5}_K_q8_K (k_quants.c:1267-1306, 1999-2055, 2340-2400; caller ggml.c:11484-11516) do not add one term per
 // 32-element group the way the legacy formats do:
@@ -278,12 +279,75 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
     }
 }
 
+
+// ---- the legacy formats' stand-alone mat-vec in the reference's association (the op-level API and the ggml-cuda.h shim under mode 2; the resident model's single-token steps
+// run the fused launches, kernels_ring.hip / kernels_decode.hip): a lane's unit IS a block, its term the reference's (fq_units.h), the strip [row][block] is added left to right
+template <int TYPE>
+__global__ void __launch_bounds__(512) k_gemv_legacy_ref(fq_weight w, fq_act act, float * dst, int64_t ldd, fq_gemv_epi ep, int rows_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int ACT = fq_act_of(TYPE), R = KQ_R;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int64_t K = w.K, M = w.M, col = blockIdx.y;
+    const int units = (int)(K / 32), ncolu = (units + 63) >> 6;
+    const unsigned SW = fq_ref_strip_stride(units);
+    const size_t imgb = fq_act_col_bytes(ACT, K);
+    float * strip_w = (float *)(smem + imgb) + (size_t) wid * R * SW;
+    {
+        const uint4 * src = (const uint4 *)(act.base + (size_t) col * imgb);
+        for (int64_t i = tid; i < (int64_t)(imgb >> 4); i += nt) ((uint4 *) smem)[i] = src[i];
+    }
+    __syncthreads();
+    const fq_actcol acol = { (const int8_t *) smem, (const float *)(smem + fq_act_d_off(ACT, K)), (const void *)(smem + fq_act_aux_off(ACT, K)) };
+    const int64_t wrow0 = ((int64_t) blockIdx.x * nw + wid) * rows_per_wave;
+    for (int64_t row0 = wrow0; row0 < wrow0 + rows_per_wave && row0 < M; row0 += R) {
+        fq_wrow rows[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int64_t row = row0 + r; rows[r] = fq_row<TYPE>(w, row < M ? row : M - 1); }
+        for (int c0 = 0; c0 < ncolu; ++c0) {
+            fq_unit_regs regs[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) regs[r] = fq_unit_load_col<TYPE>(rows[r], c0, lane, units);
+            const int u = 64 * c0 + lane, uc = u < units ? u : units - 1;      // (a lane beyond the row holds the clamped re-read of the last unit: the same term into the same word)
+#pragma unroll
+            for (int r = 0; r < R; ++r) strip_w[(size_t) r * SW + uc] = fq_unit<TYPE>::dot(regs[r], acol, uc);
+        }
+        const int cl = lane < R ? lane : 0;
+        float v = fq_ref_chain(strip_w + (size_t) cl * SW, units, 0.0f);          // ggml.c:2594-2609: sumf = 0; sumf += term_i, i ascending
+        const int64_t row = row0 + lane;
+        if (lane < R && row < M) {
+            if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+            else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[col * ep.ld_add + row]) + ep.add2[col * ep.ld_add + row];
+            dst[col * ldd + row] = v;
+        }
+    }
+}
+
+static bool legacy_ref_launch(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
+    const int ACT = fq_desc(w.type).act_type;
+    if (w.K % 32 || act.type != ACT || act.K != w.K) return false;
+    const int units = (int)(w.K / 32), nw = 8;
+    const size_t lds = fq_act_col_bytes(ACT, w.K) + (size_t) nw * KQ_R * fq_ref_strip_stride(units) * 4;
+    if (lds > 160 * 1024) return false;
+    FQ_TL(st, "gemv_legacy_ref");
+    const int n_cu = fq_ctx().n_cu;
+    int64_t rpw = (w.M + (int64_t) 4 * n_cu * nw - 1) / ((int64_t) 4 * n_cu * nw);
+    rpw = ((rpw + KQ_R - 1) / KQ_R) * KQ_R;
+    if (rpw < KQ_R) rpw = KQ_R;
+    const unsigned blocks = (unsigned)((w.M + rpw * nw - 1) / (rpw * nw));
+#define FQ_CASE(T) case T: { static size_t g = 0; if (lds > 64 * 1024 && lds > g) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemv_legacy_ref<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); g = lds; } \
+        hipLaunchKernelGGL((k_gemv_legacy_ref<T>), dim3(blocks, (unsigned) N), dim3(64 * nw), lds, st, w, act, dst, ldd, ep, (int) rpw); } break;
+    switch (w.type) { FQ_CASE(FQ_Q4_0) FQ_CASE(FQ_Q4_1) FQ_CASE(FQ_Q5_0) FQ_CASE(FQ_Q5_1) FQ_CASE(FQ_Q8_0) default: return false; }
+#undef FQ_CASE
+    return true;
+}
+
 bool fq_gemv_kq_ref_supported(const fq_weight & w) {
     return (w.type == FQ_Q2_K || w.type == FQ_Q3_K || w.type == FQ_Q4_K || w.type == FQ_Q5_K || w.type == FQ_Q6_K) && w.K % 256 == 0 && w.K >= 256 && kq_ref_lds(w.type, w.K, 4) <= 160 * 1024;
 }
 
 // dst[col * ldd + row], col < N: the mat-vec per column (N > 1: the columns one after the other over the same weights -- short batches; a prompt re-reads the matrix per token)
 bool fq_launch_gemv_kq_ref(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
+    if (fq_desc(w.type).blck == 32) return legacy_ref_launch(w, act, N, dst, ldd, ep, st);      // the legacy formats' form
     if (!fq_gemv_kq_ref_supported(w) || act.type != FQ_Q8_K || act.K != w.K) return false;
     FQ_TL(st, "gemv_kq_ref");
     int nw = 8;

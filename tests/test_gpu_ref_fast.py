@@ -106,8 +106,9 @@ def test_fast_reference_order_vs_oracle_order0(oracle):
 @pytest.mark.parametrize("K,M", [(512, 37), (4544, 70), (18176, 33)])
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 17, 40])
 def test_fast_reference_order_mul_mat_vs_oracle_order0(oracle, t, K, M, N):
-    """op level, every column count: N = 1 the one-thread-per-output kernel (the fused launches are the model-level path), N >= 2 the int8-MFMA GEMM / the streaming
-    small-batch forms with ONE left-to-right sum per row -- == the oracle's order 0 (the reference's scalar build)"""
+    """op level, every column count: N = 1 the stand-alone mat-vec k_gemv_legacy_ref (csrc/kernels_kqref.hip: a block's term per lane, the strip [row][block] added left to
+    right; the resident model's single-token steps run the fused launches instead), N >= 2 the int8-MFMA GEMM / the streaming small-batch forms with ONE left-to-right sum per
+    row -- == the oracle's order 0 (the reference's scalar build)"""
     rng = np.random.default_rng(K * 31 + M + N + t)
     w = synth.quantized_matrix(oracle, t, M, K, rng)
     x = rng.standard_normal((N, K)).astype(np.float32)
