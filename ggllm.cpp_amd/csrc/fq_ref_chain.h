@@ -27,7 +27,23 @@ __device__ __forceinline__ void fq_emit_term(float (&acc)[R], const unsigned * s
 }
 // s + row[0] + row[1] + ... + row[n - 1], strictly in this order (-ffp-contract=off, no reassociation). row: LDS, 16-byte aligned. The next 16 terms are
 // requested before the current 16 are added: the chain runs at the latency of a dependent v_add_f32, not at that of the LDS.
+// FQ_REF_CHAIN_PRIO (default 1): the chain's wave raises its issue priority for the duration (s_setprio 3) -- a dependent add should wait for nobody but its predecessor, and the
+// other waves of its SIMD are in the middle of their dots. A/B/A/B on one box: 940.9 / 941.4 against 930.5 / 932.0 tok/s in the fast reference order (profiles/r06t_ab_chain_prio.txt)
+#ifndef FQ_REF_CHAIN_PRIO
+#define FQ_REF_CHAIN_PRIO 1
+#endif
+__device__ __forceinline__ float fq_ref_chain_(const float * __restrict__ row, int n, float s);
 __device__ __forceinline__ float fq_ref_chain(const float * __restrict__ row, int n, float s) {
+#if FQ_REF_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+    const float r = fq_ref_chain_(row, n, s);
+    __builtin_amdgcn_s_setprio(0);
+    return r;
+#else
+    return fq_ref_chain_(row, n, s);
+#endif
+}
+__device__ __forceinline__ float fq_ref_chain_(const float * __restrict__ row, int n, float s) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 * r4 = (const f4 *) __builtin_assume_aligned(row, 16);
     int b = 0;
