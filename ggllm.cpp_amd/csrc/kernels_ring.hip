@@ -100,7 +100,11 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(
     if (a.dbg && tid == 0) a.dbg[(size_t) blockIdx.x * 8] = (long long) wall_clock64();
     __syncthreads();                                                       // the only workgroup barrier: before the roles split
 
+#ifndef FQ_RING_PRIO
+#define FQ_RING_PRIO 3          // bit 0: the loader wave, bit 1: the epilogue wave at raised issue priority (s_setprio 3)
+#endif
     if (wid == 0) {
+        if (FQ_RING_PRIO & 1) __builtin_amdgcn_s_setprio(3);
         // ================================================================================ loader (kernels_engine.hip's, two segments)
         const unsigned ring_lds = (unsigned)(uintptr_t) ring;
         eng_wait w{ a.err, false, nullptr, 0 };
@@ -306,6 +310,7 @@ __global__ void __launch_bounds__(RNT) k_gemv_ln_ring(
     const fq_actcol col_e2 = { (const int8_t *) img_e2, (const float *)(img_e2 + fq_act_d_off(ACT, E)), (const void *)(img_e2 + fq_act_aux_off(ACT, E)) };
     const int gA = nA2 / 32;
 
+    if ((FQ_RING_PRIO & 2) && isG) __builtin_amdgcn_s_setprio(3);
     if constexpr (REF) if (isG) {
         // ---- REF: the row sums in the reference's order, lane = row, then the default epilogues. Groups of 32 workgroup-local rows: the Wup groups first
         // (their rows stream first), then the Wqkv rows; a group's terms are complete when its counter has reached its row count.
