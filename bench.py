@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     ap.add_argument("--no-ref-order", action="store_true", help="skip the reference_order key (prompt + 16 decode steps in the reference's scalar summation order)")
     ap.add_argument("--no-cli", action="store_true", help="skip the reference_cli key (the reference's own falcon_main, linked against libggml_hip.so, on a written GGCC file)")
+    ap.add_argument("--no-other-order", action="store_true", help="tuning runs: do not time the other summation order beside the timed one")
     ap.add_argument("--order", type=int, default=-1, choices=[-1, 0, 2],
                     help="summation order of the TIMED region: 2 = the fast reference order (ggml_hip_reference_order(2): logits bit-identical to the reference's scalar build; "
                          "legacy formats), 0 = the default order; -1 (default) = 2 where the format has it, else 0. The other order is timed beside it (key other_order)")
@@ -381,6 +382,8 @@ def main():
         sys.stderr.write("bench.py: --order 2 needs a format with a fast form of the reference's association (every format has one since round 6): timing the default order\n")
         order = 0
     other = 0 if order == 2 else (2 if (legacy or kq_fast) else None)
+    if a.no_other_order:
+        other = None
     # ---- parity, measured on the benchmark's own N(0, 0.02^2) model: the timed order, the default order, the one-thread-per-output instrument (mode 1) and
     # the reference's AVX2 build against the reference's scalar build on the host, all of them also against the f64 yardstick. (A residual-dominated variant
     # -- wo / down drawn 2^-4 times smaller, block scales still normal fp16 numbers -- is reported under its own key, never as the headline.)
@@ -477,7 +480,7 @@ def main():
     other_run = timed_run(other, 1, other == 0, True) if other is not None else None
     tr = timed_run(order, a.repeats, order == 0, True)
     runs, dt, tok_s, n_past = tr["runs"], tr["dt"], tr["tok_s"], tr["n_past"]
-    run0 = tr if order == 0 else other_run                              # the default order's run: prefill_* keys
+    run0 = tr if (order == 0 or other_run is None) else other_run                              # the default order's run: prefill_* keys
     run2 = tr if order == 2 else other_run                              # the fast reference order's run (None for the k-quants)
     long_ms, prefill_ms = run0.get("long_ms"), run0["prefill_ms"]
     n_mid = n_past + a.steps // 2
