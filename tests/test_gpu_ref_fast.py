@@ -117,3 +117,30 @@ def test_fast_reference_order_mul_mat_vs_oracle_order0(oracle, t, K, M, N):
         got = dw.mul_mat(x)
     dw.free()
     assert np.array_equal(got, oracle.mul_mat(t, w, K, M, x, 4))
+
+
+@pytest.mark.parametrize("hp,t,B", [(synth.HP_TINY_MQA, ob.Q4_0, 3), (synth.HP_TINY_GQA, ob.Q5_1, 7), (synth.HP_TINY_MQA, ob.Q8_0, 12), (synth.HP_TINY_GQA, ob.Q4_1, 20),
+                                    (synth.HP_TINY_GQA, ob.Q4_K, 5), (synth.HP_TINY_GQA, ob.Q2_K, 9)])
+def test_fast_reference_order_is_batch_invariant_in_lock_step_contexts(oracle, hp, t, B):
+    """the reference's association makes a row's result independent of the rows beside it (ggml.c:11484-11516: one vec_dot per row and column), so in the fast
+    reference order B lock-step sequences through ONE weight pass per step give, for ANY B, exactly the logits of B contexts of their own (the default order promises
+    that for the column mat-vec kernels only: B <= 4) -- and those are the one-thread-per-output instrument's, i.e. the reference's"""
+    hp = dict(hp); hp["n_layer"] = 2
+    if t in ob.KQUANTS and hp["n_embd"] % 256:
+        hp["n_embd"] = 256 * ((hp["n_embd"] + 255) // 256); hp["n_head"] = hp["n_embd"] // 64; hp["n_head_kv"] = 2; hp["n_ff"] = 4 * hp["n_embd"]
+    w = synth.make_model(oracle, hp, t, seed=17)
+    streams = [synth.tokens(6, hp["n_vocab"], seed=50 + b) for b in range(B)]
+    m = g.FalconModel(w, n_ctx=32, n_batch=8)
+    with order(1):
+        inst = np.stack([m.eval(streams[0][i:i + 1], i)[0] for i in range(6)])
+    with order(2):
+        singles = [np.stack([m.eval(streams[b][i:i + 1], i)[0] for i in range(6)]) for b in range(B)]
+        sc = g.SeqContext(m, 32, B)
+        rows = [sc.eval([int(streams[b][i]) for b in range(B)], i) for i in range(6)]
+        sc.free()
+        assert m.sync_error() == 0
+    m.free()
+    assert np.array_equal(singles[0], inst)
+    for i in range(6):
+        for b in range(B):
+            assert np.array_equal(rows[i][b], singles[b][i]), (b, i)
