@@ -336,12 +336,18 @@ template <bool HAS_MIN, int TN, int SUB, int TM> struct gemm_lds {   // TN = tok
 #endif
 // two K stages per barrier (four LDS stage buffers instead of two): the 16-wave forms, whose workgroup has the CU to itself anyway
 template <int S, int TT, int RB> struct gemm_pair { static constexpr bool value = GQ_PAIR && S * TT >= 16; };
-template <int TYPE, int S, int TT, int RB>
+// SEQ16 (round 6; legacy formats, the <4, 4, 1> frame): the reference's ONE left-to-right sum per row (ggml_hip_gemm_sequential, ggml.c:2591-2609 ...) at the 16-wave form's
+// occupancy. A row's sum is a chain over all of K, so S = 1 leaves a 32 x 32 result tile to ONE wave -- 142 (568) dependent group steps of ~70 vector instructions each, on four
+// waves per workgroup: 67 us for Wqkv at 128 tokens where the four-share form takes 32. Here the sixteen waves of the 32-row x 128-token workgroup own one 16 x 16 tile each
+// (row half = wave & 1, token tile = wave >> 1; v_mfma_i32_16x16x32_i8, four results per lane) and walk EVERY group of a stage in order: the same terms, the same order, the
+// same bits as S = 1 -- a quarter of the chain per wave, four waves per SIMD to fill it. Staging, stage buffers and barriers are the frame's own.
+template <int TYPE, int S, int TT, int RB, bool SEQ16 = false>
 __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act, int64_t N, float * dst, int64_t ldd, fq_gemv_epi ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = fq_act_of(TYPE);
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN, KINT = gemm_kint<TYPE>::value;
     constexpr int TN = 32 * TT, SUB = gemm_group<TYPE>::SUB, TM = GQ_TM * RB;
+    static_assert(!SEQ16 || (S == 4 && TT == 4 && RB == 1 && !KINT && SUB == 1), "SEQ16: the legacy formats in the <4, 4, 1> frame");
     typedef gemm_lds<HAS_MIN, TN, SUB, TM> LB;
     constexpr int NT = 64 * S * TT, VT = (TN * 8) / NT, NR = 16;         // threads, token vectors per thread and stage, results per lane
     static_assert(NT >= TM * GQ_GROUPS && VT >= 1, "workgroup too small for the staging tasks");
@@ -545,7 +551,47 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
             }
         }
     };
+    float acc16[4] = { 0.0f, 0.0f, 0.0f, 0.0f };                            // SEQ16: token 16 t16 + 4 kq + i, row 16 rh + l15
+    const int l15 = lane & 15, kq = lane >> 4, rh = wid & 1, t16 = wid >> 1;
     auto compute = [&](const uint8_t * B, const bool sb_end) __attribute__((always_inline)) {
+        if constexpr (SEQ16) {
+            typedef int v2i_ __attribute__((ext_vector_type(2)));
+            const uint8_t * xa = B + LB::XQ + (16 * t16 + l15) * GQ_STRIDE + 8 * kq;
+            const uint8_t * wb = B + LB::WQ + (16 * rh + l15) * GQ_STRIDE + 8 * kq;
+            const int tok = 16 * t16 + 4 * kq, row = 16 * rh + l15;
+            // operands of PRE groups at a time (the formats with a min term hold twice the scales: two groups keep the 16-wave workgroup within its 128 registers)
+            constexpr int PRE = HAS_MIN ? 1 : GQ_GROUPS;
+#pragma unroll
+            for (int g0 = 0; g0 < GQ_GROUPS; g0 += PRE) {
+                v2i_ a[PRE], b[PRE]; float4 dx[PRE], sx[PRE]; float dw[PRE], mw[PRE];
+#pragma unroll
+                for (int q = 0; q < PRE; ++q) {
+                    const int gg = g0 + q;
+                    a[q] = *(const v2i_ *)(xa + 32 * gg); b[q] = *(const v2i_ *)(wb + 32 * gg);
+                    dx[q] = *(const float4 *)(B + LB::DX + (gg * TN + tok) * 4);
+                    dw[q] = ((const float *)(B + LB::DW))[gg * TM + row];
+                    if constexpr (HAS_MIN) { sx[q] = *(const float4 *)(B + LB::SX + (gg * TN + tok) * 4); mw[q] = ((const float *)(B + LB::MW))[gg * TM + row]; }
+                }
+                if (dbgm & 2) continue;
+#pragma unroll
+                for (int q = 0; q < PRE; ++q) {
+                    const v4i c = __builtin_amdgcn_mfma_i32_16x16x32_i8(__builtin_bit_cast(long, a[q]), __builtin_bit_cast(long, b[q]), v4i{0, 0, 0, 0}, 0, 0, 0);
+                    const float dxv[4] = { dx[q].x, dx[q].y, dx[q].z, dx[q].w };
+                    const float sxv[4] = { HAS_MIN ? sx[q].x : 0.0f, HAS_MIN ? sx[q].y : 0.0f, HAS_MIN ? sx[q].z : 0.0f, HAS_MIN ? sx[q].w : 0.0f };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float ci = (float) c[i];
+                        float t;
+                        if constexpr (TYPE == FQ_Q4_0)  t = (ci * dw[q]) * dxv[i];                              // ggml.c:2606
+                        else if constexpr (!HAS_MIN)    t = (dw[q] * dxv[i]) * ci;                              // ggml.c:2972, 3325
+                        else                            t = (dw[q] * dxv[i]) * ci + mw[q] * sxv[i];            // ggml.c:2731, 3227
+                        acc16[i] = acc16[i] + t;
+                    }
+                }
+            }
+            (void) sb_end;
+            return;
+        }
         if constexpr (KINT) {
             if (!(dbgm & 2)) {
                 int gg = sw;
@@ -762,6 +808,20 @@ __global__ void __launch_bounds__(64 * S * TT) k_gemm_q(fq_weight w, fq_act act,
         g_gemm_stamps[8001 + 2 * (blockIdx.x ? 1 : 0)] = (long long)(__builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif
+    if constexpr (SEQ16) {
+        const int64_t m = m0 + 16 * rh + l15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t n = n0 + 16 * t16 + 4 * kq + i;
+            if (n < N && m < M) {
+                float v = acc16[i];
+                if (ep.mode == FQ_EPI_GELU)      v = h2f_bits(ep.gelu_table[f2h_bits(v)]);
+                else if (ep.mode == FQ_EPI_ADD2) v = (v + ep.add1[n * ep.ld_add + m]) + ep.add2[n * ep.ld_add + m];
+                dst[n * ldd + m] = v;
+            }
+        }
+        return;
+    }
     // ---- the S partial sums of a tile: ((P0 + P1) + P2) + P3, through LDS (the stage buffers are free now)
     if constexpr (S > 1) {
         float * xch = (float *) smem;                                      // [tt][rb][i][lane]
@@ -810,20 +870,26 @@ bool fq_gemm_supported(int type) {
            type == FQ_Q2_K || type == FQ_Q3_K || type == FQ_Q4_K || type == FQ_Q5_K || type == FQ_Q6_K;
 }
 
-template <int TYPE, int S, int TT, int RB = 1>
+template <int TYPE, int S, int TT, int RB = 1, bool SEQ16 = false>
 static void launch_gemm_t(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
     constexpr bool HAS_MIN = gemm_group<TYPE>::HAS_MIN;
     constexpr int TN = 32 * TT, TM = GQ_TM * RB;
     const size_t lds = (gemm_pair<S, TT, RB>::value ? 4 : 2) * (size_t) gemm_lds<HAS_MIN, TN, gemm_group<TYPE>::SUB, TM>::BYTES;
     if (lds > 64 * 1024) {
         static bool set = false;
-        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_q<TYPE, S, TT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; }
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_q<TYPE, S, TT, RB, SEQ16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); set = true; }
     }
     const dim3 grid((unsigned)((w.M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN));
 #if GQ_STAMPS
     { long long * p = fq_ctx().dbg_stamps; HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gemm_stamps), &p, sizeof p, 0, hipMemcpyHostToDevice, st)); }
 #endif
-    hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT, RB>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
+    hipLaunchKernelGGL((k_gemm_q<TYPE, S, TT, RB, SEQ16>), grid, dim3(64 * S * TT), lds, st, w, act, N, dst, ldd, ep);
+}
+
+template <int TYPE>
+static void launch_gemm_seq16(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, hipStream_t st) {
+    if constexpr (fq_desc(TYPE).blck == 32) launch_gemm_t<TYPE, 4, 4, 1, true>(w, act, N, dst, ldd, ep, st);
+    else launch_gemm_t<TYPE, 1, 4>(w, act, N, dst, ldd, ep, st);
 }
 
 int fq_gemm_split_for(int64_t M, int64_t N, int n_cu) {
@@ -880,7 +946,13 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     static const bool fill = getenv("FQ_GEMM_FILL") && atoi(getenv("FQ_GEMM_FILL")) != 0;
     if (fill && cfg == 2 && N > 64 && ((fq_form_rows(w) + GQ_TM - 1) / GQ_TM) * ((N + 127) / 128) < n_cu) cfg = 4;
     if (const char * e = getenv("FQ_GEMM_CFG")) cfg = atoi(e);                   // tuning override: 0 = <1,4>, 1 = <4,1>, 2 = <4,4>, 3 = <2,4>, 6 = <2,4,2>, 7 = <4,4,2>
-#define FQ_CASE(T) case T: if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
+    // the sequential sum of the legacy formats: sixteen 16 x 16 tiles per workgroup instead of four 32 x 32 ones (SEQ16, k_gemm_q's header; FQ_GEMM_SEQ16=0: the S = 1 form)
+    static const bool seq16 = !(getenv("FQ_GEMM_SEQ16") && atoi(getenv("FQ_GEMM_SEQ16")) == 0);
+    // one tile row of tokens only: measured on MI355X, Falcon-7B Q4_0 prompts in the fast reference order, SEQ16 against S = 1 (scripts/gpu_prompt_lengths.py, A/B/A/B):
+    // 40 tokens 10.3 against 12.2 ms, 64: 10.5 / 12.6, 128: 11.7 / 13.3 -- but 256: 21.4 / 18.1, 512: 39.4 / 31.9, 2048: 194 / 171-180: with several token tile rows the S = 1
+    // form has the waves to fill its chains and the 16 x 16 tiles' extra operand reads cost more than they hide
+    if (cfg == 0 && seq16 && fq_desc(w.type).blck == 32 && N <= 128) cfg = 16;
+#define FQ_CASE(T) case T: if (cfg == 16) launch_gemm_seq16<T>(w, act, N, dst, ldd, ep, st); else if (cfg == 0) launch_gemm_t<T, 1, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 1) launch_gemm_t<T, 4, 1>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 2) launch_gemm_t<T, 4, 4>(w, act, N, dst, ldd, ep, st); else if (cfg == 3) launch_gemm_t<T, 2, 4>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 4) launch_gemm_t<T, 4, 2>(w, act, N, dst, ldd, ep, st); else if (cfg == 5) launch_gemm_t<T, 2, 2>(w, act, N, dst, ldd, ep, st); \
                            else if (cfg == 6) launch_gemm_t<T, 2, 4, 2>(w, act, N, dst, ldd, ep, st); else launch_gemm_t<T, 4, 4, 2>(w, act, N, dst, ldd, ep, st); break;

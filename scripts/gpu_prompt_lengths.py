@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tuning aid (GPU): prompt evaluation time by prompt length on one resident model, events around falcon_hip_eval (no logits copy in the timed region):
-python scripts/gpu_prompt_lengths.py [N ...]    PROMPT_MODEL=7b_q4_0 (default) | 40b_q4_k | ...; PROMPT_LAYERS=n keeps the first n blocks"""
+python scripts/gpu_prompt_lengths.py [N ...]    PROMPT_MODEL=7b_q4_0 (default) | 40b_q4_k | ...; PROMPT_LAYERS=n keeps the first n blocks; PROMPT_ORDER=2: the fast reference order"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +15,10 @@ if os.environ.get("PROMPT_LAYERS"):
     hp["n_layer"] = int(os.environ["PROMPT_LAYERS"])
 wtype = {"q4_0": g.Q4_0, "q4_1": g.Q4_1, "q5_0": g.Q5_0, "q5_1": g.Q5_1, "q8_0": g.Q8_0, "q2_k": g.Q2_K, "q3_k": g.Q3_K, "q4_k": g.Q4_K, "q5_k": g.Q5_K, "q6_k": g.Q6_K}[fmt]
 Ns = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 48, 64, 80, 96, 128]
-m = g.FalconModel(synth.make_model_fast(hp, wtype, seed=1234), n_ctx=512, n_batch=max(Ns))
-ctx = L.falcon_hip_context_create(m.m, 512, max(Ns), 0)
+NCTX = max(512, max(Ns))
+m = g.FalconModel(synth.make_model_fast(hp, wtype, seed=1234), n_ctx=NCTX, n_batch=max(Ns))
+ctx = L.falcon_hip_context_create(m.m, NCTX, max(Ns), 0)
+L.ggml_hip_reference_order(int(os.environ.get("PROMPT_ORDER", "0")))
 toks = synth.tokens(max(Ns), hp["n_vocab"], seed=42)
 for _ in range(2):
     L.falcon_hip_eval(ctx, toks.ctypes.data, max(Ns), 0, 0)
