@@ -59,5 +59,7 @@ constexpr int KS_TMAX = 8;                 // tiles (consumer waves) per workgro
 // the partial sums of the self-paced forms: [segment][share][16 columns][mstride rows] -> dst = the segments' ((P0 + P1) + P2) + P3 added left to right, then the epilogue
 // (kernels_gemm_skinny_k.hip)
 void fq_launch_skinny_sum4(const float * part, int64_t N, int64_t M, float * dst, int64_t ldd, const fq_gemv_epi & ep, int64_t mstride, int nseg, hipStream_t st);
+// x = (sum of part_d's segments + sum of part_w's) + x, each segment ((P0 + P1) + P2) + P3 (kernels_gemm_skinny_k.hip)
+void fq_launch_skinny_sum4_out2(const float * part_d, int nseg_d, const float * part_w, int nseg_w, int64_t mstride, int64_t N, int64_t M, float * x, int64_t ldx, hipStream_t st);
 // the k-quant forms (Q4_K / Q5_K, Q2_K / Q3_K, Q6_K at model widths): true = launched (kernels_gemm_skinny_k.hip)
 bool fq_launch_gemm_skinny_kq(const fq_weight & w, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep, int S, hipStream_t st);

@@ -345,12 +345,30 @@ void fq_prof_close(hipStream_t, double bytes) {
 bool fq_mul_mat_q_acts_pair(const fq_weight & w0, const fq_weight & w1, const fq_act & a, int64_t N, float * dst0, int64_t ldd0, const fq_gemv_epi & ep0,
                             float * dst1, int64_t ldd1, const fq_gemv_epi & ep1, hipStream_t st) {
     static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG") && !(getenv("FQ_SKINNY_PAIR") && atoi(getenv("FQ_SKINNY_PAIR")) == 0);
-    if (!skinny || g_reference_order || g_force_gemv || N <= FQ_GEMV_MAX_COLS || N > 16) return false;
+    // (round 6) 17..32 columns: two passes of the pair launch, as fq_launch_gemm runs a single matrix of that width as two passes of the streaming form -- the same K split
+    // (one token tile row: fq_gemm_split_for does not change between 16 and 32 columns), the same bits, half the launches and the fuller grid of the pair (FQ_SKINNY_PAIR2=0: off)
+    static const bool pair2 = !(getenv("FQ_SKINNY_PAIR2") && atoi(getenv("FQ_SKINNY_PAIR2")) == 0) && !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0);
+    if (!skinny || g_reference_order || g_force_gemv || N <= FQ_GEMV_MAX_COLS || N > (pair2 ? 32 : 16)) return false;
     if (fq_desc(w0.type).act_type != a.type || a.K != w0.K || w1.K != w0.K || w1.type != w0.type) return false;
     const int n_cu = fq_ctx().n_cu;
     const int S0 = fq_gemm_split_for(w0.M, N, n_cu), S1 = fq_gemm_split_for(w1.M, N, n_cu);
     if (S0 != S1) return false;
-    return fq_launch_gemm_skinny_pair(w0, w1, a, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S0, st);
+    if (N <= 16) return fq_launch_gemm_skinny_pair(w0, w1, a, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S0, st);
+    if (fq_skinny_q4k_shape(w0) || fq_skinny_q4k_shape(w1)) return false;                 // (the k-quants' small-batch forms have their own passes)
+    for (int64_t n0 = 0; n0 < N; n0 += 16) {
+        const int64_t nc = N - n0 < 16 ? N - n0 : 16;
+        fq_act a1 = a; a1.ncols = nc; a1.base = a.base + n0 * fq_act_col_bytes(a.type, a.K);
+        fq_gemv_epi e0 = ep0, e1 = ep1;
+        if (e0.add1) e0.add1 += n0 * e0.ld_add;
+        if (e0.add2) e0.add2 += n0 * e0.ld_add;
+        if (e1.add1) e1.add1 += n0 * e1.ld_add;
+        if (e1.add2) e1.add2 += n0 * e1.ld_add;
+        if (!fq_launch_gemm_skinny_pair(w0, w1, a1, nc, dst0 + n0 * ldd0, ldd0, e0, dst1 + n0 * ldd1, ldd1, e1, S0, st)) {
+            if (n0 == 0) return false;
+            fprintf(stderr, "ggml-hip: pair mat-mul: the second pass refused\n"); exit(1);
+        }
+    }
+    return true;
 }
 
 // Q4_K blocks at 5..16 columns, default order: the fused sum launches of the small-batch form. false: nothing launched, the caller runs the generic calls
@@ -363,8 +381,26 @@ bool fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N
     return fq_launch_gemm_skinny_q4k_gelu_q8k(w, a, N, dst, ldd, fq_ctx().gelu_table, out, st);
 }
 bool fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st, int min_cols) {
-    if (!q4k_fused_ok(N, min_cols) || a_att.K != wo.K || a_ff.K != down.K) return false;
-    return fq_launch_gemm_skinny_q4k_out2(wo, a_att, down, a_ff, N, x, ldx, st);
+    if (a_att.K != wo.K || a_ff.K != down.K) return false;
+    if (q4k_fused_ok(N, min_cols) && fq_launch_gemm_skinny_q4k_out2(wo, a_att, down, a_ff, N, x, ldx, st)) return true;
+    // legacy formats (round 6): both matrices in the K-share form in one launch; 17..32 columns as two passes of it (the streaming forms' own rule for that width)
+    static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG");
+    static const bool skinny2 = !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0);
+    if (!skinny || g_reference_order || g_force_gemv || N <= FQ_GEMV_MAX_COLS || N > (skinny2 ? 32 : 16)) return false;
+    if (fq_desc(wo.type).act_type != a_att.type || fq_desc(down.type).act_type != a_ff.type) return false;
+    const int n_cu = fq_ctx().n_cu;
+    if (fq_gemm_split_for(wo.M, N, n_cu) != 4 || fq_gemm_split_for(down.M, N, n_cu) != 4) return false;
+    for (int64_t n0 = 0; n0 < N; n0 += 16) {
+        const int64_t nc = N - n0 < 16 ? N - n0 : 16;
+        fq_act a1 = a_att, a2 = a_ff;
+        a1.ncols = nc; a1.base = a_att.base + n0 * fq_act_col_bytes(a_att.type, a_att.K);
+        a2.ncols = nc; a2.base = a_ff.base + n0 * fq_act_col_bytes(a_ff.type, a_ff.K);
+        if (!fq_launch_gemm_skinny_out2(wo, a1, down, a2, nc, x + n0 * ldx, ldx, st)) {
+            if (n0 == 0) return false;
+            fprintf(stderr, "ggml-hip: output pair: the second pass refused\n"); exit(1);
+        }
+    }
+    return true;
 }
 
 // lock-step contexts of 3 and 4 sequences on the k-quant formats with a small-batch form at this shape: that form (a pass of 16 columns costs less than

@@ -596,9 +596,9 @@ template <int TYPE> struct ks_fmt {
     }
 };
 
+// (bid: the workgroup's index within ITS matrix's part of the grid -- k_gemm_skinny_ks2 runs two matrices in one launch)
 template <int TYPE, int NBW>
-__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int nslots, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void ks_body(const fq_weight & w, const fq_act & act, int N, float * part, int T, int nrb, int nslots, int dbg, const int bid, uint8_t * smem) {
     typedef ks_fmt<TYPE> F;
     constexpr int ACT = fq_act_of(TYPE);
     constexpr int WSTAGE = F::WSTAGE, KOPS = F::KOPS;
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     const int nblk = (int) w.nblk;
     const int nsp = (nblk + 31) / 32;                                      // stages: spans of 32 blocks
     // workgroup -> (row block, share): the four shares of a row block on one XCD
-    const int xcd = (int) blockIdx.x & 7, kk = (int) blockIdx.x >> 3;
+    const int xcd = bid & 7, kk = bid >> 3;
     const int slot = (kk >> 2) * 8 + xcd, s = kk & 3;                     // row blocks slot, slot + nslots, .. (one round when they all fit the chip)
     if (slot >= nrb) return;
     const size_t img = fq_act_col_bytes(ACT, K);
@@ -784,6 +784,21 @@ __global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq
     }
   }
 }
+template <int TYPE, int NBW>
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks(fq_weight w, fq_act act, int N, float * part, int T, int nrb, int nslots, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ks_body<TYPE, NBW>(w, act, N, part, T, nrb, nslots, dbg, (int) blockIdx.x, smem);
+}
+// Two matrices of one format and row count behind their own columns in ONE launch (round 6: Wdown and Wo of a block, x = (Wdown a_ff + Wo a_att) + x): workgroups [0, g0) are
+// matrix 0's grid, [g0, g0 + g1) matrix 1's (g0 a multiple of 8: the XCD of a workgroup index does not change), each with its own tiles-per-workgroup and LDS carve-up.
+// The shorter matrix's workgroups follow the longer one's onto the CUs as those retire -- no launch boundary, no second grid of 142 workgroups on 256 CUs.
+template <int TYPE, int NBW>
+__global__ void __launch_bounds__(64 * KS_TMAX) k_gemm_skinny_ks2(fq_weight w0, fq_act act0, float * part0, int T0, int nrb0, int nslots0, int g0,
+                                                                 fq_weight w1, fq_act act1, float * part1, int T1, int nrb1, int nslots1, int N, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if ((int) blockIdx.x < g0) ks_body<TYPE, NBW>(w0, act0, N, part0, T0, nrb0, nslots0, dbg, (int) blockIdx.x, smem);
+    else                       ks_body<TYPE, NBW>(w1, act1, N, part1, T1, nrb1, nslots1, dbg, (int) blockIdx.x - g0, smem);
+}
 
 // the resident form for one matrix (w1.M == 0) or two of the same K and format sharing their columns (e.g. Wqkv and Wup behind one LayerNorm)
 static bool fq_launch_gemm_skinny_res(const fq_weight & w, const fq_weight & w1, const fq_act & act, int64_t N, float * dst, int64_t ldd, const fq_gemv_epi & ep,
@@ -825,6 +840,63 @@ bool fq_launch_gemm_skinny_pair(const fq_weight & w0, const fq_weight & w1, cons
     FQ_TL(st, "gemm_skinny_pair");
     if (N < 1 || N > SK_TN || (S != 1 && S != 2 && S != 4) || w0.type != w1.type || w0.K != w1.K || w0.nblk != w1.nblk) return false;
     return fq_launch_gemm_skinny_res(w0, w1, act, N, dst0, ldd0, ep0, dst1, ldd1, ep1, S, st);
+}
+
+// the K-share form's plan for a matrix: tiles per workgroup, row blocks, slots, LDS bytes with nbw weight stages
+struct ks_plan { int T, nrb, nslots; unsigned grid; };
+static size_t ks_need(int type, int nblk, int T, int nbw) {
+    switch (type) {
+        case FQ_Q4_0: return ks_fmt<FQ_Q4_0>::lds(nblk, T, nbw); case FQ_Q4_1: return ks_fmt<FQ_Q4_1>::lds(nblk, T, nbw);
+        case FQ_Q5_0: return ks_fmt<FQ_Q5_0>::lds(nblk, T, nbw); case FQ_Q5_1: return ks_fmt<FQ_Q5_1>::lds(nblk, T, nbw);
+        default:      return ks_fmt<FQ_Q8_0>::lds(nblk, T, nbw);
+    }
+}
+static ks_plan ks_make_plan(const fq_weight & w, int n_cu) {
+    const int ntiles = (int)((w.M + 15) / 16);
+    int T = (ntiles * 4 + n_cu - 1) / n_cu;
+    if (T < 1) T = 1;
+    if (T > KS_TMAX) T = KS_TMAX;
+    const int nrb = (ntiles + T - 1) / T;
+    int nslots = 8 * ((nrb + 7) / 8);
+    if (4 * nslots > n_cu) nslots = (n_cu / 32) * 8 > 8 ? (n_cu / 32) * 8 : 8;
+    return ks_plan{ T, nrb, nslots, (unsigned)(4 * nslots) };
+}
+
+// x = (Wdown a_ff + Wo a_att) + x (libfalcon.cpp:2394-2400) for 5..16 columns of a legacy format: BOTH matrices in the K-share form in ONE launch (k_gemm_skinny_ks2) and one
+// sum launch that adds each matrix's four partial sums as ((P0 + P1) + P2) + P3 and then (down + wo) + x -- the bits of the two separate mat-muls (Wo's four-share sums are
+// k_gemm_q<S = 4>'s whichever form computes them), minus Wo's own launch of 142 workgroups, its result matrix and a launch boundary. false: nothing launched.
+bool fq_launch_gemm_skinny_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
+    FQ_TL(st, "gemm_skinny_out2");
+    static const bool on = !(getenv("FQ_SKINNY_OUT2") && atoi(getenv("FQ_SKINNY_OUT2")) == 0) && !(getenv("FQ_SKINNY_KS") && atoi(getenv("FQ_SKINNY_KS")) == 0);
+    const int t = wo.type;
+    if (!on || N < 1 || N > SK_TN || t != down.type || wo.M != down.M || wo.M > FQ_KS_MAX_M) return false;
+    if (t != FQ_Q4_0 && t != FQ_Q4_1 && t != FQ_Q5_0 && t != FQ_Q5_1 && t != FQ_Q8_0) return false;
+    if (down.nblk < 256 || wo.nblk < 32 || a_att.type != a_ff.type) return false;      // (Wdown alone would not take this form: leave the pair to the generic path)
+    const int n_cu = fq_ctx().n_cu;
+    const ks_plan pd = ks_make_plan(down, n_cu), pw = ks_make_plan(wo, n_cu);
+    int nbw = 0; size_t need = 0;
+    for (int n : { 3, 2 }) {
+        const size_t nd = ks_need(t, (int) down.nblk, pd.T, n), nw = ks_need(t, (int) wo.nblk, pw.T, n);
+        need = nd > nw ? nd : nw;
+        if (need <= 160 * 1024) { nbw = n; break; }
+    }
+    if (!nbw) return false;
+    float * part_d = fq_ctx().ks_scratch, * part_w = part_d + (size_t) 4 * SK_TN * FQ_KS_MAX_M;
+    if ((size_t) 8 * SK_TN * FQ_KS_MAX_M > (size_t) FQ_KS_FLOATS) return false;
+#define FQ_KS2_LAUNCH(TT, NB) { \
+        static bool set = false; \
+        if (!set) { HIP_CHECK(hipFuncSetAttribute((const void *) k_gemm_skinny_ks2<TT, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((k_gemm_skinny_ks2<TT, NB>), dim3(pd.grid + pw.grid), dim3(64 * KS_TMAX), need, st, down, a_ff, part_d, pd.T, pd.nrb, pd.nslots, (int) pd.grid, \
+                           wo, a_att, part_w, pw.T, pw.nrb, pw.nslots, (int) N, fq_gemm_debug_get()); }
+#define FQ_KS2_CASE(TT) case TT: if (nbw == 3) FQ_KS2_LAUNCH(TT, 3) else FQ_KS2_LAUNCH(TT, 2) break;
+    switch (t) {
+        FQ_KS2_CASE(FQ_Q4_0) FQ_KS2_CASE(FQ_Q4_1) FQ_KS2_CASE(FQ_Q5_0) FQ_KS2_CASE(FQ_Q5_1) FQ_KS2_CASE(FQ_Q8_0)
+        default: return false;
+    }
+#undef FQ_KS2_CASE
+#undef FQ_KS2_LAUNCH
+    fq_launch_skinny_sum4_out2(part_d, 1, part_w, 1, (int64_t) FQ_KS_MAX_M, N, down.M, x, ldx, st);
+    return true;
 }
 
 // true (and launched) when the shape is this kernel's: a legacy format, 5 <= N <= 16; S = the K split k_gemm_q would use

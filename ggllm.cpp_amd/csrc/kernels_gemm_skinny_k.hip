@@ -878,6 +878,9 @@ bool fq_launch_gemm_skinny_q4k_gelu_q8k(const fq_weight & w, const fq_act & act,
     hipLaunchKernelGGL(k_skinny_sum4_gelu_q8k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fq_ctx().ks_scratch, (int) N, w.M, dst, ldd, gelu_table, out, mstride, nseg);
     return true;
 }
+void fq_launch_skinny_sum4_out2(const float * part_d, int nseg_d, const float * part_w, int nseg_w, int64_t mstride, int64_t N, int64_t M, float * x, int64_t ldx, hipStream_t st) {
+    hipLaunchKernelGGL(k_skinny_sum4_out2, dim3((unsigned)((M + 255) / 256), (unsigned) N), dim3(256), 0, st, part_d, nseg_d, part_w, nseg_w, mstride, (int) N, M, x, ldx);
+}
 // x = (Wdown a_ff + Wo a_att) + x for both matrices in this form: two main launches, ONE sum launch (Wo's result never exists as a matrix)
 bool fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st) {
     FQ_TL(st, "gemm_skinny_q4k_out2");
