@@ -376,13 +376,45 @@ static bool q4k_fused_ok(int64_t N, int64_t min_cols = FQ_GEMV_MAX_COLS + 1) {
     static const bool on = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG") && !(getenv("FQ_SKINNY_Q4K_FUSED") && atoi(getenv("FQ_SKINNY_Q4K_FUSED")) == 0);
     return on && !g_reference_order && !g_force_gemv && fq_gemm_split_for(16, N, fq_ctx().n_cu) != 1 && N >= min_cols && N <= 16;
 }
+// (round 6) 17 .. fq_skinny_kq_max_cols columns -- the widths fq_launch_gemm runs as passes of 16 of the same form -- keep the fused sum launches: one pass of 16 columns at a time
+static bool q4k_fused_passes(const fq_weight & w, int64_t N) {
+    static const bool on = !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0) && !(getenv("FQ_SKINNY_Q4K_FUSED2") && atoi(getenv("FQ_SKINNY_Q4K_FUSED2")) == 0);
+    return on && N > 16 && fq_skinny_q4k_shape(w) && N <= fq_skinny_kq_max_cols(w.type) && q4k_fused_ok(16);
+}
 bool fq_mul_mat_q_acts_gelu_q8k(const fq_weight & w, const fq_act & a, int64_t N, float * dst, int64_t ldd, const fq_act & out, hipStream_t st, int min_cols) {
-    if (!q4k_fused_ok(N, min_cols) || fq_desc(w.type).act_type != a.type || a.K != w.K) return false;
+    if (fq_desc(w.type).act_type != a.type || a.K != w.K) return false;
+    if (q4k_fused_passes(w, N)) {
+        for (int64_t n0 = 0; n0 < N; n0 += 16) {
+            const int64_t nc = N - n0 < 16 ? N - n0 : 16;
+            fq_act a1 = a, o1 = out;
+            a1.ncols = nc; a1.base = a.base + n0 * fq_act_col_bytes(a.type, a.K);
+            o1.ncols = nc; o1.base = out.base + n0 * fq_act_col_bytes(out.type, out.K);
+            if (!fq_launch_gemm_skinny_q4k_gelu_q8k(w, a1, nc, dst + n0 * ldd, ldd, fq_ctx().gelu_table, o1, st)) {
+                if (n0 == 0) return false;
+                fprintf(stderr, "ggml-hip: gelu + Q8_K mat-mul: a later pass refused\n"); exit(1);
+            }
+        }
+        return true;
+    }
+    if (!q4k_fused_ok(N, min_cols)) return false;
     return fq_launch_gemm_skinny_q4k_gelu_q8k(w, a, N, dst, ldd, fq_ctx().gelu_table, out, st);
 }
 bool fq_mul_mat_q_acts_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st, int min_cols) {
     if (a_att.K != wo.K || a_ff.K != down.K) return false;
     if (q4k_fused_ok(N, min_cols) && fq_launch_gemm_skinny_q4k_out2(wo, a_att, down, a_ff, N, x, ldx, st)) return true;
+    if (q4k_fused_passes(wo, N) && q4k_fused_passes(down, N)) {
+        for (int64_t n0 = 0; n0 < N; n0 += 16) {
+            const int64_t nc = N - n0 < 16 ? N - n0 : 16;
+            fq_act a1 = a_att, a2 = a_ff;
+            a1.ncols = nc; a1.base = a_att.base + n0 * fq_act_col_bytes(a_att.type, a_att.K);
+            a2.ncols = nc; a2.base = a_ff.base + n0 * fq_act_col_bytes(a_ff.type, a_ff.K);
+            if (!fq_launch_gemm_skinny_q4k_out2(wo, a1, down, a2, nc, x + n0 * ldx, ldx, st)) {
+                if (n0 == 0) break;
+                fprintf(stderr, "ggml-hip: output pair (k-quants): a later pass refused\n"); exit(1);
+            }
+            if (n0 + 16 >= N) return true;
+        }
+    }
     // legacy formats (round 6): both matrices in the K-share form in one launch; 17..32 columns as two passes of it (the streaming forms' own rule for that width)
     static const bool skinny = !(getenv("FQ_GEMM_SKINNY") && atoi(getenv("FQ_GEMM_SKINNY")) == 0) && !getenv("FQ_GEMM_CFG");
     static const bool skinny2 = !(getenv("FQ_GEMM_SKINNY2") && atoi(getenv("FQ_GEMM_SKINNY2")) == 0);
