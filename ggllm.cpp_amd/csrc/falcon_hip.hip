@@ -991,7 +991,20 @@ __global__ void __launch_bounds__(1024) k_argmax_rows(const float * __restrict__
     __shared__ int   bi[16];
     const float * vals = logits + (int64_t) blockIdx.x * n;
     float best = -INFINITY; int idx = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = vals[i]; if (v > best || (v == best && i < idx)) { best = v; idx = i; } }
+    if ((n & 3) == 0) {
+        // four rows of 16 bytes in flight per thread (the scalar loop below was a chain of 64 dependent round trips: 25 us per step for 65024 logits)
+        const float4 * v4 = (const float4 *) vals;
+        const int n4 = n >> 2;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 v = v4[i];
+            const float e[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (e[k] > best || (e[k] == best && 4 * i + k < idx)) { best = e[k]; idx = 4 * i + k; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = vals[i]; if (v > best || (v == best && i < idx)) { best = v; idx = i; } }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(idx, o);
