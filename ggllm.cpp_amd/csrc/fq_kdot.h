@@ -19,6 +19,13 @@ FQ_HD int fq_dot2(uint32_t a, uint32_t b, int c) {         // 2 x int16 . int16 
     return c + (int)(int16_t)(a & 0xFFFFu) * (int)(int16_t)(b & 0xFFFFu) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
 #endif
 }
+FQ_HD int fq_dot2z(uint32_t a, uint32_t b) {                // the first dot of a chain (fq_units.h: fq_dot4z)
+#if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
+    int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fq_dot2(a, b, 0);
+#endif
+}
 FQ_HD uint32_t fq_pack16(int lo, int hi) {                  // the low 16 bits of two integers side by side (v_perm_b32)
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm((uint32_t) hi, (uint32_t) lo, 0x05040100u);
@@ -97,7 +104,7 @@ template <int TYPE> struct fq_kdot45 {
             hi = or4(hi, shl4(and4(t, 0x02020202u), 3));
         }
         const int isum = fq_mul24((int)(psc & 0xFFu), dot16r(lo, y.x0)) + fq_mul24((int)(psc >> 8), dot16r(hi, y.x1));      // (|dot| <= 16 * 31 * 128)
-        const int msum = fq_dot2((pmn | (pmn << 8)) & 0x00FF00FFu, y.bs, 0);
+        const int msum = fq_dot2z((pmn | (pmn << 8)) & 0x00FF00FFu, y.bs);
         return (fq_h2f((uint16_t) w.dm) * y.dy) * (float) isum - (fq_h2f((uint16_t)(w.dm >> 16)) * y.dy) * (float) msum;
     }
 };
@@ -110,7 +117,7 @@ template <> struct fq_kdot<FQ_Q6_K> {
     static constexpr int CB = fq_lay<FQ_Q6_K>::CB;
     static constexpr int O_QH = CB * 128, O_SC = CB * 192, O_D = CB * 208;
     struct lane_t { uint32_t ssh, tsh; int qoff, hoff, soff, doff, aoff, boff, sbl; };
-    struct act_t { fq_u4 x0, x1; int b0, b1; float dy; };               // b0, b1 = 32 x the two block sums
+    struct act_t { fq_u4 x0, x1; int b0, b1; float dy; };               // b0, b1 = -32 x the two block sums (the dot chains start from them)
     struct w_t { fq_u4 q, qh; uint32_t s0, s1, d; };
     FQ_HDM static lane_t lane_init(int ju) {
         lane_t L{};
@@ -125,7 +132,7 @@ template <> struct fq_kdot<FQ_Q6_K> {
         const int8_t * x = a.qs + 256 * CB * (size_t) p + L.aoff;
         const int16_t * bs = (const int16_t *) a.aux + 16 * CB * (size_t) p + L.boff;
         y.x0 = ld_u4(x); y.x1 = ld_u4(x + 64);
-        y.b0 = 32 * (int) bs[0]; y.b1 = 32 * (int) bs[4];
+        y.b0 = -32 * (int) bs[0]; y.b1 = -32 * (int) bs[4];
         y.dy = a.d[CB * p + L.sbl];
         return y;
     }
@@ -143,7 +150,7 @@ template <> struct fq_kdot<FQ_Q6_K> {
         const fq_u4 t = shr4(w.qh, (int) L.tsh);                          // bits 0-1 of a byte: quarter t, bits 4-5: quarter t + 2
         const fq_u4 lo = or4(and4(w.q, 0x0F0F0F0Fu), shl4(and4(t, 0x03030303u), 4));
         const fq_u4 hi = or4(and4(shr4(w.q, 4), 0x0F0F0F0Fu), and4(t, 0x30303030u));
-        const int isum = fq_mul24(sc_lo, dot16r(lo, y.x0) - y.b0) + fq_mul24(sc_hi, dot16r(hi, y.x1) - y.b1);      // (|dot - 32 bsum| < 2^18)
+        const int isum = fq_mul24(sc_lo, dot16rs(lo, y.x0, y.b0)) + fq_mul24(sc_hi, dot16rs(hi, y.x1, y.b1));      // (|dot - 32 bsum| < 2^18)
         return (fq_h2f((uint16_t) w.d) * y.dy) * (float) isum;
     }
 };
@@ -192,8 +199,8 @@ template <> struct fq_kdot<FQ_Q2_K> {
         const int d1 = dot16r(and4(w.q, 0x0C0C0C0Cu), y.x[1]) >> 2;
         const int d2 = dot16r(and4(w.q, 0x30303030u), y.x[2]) >> 4;
         const int d3 = dot16r(and4(shr4(w.q, 1), 0x60606060u), y.x[3]) >> 5;
-        const int isum = fq_dot2(sc23, fq_pack16(d2, d3), fq_dot2(sc01, fq_pack16(d0, d1), 0));
-        const int msum = fq_dot2(mn23, y.bs23, fq_dot2(mn01, y.bs01, 0));
+        const int isum = fq_dot2(sc23, fq_pack16(d2, d3), fq_dot2z(sc01, fq_pack16(d0, d1)));
+        const int msum = fq_dot2(mn23, y.bs23, fq_dot2z(mn01, y.bs01));
         return (y.dy * fq_h2f((uint16_t) w.dm)) * (float) isum - (y.dy * fq_h2f((uint16_t)(w.dm >> 16))) * (float) msum;
     }
 };
@@ -201,13 +208,13 @@ template <> struct fq_kdot<FQ_Q3_K> {
     static constexpr bool ok = true;
     static constexpr int CB = fq_lay<FQ_Q3_K>::CB;
     static constexpr int O_HM = CB * 64, O_SC = CB * 96, O_D = CB * 108;
-    struct lane_t { uint32_t gsh, hsh; int qoff, hoff, soff, doff, aoff, boff, sbl; };
-    struct act_t { fq_u4 x[4]; int b4[4]; float dy; };                  // b4[j] = 4 x block sum j
+    struct lane_t { uint32_t ssh, hsh; int qoff, hoff, soff, doff, aoff, boff, sbl; };
+    struct act_t { fq_u4 x[4]; int b4[4]; float dy; };                  // b4[j] = -4 x block sum j x the factor its dot carries (1, 4, 1, 16): the dot chains start from them
     struct w_t { fq_u4 q, hm; uint32_t s0, s1, s2, d; };
     FQ_HDM static lane_t lane_init(int ju) {
         lane_t L{};
         const int sbl = ju >> 2, hf = (ju >> 1) & 1, g = ju & 1;
-        L.sbl = sbl; L.gsh = 8u * (uint32_t) g; L.hsh = 4u * (uint32_t) hf;
+        L.sbl = sbl; L.ssh = 8u * (uint32_t) g + 4u * (uint32_t) hf; L.hsh = 4u * (uint32_t) hf;
         L.qoff = 16 * ju; L.hoff = O_HM + 32 * sbl + 16 * g; L.soff = O_SC + 12 * sbl; L.doff = O_D + 2 * sbl;
         L.aoff = 256 * sbl + 128 * hf + 16 * g; L.boff = 16 * sbl + 8 * hf + g;
         return L;
@@ -217,7 +224,7 @@ template <> struct fq_kdot<FQ_Q3_K> {
         const int8_t * x = a.qs + 256 * CB * (size_t) p + L.aoff;
         const int16_t * bs = (const int16_t *) a.aux + 16 * CB * (size_t) p + L.boff;
         y.x[0] = ld_u4(x); y.x[1] = ld_u4(x + 32); y.x[2] = ld_u4(x + 64); y.x[3] = ld_u4(x + 96);
-        y.b4[0] = 4 * (int) bs[0]; y.b4[1] = 4 * (int) bs[2]; y.b4[2] = 4 * (int) bs[4]; y.b4[3] = 4 * (int) bs[6];
+        y.b4[0] = -4 * (int) bs[0]; y.b4[1] = -16 * (int) bs[2]; y.b4[2] = -4 * (int) bs[4]; y.b4[3] = -64 * (int) bs[6];
         y.dy = a.d[CB * p + L.sbl];
         return y;
     }
@@ -233,18 +240,21 @@ template <> struct fq_kdot<FQ_Q3_K> {
     FQ_HDM static float dot(const w_t & w, const act_t & y, const lane_t & L) {
         // scale is = 8hf + 2j + g (k_quants.c:491-496): low 4 bits = nibble hf of byte (2j + g) & 3 of s0 (j < 2) / s1 (j >= 2); high 2 bits = bits
         // 2 (is >> 2), +1 of byte (2j + g) & 3 of s2, is >> 2 = 2hf + (j >> 1)
-        const uint32_t n0 = ((w.s0 >> L.gsh) >> L.hsh) & 0x000F000Fu, n1 = ((w.s1 >> L.gsh) >> L.hsh) & 0x000F000Fu;      // j = 0 | 1 << 16,  j = 2 | 3 << 16
-        const uint32_t t = (w.s2 >> L.gsh) >> L.hsh;
+        const uint32_t n0 = (w.s0 >> L.ssh) & 0x000F000Fu, n1 = (w.s1 >> L.ssh) & 0x000F000Fu;      // j = 0 | 1 << 16,  j = 2 | 3 << 16
+        const uint32_t t = w.s2 >> L.ssh;
         const uint32_t s01 = n0 | ((t & 0x00030003u) << 4), s23 = n1 | (((t >> 2) & 0x00030003u) << 4);
         const fq_u4 u = shr4(w.hm, (int) L.hsh);                          // bit j of a byte: the high bit of the element in group j of this half
+        // groups 1 and 3 stay where a single shift of u serves both: 4 x (low pair at bits 2-3, high bit at 4) and 16 x (low pair at 4-5, high bit at 6: <= 112, a
+        // positive int8); their 16-element dots start from -16 / -64 x the block sum and are shifted back exactly
+        const fq_u4 u3 = shl4(u, 3);
         const fq_u4 q0 = or4(and4(w.q, 0x03030303u),          and4(shl4(u, 2), 0x04040404u));
-        const fq_u4 q1 = or4(and4(shr4(w.q, 2), 0x03030303u), and4(shl4(u, 1), 0x04040404u));
+        const fq_u4 q1 = or4(and4(w.q, 0x0C0C0C0Cu),          and4(u3, 0x10101010u));
         const fq_u4 q2 = or4(and4(shr4(w.q, 4), 0x03030303u), and4(u, 0x04040404u));
-        const fq_u4 q3 = or4(and4(shr4(w.q, 6), 0x03030303u), and4(shr4(u, 1), 0x04040404u));
+        const fq_u4 q3 = or4(and4(shr4(w.q, 2), 0x30303030u), and4(u3, 0x40404040u));
         // (scale - 32) of both 16-bit lanes at once, the four sub-block dots (|dot - 4 bsum| <= 22 464) as int16 pairs: two v_dot2_i32_i16
         const uint32_t c01 = fq_pk_sub16(s01, 0x00200020u), c23 = fq_pk_sub16(s23, 0x00200020u);
-        const int e0 = dot16r(q0, y.x[0]) - y.b4[0], e1 = dot16r(q1, y.x[1]) - y.b4[1], e2 = dot16r(q2, y.x[2]) - y.b4[2], e3 = dot16r(q3, y.x[3]) - y.b4[3];
-        const int isum = fq_dot2(c23, fq_pack16(e2, e3), fq_dot2(c01, fq_pack16(e0, e1), 0));
+        const int e0 = dot16rs(q0, y.x[0], y.b4[0]), e1 = dot16rs(q1, y.x[1], y.b4[1]) >> 2, e2 = dot16rs(q2, y.x[2], y.b4[2]), e3 = dot16rs(q3, y.x[3], y.b4[3]) >> 4;
+        const int isum = fq_dot2(c23, fq_pack16(e2, e3), fq_dot2z(c01, fq_pack16(e0, e1)));
         return (fq_h2f((uint16_t) w.d) * y.dy) * (float) isum;
     }
 };

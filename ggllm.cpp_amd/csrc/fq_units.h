@@ -28,6 +28,26 @@ FQ_HD int fq_dot4(uint32_t a, uint32_t b, int c) {      // 4 x int8 . int8 + c
     return fq_dot4_ref(a, b, c);
 #endif
 }
+// the FIRST dot of a chain: c + a . b with c a value that must survive (or the constant 0). The builtin always selects the two-operand form v_dot4c_i32_i8 (the
+// accumulator is the destination), which costs a v_mov_b32 per chain to set it up; the three-operand VOP3P form takes the start value as a source (round 6:
+// 6 of the 69 vector instructions of a Q2_K unit were such moves). FQ_DOT_VOP3P=0 restores the builtin.
+#ifndef FQ_DOT_VOP3P
+#define FQ_DOT_VOP3P 1
+#endif
+FQ_HD int fq_dot4z(uint32_t a, uint32_t b) {             // 4 x int8 . int8
+#if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
+    int r; asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fq_dot4(a, b, 0);
+#endif
+}
+FQ_HD int fq_dot4s(uint32_t a, uint32_t b, int c) {      // 4 x int8 . int8 + c, c stays alive
+#if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
+    int r; asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+    return fq_dot4(a, b, c);
+#endif
+}
 FQ_HD float fq_h2f(uint16_t h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (float) __builtin_bit_cast(_Float16, h);
@@ -97,7 +117,10 @@ FQ_HD uint16_t ld_u16(const void * p) { return *(const uint16_t *) p; }
 FQ_HD uint32_t spread4(uint32_t bits4) { return ((bits4 & 0xFu) * 0x00204081u) & 0x01010101u; }   // bit k -> byte k bit 0
 
 FQ_HD int dot16r(const fq_u4 & a, const fq_u4 & b) {     // 16 int8 x 16 int8, both in registers
-    int s = fq_dot4(a.x, b.x, 0); s = fq_dot4(a.y, b.y, s); s = fq_dot4(a.z, b.z, s); return fq_dot4(a.w, b.w, s);
+    int s = fq_dot4z(a.x, b.x); s = fq_dot4(a.y, b.y, s); s = fq_dot4(a.z, b.z, s); return fq_dot4(a.w, b.w, s);
+}
+FQ_HD int dot16rs(const fq_u4 & a, const fq_u4 & b, int c) {     // c + 16 int8 x 16 int8 (c: a register that stays alive, e.g. a pre-negated block-sum term)
+    int s = fq_dot4s(a.x, b.x, c); s = fq_dot4(a.y, b.y, s); s = fq_dot4(a.z, b.z, s); return fq_dot4(a.w, b.w, s);
 }
 FQ_HD int dot16(const fq_u4 & a, const int8_t * x) { return dot16r(a, ld_u4(x)); }     // 16 int8 x 16 int8
 FQ_HD fq_u4 and4(const fq_u4 & a, uint32_t m) { return { a.x & m, a.y & m, a.z & m, a.w & m }; }

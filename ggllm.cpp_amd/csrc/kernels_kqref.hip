@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
                     auto p23 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07030602u); };
                     auto lanes8 = [&](const fq_u4 & v, const uint4 & x0, const uint4 & x1, int (&A)[8]) {
                         const unsigned e01 = p01(v.x, v.z), e23 = p23(v.x, v.z), o01 = p01(v.y, v.w), o23 = p23(v.y, v.w);
-                        A[0] = fq_dot4(e01, x0.x, 0); A[1] = fq_dot4(e01, x0.y, 0); A[2] = fq_dot4(e23, x0.z, 0); A[3] = fq_dot4(e23, x0.w, 0);
-                        A[4] = fq_dot4(o01, x1.x, 0); A[5] = fq_dot4(o01, x1.y, 0); A[6] = fq_dot4(o23, x1.z, 0); A[7] = fq_dot4(o23, x1.w, 0);
+                        A[0] = fq_dot4z(e01, x0.x); A[1] = fq_dot4z(e01, x0.y); A[2] = fq_dot4z(e23, x0.z); A[3] = fq_dot4z(e23, x0.w);
+                        A[4] = fq_dot4z(o01, x1.x); A[5] = fq_dot4z(o01, x1.y); A[6] = fq_dot4z(o23, x1.z); A[7] = fq_dot4z(o23, x1.w);
                     };
                     int Al[8], Ah[8], a[8];
                     lanes8(lo, xl0, xl1, Al); lanes8(hi, xh0, xh1, Ah);
@@ -214,8 +214,8 @@ __global__ void __launch_bounds__(512) k_gemv_kq_ref(fq_weight w, fq_act act, fl
                         const fq_u4 v = { m4(l2.x | hb.x), m4(l2.y | hb.y), m4(l2.z | hb.z), m4(l2.w | hb.w) };
                         const int sc = q3_scale(q.s0, q.s1, q.s2, 8 * hf + 2 * j + g) - 32;
                         const unsigned e01 = p01(v.x, v.z), e23 = p23(v.x, v.z), o01 = p01(v.y, v.w), o23 = p23(v.y, v.w);
-                        a[r][0] += sc * fq_dot4(e01, x0.x, 0); a[r][1] += sc * fq_dot4(e01, x0.y, 0); a[r][2] += sc * fq_dot4(e23, x0.z, 0); a[r][3] += sc * fq_dot4(e23, x0.w, 0);
-                        a[r][4] += sc * fq_dot4(o01, x1.x, 0); a[r][5] += sc * fq_dot4(o01, x1.y, 0); a[r][6] += sc * fq_dot4(o23, x1.z, 0); a[r][7] += sc * fq_dot4(o23, x1.w, 0);
+                        a[r][0] += sc * fq_dot4z(e01, x0.x); a[r][1] += sc * fq_dot4z(e01, x0.y); a[r][2] += sc * fq_dot4z(e23, x0.z); a[r][3] += sc * fq_dot4z(e23, x0.w);
+                        a[r][4] += sc * fq_dot4z(o01, x1.x); a[r][5] += sc * fq_dot4z(o01, x1.y); a[r][6] += sc * fq_dot4z(o23, x1.z); a[r][7] += sc * fq_dot4z(o23, x1.w);
                     }
                 }
 #pragma unroll
