@@ -21,7 +21,8 @@ FQ_HD int fq_dot2(uint32_t a, uint32_t b, int c) {         // 2 x int16 . int16 
 }
 FQ_HD int fq_dot2z(uint32_t a, uint32_t b) {                // the first dot of a chain (fq_units.h: fq_dot4z)
 #if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
-    int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r;
+    typedef short fq_s2z __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(fq_s2z, a), __builtin_bit_cast(fq_s2z, b), 0, true);
 #else
     return fq_dot2(a, b, 0);
 #endif

@@ -28,22 +28,24 @@ FQ_HD int fq_dot4(uint32_t a, uint32_t b, int c) {      // 4 x int8 . int8 + c
     return fq_dot4_ref(a, b, c);
 #endif
 }
-// the FIRST dot of a chain: c + a . b with c a value that must survive (or the constant 0). The builtin always selects the two-operand form v_dot4c_i32_i8 (the
-// accumulator is the destination), which costs a v_mov_b32 per chain to set it up; the three-operand VOP3P form takes the start value as a source (round 6:
-// 6 of the 69 vector instructions of a Q2_K unit were such moves). FQ_DOT_VOP3P=0 restores the builtin.
+// the FIRST dot of a chain: c + a . b with c a value that must survive (or the constant 0). With clamp = false the builtin always selects the two-operand form
+// v_dot4c_i32_i8 (the accumulator is the destination), which costs a v_mov_b32 per chain to set it up; with clamp = true it selects the three-operand VOP3P form, which
+// takes the start value as a source (round 6: 6 of the 69 vector instructions of a Q2_K unit were such moves). The clamp saturates at the int32 range, which no sum of
+// this library comes near (|sum| < 2^25): the same integers. (NOT inline assembly: gfx950 needs three wait states between a dot instruction and a reader with another
+// opcode -- the compiler inserts them for instructions it knows, not for an asm statement; tests/test_gpu_kqref.py caught exactly that.) FQ_DOT_VOP3P=0 restores v_dot4c.
 #ifndef FQ_DOT_VOP3P
 #define FQ_DOT_VOP3P 1
 #endif
 FQ_HD int fq_dot4z(uint32_t a, uint32_t b) {             // 4 x int8 . int8
 #if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
-    int r; asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r;
+    return __builtin_amdgcn_sdot4((int) a, (int) b, 0, true);
 #else
     return fq_dot4(a, b, 0);
 #endif
 }
 FQ_HD int fq_dot4s(uint32_t a, uint32_t b, int c) {      // 4 x int8 . int8 + c, c stays alive
 #if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
-    int r; asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+    return __builtin_amdgcn_sdot4((int) a, (int) b, c, true);
 #else
     return fq_dot4(a, b, c);
 #endif
