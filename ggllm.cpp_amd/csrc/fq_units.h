@@ -29,12 +29,14 @@ FQ_HD int fq_dot4(uint32_t a, uint32_t b, int c) {      // 4 x int8 . int8 + c
 #endif
 }
 // the FIRST dot of a chain: c + a . b with c a value that must survive (or the constant 0). With clamp = false the builtin always selects the two-operand form
-// v_dot4c_i32_i8 (the accumulator is the destination), which costs a v_mov_b32 per chain to set it up; with clamp = true it selects the three-operand VOP3P form, which
-// takes the start value as a source (round 6: 6 of the 69 vector instructions of a Q2_K unit were such moves). The clamp saturates at the int32 range, which no sum of
-// this library comes near (|sum| < 2^25): the same integers. (NOT inline assembly: gfx950 needs three wait states between a dot instruction and a reader with another
-// opcode -- the compiler inserts them for instructions it knows, not for an asm statement; tests/test_gpu_kqref.py caught exactly that.) FQ_DOT_VOP3P=0 restores v_dot4c.
+// v_dot4c_i32_i8 (the accumulator is the destination), which costs a v_mov_b32 per chain to set it up (round 6: 6 of the 69 vector instructions of a Q2_K unit are such
+// moves); with clamp = true it selects the three-operand VOP3P form v_dot4_i32_i8 v, a, b, src2 (inline 0 or a live register; the clamp saturates at the int32 range, which
+// no sum here comes near: the same integers, scripts/microbench/mb_dot_clamp.hip). FQ_DOT_VOP3P=1 selects that form -- and is OFF: measured +0.6 % (Q2_K) .. +3 % (Q3_K, with
+// the in-place decode) on the Falcon-40B decode, but k_gemv_kq_ref<Q3_K> then reads a STALE register in `sc * dot` (v_mul_lo_u32 three instructions behind the VOP3P dot, the
+// distance the compiler's hazard table asks for; garbage on the box, tests/test_gpu_kqref.py) while every ring kernel passes. An instruction form whose latency the compiler
+// misjudges somewhere is not one to ship for 1 %: NOTEBOOK 10.15. (An inline-assembly form is wrong for the same reason, without any s_nop at all.)
 #ifndef FQ_DOT_VOP3P
-#define FQ_DOT_VOP3P 1
+#define FQ_DOT_VOP3P 0
 #endif
 FQ_HD int fq_dot4z(uint32_t a, uint32_t b) {             // 4 x int8 . int8
 #if defined(__HIP_DEVICE_COMPILE__) && FQ_DOT_VOP3P
