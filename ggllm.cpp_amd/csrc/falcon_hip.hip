@@ -665,6 +665,23 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, 0);
             fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, 0, &c->att_scratch);
             fq_launch_quantize_act(c->att, E, a_att, st);
+            // (round 6) Short prompts: neither branch waits for the other to carry the residual sum in an epilogue. Wdown -- the long launch of a short prompt (K = 4 n_embd,
+            // 142 workgroups on 256 CUs at 128 tokens) -- follows Wup on the side stream and leaves its result in the (free again) f32 Wup matrix, Wo leaves its own, and
+            // x = (down + wo) + x (libfalcon.cpp:2399-2400, the same additions in the same order) is a small launch behind the join.
+            // Measured on MI355X, Falcon-7B Q4_0, epilogue form -> this (scripts/gpu_prompt_lengths.py, A/B/A/B on one box, profiles/r06zm_*): 40 tokens 6.80 -> 6.25 ms,
+            // 64: 6.88 -> 6.40, 128: 8.17 -> 7.03 (18.2 k tok/s), 256: 14.3 -> 12.2, 512: 23.08 -> 23.00, 1024: 42.1 -> 41.6 -- but 384: 17.5 -> 18.2: Wdown's 426 workgroups
+            // are 1.7 rounds of the chip there and the attention branch beside them only stretches the second. Hence: Wdown's launch at most 1.25 rounds or at least 2.
+            // FALCON_HIP_PAR2_DOWN_FIRST=0: never (the epilogue form below), 2: always
+            static const int down_first = getenv("FALCON_HIP_PAR2_DOWN_FIRST") ? atoi(getenv("FALCON_HIP_PAR2_DOWN_FIRST")) : 1;
+            const int64_t down_wgs = ((L.down.M + 31) / 32) * ((N + 127) / 128);
+            if ((E & 3) == 0 && (down_first == 2 || (down_first == 1 && (4 * down_wgs <= 5 * (int64_t) hc.n_cu || down_wgs >= 2 * (int64_t) hc.n_cu)))) {
+                fq_mul_mat_q_acts(L.down, a_ff, N, c->up, E, store, c->side);
+                HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
+                fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
+                HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
+                fq_launch_add2_inplace(c->x, c->up, c->wo_out, (int64_t) N * E, st);
+                continue;
+            }
             fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
             HIP_CHECK(hipEventRecord(c->ev_attn[li], st));
             HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_attn[li], 0));

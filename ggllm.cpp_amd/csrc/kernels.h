@@ -62,6 +62,7 @@ int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
+void   fq_launch_add2_inplace(float * x, const float * a, const float * b, int64_t n, hipStream_t st);      // x = (a + b) + x, n % 4 == 0 (the residual sum of a block whose two branches ran on two streams)
 void   fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st);
 bool   fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const float * w0, const float * b0, const fq_act & a0,
                                    const float * w1, const float * b1, const fq_act & a1, hipStream_t st);      // two norms of the same rows, one launch (same image type; else false)

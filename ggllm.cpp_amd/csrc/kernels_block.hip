@@ -53,6 +53,22 @@ void fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const 
     else                        hipLaunchKernelGGL(k_layer_norm_quant<FQ_Q8_K>, dim3((unsigned) rows), dim3(256), lds, st, x, n, w, b, y, a);
 }
 
+// x = (a + b) + x: the residual sum of a block (libfalcon.cpp:2399-2400: inpL = (ffn_out + attn_out) + inpL) as a launch of its own -- the short prompts' two-stream form,
+// where neither mat-mul should wait for the other just to carry the sum in its epilogue (falcon_hip.hip)
+__global__ void __launch_bounds__(256) k_add2_inplace(float * __restrict__ x, const float * __restrict__ a, const float * __restrict__ b, int64_t nv) {
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t) gridDim.x * blockDim.x) {
+        const float4 p = ((const float4 *) a)[i], q = ((const float4 *) b)[i]; float4 v = ((float4 *) x)[i];
+        v.x = (p.x + q.x) + v.x; v.y = (p.y + q.y) + v.y; v.z = (p.z + q.z) + v.z; v.w = (p.w + q.w) + v.w;
+        ((float4 *) x)[i] = v;
+    }
+}
+void fq_launch_add2_inplace(float * x, const float * a, const float * b, int64_t n, hipStream_t st) {
+    FQ_TL(st, "add2");
+    const int64_t nv = n >> 2;
+    const unsigned grid = (unsigned)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_add2_inplace, dim3(grid ? grid : 1), dim3(256), 0, st, x, a, b, nv);
+}
+
 // two norms of the same rows in one launch (Falcon-40B's ln_mlp and ln_attn: blockIdx.y picks the weights and the image)
 template <int ACT>
 __global__ void __launch_bounds__(256) k_layer_norm_quant2(const float * __restrict__ x, int64_t n, const float * __restrict__ w0, const float * __restrict__ b0, fq_act a0,
