@@ -602,6 +602,21 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         }
         return;
     }
+    // The LayerNorm(s) in front of a block (and the output norm) come out of the PREVIOUS block's residual-sum launch where that is a launch of its own (the short prompts'
+    // two-stream form below): norm_of(li) = what block li (li == #blocks: the head) needs, ln_done = the images are there
+    auto norm_of = [&](size_t li, fq_next_norm & nn) -> bool {
+        nn = fq_next_norm{};
+        if (li == m->layers.size()) {
+            if (!m->last_stage()) return false;
+            nn.w0 = m->out_norm_w; nn.b0 = m->out_norm_b; nn.a0 = act_for(c->buf_e, m->lm_head, N);
+            return fq_add2_ln_ok(nn, E);
+        }
+        const layer_weights & Ln = m->layers[li];
+        nn.w0 = Ln.ln_w; nn.b0 = Ln.ln_b; nn.a0 = act_for(c->buf_e, Ln.up, N);
+        if (hp.two_norms) { nn.w1 = Ln.ln2_w; nn.b1 = Ln.ln2_b; nn.a1 = act_for(c->buf_e2, Ln.qkv, N); return fq_add2_ln_ok(nn, E); }
+        return fq_desc(Ln.qkv.type).act_type == nn.a0.type && fq_add2_ln_ok(nn, E);      // (one norm, two activation families: two images of it -- the launches below)
+    };
+    bool ln_done = false;
     for (size_t li = 0; li < m->layers.size(); ++li) {
         const layer_weights & L = m->layers[li];
         if (c->keep_hidden) HIP_CHECK(hipMemcpyAsync(c->hidden_dev + li * (size_t) N * E, c->x, (size_t) N * E * 4, hipMemcpyDeviceToDevice, st));
@@ -609,11 +624,13 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         fq_act a_qkv = a_up;
         if (hp.two_norms) {                                                              // ln_mlp and ln_attn: one launch when both images are of one type
             a_qkv = act_for(c->buf_e2, L.qkv, N);
-            if (!fq_launch_layer_norm_quant2(c->x, E, N, L.ln_w, L.ln_b, a_up, L.ln2_w, L.ln2_b, a_qkv, st)) {
+            if (ln_done) {
+            } else if (!fq_launch_layer_norm_quant2(c->x, E, N, L.ln_w, L.ln_b, a_up, L.ln2_w, L.ln2_b, a_qkv, st)) {
                 fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);
                 fq_launch_layer_norm_quant(c->x, E, N, L.ln2_w, L.ln2_b, nullptr, a_qkv, st);
             }
-        } else fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);      // (the f32 row is not needed)
+        } else if (!ln_done) fq_launch_layer_norm_quant(c->x, E, N, L.ln_w, L.ln_b, nullptr, a_up, st);      // (the f32 row is not needed)
+        ln_done = false;
         if (hp.two_norms) {
         } else if (fq_desc(L.qkv.type).act_type != a_up.type) {                          // same norm, the other activation family
             a_qkv = act_for(c->buf_e2, L.qkv, N);
@@ -679,7 +696,9 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
                 HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));
                 fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
                 HIP_CHECK(hipStreamWaitEvent(st, c->ev_join[li], 0));
-                fq_launch_add2_inplace(c->x, c->up, c->wo_out, (int64_t) N * E, st);
+                fq_next_norm nn;
+                if (norm_of(li + 1, nn)) { fq_launch_add2_ln(c->x, c->up, c->wo_out, E, N, nn, st); ln_done = true; }
+                else fq_launch_add2_inplace(c->x, c->up, c->wo_out, (int64_t) N * E, st);
                 continue;
             }
             fq_mul_mat_q_acts(L.wo, a_att, N, c->wo_out, E, store, st);
@@ -746,7 +765,7 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
     }
     if (m->last_stage()) {
         const fq_act a_head = act_for(c->buf_e, m->lm_head, N);
-        fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, a_head, st);
+        if (!ln_done) fq_launch_layer_norm_quant(c->x, E, N, m->out_norm_w, m->out_norm_b, nullptr, a_head, st);
         bool head_done = false;
         if (seq_stride && N >= 2 && N <= FQ_COLS_MAX_N && c->fused_decode && !fq_reference_order()) {
             head_done = true;

@@ -153,6 +153,50 @@ __device__ __forceinline__ void layer_norm_issue(const float * __restrict__ x, i
     for (int k = 0; k < NLN; ++k) { const int64_t i = (int64_t) k * nt + tid; r.t[k] = ((const float4 *) x)[i < nv ? i : nv - 1]; }
 }
 
+// the rest of the norm once the row is in LDS (element i written by the thread that reads it here: i = tid, tid + nt, ..) and every thread holds the f64 sum of
+// ITS elements, added in ascending i: mean, deviations, variance, scale, * w + b (w == nullptr: the plain norm) -> out (LDS; may be row). Ends in a workgroup barrier.
+// out != row: row keeps (x - mean) * scale, so that a second norm of the same row (Falcon-40B's ln_attn beside ln_mlp) only repeats the last step (layer_norm_apply).
+__device__ __forceinline__ void layer_norm_from_row(double s, int64_t n, const float * __restrict__ w, const float * __restrict__ b, float * row, float * out, double * red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t nv = n >> 2;
+    s = block_sum(s, red);
+    const float mean = (float)(s / (double) n);
+    double s2 = 0.0;
+    for (int64_t i = tid; i < nv; i += nt) {
+        float4 v = ((float4 *) row)[i];
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        ((float4 *) row)[i] = v;
+        s2 += (double)(v.x * v.x); s2 += (double)(v.y * v.y); s2 += (double)(v.z * v.z); s2 += (double)(v.w * v.w);
+    }
+    s2 = block_sum(s2, red);
+    const float variance = (float)(s2 / (double) n);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+    for (int64_t i = tid; i < nv; i += nt) {
+        float4 v = ((float4 *) row)[i];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (out != row) ((float4 *) row)[i] = v;
+        if (w) {
+            const float4 ww = ((const float4 *) w)[i], bb = ((const float4 *) b)[i];
+            v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
+        }
+        ((float4 *) out)[i] = v;
+    }
+    __syncthreads();
+}
+// out = row * w + b for a row that holds (x - mean) * scale (layer_norm_from_row with out != row). Ends in a workgroup barrier; the caller puts one in FRONT of it when
+// `out` is still being read.
+__device__ __forceinline__ void layer_norm_apply(int64_t n, const float * __restrict__ w, const float * __restrict__ b, const float * row, float * out) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t nv = n >> 2;
+    for (int64_t i = tid; i < nv; i += nt) {
+        float4 v = ((const float4 *) row)[i];
+        const float4 ww = ((const float4 *) w)[i], bb = ((const float4 *) b)[i];
+        v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
+        ((float4 *) out)[i] = v;
+    }
+    __syncthreads();
+}
+
 template <int NLN>
 __device__ __forceinline__ void layer_norm_finish(const ln_row_regs<NLN> & r, const float * __restrict__ x, int64_t n,
                                                   const float * __restrict__ w, const float * __restrict__ b, float * row, double * red) {
@@ -174,28 +218,7 @@ __device__ __forceinline__ void layer_norm_finish(const ln_row_regs<NLN> & r, co
             if (i < nv) { ((float4 *) row)[i] = t[k]; s += (double) t[k].x; s += (double) t[k].y; s += (double) t[k].z; s += (double) t[k].w; }
         }
     }
-    s = block_sum(s, red);
-    const float mean = (float)(s / (double) n);
-    double s2 = 0.0;
-    for (int64_t i = tid; i < nv; i += nt) {
-        float4 v = ((float4 *) row)[i];
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        ((float4 *) row)[i] = v;
-        s2 += (double)(v.x * v.x); s2 += (double)(v.y * v.y); s2 += (double)(v.z * v.z); s2 += (double)(v.w * v.w);
-    }
-    s2 = block_sum(s2, red);
-    const float variance = (float)(s2 / (double) n);
-    const float scale = 1.0f / sqrtf(variance + 1e-5f);
-    for (int64_t i = tid; i < nv; i += nt) {
-        float4 v = ((float4 *) row)[i];
-        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        if (w) {
-            const float4 ww = ((const float4 *) w)[i], bb = ((const float4 *) b)[i];
-            v.x = v.x * ww.x + bb.x; v.y = v.y * ww.y + bb.y; v.z = v.z * ww.z + bb.z; v.w = v.w * ww.w + bb.w;
-        }
-        ((float4 *) row)[i] = v;
-    }
-    __syncthreads();
+    layer_norm_from_row(s, n, w, b, row, row, red);
 }
 
 // ---- LayerNorm + activation quantizer of one row entirely in registers (the fused decode prologue), run by the first

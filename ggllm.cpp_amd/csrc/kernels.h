@@ -62,6 +62,11 @@ int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1
 
 // kernels_block.hip
 void   fq_launch_layer_norm(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, hipStream_t st);
+// the LayerNorm(s) + activation image(s) that FOLLOW a block's residual sum (the next block's ln_mlp [+ ln_attn], or the output norm), for fq_launch_add2_ln: one workgroup per
+// token sums its row, keeps it in LDS and runs k_layer_norm_quant's device code on it. a0 / a1: images, column 0 first; w1 == nullptr: one norm; a0.type == a1.type
+struct fq_next_norm { const float * w0, * b0; fq_act a0; const float * w1, * b1; fq_act a1; };
+bool   fq_add2_ln_ok(const fq_next_norm & nn, int64_t E);
+void   fq_launch_add2_ln(float * x, const float * a, const float * b, int64_t E, int64_t rows, const fq_next_norm & nn, hipStream_t st);      // x = (a + b) + x, then the norm(s) of x
 void   fq_launch_add2_inplace(float * x, const float * a, const float * b, int64_t n, hipStream_t st);      // x = (a + b) + x, n % 4 == 0 (the residual sum of a block whose two branches ran on two streams)
 void   fq_launch_layer_norm_quant(const float * x, int64_t n, int64_t rows, const float * w, const float * b, float * y, const fq_act & a, hipStream_t st);
 bool   fq_launch_layer_norm_quant2(const float * x, int64_t n, int64_t rows, const float * w0, const float * b0, const fq_act & a0,

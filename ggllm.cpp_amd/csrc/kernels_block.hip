@@ -69,6 +69,48 @@ void fq_launch_add2_inplace(float * x, const float * a, const float * b, int64_t
     hipLaunchKernelGGL(k_add2_inplace, dim3(grid ? grid : 1), dim3(256), 0, st, x, a, b, nv);
 }
 
+// ... and, one workgroup per token, with the LayerNorm(s) + activation image(s) that follow (fq_next_norm): the sum, then k_layer_norm_quant's own device code on the row it left
+// in LDS (per thread the same elements in the same order: the same f64 sums, the same bits); a second norm of a two-norm block repeats only * w + b
+template <int ACT>
+__global__ void __launch_bounds__(256) k_add2_ln(float * __restrict__ x, const float * __restrict__ a, const float * __restrict__ b, int64_t n, fq_next_norm nn) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const size_t rowb = ((size_t) n * 4 + 15) & ~(size_t) 15;
+    float  * row = (float *) smem;
+    float  * out = nn.w1 ? (float *)(smem + rowb) : row;
+    double * red = (double *)(smem + (nn.w1 ? 2 : 1) * rowb);
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t) blockIdx.x * n, nv = n >> 2;
+    double s = 0.0;
+    for (int64_t i = tid; i < nv; i += 256) {
+        const float4 p = ((const float4 *)(a + r0))[i], q = ((const float4 *)(b + r0))[i]; float4 v = ((float4 *)(x + r0))[i];
+        v.x = (p.x + q.x) + v.x; v.y = (p.y + q.y) + v.y; v.z = (p.z + q.z) + v.z; v.w = (p.w + q.w) + v.w;
+        ((float4 *)(x + r0))[i] = v; ((float4 *) row)[i] = v;
+        s += (double) v.x; s += (double) v.y; s += (double) v.z; s += (double) v.w;
+    }
+    layer_norm_from_row(s, n, nn.w0, nn.b0, row, out, red);
+    quantize_row_block<ACT>(out, n, act_image_at(nn.a0.base + (size_t) blockIdx.x * fq_act_col_bytes(ACT, n), ACT, n));
+    if (nn.w1) {
+        __syncthreads();
+        layer_norm_apply(n, nn.w1, nn.b1, row, out);
+        quantize_row_block<ACT>(out, n, act_image_at(nn.a1.base + (size_t) blockIdx.x * fq_act_col_bytes(ACT, n), ACT, n));
+    }
+}
+bool fq_add2_ln_ok(const fq_next_norm & nn, int64_t E) {
+    static const bool on = !(getenv("FALCON_HIP_ADD2_LN") && atoi(getenv("FALCON_HIP_ADD2_LN")) == 0);
+    if (!on || !nn.w0 || E % 4 || nn.a0.K != E || (nn.w1 && (nn.a1.type != nn.a0.type || nn.a1.K != E))) return false;
+    if (nn.a0.type != FQ_Q8_0 && nn.a0.type != FQ_Q8_1 && nn.a0.type != FQ_Q8_K) return false;
+    if (nn.a0.type == FQ_Q8_K ? E % 256 : E % 32) return false;
+    return (nn.w1 ? 2 : 1) * (((size_t) E * 4 + 15) & ~(size_t) 15) + 64 <= 160 * 1024;
+}
+void fq_launch_add2_ln(float * x, const float * a, const float * b, int64_t E, int64_t rows, const fq_next_norm & nn, hipStream_t st) {
+    FQ_TL(st, "add2_ln");
+    const size_t lds = (nn.w1 ? 2 : 1) * (((size_t) E * 4 + 15) & ~(size_t) 15) + 64;
+#define FQ_A2LN(A) { static size_t gmax = 64 * 1024; if (lds > gmax) { HIP_CHECK(hipFuncSetAttribute((const void *) k_add2_ln<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); gmax = lds; } \
+        hipLaunchKernelGGL(k_add2_ln<A>, dim3((unsigned) rows), dim3(256), lds, st, x, a, b, E, nn); }
+    if (nn.a0.type == FQ_Q8_0) FQ_A2LN(FQ_Q8_0) else if (nn.a0.type == FQ_Q8_1) FQ_A2LN(FQ_Q8_1) else FQ_A2LN(FQ_Q8_K)
+#undef FQ_A2LN
+}
+
 // two norms of the same rows in one launch (Falcon-40B's ln_mlp and ln_attn: blockIdx.y picks the weights and the image)
 template <int ACT>
 __global__ void __launch_bounds__(256) k_layer_norm_quant2(const float * __restrict__ x, int64_t n, const float * __restrict__ w0, const float * __restrict__ b0, fq_act a0,
