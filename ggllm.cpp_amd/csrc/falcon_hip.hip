@@ -671,7 +671,10 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         // (not where the mat-muls are passes of the Q4_K small-batch form: they fill the chip and share one partial-sum scratch)
         auto passes_of = [&](const fq_weight & w) { return N <= fq_skinny_kq_max_cols(w.type) && fq_skinny_q4k_shape(w); };      // per matrix: a block may mix k-quant formats with different column limits
         const bool q4k_passes = passes_of(L.qkv) || passes_of(L.up) || passes_of(L.wo) || passes_of(L.down);
-        const bool par2 = !cols_path && !seq_stride && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
+        // (round 6: lock-step passes of more than 32 sequences as well -- the same launches of ~50-100 us each, the decode attention of all sequences in the attention branch;
+        // FALCON_HIP_PAR2_SEQS=0: those in stream order, as before)
+        static const bool par2_seqs = !(getenv("FALCON_HIP_PAR2_SEQS") && atoi(getenv("FALCON_HIP_PAR2_SEQS")) == 0);
+        const bool par2 = !cols_path && (!seq_stride || par2_seqs) && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
             HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
@@ -679,9 +682,15 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             fq_mul_mat_q_acts(L.up, a_up, N, c->up, FF, gelu, c->side);
             fq_launch_quantize_act(c->up, FF, a_ff, c->side);
             fq_mul_mat_q_acts(L.qkv, a_qkv, N, c->qkv, QKV, store, st);
-            fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, 0);
-            fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, 0, &c->att_scratch);
-            fq_launch_quantize_act(c->att, E, a_att, st);
+            if (seq_stride && !fq_reference_order() && !fq_attn_f64()) {
+                fq_launch_attn_decode_seqs(c->qkv, N, (int) H, (int) HKV, c->n_past_dev, max_n_kv, c->rope_cs, kc, vc, seq_stride, hc.exp_table_attn,
+                                           att_q ? nullptr : c->att, att_q ? c->buf_att : nullptr, a_att.type, (int64_t) fq_act_col_bytes(a_att.type, E), st, nullptr, FF, nullptr);
+                if (!att_q) fq_launch_quantize_act(c->att, E, a_att, st);
+            } else {
+                fq_launch_rope_kv(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, c->rope_cs, kc, vc, st, seq_stride);
+                fq_launch_attention(c->qkv, N, (int) H, (int) HKV, (int) D, c->n_past_dev, max_n_kv, kc, vc, hc.exp_table_attn, c->att, st, seq_stride, &c->att_scratch);
+                fq_launch_quantize_act(c->att, E, a_att, st);
+            }
             // (round 6) Short prompts: neither branch waits for the other to carry the residual sum in an epilogue. Wdown -- the long launch of a short prompt (K = 4 n_embd,
             // 142 workgroups on 256 CUs at 128 tokens) -- follows Wup on the side stream and leaves its result in the (free again) f32 Wup matrix, Wo leaves its own, and
             // x = (down + wo) + x (libfalcon.cpp:2399-2400, the same additions in the same order) is a small launch behind the join.
