@@ -673,8 +673,12 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
         const bool q4k_passes = passes_of(L.qkv) || passes_of(L.up) || passes_of(L.wo) || passes_of(L.down);
         // (round 6: lock-step passes of more than 32 sequences as well -- the same launches of ~50-100 us each, the decode attention of all sequences in the attention branch;
         // FALCON_HIP_PAR2_SEQS=0: those in stream order, as before)
+        // (from 17 tokens for prompts -- 32 tokens 4.86 -> 4.70 ms, 20: 4.70 -> 4.62 --, from 33 sequences for lock-step passes, whose launches sit in the step's hipGraph:
+        // 32 per pass 4.78 -> 5.0 ms with it; profiles/r06zu_ab_par2_min_n.txt. FALCON_HIP_PAR2_MIN_N=n: both from n)
+        static const int par2_min_env = getenv("FALCON_HIP_PAR2_MIN_N") ? atoi(getenv("FALCON_HIP_PAR2_MIN_N")) : 0;
+        const int par2_min_n = par2_min_env ? par2_min_env : (seq_stride ? 33 : 17);
         static const bool par2_seqs = !(getenv("FALCON_HIP_PAR2_SEQS") && atoi(getenv("FALCON_HIP_PAR2_SEQS")) == 0);
-        const bool par2 = !cols_path && (!seq_stride || par2_seqs) && N > 32 && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
+        const bool par2 = !cols_path && (!seq_stride || par2_seqs) && N >= par2_min_n && N <= c->par2_max_n && !q4k_passes && !fq_prof_active() && !fq_ctx().dbg_stamps;
         if (par2) {
             HIP_CHECK(hipEventRecord(c->ev_fork[li], st));
             HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork[li], 0));
