@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times (same positions); value = the median run")
     ap.add_argument("--force-pipeline", action="store_true", help="run the multi-GPU pipeline driver even with one GPU (testing)")
     ap.add_argument("--streams", type=int, default=2, help="groups of decode streams in flight for --force-pipeline at one GPU")
-    ap.add_argument("--pipe-batch", type=int, default=16, help="pipeline: lock-step streams per group (one weight pass serves them; 1..256; 5..16 through the small-batch mat-muls -- 16 is their best operating point --, beyond in passes of them or through the int8-MFMA tile GEMM)")
+    ap.add_argument("--pipe-batch", type=int, default=128, help="pipeline: lock-step streams per group (one weight pass serves them; 1..256; 5..16 through the small-batch mat-muls, 17..32 in two passes of them, beyond through the int8-MFMA tile GEMM with a block's two branches on two streams -- round 6: 128 per pass is the best operating point of both bench models on one GPU (Falcon-7B Q4_0 16.5 k tok/s against 5.9 k at 16; Falcon-40B Q4_K 2.96 k against 1.6 k), and a stage's slot is long against the hand-off)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra keys of the north-star configuration (Falcon-40B Q4_K, all 60 blocks, on the same GPUs)")
     ap.add_argument("--no-lock-step", action="store_true", help="skip the extra keys of the multi-stream (lock-step) decode measurement")
     ap.add_argument("--no-ref-order", action="store_true", help="skip the reference_order key (prompt + 16 decode steps in the reference's scalar summation order)")
