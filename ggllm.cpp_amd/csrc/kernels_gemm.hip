@@ -934,7 +934,12 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     }
     // 64-row workgroups (RB = 2) where there are tiles enough to fill the chip with them: two partial sums as <2,4> above,
     // or four (<4,4,2>: 16 waves) for the formats whose 64-row kernel stays within 128 VGPRs
-    static const int64_t rb_min = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : 32;      // x #CU tiles; 0 = never
+    // (round 6: from 512 tokens on already at 8 x #CU tiles -- the short matrices of a long prompt (Wqkv, Wo, Wdown: 4 672 tiles at 1024 tokens) had fallen between the two
+    // rules: Falcon-7B Q4_0 1024 tokens 40.7 -> 36.8 ms, 512: 22.75 -> 22.27; below 512 tokens the same threshold costs Wup 6 % at 256 and 7 % at 128. The same S: the same bits.
+    // FQ_GEMM_RB_TILES=n: n x #CU for every length (A/B, profiles/r06zz_ab_rb_tiles.txt); FQ_GEMM_RB_TILES_LONG=n: the threshold from 512 tokens on)
+    static const int64_t rb_env = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : -1;      // x #CU tiles; 0 = never
+    static const int64_t rb_long = getenv("FQ_GEMM_RB_TILES_LONG") ? atoll(getenv("FQ_GEMM_RB_TILES_LONG")) : 8;
+    const int64_t rb_min = rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : 32);
     if (cfg == 3 && rb_min > 0 && tiles >= rb_min * (int64_t) n_cu) cfg = 6;
     // few columns (round 6): token tiles of 32 / 64 instead of 128 -- the same four-way K split (S = 4: the same association, the same bits), a quarter /
     // half of the matrix work on padding columns gone and 4 / 8 waves per workgroup instead of 16 (FQ_GEMM_SMALL_TT=0: the 128-token tiles, as before)
