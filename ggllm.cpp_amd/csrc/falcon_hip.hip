@@ -703,7 +703,8 @@ static void launch_stage(falcon_hip_context * c, int N, int max_n_kv, hipStream_
             // are 1.7 rounds of the chip there and the attention branch beside them only stretches the second. Hence: Wdown's launch at most 1.25 rounds or at least 2.
             // FALCON_HIP_PAR2_DOWN_FIRST=0: never (the epilogue form below), 2: always
             static const int down_first = getenv("FALCON_HIP_PAR2_DOWN_FIRST") ? atoi(getenv("FALCON_HIP_PAR2_DOWN_FIRST")) : 1;
-            const int64_t down_wgs = ((L.down.M + 31) / 32) * ((N + 127) / 128);
+            const int64_t down_rows = fq_gemm_wg_rows(L.down.type, fq_form_rows(L.down), N, hc.n_cu);
+            const int64_t down_wgs = ((L.down.M + down_rows - 1) / down_rows) * ((N + 127) / 128);
             if ((E & 3) == 0 && (down_first == 2 || (down_first == 1 && (4 * down_wgs <= 5 * (int64_t) hc.n_cu || down_wgs >= 2 * (int64_t) hc.n_cu)))) {
                 fq_mul_mat_q_acts(L.down, a_ff, N, c->up, E, store, c->side);
                 HIP_CHECK(hipEventRecord(c->ev_join[li], c->side));

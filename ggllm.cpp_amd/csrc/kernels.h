@@ -58,6 +58,7 @@ bool   fq_launch_gemm_skinny_q4k_out2(const fq_weight & wo, const fq_act & a_att
 static inline int fq_skinny_kq_max_cols(int type) { return (type == FQ_Q2_K || type == FQ_Q3_K) ? 112 : 80; }
 bool   fq_launch_gemm_skinny_out2(const fq_weight & wo, const fq_act & a_att, const fq_weight & down, const fq_act & a_ff, int64_t N, float * x, int64_t ldx, hipStream_t st);      // legacy formats, N <= 16: Wdown and Wo in one K-share launch + one sum launch
 bool   fq_skinny_q4k_shape(const fq_weight & w);          // Q4_K shapes the small-batch form takes (N <= 16: always four partial sums)
+int    fq_gemm_wg_rows(int type, int64_t M, int64_t N, int n_cu);        // weight rows per workgroup of the tile form (32 / 64)
 int    fq_gemm_split_for(int64_t M, int64_t N, int n_cu);      // the K split (1, 2, 4) fq_launch_gemm gives an M x N result
 
 // kernels_block.hip

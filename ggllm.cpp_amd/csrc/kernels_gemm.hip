@@ -892,6 +892,22 @@ static void launch_gemm_seq16(const fq_weight & w, const fq_act & act, int64_t N
     else launch_gemm_t<TYPE, 1, 4>(w, act, N, dst, ldd, ep, st);
 }
 
+// the 64-row workgroups' threshold (x #CU tiles of 32 x 32; 0 = never) by prompt length
+static int64_t gemm_rb_min(int64_t N, int type) {
+    static const int64_t rb_env = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : -1;
+    static const int64_t rb_long = getenv("FQ_GEMM_RB_TILES_LONG") ? atoll(getenv("FQ_GEMM_RB_TILES_LONG")) : 8;
+    static const int64_t rb_mid = getenv("FQ_GEMM_RB_TILES_MID") ? atoll(getenv("FQ_GEMM_RB_TILES_MID")) : 4;
+    // (the 257..511 rule for the legacy formats only: the k-quants' integer-domain GEMM loses with 64-row workgroups there -- Falcon-40B Q2_K 288-384 tokens 29-30 -> 32.5-33 ms,
+    // Q4_K 23.0-23.8 -> 23.8-24.4; profiles/r06zzd_ab_rb_mid.txt)
+    return rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : (N > 256 && fq_desc(type).blck == 32 ? rb_mid : 32));
+}
+// weight rows per workgroup fq_launch_gemm's tile form gives an M-row matrix at N columns (32 or 64): the callers that reason about a launch's workgroup count
+int fq_gemm_wg_rows(int type, int64_t M, int64_t N, int n_cu) {
+    if (g_gemm_sequential) return 32;
+    const int64_t tiles = ((M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
+    const int64_t rb = gemm_rb_min(N, type);
+    return (tiles >= 4 * (int64_t) n_cu && rb > 0 && tiles >= rb * (int64_t) n_cu) ? 64 : 32;
+}
 int fq_gemm_split_for(int64_t M, int64_t N, int n_cu) {
     if (g_gemm_sequential) return 1;
     const int64_t tiles = ((M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
@@ -937,10 +953,9 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // (round 6: from 512 tokens on already at 8 x #CU tiles -- the short matrices of a long prompt (Wqkv, Wo, Wdown: 4 672 tiles at 1024 tokens) had fallen between the two
     // rules: Falcon-7B Q4_0 1024 tokens 40.7 -> 36.8 ms, 512: 22.75 -> 22.27; below 512 tokens the same threshold costs Wup 6 % at 256 and 7 % at 128. The same S: the same bits.
     // FQ_GEMM_RB_TILES=n: n x #CU for every length (A/B, profiles/r06zz_ab_rb_tiles.txt); FQ_GEMM_RB_TILES_LONG=n: the threshold from 512 tokens on)
-    static const int64_t rb_env = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : -1;      // x #CU tiles; 0 = never
-    static const int64_t rb_long = getenv("FQ_GEMM_RB_TILES_LONG") ? atoll(getenv("FQ_GEMM_RB_TILES_LONG")) : 8;
-    const int64_t rb_min = rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : 32);
-    if (cfg == 3 && rb_min > 0 && tiles >= rb_min * (int64_t) n_cu) cfg = 6;
+    // (and from 257 tokens on at 4 x #CU -- every matrix of a block that takes two partial sums: three token tile rows were the other hole, 288-384 tokens 16.4-17.6 -> 13.8-14.6 ms
+    // together with the residual-sum launch of falcon_hip.hip, profiles/r06zzc_*; FQ_GEMM_RB_TILES_MID=n)
+    if (cfg == 3 && tiles >= gemm_rb_min(N, w.type) * (int64_t) n_cu && gemm_rb_min(N, w.type) > 0) cfg = 6;
     // few columns (round 6): token tiles of 32 / 64 instead of 128 -- the same four-way K split (S = 4: the same association, the same bits), a quarter /
     // half of the matrix work on padding columns gone and 4 / 8 waves per workgroup instead of 16 (FQ_GEMM_SMALL_TT=0: the 128-token tiles, as before)
     static const bool small_tt = !(getenv("FQ_GEMM_SMALL_TT") && atoi(getenv("FQ_GEMM_SMALL_TT")) == 0);
