@@ -897,9 +897,10 @@ static int64_t gemm_rb_min(int64_t N, int type) {
     static const int64_t rb_env = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : -1;
     static const int64_t rb_long = getenv("FQ_GEMM_RB_TILES_LONG") ? atoll(getenv("FQ_GEMM_RB_TILES_LONG")) : 8;
     static const int64_t rb_mid = getenv("FQ_GEMM_RB_TILES_MID") ? atoll(getenv("FQ_GEMM_RB_TILES_MID")) : 4;
-    // (the 257..511 rule for the legacy formats only: the k-quants' integer-domain GEMM loses with 64-row workgroups there -- Falcon-40B Q2_K 288-384 tokens 29-30 -> 32.5-33 ms,
+    // (256 tokens included: a prompt of 256 does not move, 12.0 ms, a lock-step pass of 256 sequences does, 14.76 -> 13.18 ms, profiles/r06zzf_lockstep_sweep.txt)
+    // (the 256..511 rule for the legacy formats only: the k-quants' integer-domain GEMM loses with 64-row workgroups there -- Falcon-40B Q2_K 288-384 tokens 29-30 -> 32.5-33 ms,
     // Q4_K 23.0-23.8 -> 23.8-24.4; profiles/r06zzd_ab_rb_mid.txt)
-    return rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : (N > 256 && fq_desc(type).blck == 32 ? rb_mid : 32));
+    return rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : (N >= 256 && fq_desc(type).blck == 32 ? rb_mid : 32));
 }
 // weight rows per workgroup fq_launch_gemm's tile form gives an M-row matrix at N columns (32 or 64): the callers that reason about a launch's workgroup count
 int fq_gemm_wg_rows(int type, int64_t M, int64_t N, int n_cu) {
