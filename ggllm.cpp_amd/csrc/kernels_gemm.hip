@@ -900,7 +900,13 @@ static int64_t gemm_rb_min(int64_t N, int type) {
     // (256 tokens included: a prompt of 256 does not move, 12.0 ms, a lock-step pass of 256 sequences does, 14.76 -> 13.18 ms, profiles/r06zzf_lockstep_sweep.txt)
     // (the 256..511 rule for the legacy formats only: the k-quants' integer-domain GEMM loses with 64-row workgroups there -- Falcon-40B Q2_K 288-384 tokens 29-30 -> 32.5-33 ms,
     // Q4_K 23.0-23.8 -> 23.8-24.4; profiles/r06zzd_ab_rb_mid.txt)
-    return rb_env >= 0 ? rb_env : (N >= 512 ? rb_long : (N >= 256 && fq_desc(type).blck == 32 ? rb_mid : 32));
+    // (Q4_K / Q5_K below 512 tokens: 8 x #CU except at three token tile rows -- Falcon-40B shapes, 12 blocks, threshold 32 -> 8: Q4_K 128 tokens 8.91 -> 8.42 ms, 256: 16.24 -> 14.92,
+    // 448: 31.06 -> 28.65, lock-step 128 / 256 per pass 9.34 -> 9.00 / 18.14 -> 17.03, but 320-384 tokens 23.4-24.0 -> 23.9-24.4; Q5_K alike; Q2_K loses up to 11 % with it and keeps 32
+    // (profiles/r06zzi_kq_rb.txt, r06zzj_kq_rb8.txt))
+    if (rb_env >= 0) return rb_env;
+    if (N >= 512) return rb_long;
+    if (type == FQ_Q4_K || type == FQ_Q5_K) return (N + 127) / 128 == 3 ? 32 : 8;
+    return N >= 256 && fq_desc(type).blck == 32 ? rb_mid : 32;
 }
 // weight rows per workgroup fq_launch_gemm's tile form gives an M-row matrix at N columns (32 or 64): the callers that reason about a launch's workgroup count
 int fq_gemm_wg_rows(int type, int64_t M, int64_t N, int n_cu) {
