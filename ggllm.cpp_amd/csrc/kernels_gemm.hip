@@ -893,7 +893,7 @@ static void launch_gemm_seq16(const fq_weight & w, const fq_act & act, int64_t N
 }
 
 // the 64-row workgroups' threshold (x #CU tiles of 32 x 32; 0 = never) by prompt length
-static int64_t gemm_rb_min(int64_t N, int type) {
+static int64_t gemm_rb_min(int64_t N, int type, int64_t M, int n_cu) {
     static const int64_t rb_env = getenv("FQ_GEMM_RB_TILES") ? atoll(getenv("FQ_GEMM_RB_TILES")) : -1;
     static const int64_t rb_long = getenv("FQ_GEMM_RB_TILES_LONG") ? atoll(getenv("FQ_GEMM_RB_TILES_LONG")) : 8;
     static const int64_t rb_mid = getenv("FQ_GEMM_RB_TILES_MID") ? atoll(getenv("FQ_GEMM_RB_TILES_MID")) : 4;
@@ -906,13 +906,18 @@ static int64_t gemm_rb_min(int64_t N, int type) {
     if (rb_env >= 0) return rb_env;
     if (N >= 512) return rb_long;
     if (type == FQ_Q4_K || type == FQ_Q5_K) return (N + 127) / 128 == 3 ? 32 : 8;
+    // (one token tile row, legacy formats: only a matrix whose 64-row workgroups still fill the chip twice over -- Falcon-40B's Wup: 512 of them; 128-token prompt 8.65 -> 8.23 ms on
+    // Falcon-40B Q5_1 shapes, profiles/r06zzl_*, r06zzm_*; Falcon-7B's 284 lose: 6.8 -> 7.27 ms; a full tile row only: at 40-96 tokens the same matrix loses 2-5 % as a prompt
+    // and wins 12 % as a lock-step pass of 64 -- left alone)
+    static const bool big_up = !(getenv("FQ_GEMM_RB_BIG_M") && atoi(getenv("FQ_GEMM_RB_BIG_M")) == 0);
+    if (big_up && N > 96 && N <= 128 && fq_desc(type).blck == 32 && (M + 63) / 64 >= 2 * (int64_t) n_cu) return 1;
     return N >= 256 && fq_desc(type).blck == 32 ? rb_mid : 32;
 }
 // weight rows per workgroup fq_launch_gemm's tile form gives an M-row matrix at N columns (32 or 64): the callers that reason about a launch's workgroup count
 int fq_gemm_wg_rows(int type, int64_t M, int64_t N, int n_cu) {
     if (g_gemm_sequential) return 32;
     const int64_t tiles = ((M + GQ_TM - 1) / GQ_TM) * ((N + 31) / 32);
-    const int64_t rb = gemm_rb_min(N, type);
+    const int64_t rb = gemm_rb_min(N, type, M, n_cu);
     return (tiles >= 4 * (int64_t) n_cu && rb > 0 && tiles >= rb * (int64_t) n_cu) ? 64 : 32;
 }
 int fq_gemm_split_for(int64_t M, int64_t N, int n_cu) {
@@ -962,7 +967,7 @@ void fq_launch_gemm(const fq_weight & w, const fq_act & act, int64_t N, float * 
     // FQ_GEMM_RB_TILES=n: n x #CU for every length (A/B, profiles/r06zz_ab_rb_tiles.txt); FQ_GEMM_RB_TILES_LONG=n: the threshold from 512 tokens on)
     // (and from 257 tokens on at 4 x #CU -- every matrix of a block that takes two partial sums: three token tile rows were the other hole, 288-384 tokens 16.4-17.6 -> 13.8-14.6 ms
     // together with the residual-sum launch of falcon_hip.hip, profiles/r06zzc_*; FQ_GEMM_RB_TILES_MID=n)
-    if (cfg == 3 && tiles >= gemm_rb_min(N, w.type) * (int64_t) n_cu && gemm_rb_min(N, w.type) > 0) cfg = 6;
+    { const int64_t rbm = gemm_rb_min(N, w.type, fq_form_rows(w), n_cu); if (cfg == 3 && rbm > 0 && tiles >= rbm * (int64_t) n_cu) cfg = 6; }
     // few columns (round 6): token tiles of 32 / 64 instead of 128 -- the same four-way K split (S = 4: the same association, the same bits), a quarter /
     // half of the matrix work on padding columns gone and 4 / 8 waves per workgroup instead of 16 (FQ_GEMM_SMALL_TT=0: the 128-token tiles, as before)
     static const bool small_tt = !(getenv("FQ_GEMM_SMALL_TT") && atoi(getenv("FQ_GEMM_SMALL_TT")) == 0);
